@@ -1,0 +1,56 @@
+// Shared device/host helpers for the owc HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define OWC_WAVE 64
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// 16-byte async global -> LDS copy (LDS dest = wave-uniform base + lane*16).
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
+__device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }
+// round-trip through bf16 (the rounding point of a bf16 torch op)
+__device__ __forceinline__ float rbf(float x) { return (float)(bf16_t)x; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Epilogue selectors shared by the GEMM kernels and the C ABI (include/owc.h).
+enum {
+  OWC_EPI_NONE = 0,        // C = bf16(acc + bias)
+  OWC_EPI_QUICK_GELU = 1,  // C = bf16(x * sigmoid(1.702 x)), x = bf16(acc + bias)
+  OWC_EPI_GELU_ERF = 2,    // C = bf16(gelu_erf(x))
+  OWC_EPI_RESIDUAL = 3,    // C = bf16(res + bf16(acc + bias))
+  OWC_EPI_SWIGLU = 4,      // interleaved gate/up rows: C[m][f] = bf16(bf16(silu(g)) * u)
+  OWC_EPI_F32 = 5,         // C (fp32) = acc + bias   (no rounding)
+};
+
+#define OWC_OK 0
+#define OWC_ERR_ARG -1
+#define OWC_ERR_HIP -2
+#define OWC_ERR_SHAPE -3
+#define OWC_ERR_WORKSPACE -4
