@@ -6,14 +6,17 @@
  * header is the boundary UNDER those plug points: every entry replaces arithmetic the reference
  * reaches through HF transformers / torch, and is what a ctypes stub in the reference's
  * `src/models/_qwen2_vl.py` / `src/data/pipelines/text/_text.py` would bind.
+ * `HF:` = transformers/models/qwen2_vl/modeling_qwen2_vl.py (the third-party code the reference
+ * calls at src/models/_qwen2_vl.py:319-329); `BERT:` = transformers/models/bert/modeling_bert.py
+ * (called at src/data/pipelines/text/_text.py:197-198).
  *
  * Conventions
- *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host` or the comment says host;
  *   - the caller owns every buffer (inputs, outputs, weights, workspaces); the library owns only a
  *     small zero page inside `owc_ctx`;
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
- *     no hidden synchronisation, no internal threads;
- *   - return value: 0 (OWC_OK) or a negative owc_status; `owc_last_error(ctx)` gives the text;
+ *     no hidden synchronisation, no internal threads, safe to capture into a hipGraph;
+ *   - return value: 0 (OWC_STATUS_OK) or a negative owc_status; `owc_last_error(ctx)` has the text;
  *   - bf16 tensors are raw 16-bit brain-float, row-major, leading dimensions in ELEMENTS.
  */
 #ifndef OWC_H_
@@ -36,13 +39,13 @@ enum owc_status {
   OWC_STATUS_ERR_WORKSPACE = -4
 };
 
-/* GEMM epilogues (what a bf16 torch module would do after the matmul, same rounding points). */
+/* GEMM epilogues (what a bf16 torch module does after the matmul, same rounding points). */
 enum owc_epilogue {
   OWC_EPILOGUE_NONE = 0,       /* C = bf16(acc + bias) */
-  OWC_EPILOGUE_QUICK_GELU = 1, /* HF ACT2FN["quick_gelu"], vision MLP (modeling_qwen2_vl.py:293-302) */
-  OWC_EPILOGUE_GELU_ERF = 2,   /* nn.GELU(), PatchMerger (modeling_qwen2_vl.py:281-286) */
+  OWC_EPILOGUE_QUICK_GELU = 1, /* HF ACT2FN["quick_gelu"], vision MLP (HF:293-302) */
+  OWC_EPILOGUE_GELU_ERF = 2,   /* nn.GELU(), PatchMerger (HF:281-286); BERT intermediate */
   OWC_EPILOGUE_RESIDUAL = 3,   /* C = bf16(residual + bf16(acc + bias)) */
-  OWC_EPILOGUE_SWIGLU = 4,     /* gate/up rows interleaved in 16-row groups; C[M, N/2] */
+  OWC_EPILOGUE_SWIGLU = 4,     /* gate/up rows interleaved in 16-row groups; C[M, N/2] (HF:464-466) */
   OWC_EPILOGUE_F32 = 5         /* fp32 output, no rounding */
 };
 
@@ -50,16 +53,195 @@ enum owc_epilogue {
 int owc_init(int device, owc_ctx** out);
 int owc_destroy(owc_ctx* ctx);
 const char* owc_last_error(const owc_ctx* ctx);
-/* ABI version of this header; bumped whenever a signature changes. */
-int owc_abi_version(void);
+int owc_abi_version(void); /* bumped whenever a signature in this header changes */
 
-/* ---- op level ------------------------------------------------------------------------------ */
-/* C[M,N] = A[M,K] . W[N,K]^T  (+bias[N]) with a fused epilogue.  Replaces torch.nn.Linear.forward
- * as called from HF modeling_qwen2_vl.py (:349-350, :296-301, :501-504, :460-466).
- * Requirements: K % 8 == 0, lda % 8 == 0, ldw % 8 == 0, N % 4 == 0, ldc % 4 == 0. */
+/* ---- op level (each is one kernel launch; used by the model drivers below and by tests) ------ */
+
+/* C[M,N] = A[M,K] . W[N,K]^T (+bias[N]) with a fused epilogue.  Replaces torch.nn.Linear.forward as
+ * called from HF:268-275 (patch-embed conv == GEMM), :349-350, :296-301, :281-291, :501-504, :460-466.
+ * K % 8 == 0, lda % 8 == 0, ldw % 8 == 0, N % 4 == 0, ldc % 4 == 0. */
 int owc_gemm_bf16(owc_ctx* ctx, const void* A, int64_t lda, const void* W, int64_t ldw,
                   const void* bias, const void* residual, int64_t ldr, void* C, int64_t ldc,
                   int M, int N, int K, int epilogue, void* stream);
+
+/* fp32 variant on the f32-input MFMA (exact fp32 products) for the sentence encoder
+ * (BERT:  BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput linears).
+ * epilogue: NONE, GELU_ERF or RESIDUAL (all fp32).  K % 4 == 0, N % 4 == 0. */
+int owc_gemm_f32(owc_ctx* ctx, const float* A, int64_t lda, const float* W, int64_t ldw,
+                 const float* bias, const float* residual, int64_t ldr, float* C, int64_t ldc,
+                 int M, int N, int K, int epilogue, void* stream);
+
+/* torch.nn.LayerNorm over rows of a bf16 matrix (HF:428-429 norm1/norm2, HF:281 ln_q). d % 8 == 0. */
+int owc_layernorm_bf16(owc_ctx* ctx, const void* X, int64_t ldx, const void* weight,
+                       const void* bias, void* Y, int64_t ldy, int rows, int d, float eps,
+                       void* stream);
+
+/* Qwen2VLRMSNorm (HF:105-110).  `row_index` (int32[rows], may be NULL) gathers source rows. */
+int owc_rmsnorm_bf16(owc_ctx* ctx, const void* X, int64_t ldx, const void* weight, void* Y,
+                     int64_t ldy, int rows, int d, float eps, const int32_t* row_index,
+                     void* stream);
+
+/* cos/sin tables: entry [p][j] = cos|sin(p * theta^(-2j/dim)), fp32, optionally rounded to bf16
+ * (HF:156-170 casts the decoder's cos/sin to the activation dtype; HF:239-248 vision keeps fp32). */
+int owc_rope_table(owc_ctx* ctx, float* cos_t, float* sin_t, int n_pos, int n_freq, int dim,
+                   float theta, int round_bf16, void* stream);
+
+/* apply_rotary_pos_emb_vision (HF:225-236) in place on the q and k parts of qkv[T, 3*H*hd];
+ * pos_hw[T][2] = (h, w) patch coordinates in merge-block order (vision_utils.get_vision_position_ids). */
+int owc_vision_rope(owc_ctx* ctx, void* qkv, int64_t ld, const int32_t* pos_hw, const float* cos_t,
+                    const float* sin_t, int T, int n_heads, int head_dim, void* stream);
+
+/* apply_multimodal_rotary_pos_emb (HF:180-222) + DynamicCache.update: rotates q in place inside
+ * qkv[T, (Hq + 2 Hkv) * 128] and writes rotated k / plain v to cache rows
+ * [(tok_slot[t] * Hkv + kvh) * s_max + tok_idx[t]].  pos3 = int32 [3][pos_stride]. */
+int owc_mrope_kv_write(owc_ctx* ctx, void* qkv, int64_t ld, const int32_t* pos3, int64_t pos_stride,
+                       const float* cos_t, const float* sin_t, void* k_cache, void* v_cache,
+                       const int32_t* tok_slot, const int32_t* tok_idx, int T, int n_q_heads,
+                       int n_kv_heads, int s_max, int mrope_sec0, int mrope_sec1, void* stream);
+
+/* softmax(Q K^T * scale [+ causal mask]) V for packed variable-length sequences (flash-style).
+ * Element (seq b, head h, row i, dim d) lives at
+ *   Q: Q + (q_start[b] + i) * q_ts + h * q_hs + d        K/V: K + (k_start[b] + j) * k_ts + (h / kv_group) * k_hs + d
+ *   O: O + (o_start[b] + i) * o_ts + h * o_hs + d        (o_start == NULL -> q_start)
+ * seq_len[b] = number of keys; q_len[b] = number of query rows (NULL -> seq_len).
+ * head_dim in {80, 128, 64, 32}.  Replaces HF:317-339 / sdpa / flash-attn (vision HF:381-419,
+ * decoder HF:537-552). */
+int owc_attention_bf16(owc_ctx* ctx, const void* Q, int64_t q_ts, int64_t q_hs, const void* K,
+                       int64_t k_ts, int64_t k_hs, const void* V, int64_t v_ts, int64_t v_hs,
+                       void* O, int64_t o_ts, int64_t o_hs, const int32_t* q_start,
+                       const int32_t* o_start, const int32_t* k_start, const int32_t* seq_len,
+                       const int32_t* q_len, int n_seq, int n_heads, int kv_group, int head_dim,
+                       int max_q_len, int causal, float scale, void* stream);
+
+/* inputs_embeds = embed_tokens(ids) with image rows scattered in (HF:1160-1168):
+ * out[t] = img_index[t] >= 0 ? img_embeds[img_index[t]] : table[ids[t]]   (img_index may be NULL). */
+int owc_embed_tokens(owc_ctx* ctx, const int32_t* ids, const int32_t* img_index, const void* table,
+                     const void* img_embeds, void* out, int T, int d, void* stream);
+
+/* greedy argmax over bf16 logits rows (lowest index on ties). */
+int owc_argmax_bf16(owc_ctx* ctx, const void* logits, int64_t ld, int rows, int vocab,
+                    int32_t* out, void* stream);
+
+/* uint8 [n,3,H,W] -> pixel_values rows [n * (H/14)*(W/14), 1176] bf16
+ * (HF image_processing_qwen2_vl.py:164-246: rescale, normalise, duplicate frame, patchify). */
+int owc_patchify_u8(owc_ctx* ctx, const uint8_t* images, void* pixel_values, int64_t ld, int n,
+                    int H, int W, const float* mean_host, const float* std_host, void* stream);
+
+/* ---- model level: Qwen2-VL vision tower ----------------------------------------------------- */
+typedef struct owc_vit_layer {
+  const void *ln1_w, *ln1_b, *qkv_w, *qkv_b, *proj_w, *proj_b;
+  const void *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} owc_vit_layer;
+
+typedef struct owc_vit_weights {
+  int32_t depth, embed_dim, num_heads, mlp_hidden, patch_k, out_dim, merge_unit; /* merge_unit = 4 */
+  float ln_eps;
+  const void* patch_w;            /* [embed_dim, patch_k] (Conv3d weight flattened, HF:266) */
+  const owc_vit_layer* layers;    /* HOST array of `depth` entries */
+  const void *merger_ln_w, *merger_ln_b, *merger_fc1_w, *merger_fc1_b, *merger_fc2_w, *merger_fc2_b;
+  const float *rope_cos, *rope_sin; /* [rope_positions][head_dim/4] from owc_rope_table(dim = head_dim/2) */
+  int32_t rope_positions;
+} owc_vit_weights;
+
+size_t owc_vit_workspace_bytes(const owc_vit_weights* w, int T);
+
+/* Qwen2VisionTransformerPretrainedModel.forward (HF:700-731): pixel_values[T, patch_k] ->
+ * merged image embeddings out[T / merge_unit, out_dim].  seq_start/seq_len (int32[n_img]) are the
+ * cu_seqlens of HF:711; pos_hw as in owc_vision_rope. */
+int owc_vit_forward(owc_ctx* ctx, const owc_vit_weights* w, const void* pixel_values, int64_t ld_pix,
+                    const int32_t* pos_hw, const int32_t* seq_start, const int32_t* seq_len,
+                    int n_img, int T, int max_len, void* out, void* workspace, size_t ws_bytes,
+                    void* stream);
+
+/* ---- model level: Qwen2-VL decoder ---------------------------------------------------------- */
+typedef struct owc_llm_layer {
+  const void *ln1_w, *qkv_w, *qkv_b, *o_w, *ln2_w, *gateup_w, *down_w;
+  /* qkv_w = cat(q_proj, k_proj, v_proj) rows; gateup_w = gate/up rows interleaved per 16 */
+} owc_llm_layer;
+
+typedef struct owc_llm_weights {
+  int32_t n_layers, d_model, n_q_heads, n_kv_heads, head_dim, d_ff, vocab;
+  int32_t mrope_sec0, mrope_sec1; /* mrope_section[0], [1] (HF:214) */
+  float rms_eps;
+  const void* embed;             /* [vocab, d_model] */
+  const owc_llm_layer* layers;   /* HOST array of n_layers entries */
+  const void* final_norm_w;
+  const void* lm_head_w;         /* [vocab, d_model] (== embed when tied) */
+  const float *rope_cos, *rope_sin; /* [rope_positions][head_dim/2], bf16-rounded values */
+  int32_t rope_positions;
+} owc_llm_weights;
+
+typedef struct owc_kv_cache {
+  void* k; /* [n_layers][n_slots][n_kv_heads][s_max][head_dim] bf16 */
+  void* v;
+  int32_t n_slots, s_max;
+} owc_kv_cache;
+
+size_t owc_llm_workspace_bytes(const owc_llm_weights* w, int T, int n_seq);
+
+/* Prefill of `n_seq` packed prompts (T tokens in total), HF:1144-1205 + :762-846 + lm_head:
+ *   ids/img_index/tok_slot/tok_idx: int32[T]; pos3: int32[3][T] from get_rope_index (HF:914-1019);
+ *   seq_start/seq_len/k_start: int32[n_seq] (k_start[b] = slot * n_kv_heads * s_max);
+ *   last_index: int32[n_seq] = packed index of each prompt's last token.
+ * Writes the KV cache and next_tok[n_seq] = argmax of the last position's logits.
+ * `logits_out` (optional, [n_seq, vocab] bf16) receives those logits. */
+int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* cache,
+                    const int32_t* ids, const int32_t* img_index, const void* img_embeds,
+                    const int32_t* pos3, const int32_t* tok_slot, const int32_t* tok_idx,
+                    const int32_t* seq_start, const int32_t* seq_len, const int32_t* k_start,
+                    const int32_t* last_index, int n_seq, int T, int max_len, int32_t* next_tok,
+                    void* logits_out, void* workspace, size_t ws_bytes, void* stream);
+
+/* One greedy decode step for B sequences (HF GenerationMixin loop body, one token each):
+ *   tok_io: int32[B] in = tokens to feed, out = next tokens (pad once a sequence is done);
+ *   pos: int32[B] rope position of the fed token (same for the 3 mrope streams);
+ *   slot/write_idx/k_start/k_len/q_start/o_start/q_len: int32[B] cache addressing
+ *     (k_len = write_idx + 1; q_start[b] = b * (Hq + 2 Hkv); o_start[b] = b * Hq; q_len[b] = Hq / Hkv);
+ *   done: uint8[B]; out_tokens[b * out_stride + step] receives the emitted token. */
+int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* cache,
+                        int32_t* tok_io, const int32_t* pos, const int32_t* slot,
+                        const int32_t* write_idx, const int32_t* k_start, const int32_t* k_len,
+                        const int32_t* q_start, const int32_t* o_start, const int32_t* q_len,
+                        uint8_t* done, int32_t* out_tokens, int out_stride, int step, int B,
+                        int eos_id0, int eos_id1, int pad_id, void* logits_out, void* workspace,
+                        size_t ws_bytes, void* stream);
+
+/* first-token bookkeeping after prefill: same done/pad/out_tokens update as a decode step. */
+int owc_decode_update(owc_ctx* ctx, int32_t* next_tok, uint8_t* done, int32_t* out_tokens,
+                      int out_stride, int step, int B, int eos_id0, int eos_id1, int pad_id,
+                      void* stream);
+
+/* ---- model level: sentence encoder + cosine scorer (fp32) ------------------------------------- */
+typedef struct owc_bert_layer {
+  const float *qkv_w, *qkv_b; /* cat(query, key, value) [3h, h] */
+  const float *o_w, *o_b, *ln1_w, *ln1_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ln2_w, *ln2_b;
+} owc_bert_layer;
+
+typedef struct owc_bert_weights {
+  int32_t n_layers, hidden, n_heads, inter, vocab, max_pos;
+  float ln_eps;
+  const float *word_emb, *pos_emb, *type_emb, *emb_ln_w, *emb_ln_b;
+  const owc_bert_layer* layers; /* HOST array */
+} owc_bert_weights;
+
+size_t owc_bert_workspace_bytes(const owc_bert_weights* w, int n, int L);
+
+/* encode_sentence_bert's arithmetic (src/data/pipelines/text/_text.py:197-202): BertModel forward,
+ * mask-weighted mean pool (clamp 1e-9), L2 normalisation.  ids/mask: int32[n][L]; out fp32 [n][hidden]. */
+int owc_bert_embed(owc_ctx* ctx, const owc_bert_weights* w, const int32_t* ids, const int32_t* mask,
+                   int n, int L, float* out, void* workspace, size_t ws_bytes, void* stream);
+
+/* Cosine scorer: sim = preds[N,D] . classes[C,D]^T (rows already L2-normalised), never materialised:
+ * top_val/top_idx[N][k] = k best classes per prediction (descending, lowest index on ties),
+ * paired[N] = sim[i, label[i]] — the reference's torch.bmm pairing
+ * (src/data/metrics/_group.py:537-544).  label / paired / top_* may be NULL. k <= 16. */
+int owc_cosine_topk(owc_ctx* ctx, const float* preds, const float* classes, const int32_t* label,
+                    int N, int C, int D, int k, float* top_val, int32_t* top_idx, float* paired,
+                    void* stream);
+
+/* paired[i] = <a[i], b[i]> for two [N,D] fp32 matrices (torch.bmm(refs[N,1,D], preds[N,D,1])). */
+int owc_paired_dot(owc_ctx* ctx, const float* a, const float* b, int N, int D, float* out,
+                   void* stream);
 
 #ifdef __cplusplus
 }

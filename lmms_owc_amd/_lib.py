@@ -15,35 +15,107 @@ _lock = threading.Lock()
 _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = range(6)
 
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
 
 class OwcError(RuntimeError):
-    """A libowc_hip.so call returned a negative status."""
+    """A libowc_hip.so call returned a negative status (or the extension is missing)."""
+
+
+class VitLayer(C.Structure):
+    _fields_ = [(n, vp) for n in (
+        "ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
+        "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class VitWeights(C.Structure):
+    _fields_ = [
+        ("depth", C.c_int32), ("embed_dim", C.c_int32), ("num_heads", C.c_int32),
+        ("mlp_hidden", C.c_int32), ("patch_k", C.c_int32), ("out_dim", C.c_int32),
+        ("merge_unit", C.c_int32), ("ln_eps", f32),
+        ("patch_w", vp), ("layers", C.POINTER(VitLayer)),
+        ("merger_ln_w", vp), ("merger_ln_b", vp), ("merger_fc1_w", vp), ("merger_fc1_b", vp),
+        ("merger_fc2_w", vp), ("merger_fc2_b", vp),
+        ("rope_cos", vp), ("rope_sin", vp), ("rope_positions", C.c_int32),
+    ]
+
+
+class LlmLayer(C.Structure):
+    _fields_ = [(n, vp) for n in ("ln1_w", "qkv_w", "qkv_b", "o_w", "ln2_w", "gateup_w", "down_w")]
+
+
+class LlmWeights(C.Structure):
+    _fields_ = [
+        ("n_layers", C.c_int32), ("d_model", C.c_int32), ("n_q_heads", C.c_int32),
+        ("n_kv_heads", C.c_int32), ("head_dim", C.c_int32), ("d_ff", C.c_int32), ("vocab", C.c_int32),
+        ("mrope_sec0", C.c_int32), ("mrope_sec1", C.c_int32), ("rms_eps", f32),
+        ("embed", vp), ("layers", C.POINTER(LlmLayer)), ("final_norm_w", vp), ("lm_head_w", vp),
+        ("rope_cos", vp), ("rope_sin", vp), ("rope_positions", C.c_int32),
+    ]
+
+
+class KvCache(C.Structure):
+    _fields_ = [("k", vp), ("v", vp), ("n_slots", C.c_int32), ("s_max", C.c_int32)]
+
+
+class BertLayer(C.Structure):
+    _fields_ = [(n, vp) for n in (
+        "qkv_w", "qkv_b", "o_w", "o_b", "ln1_w", "ln1_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+        "ln2_w", "ln2_b")]
+
+
+class BertWeights(C.Structure):
+    _fields_ = [
+        ("n_layers", C.c_int32), ("hidden", C.c_int32), ("n_heads", C.c_int32), ("inter", C.c_int32),
+        ("vocab", C.c_int32), ("max_pos", C.c_int32), ("ln_eps", f32),
+        ("word_emb", vp), ("pos_emb", vp), ("type_emb", vp), ("emb_ln_w", vp), ("emb_ln_b", vp),
+        ("layers", C.POINTER(BertLayer)),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/owc.h declares
+SIGNATURES: dict[str, tuple] = {
+    "owc_abi_version": (i32, []),
+    "owc_init": (i32, [i32, C.POINTER(vp)]),
+    "owc_destroy": (i32, [vp]),
+    "owc_last_error": (C.c_char_p, [vp]),
+    "owc_gemm_bf16": (i32, [vp, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
+    "owc_gemm_f32": (i32, [vp, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
+    "owc_layernorm_bf16": (i32, [vp, vp, i64, vp, vp, vp, i64, i32, i32, f32, vp]),
+    "owc_rmsnorm_bf16": (i32, [vp, vp, i64, vp, vp, i64, i32, i32, f32, vp, vp]),
+    "owc_rope_table": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, vp]),
+    "owc_vision_rope": (i32, [vp, vp, i64, vp, vp, vp, i32, i32, i32, vp]),
+    "owc_mrope_kv_write": (i32, [vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "owc_attention_bf16": (i32, [vp, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, vp,
+                                 i32, i32, i32, i32, i32, i32, f32, vp]),
+    "owc_embed_tokens": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "owc_argmax_bf16": (i32, [vp, vp, i64, i32, i32, vp, vp]),
+    "owc_patchify_u8": (i32, [vp, vp, vp, i64, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp]),
+    "owc_vit_workspace_bytes": (sz, [C.POINTER(VitWeights), i32]),
+    "owc_vit_forward": (i32, [vp, C.POINTER(VitWeights), vp, i64, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]),
+    "owc_llm_workspace_bytes": (sz, [C.POINTER(LlmWeights), i32, i32]),
+    "owc_llm_prefill": (i32, [vp, C.POINTER(LlmWeights), C.POINTER(KvCache), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                              i32, i32, i32, vp, vp, vp, sz, vp]),
+    "owc_llm_decode_step": (i32, [vp, C.POINTER(LlmWeights), C.POINTER(KvCache), vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                  vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "owc_decode_update": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "owc_bert_workspace_bytes": (sz, [C.POINTER(BertWeights), i32, i32]),
+    "owc_bert_embed": (i32, [vp, C.POINTER(BertWeights), vp, vp, i32, i32, vp, vp, sz, vp]),
+    "owc_cosine_topk": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "owc_paired_dot": (i32, [vp, vp, vp, i32, i32, vp, vp]),
+}
 
 
 def lib_path() -> Path:
     return _LIB_PATH
 
 
-def _declare(lib: C.CDLL) -> None:
-    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
-    lib.owc_abi_version.restype = i32
-    lib.owc_abi_version.argtypes = []
-    lib.owc_init.restype = i32
-    lib.owc_init.argtypes = [i32, C.POINTER(vp)]
-    lib.owc_destroy.restype = i32
-    lib.owc_destroy.argtypes = [vp]
-    lib.owc_last_error.restype = C.c_char_p
-    lib.owc_last_error.argtypes = [vp]
-    lib.owc_gemm_bf16.restype = i32
-    lib.owc_gemm_bf16.argtypes = [vp, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]
-
-
 def load() -> C.CDLL:
-    """Load libowc_hip.so; raises (loudly) if it has not been built."""
+    """Load libowc_hip.so; raises (loudly) if it has not been built or lacks a symbol."""
     global _lib
     with _lock:
         if _lib is None:
@@ -53,7 +125,10 @@ def load() -> C.CDLL:
                     "(the HIP extension is mandatory, there is no fallback path)"
                 )
             lib = C.CDLL(str(_LIB_PATH))
-            _declare(lib)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+                fn.restype = res
+                fn.argtypes = args
             if lib.owc_abi_version() != ABI_VERSION:
                 raise OwcError("libowc_hip.so ABI version mismatch: rebuild the extension")
             _lib = lib

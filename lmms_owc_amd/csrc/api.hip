@@ -1,10 +1,19 @@
-// C ABI of libowc_hip.so (declared in include/owc.h).
+// C ABI of libowc_hip.so (declared in include/owc.h): lifetime + op-level entry points.
+// The model-level entries live in qwen2vl.hip / bert.hip.
 #include "../../include/owc.h"
 #include "owc_internal.h"
 
+#define ST(s) ((hipStream_t)(s))
+#define RET(ctx, name, rc)                                                        \
+  do {                                                                            \
+    int rc__ = (rc);                                                              \
+    if (rc__ != OWC_OK) (ctx)->err = name ": bad shape/argument or launch failure"; \
+    return rc__;                                                                  \
+  } while (0)
+
 extern "C" {
 
-int owc_abi_version(void) { return 1; }
+int owc_abi_version(void) { return 2; }
 
 int owc_init(int device, owc_ctx** out) {
   if (out == nullptr) return OWC_ERR_ARG;
@@ -33,10 +42,90 @@ int owc_gemm_bf16(owc_ctx* ctx, const void* A, int64_t lda, const void* W, int64
                   const void* bias, const void* residual, int64_t ldr, void* C, int64_t ldc, int M,
                   int N, int K, int epilogue, void* stream) {
   if (!ctx || !A || !W || !C) return OWC_ERR_ARG;
-  int rc = owc_launch_gemm_bf16(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, epilogue,
-                                ctx->zeros, (hipStream_t)stream);
-  if (rc != OWC_OK) ctx->err = "owc_gemm_bf16: bad shape/argument or launch failure";
-  return rc;
+  RET(ctx, "owc_gemm_bf16",
+      owc_launch_gemm_bf16(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, epilogue, ctx->zeros, ST(stream)));
+}
+
+int owc_gemm_f32(owc_ctx* ctx, const float* A, int64_t lda, const float* W, int64_t ldw,
+                 const float* bias, const float* residual, int64_t ldr, float* C, int64_t ldc, int M,
+                 int N, int K, int epilogue, void* stream) {
+  if (!ctx || !A || !W || !C) return OWC_ERR_ARG;
+  RET(ctx, "owc_gemm_f32",
+      owc_launch_gemm_f32(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, epilogue, ctx->zeros, ST(stream)));
+}
+
+int owc_layernorm_bf16(owc_ctx* ctx, const void* X, int64_t ldx, const void* weight, const void* bias,
+                       void* Y, int64_t ldy, int rows, int d, float eps, void* stream) {
+  if (!ctx || !X || !weight || !bias || !Y) return OWC_ERR_ARG;
+  RET(ctx, "owc_layernorm_bf16", owc_launch_layernorm(X, ldx, weight, bias, Y, ldy, rows, d, eps, ST(stream)));
+}
+
+int owc_rmsnorm_bf16(owc_ctx* ctx, const void* X, int64_t ldx, const void* weight, void* Y,
+                     int64_t ldy, int rows, int d, float eps, const int32_t* row_index, void* stream) {
+  if (!ctx || !X || !weight || !Y) return OWC_ERR_ARG;
+  RET(ctx, "owc_rmsnorm_bf16", owc_launch_rmsnorm(X, ldx, weight, Y, ldy, rows, d, eps, row_index, ST(stream)));
+}
+
+int owc_rope_table(owc_ctx* ctx, float* cos_t, float* sin_t, int n_pos, int n_freq, int dim,
+                   float theta, int round_bf16, void* stream) {
+  if (!ctx || !cos_t || !sin_t) return OWC_ERR_ARG;
+  RET(ctx, "owc_rope_table", owc_launch_rope_table(cos_t, sin_t, n_pos, n_freq, dim, theta, round_bf16, ST(stream)));
+}
+
+int owc_vision_rope(owc_ctx* ctx, void* qkv, int64_t ld, const int32_t* pos_hw, const float* cos_t,
+                    const float* sin_t, int T, int n_heads, int head_dim, void* stream) {
+  if (!ctx || !qkv || !pos_hw || !cos_t || !sin_t) return OWC_ERR_ARG;
+  RET(ctx, "owc_vision_rope", owc_launch_vision_rope(qkv, ld, pos_hw, cos_t, sin_t, T, n_heads, head_dim, ST(stream)));
+}
+
+int owc_mrope_kv_write(owc_ctx* ctx, void* qkv, int64_t ld, const int32_t* pos3, int64_t pos_stride,
+                       const float* cos_t, const float* sin_t, void* k_cache, void* v_cache,
+                       const int32_t* tok_slot, const int32_t* tok_idx, int T, int n_q_heads,
+                       int n_kv_heads, int s_max, int mrope_sec0, int mrope_sec1, void* stream) {
+  if (!ctx || !qkv || !pos3 || !cos_t || !sin_t || !k_cache || !v_cache || !tok_slot || !tok_idx)
+    return OWC_ERR_ARG;
+  RET(ctx, "owc_mrope_kv_write",
+      owc_launch_mrope_kv(qkv, ld, pos3, pos_stride, cos_t, sin_t, k_cache, v_cache, tok_slot, tok_idx, T,
+                          n_q_heads, n_kv_heads, s_max, mrope_sec0, mrope_sec1, ST(stream)));
+}
+
+int owc_attention_bf16(owc_ctx* ctx, const void* Q, int64_t q_ts, int64_t q_hs, const void* K,
+                       int64_t k_ts, int64_t k_hs, const void* V, int64_t v_ts, int64_t v_hs, void* O,
+                       int64_t o_ts, int64_t o_hs, const int32_t* q_start, const int32_t* o_start,
+                       const int32_t* k_start, const int32_t* seq_len, const int32_t* q_len, int n_seq,
+                       int n_heads, int kv_group, int head_dim, int max_q_len, int causal, float scale,
+                       void* stream) {
+  if (!ctx || !Q || !K || !V || !O || !q_start || !k_start || !seq_len) return OWC_ERR_ARG;
+  RET(ctx, "owc_attention_bf16",
+      owc_launch_attention(Q, q_ts, q_hs, K, k_ts, k_hs, V, v_ts, v_hs, O, o_ts, o_hs, q_start, o_start,
+                           k_start, seq_len, q_len, n_seq, n_heads, kv_group, head_dim, max_q_len, causal,
+                           scale, ST(stream)));
+}
+
+int owc_embed_tokens(owc_ctx* ctx, const int32_t* ids, const int32_t* img_index, const void* table,
+                     const void* img_embeds, void* out, int T, int d, void* stream) {
+  if (!ctx || !ids || !table || !out) return OWC_ERR_ARG;
+  RET(ctx, "owc_embed_tokens", owc_launch_embed(ids, img_index, table, img_embeds, out, T, d, ST(stream)));
+}
+
+int owc_argmax_bf16(owc_ctx* ctx, const void* logits, int64_t ld, int rows, int vocab, int32_t* out,
+                    void* stream) {
+  if (!ctx || !logits || !out) return OWC_ERR_ARG;
+  RET(ctx, "owc_argmax_bf16", owc_launch_argmax(logits, ld, rows, vocab, out, ST(stream)));
+}
+
+int owc_patchify_u8(owc_ctx* ctx, const uint8_t* images, void* pixel_values, int64_t ld, int n, int H,
+                    int W, const float* mean_host, const float* std_host, void* stream) {
+  if (!ctx || !images || !pixel_values || !mean_host || !std_host) return OWC_ERR_ARG;
+  RET(ctx, "owc_patchify_u8", owc_launch_patchify(images, pixel_values, ld, n, H, W, mean_host, std_host, ST(stream)));
+}
+
+int owc_decode_update(owc_ctx* ctx, int32_t* next_tok, uint8_t* done, int32_t* out_tokens,
+                      int out_stride, int step, int B, int eos_id0, int eos_id1, int pad_id,
+                      void* stream) {
+  if (!ctx || !next_tok || !done || !out_tokens) return OWC_ERR_ARG;
+  RET(ctx, "owc_decode_update",
+      owc_launch_decode_update(next_tok, done, out_tokens, out_stride, step, B, eos_id0, eos_id1, pad_id, ST(stream)));
 }
 
 }  // extern "C"

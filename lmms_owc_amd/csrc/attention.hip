@@ -1,0 +1,309 @@
+// Flash-style attention forward on the MFMA pipe, for both attention shapes of the Qwen2-VL path:
+//   * vision tower: non-causal, per-image (cu_seqlens) attention, 16 heads x head_dim 80
+//     (HF:models/qwen2_vl/modeling_qwen2_vl.py:356-422, eager reference :317-339)
+//   * decoder prefill: causal GQA attention, head_dim 128 (HF: :508-556)
+//
+// CDNA4 design (one 256-thread block = 4 waves = 128 query rows of one (sequence, head)):
+//  * S^T = K . Q^T with v_mfma_f32_16x16x32_bf16 (keys on the MFMA rows, queries on the lanes), so a
+//    lane owns ONE query column: the running max / rescale factor of the online softmax is lane
+//    local and a row reduction is 15 VALU max/add + 2 cross-lane steps (xor 16, 32).
+//  * O^T = V^T . P^T: the S^T accumulator registers, converted pairwise to bf16, ARE the B operand of
+//    the second product (key order permuted identically on the V side), so P never touches LDS.
+//  * V^T fragments come from row-major V tiles through ds_read_b64_tr_b16 (hardware transpose).
+//  * K/V tiles (64 keys) are staged by 16-byte LDS-DMA into double-buffered LDS; each wave computes
+//    two 16-query tiles against every K/V fragment it reads (halves LDS bytes per FLOP).
+//  * LDS images: head_dim 80 -> natural 160-B rows (conflict-free for both read kinds);
+//    head_dim 128 -> 256-B rows with chunk ^= (key & 7) << 1 applied on the DMA source and on both reads.
+//  * softmax in fp32 with exp2; masked/ragged keys handled on the last tile only.
+#include "owc_internal.h"
+
+namespace {
+
+constexpr int QB = 128;  // query rows per block
+constexpr int KB = 64;   // keys per tile
+
+template <int HD>
+struct Cfg {
+  static constexpr int CPR = HD / 8;              // 16-byte chunks per row
+  static constexpr int ROWB = HD * 2;             // bytes per row
+  static constexpr int TILE = KB * ROWB;          // bytes per K (or V) tile
+  static constexpr int NP = TILE / 1024;          // LDS-DMA pieces per tile
+  static constexpr int KS = (HD + 31) / 32;       // 32-wide k-steps of Q.K^T
+  static constexpr int DT = HD / 16;              // 16-wide d tiles of O
+  static constexpr bool SWZ = (HD % 128) == 0;    // 256-B rows need the XOR swizzle
+};
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(
+    const bf16_t* __restrict__ Q, long q_ts, long q_hs, const bf16_t* __restrict__ K, long k_ts,
+    long k_hs, const bf16_t* __restrict__ V, long v_ts, long v_hs, bf16_t* __restrict__ O, long o_ts,
+    long o_hs, const int* __restrict__ q_start, const int* __restrict__ o_start,
+    const int* __restrict__ k_start, const int* __restrict__ seq_len, const int* __restrict__ q_len, int n_heads, int kv_group, int nqb,
+    int n_pairs, float scale_log2e) {
+  using C = Cfg<HD>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // [2 buf][K tile | V tile]
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int fr = l & 15, g = l >> 4;
+
+  // block -> (pair = sequence*head, q block); the q blocks of one pair share an XCD when possible
+  const int bid = blockIdx.x;
+  int qb, pair;
+  if ((n_pairs & 7) == 0) {
+    qb = (bid >> 3) % nqb;
+    pair = (bid / (8 * nqb)) * 8 + (bid & 7);
+  } else {
+    qb = bid % nqb;
+    pair = bid / nqb;
+  }
+  const int b = pair / n_heads, h = pair % n_heads;
+  const int hk = h / kv_group;
+  const int L = seq_len[b];                  // keys
+  const int Lq = q_len ? q_len[b] : L;       // query rows (== L except for the decode mapping)
+  if (qb * QB >= Lq) return;
+  const bool active = (qb * QB + w * 32) < Lq;  // wave-uniform: waves without rows only stage tiles
+  const long qs = q_start[b], ks0 = k_start[b];
+  const long os = o_start ? (long)o_start[b] : qs;
+
+  const int kmax = CAUSAL ? min(L, qb * QB + QB) : L;
+  const int ntiles = (kmax + KB - 1) / KB;
+
+  // ---- Q fragments (B operand): lane = query column fr, 8 consecutive d per k-step ----
+  bf16x8 qf[2][C::KS];
+  int qrow[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    qrow[qt] = qb * QB + w * 32 + qt * 16 + fr;
+    const bf16_t* qp = Q + (qs + min(qrow[qt], Lq - 1)) * q_ts + (long)h * q_hs;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      const int c = ks * 4 + g;
+      if (c < C::CPR) {
+        qf[qt][ks] = *(const bf16x8*)(qp + c * 8);
+      } else {
+        qf[qt][ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+  }
+
+  const bf16_t* Kb = K + (long)hk * k_hs;
+  const bf16_t* Vb = V + (long)hk * v_hs;
+
+  auto stage = [&](int buf, int t) {
+    char* base = lds + buf * (2 * C::TILE);
+#pragma unroll
+    for (int i = 0; i < (2 * C::NP + 3) / 4; ++i) {
+      const int p = w + 4 * i;  // wave-uniform piece id
+      if (p < 2 * C::NP) {
+        const bool isv = p >= C::NP;
+        const int pp = isv ? p - C::NP : p;
+        const int ci = pp * 64 + l;
+        const int key = ci / C::CPR;
+        const int pos = ci - key * C::CPR;
+        const int c = C::SWZ ? (pos ^ ((key & 7) << 1)) : pos;
+        const long tok = ks0 + min(t * KB + key, L - 1);
+        const bf16_t* src = isv ? (Vb + tok * v_ts + c * 8) : (Kb + tok * k_ts + c * 8);
+        glds16(src, base + (isv ? C::TILE : 0) + pp * 1024);
+      }
+    }
+  };
+
+  f32x4 o[C::DT][2];
+#pragma unroll
+  for (int d = 0; d < C::DT; ++d) {
+    o[d][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    o[d][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float mrun[2] = {-1e30f, -1e30f};
+  float lrun[2] = {0.f, 0.f};
+
+  // fragment byte offsets inside a tile
+  // K (A operand of S^T): row key = 16*kt + fr, chunk ks*4+g
+  // V (A operand of O^T via transposed read): rows 32s+4g+q' (and +16), q' = fr>>2, p = fr&3
+  const int kswz = C::SWZ ? ((fr & 7) << 1) : 0;
+  const int vq = fr >> 2, vp = fr & 3;
+
+  stage(0, 0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntiles) stage(cur ^ 1, t + 1);
+    const char* kt_ = lds + cur * (2 * C::TILE);
+    const char* vt_ = kt_ + C::TILE;
+    if (active) {
+
+    // ---- S^T = K . Q^T ----
+    f32x4 s[4][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      s[kt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const char* krow = kt_ + (kt * 16 + fr) * C::ROWB;
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        const int c = ks * 4 + g;
+        bf16x8 kf;
+        if (C::CPR % 4 == 0 || ks < C::KS - 1) {
+          kf = *(const bf16x8*)(krow + ((c ^ kswz) << 4));
+        } else {
+          const int cc = min(c, C::CPR - 1);
+          kf = *(const bf16x8*)(krow + ((cc ^ kswz) << 4));
+          if (c >= C::CPR) kf = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
+        s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
+      }
+    }
+
+    // ---- online softmax (lane = query column; keys 16kt + 4g + r) ----
+    const bool edge = (t * KB + KB > L) || (CAUSAL && (t * KB + KB - 1 > qb * QB + w * 32));
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float x[4][4];
+      float mx = -1e30f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = s[kt][qt][r] * scale_log2e;
+          if (edge) {
+            const int key = t * KB + kt * 16 + g * 4 + r;
+            if (key >= L || (CAUSAL && key > qrow[qt])) v = -1e30f;
+          }
+          x[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrun[qt], mx);
+      const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+      mrun[qt] = mnew;
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // a fully masked entry stays at -1e30 - mnew -> exp2 -> 0
+          const float p = __builtin_amdgcn_exp2f(x[kt][r] - mnew);
+          x[kt][r] = p;
+          sum += p;
+        }
+      lrun[qt] = lrun[qt] * alpha + sum;
+#pragma unroll
+      for (int d = 0; d < C::DT; ++d) {
+        o[d][qt][0] *= alpha;
+        o[d][qt][1] *= alpha;
+        o[d][qt][2] *= alpha;
+        o[d][qt][3] *= alpha;
+      }
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx) {
+        bf16x8 f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f[r] = f2bf(x[2 * sx][r]);
+          f[4 + r] = f2bf(x[2 * sx + 1][r]);
+        }
+        pf[qt][sx] = f;
+      }
+    }
+
+    // ---- O^T += V^T . P^T ----
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+      const int key0 = sx * 32 + g * 4 + vq;
+      const int key1 = key0 + 16;
+#pragma unroll
+      for (int d = 0; d < C::DT; ++d) {
+        int a0, a1;
+        if (C::SWZ) {
+          const int ch = 2 * d + (vp >> 1);
+          a0 = key0 * C::ROWB + ((ch ^ ((key0 & 7) << 1)) << 4) + (vp & 1) * 8;
+          a1 = key1 * C::ROWB + ((ch ^ ((key1 & 7) << 1)) << 4) + (vp & 1) * 8;
+        } else {
+          a0 = key0 * C::ROWB + d * 32 + vp * 8;
+          a1 = key1 * C::ROWB + d * 32 + vp * 8;
+        }
+        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vt_ + a0));
+        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vt_ + a1));
+        const bf16x8 vf = (bf16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        o[d][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][sx], o[d][0], 0, 0, 0);
+        o[d][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][sx], o[d][1], 0, 0, 0);
+      }
+    }
+    }  // active
+    __syncthreads();
+  }
+
+  // ---- epilogue: O[q][16d + 4g + r] = o[d][qt][r] / l ----
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float lsum = lrun[qt];
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / lsum;
+    if (qrow[qt] < Lq) {
+      bf16_t* op = O + (os + qrow[qt]) * o_ts + (long)h * o_hs + g * 4;
+#pragma unroll
+      for (int d = 0; d < C::DT; ++d) {
+        bf16x4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = f2bf(o[d][qt][r] * inv);
+        *(bf16x4*)(op + d * 16) = ov;
+      }
+    }
+  }
+}
+
+template <int HD, bool CAUSAL>
+int launch(const void* Q, long q_ts, long q_hs, const void* K, long k_ts, long k_hs, const void* V,
+           long v_ts, long v_hs, void* O, long o_ts, long o_hs, const int* q_start,
+           const int* o_start, const int* k_start, const int* seq_len, const int* q_len, int n_seq, int n_heads,
+           int kv_group, int max_len, float scale, hipStream_t st) {
+  using C = Cfg<HD>;
+  const int nqb = (max_len + QB - 1) / QB;
+  const int n_pairs = n_seq * n_heads;
+  const int lds_bytes = 4 * C::TILE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, CAUSAL>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+      return OWC_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_fwd_kernel<HD, CAUSAL>), dim3(n_pairs * nqb), dim3(256), lds_bytes, st,
+                     (const bf16_t*)Q, q_ts, q_hs, (const bf16_t*)K, k_ts, k_hs, (const bf16_t*)V,
+                     v_ts, v_hs, (bf16_t*)O, o_ts, o_hs, q_start, o_start, k_start, seq_len, q_len, n_heads,
+                     kv_group, nqb, n_pairs, scale * 1.4426950408889634f);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+}  // namespace
+
+int owc_launch_attention(const void* Q, long q_ts, long q_hs, const void* K, long k_ts, long k_hs,
+                         const void* V, long v_ts, long v_hs, void* O, long o_ts, long o_hs,
+                         const int* q_start, const int* o_start, const int* k_start,
+                         const int* seq_len, const int* q_len, int n_seq, int n_heads, int kv_group, int head_dim,
+                         int max_q_len, int causal, float scale, hipStream_t st) {
+  const int max_len = max_q_len;
+  if (n_seq <= 0 || n_heads <= 0 || kv_group <= 0 || max_len <= 0) return OWC_ERR_SHAPE;
+  if ((q_ts & 7) || (q_hs & 7) || (k_ts & 7) || (k_hs & 7) || (v_ts & 7) || (v_hs & 7) || (o_ts & 3) || (o_hs & 3))
+    return OWC_ERR_SHAPE;
+#define OWC_ATTN_CASE(HD_)                                                                         \
+  if (head_dim == HD_)                                                                             \
+    return causal ? launch<HD_, true>(Q, q_ts, q_hs, K, k_ts, k_hs, V, v_ts, v_hs, O, o_ts, o_hs, \
+                                      q_start, o_start, k_start, seq_len, q_len, n_seq, n_heads, kv_group, \
+                                      max_len, scale, st)                                          \
+                  : launch<HD_, false>(Q, q_ts, q_hs, K, k_ts, k_hs, V, v_ts, v_hs, O, o_ts, o_hs,\
+                                       q_start, o_start, k_start, seq_len, q_len, n_seq, n_heads, kv_group,\
+                                       max_len, scale, st);
+  OWC_ATTN_CASE(80)
+  OWC_ATTN_CASE(128)
+  OWC_ATTN_CASE(32)
+  OWC_ATTN_CASE(64)
+#undef OWC_ATTN_CASE
+  return OWC_ERR_SHAPE;
+}

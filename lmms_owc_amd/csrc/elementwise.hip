@@ -1,0 +1,391 @@
+// HBM-bound glue kernels of the Qwen2-VL path: norms, rotary embeddings, KV-cache write, token
+// embedding gather, greedy argmax, pixel patchify.  All loads/stores are 8/16-byte vectors; every
+// kernel rounds to bf16 exactly where the bf16 torch module it replaces rounds.
+#include "owc_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm / RMSNorm: one wave per row, row cached in registers (bf16x8 chunks), fp32 stats.
+//   LayerNorm  = torch.nn.LayerNorm (vision blocks, merger ln_q: HF modeling_qwen2_vl.py:428-429, :281)
+//   RMSNorm    = Qwen2VLRMSNorm (HF modeling_qwen2_vl.py:105-110): x*rsqrt(var+eps) -> bf16 -> *w -> bf16
+// ------------------------------------------------------------------------------------------
+constexpr int NORM_MAXC = 16;  // chunks of 8 per lane -> rows up to 8192
+
+template <bool RMS>
+__global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ X, long ldx,
+                                                   const bf16_t* __restrict__ Wt,
+                                                   const bf16_t* __restrict__ Bs,
+                                                   bf16_t* __restrict__ Y, long ldy, int rows, int d,
+                                                   float eps, const int* __restrict__ row_index) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= rows) return;
+  const long src_row = row_index ? (long)row_index[row] : (long)row;
+  const bf16_t* x = X + src_row * ldx;
+  const int nch = d >> 3;
+  bf16x8 c[NORM_MAXC];
+  float sum = 0.f, sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int ch = i * 64 + l;
+    if (ch < nch) {
+      c[i] = *(const bf16x8*)(x + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = bf2f(c[i][e]);
+        sum += v;
+        sq += v * v;
+      }
+    }
+  }
+  sum = wave_sum(sum);
+  sq = wave_sum(sq);
+  const float inv_d = 1.0f / (float)d;
+  float mean = 0.f, rstd;
+  if (RMS) {
+    rstd = rsqrtf(sq * inv_d + eps);
+  } else {
+    mean = sum * inv_d;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < NORM_MAXC; ++i) {
+      const int ch = i * 64 + l;
+      if (ch < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = bf2f(c[i][e]) - mean;
+          var += v * v;
+        }
+      }
+    }
+    var = wave_sum(var) * inv_d;
+    rstd = rsqrtf(var + eps);
+  }
+  bf16_t* y = Y + (long)row * ldy;
+#pragma unroll
+  for (int i = 0; i < NORM_MAXC; ++i) {
+    const int ch = i * 64 + l;
+    if (ch < nch) {
+      const bf16x8 wv = *(const bf16x8*)(Wt + ch * 8);
+      bf16x8 o;
+      if (RMS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(wv[e]) * rbf(bf2f(c[i][e]) * rstd));
+      } else {
+        const bf16x8 bv = *(const bf16x8*)(Bs + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          o[e] = f2bf((bf2f(c[i][e]) - mean) * rstd * bf2f(wv[e]) + bf2f(bv[e]));
+      }
+      *(bf16x8*)(y + ch * 8) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Rotary tables (built once per model on the device).
+//   vision : freq[j] = 10000^(-2j/40), j < 20        (HF :239-248 VisionRotaryEmbedding(head_dim/2))
+//   decoder: freq[i] = theta^(-2i/128), i < 64, table entries rounded to bf16 (HF :156-170 casts
+//            cos/sin to the activation dtype before apply_multimodal_rotary_pos_emb)
+// ------------------------------------------------------------------------------------------
+__global__ void rope_table_kernel(float* __restrict__ cos_t, float* __restrict__ sin_t, int n_pos,
+                                  int n_freq, int dim, float theta, int round_bf16) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pos * n_freq) return;
+  const int p = i / n_freq, j = i % n_freq;
+  const float inv = (float)(1.0 / pow((double)theta, (double)(2 * j) / (double)dim));
+  const float ang = (float)p * inv;
+  float c = cosf(ang), s = sinf(ang);
+  if (round_bf16) {
+    c = rbf(c);
+    s = rbf(s);
+  }
+  cos_t[i] = c;
+  sin_t[i] = s;
+}
+
+// Vision 2-D RoPE, in place on the fused qkv buffer [T, 3, H, 80] (q and k parts only).
+// HF apply_rotary_pos_emb_vision (:225-236): fp32 math, one rounding.  pos_hw[t] = {h, w}.
+__global__ __launch_bounds__(256) void vision_rope_kernel(bf16_t* __restrict__ qkv, long ld,
+                                                          const int* __restrict__ pos_hw,
+                                                          const float* __restrict__ cos_t,
+                                                          const float* __restrict__ sin_t, int T,
+                                                          int n_heads, int hd) {
+  // one thread handles 4 rotation pairs (i..i+3, i+hd/2..) of one (token, q|k, head)
+  const int half = hd >> 1, quads = half >> 2, quarter = half >> 1;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)T * 2 * n_heads * quads;
+  if (idx >= total) return;
+  const int qd = idx % quads;
+  long r = idx / quads;
+  const int h = r % n_heads;
+  r /= n_heads;
+  const int which = r & 1;
+  const int t = r >> 1;
+  const int i0 = qd * 4;
+  bf16_t* p = qkv + (long)t * ld + (long)which * n_heads * hd + (long)h * hd;
+  const bf16x4 a = *(const bf16x4*)(p + i0);
+  const bf16x4 b = *(const bf16x4*)(p + i0 + half);
+  const int ph = pos_hw[2 * t], pw = pos_hw[2 * t + 1];
+  bf16x4 oa, ob;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = i0 + e;
+    const int ti = (i < quarter) ? (ph * quarter + i) : (pw * quarter + (i - quarter));
+    const float c = cos_t[ti], s = sin_t[ti];
+    const float x1 = bf2f(a[e]), x2 = bf2f(b[e]);
+    oa[e] = f2bf(x1 * c - x2 * s);
+    ob[e] = f2bf(x2 * c + x1 * s);
+  }
+  *(bf16x4*)(p + i0) = oa;
+  *(bf16x4*)(p + i0 + half) = ob;
+}
+
+// Decoder M-RoPE (HF apply_multimodal_rotary_pos_emb :180-222) on the fused qkv buffer
+// [T, (H + 2 KV) * 128]: q rotated in place, rotated k and v written into the KV cache
+// cache[(slot*KV + kvh) * s_max + idx][128].  bf16 arithmetic with torch's rounding sequence:
+// bf16(bf16(x*cos) + bf16(rot*sin)), cos/sin already bf16-rounded in the table.
+__global__ __launch_bounds__(256) void mrope_kv_kernel(
+    bf16_t* __restrict__ qkv, long ld, const int* __restrict__ pos3, long pos_stride,
+    const float* __restrict__ cos_t, const float* __restrict__ sin_t, bf16_t* __restrict__ kc,
+    bf16_t* __restrict__ vc, const int* __restrict__ tok_slot, const int* __restrict__ tok_idx,
+    int T, int n_q, int n_kv, int s_max, int sec0, int sec1) {
+  // thread = (token, head among q+2kv, group of 4 dims in [0,64))
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_h = n_q + 2 * n_kv;
+  const long total = (long)T * n_h * 16;
+  if (idx >= total) return;
+  const int qd = idx & 15;
+  long r = idx >> 4;
+  const int h = r % n_h;
+  const int t = r / n_h;
+  const int i0 = qd * 4;
+  bf16_t* p = qkv + (long)t * ld + (long)h * 128;
+  const bf16x4 a = *(const bf16x4*)(p + i0);
+  const bf16x4 b = *(const bf16x4*)(p + i0 + 64);
+  if (h >= n_q + n_kv) {  // v: straight copy into the cache
+    const int kvh = h - n_q - n_kv;
+    bf16_t* dst = vc + (((long)tok_slot[t] * n_kv + kvh) * s_max + tok_idx[t]) * 128;
+    *(bf16x4*)(dst + i0) = a;
+    *(bf16x4*)(dst + i0 + 64) = b;
+    return;
+  }
+  bf16x4 oa, ob;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = i0 + e;
+    const int stream = (i < sec0) ? 0 : ((i < sec0 + sec1) ? 1 : 2);
+    const int pos = pos3[stream * pos_stride + t];
+    const float c = cos_t[pos * 64 + i], s = sin_t[pos * 64 + i];
+    const float x1 = bf2f(a[e]), x2 = bf2f(b[e]);
+    oa[e] = f2bf(rbf(x1 * c) + rbf(-x2 * s));
+    ob[e] = f2bf(rbf(x2 * c) + rbf(x1 * s));
+  }
+  if (h < n_q) {
+    *(bf16x4*)(p + i0) = oa;
+    *(bf16x4*)(p + i0 + 64) = ob;
+  } else {
+    const int kvh = h - n_q;
+    bf16_t* dst = kc + (((long)tok_slot[t] * n_kv + kvh) * s_max + tok_idx[t]) * 128;
+    *(bf16x4*)(dst + i0) = oa;
+    *(bf16x4*)(dst + i0 + 64) = ob;
+  }
+}
+
+// Token embedding gather with image-embedding scatter (HF Qwen2VLModel.forward :1160-1168):
+// out[t] = ids[t] == image_token ? img[img_index[t]] : table[ids[t]]
+__global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ ids,
+                                                    const int* __restrict__ img_index,
+                                                    const bf16_t* __restrict__ table,
+                                                    const bf16_t* __restrict__ img,
+                                                    bf16_t* __restrict__ out, int T, int d) {
+  const int nch = d >> 3;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)T * nch) return;
+  const int t = idx / nch, ch = idx % nch;
+  const int ii = img_index ? img_index[t] : -1;
+  const bf16_t* src = (ii >= 0) ? (img + (long)ii * d) : (table + (long)ids[t] * d);
+  *(bf16x8*)(out + (long)t * d + ch * 8) = *(const bf16x8*)(src + ch * 8);
+}
+
+// Greedy argmax over bf16 logits (HF generation: logits.float().argmax(-1); lowest index on ties).
+__global__ __launch_bounds__(256) void argmax_kernel(const bf16_t* __restrict__ logits, long ld,
+                                                     int V, int* __restrict__ out) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int row = blockIdx.x;
+  const bf16_t* x = logits + (long)row * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  const int nch = V >> 3;
+  for (int ch = threadIdx.x; ch < nch; ch += 256) {
+    const bf16x8 v = *(const bf16x8*)(x + ch * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float f = bf2f(v[e]);
+      const int i = ch * 8 + e;
+      if (f > best || (f == best && i < bi)) {
+        best = f;
+        bi = i;
+      }
+    }
+  }
+  for (int i = nch * 8 + threadIdx.x; i < V; i += 256) {
+    const float f = bf2f(x[i]);
+    if (f > best || (f == best && i < bi)) {
+      best = f;
+      bi = i;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sv[w] = best;
+    si[w] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k)
+      if (sv[k] > best || (sv[k] == best && si[k] < bi)) {
+        best = sv[k];
+        bi = si[k];
+      }
+    out[row] = bi;
+  }
+}
+
+// Decode bookkeeping (HF GenerationMixin greedy loop): finished sequences emit pad, EOS marks done.
+__global__ void decode_update_kernel(int* __restrict__ next_tok, uint8_t* __restrict__ done,
+                                     int* __restrict__ out_tokens, int out_stride, int step, int B,
+                                     int eos0, int eos1, int pad) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int t = next_tok[b];
+  if (done[b]) t = pad;
+  out_tokens[(long)b * out_stride + step] = t;
+  if (t == eos0 || t == eos1) done[b] = 1;
+  next_tok[b] = t;
+}
+
+// uint8 CHW image -> normalised, patchified pixel_values row (HF Qwen2VLImageProcessor._preprocess,
+// image_processing_qwen2_vl.py:164-246: x/255, (x-mean)/std, temporal frame duplicated,
+// rows ordered [gh/2, gw/2, 2, 2], columns [C, T=2, 14, 14]).  The image is already H,W % 28 == 0.
+__global__ __launch_bounds__(256) void patchify_kernel(const uint8_t* __restrict__ img,
+                                                       bf16_t* __restrict__ out, long ldo, int n_img,
+                                                       int H, int Wd, float m0, float m1, float m2,
+                                                       float s0, float s1, float s2) {
+  const int gh = H / 14, gw = Wd / 14;
+  const int P = gh * gw;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (img, patch, c, py) -> 14 px
+  const long total = (long)n_img * P * 3 * 14;
+  if (idx >= total) return;
+  const int py = idx % 14;
+  long r = idx / 14;
+  const int c = r % 3;
+  r /= 3;
+  const int pi = r % P;
+  const int n = r / P;
+  // patch index -> (block row, block col, in-block row, in-block col)
+  const int bw = gw / 2;
+  const int blk = pi >> 2, in = pi & 3;
+  const int gy = (blk / bw) * 2 + (in >> 1), gx = (blk % bw) * 2 + (in & 1);
+  const uint8_t* src = img + (((long)n * 3 + c) * H + (gy * 14 + py)) * Wd + gx * 14;
+  const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+  const float stdv = c == 0 ? s0 : (c == 1 ? s1 : s2);
+  bf16_t* dst = out + ((long)n * P + pi) * ldo + c * 392 + py * 14;
+#pragma unroll
+  for (int px = 0; px < 14; ++px) {
+    const float v = ((float)src[px] * (1.0f / 255.0f) - mean) / stdv;
+    const bf16_t o = f2bf(v);
+    dst[px] = o;
+    dst[196 + px] = o;
+  }
+}
+
+}  // namespace
+
+int owc_launch_layernorm(const void* X, long ldx, const void* W, const void* B, void* Y, long ldy,
+                         int rows, int d, float eps, hipStream_t st) {
+  if ((d & 7) || d > NORM_MAXC * 512 || (ldx & 7) || (ldy & 7) || rows <= 0) return OWC_ERR_SHAPE;
+  hipLaunchKernelGGL(norm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, (const bf16_t*)X, ldx,
+                     (const bf16_t*)W, (const bf16_t*)B, (bf16_t*)Y, ldy, rows, d, eps, (const int*)nullptr);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_rmsnorm(const void* X, long ldx, const void* W, void* Y, long ldy, int rows, int d,
+                       float eps, const int* row_index, hipStream_t st) {
+  if ((d & 7) || d > NORM_MAXC * 512 || (ldx & 7) || (ldy & 7) || rows <= 0) return OWC_ERR_SHAPE;
+  hipLaunchKernelGGL(norm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, st, (const bf16_t*)X, ldx,
+                     (const bf16_t*)W, (const bf16_t*)nullptr, (bf16_t*)Y, ldy, rows, d, eps, row_index);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_rope_table(float* cos_t, float* sin_t, int n_pos, int n_freq, int dim, float theta,
+                          int round_bf16, hipStream_t st) {
+  const int n = n_pos * n_freq;
+  if (n <= 0) return OWC_ERR_SHAPE;
+  hipLaunchKernelGGL(rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cos_t, sin_t, n_pos,
+                     n_freq, dim, theta, round_bf16);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_vision_rope(void* qkv, long ld, const int* pos_hw, const float* cos_t,
+                           const float* sin_t, int T, int n_heads, int hd, hipStream_t st) {
+  if ((hd & 15) || (ld & 3) || T <= 0) return OWC_ERR_SHAPE;
+  const long total = (long)T * 2 * n_heads * (hd / 8);
+  hipLaunchKernelGGL(vision_rope_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                     (bf16_t*)qkv, ld, pos_hw, cos_t, sin_t, T, n_heads, hd);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_mrope_kv(void* qkv, long ld, const int* pos3, long pos_stride, const float* cos_t,
+                        const float* sin_t, void* kc, void* vc, const int* tok_slot,
+                        const int* tok_idx, int T, int n_q, int n_kv, int s_max, int sec0, int sec1,
+                        hipStream_t st) {
+  if (T <= 0 || (ld & 3)) return OWC_ERR_SHAPE;
+  const long total = (long)T * (n_q + 2 * n_kv) * 16;
+  hipLaunchKernelGGL(mrope_kv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                     (bf16_t*)qkv, ld, pos3, pos_stride, cos_t, sin_t, (bf16_t*)kc, (bf16_t*)vc,
+                     tok_slot, tok_idx, T, n_q, n_kv, s_max, sec0, sec1);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_embed(const int* ids, const int* img_index, const void* table, const void* img,
+                     void* out, int T, int d, hipStream_t st) {
+  if ((d & 7) || T <= 0) return OWC_ERR_SHAPE;
+  const long total = (long)T * (d / 8);
+  hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ids,
+                     img_index, (const bf16_t*)table, (const bf16_t*)img, (bf16_t*)out, T, d);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_argmax(const void* logits, long ld, int rows, int V, int* out, hipStream_t st) {
+  if (rows <= 0 || V <= 0 || (ld & 7)) return OWC_ERR_SHAPE;
+  hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, st, (const bf16_t*)logits, ld, V, out);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_decode_update(int* next_tok, uint8_t* done, int* out_tokens, int out_stride, int step,
+                             int B, int eos0, int eos1, int pad, hipStream_t st) {
+  hipLaunchKernelGGL(decode_update_kernel, dim3((B + 255) / 256), dim3(256), 0, st, next_tok, done,
+                     out_tokens, out_stride, step, B, eos0, eos1, pad);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_patchify(const uint8_t* img, void* out, long ldo, int n_img, int H, int W,
+                        const float* mean, const float* stdv, hipStream_t st) {
+  if (n_img <= 0 || H % 28 || W % 28 || ldo < 1176) return OWC_ERR_SHAPE;
+  const long total = (long)n_img * (H / 14) * (W / 14) * 3 * 14;
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img,
+                     (bf16_t*)out, ldo, n_img, H, W, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2]);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}

@@ -36,7 +36,7 @@ __device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
     const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
-    const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R, long ldr, void* __restrict__ Cv,
+    const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv,
     long ldc, int M, int N, int K, const void* __restrict__ zeros, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   // [buf][A|W][128 rows][128 B]

@@ -34,3 +34,30 @@ struct owc_ctx {
 int owc_launch_gemm_bf16(const void* A, long lda, const void* W, long ldw, const void* bias,
                          const void* R, long ldr, void* C, long ldc, int M, int N, int K, int epi,
                          const void* zeros, hipStream_t s);
+int owc_launch_attention(const void* Q, long q_ts, long q_hs, const void* K, long k_ts, long k_hs,
+                         const void* V, long v_ts, long v_hs, void* O, long o_ts, long o_hs,
+                         const int* q_start, const int* o_start, const int* k_start,
+                         const int* seq_len, const int* q_len, int n_seq, int n_heads, int kv_group, int head_dim,
+                         int max_q_len, int causal, float scale, hipStream_t st);
+int owc_launch_layernorm(const void* X, long ldx, const void* W, const void* B, void* Y, long ldy,
+                         int rows, int d, float eps, hipStream_t st);
+int owc_launch_rmsnorm(const void* X, long ldx, const void* W, void* Y, long ldy, int rows, int d,
+                       float eps, const int* row_index, hipStream_t st);
+int owc_launch_rope_table(float* cos_t, float* sin_t, int n_pos, int n_freq, int dim, float theta,
+                          int round_bf16, hipStream_t st);
+int owc_launch_vision_rope(void* qkv, long ld, const int* pos_hw, const float* cos_t,
+                           const float* sin_t, int T, int n_heads, int hd, hipStream_t st);
+int owc_launch_mrope_kv(void* qkv, long ld, const int* pos3, long pos_stride, const float* cos_t,
+                        const float* sin_t, void* kc, void* vc, const int* tok_slot,
+                        const int* tok_idx, int T, int n_q, int n_kv, int s_max, int sec0, int sec1,
+                        hipStream_t st);
+int owc_launch_embed(const int* ids, const int* img_index, const void* table, const void* img,
+                     void* out, int T, int d, hipStream_t st);
+int owc_launch_argmax(const void* logits, long ld, int rows, int V, int* out, hipStream_t st);
+int owc_launch_decode_update(int* next_tok, uint8_t* done, int* out_tokens, int out_stride, int step,
+                             int B, int eos0, int eos1, int pad, hipStream_t st);
+int owc_launch_patchify(const uint8_t* img, void* out, long ldo, int n_img, int H, int W,
+                        const float* mean, const float* stdv, hipStream_t st);
+int owc_launch_gemm_f32(const float* A, long lda, const float* W, long ldw, const float* bias,
+                        const float* R, long ldr, float* C, long ldc, int M, int N, int K, int epi,
+                        const void* zeros, hipStream_t s);

@@ -1,0 +1,218 @@
+// Host-side drivers of the Qwen2-VL forward pass: they only enqueue the hand-written kernels of this
+// library on the caller's stream, in the order HF transformers runs the corresponding modules.
+//   owc_vit_forward     <- Qwen2VisionTransformerPretrainedModel.forward (HF:700-731)
+//   owc_llm_prefill     <- Qwen2VLModel.forward + Qwen2VLTextModel.forward + lm_head (HF:1144-1205, :762-846)
+//   owc_llm_decode_step <- one iteration of GenerationMixin's greedy loop with the KV cache
+// No allocation, no synchronisation: graph-capturable.
+#include "../../include/owc.h"
+#include "owc_internal.h"
+
+namespace {
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Carver {
+  char* base;
+  size_t off = 0, cap;
+  Carver(void* p, size_t c) : base((char*)p), cap(c) {}
+  void* take(size_t bytes) {
+    void* r = base + off;
+    off += align256(bytes);
+    return r;
+  }
+  bool ok() const { return off <= cap; }
+};
+
+}  // namespace
+
+extern "C" {
+
+size_t owc_vit_workspace_bytes(const owc_vit_weights* w, int T) {
+  if (!w || T <= 0) return 0;
+  const size_t e = (size_t)w->embed_dim, t = (size_t)T;
+  size_t b = 0;
+  b += align256(t * e * 2) * 3;                 // x, h, attn
+  b += align256(t * e * 3 * 2);                 // qkv
+  b += align256(t * (size_t)w->mlp_hidden * 2); // mlp hidden (also merger hidden)
+  return b + 1024;
+}
+
+int owc_vit_forward(owc_ctx* ctx, const owc_vit_weights* w, const void* pixel_values, int64_t ld_pix,
+                    const int32_t* pos_hw, const int32_t* seq_start, const int32_t* seq_len,
+                    int n_img, int T, int max_len, void* out, void* workspace, size_t ws_bytes,
+                    void* stream) {
+  if (!ctx || !w || !pixel_values || !pos_hw || !seq_start || !seq_len || !out || !workspace)
+    return OWC_ERR_ARG;
+  if (T <= 0 || n_img <= 0 || (T % w->merge_unit) != 0) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_vit_forward: bad T");
+  if (ws_bytes < owc_vit_workspace_bytes(w, T)) OWC_FAIL(ctx, OWC_ERR_WORKSPACE, "owc_vit_forward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int E = w->embed_dim, H = w->num_heads, hd = E / H, F = w->mlp_hidden;
+  Carver cv(workspace, ws_bytes);
+  void* x = cv.take((size_t)T * E * 2);
+  void* h = cv.take((size_t)T * E * 2);
+  void* attn = cv.take((size_t)T * E * 2);
+  void* qkv = cv.take((size_t)T * E * 3 * 2);
+  void* mlp = cv.take((size_t)T * F * 2);
+  const float scale = 1.0f / sqrtf((float)hd);
+
+  // patch embed: Conv3d(kernel == stride) == GEMM [T, patch_k] x [E, patch_k]^T, no bias (HF:268-275)
+  OWC_TRY(owc_launch_gemm_bf16(pixel_values, ld_pix, w->patch_w, w->patch_k, nullptr, nullptr, 0, x, E,
+                               T, E, w->patch_k, OWC_EPI_NONE, ctx->zeros, st));
+  for (int i = 0; i < w->depth; ++i) {
+    const owc_vit_layer& L = w->layers[i];
+    // x = x + proj(attn(rope(qkv(norm1(x)))))            (HF:442-449, :356-422)
+    OWC_TRY(owc_launch_layernorm(x, E, L.ln1_w, L.ln1_b, h, E, T, E, w->ln_eps, st));
+    OWC_TRY(owc_launch_gemm_bf16(h, E, L.qkv_w, E, L.qkv_b, nullptr, 0, qkv, 3 * E, T, 3 * E, E,
+                                 OWC_EPI_NONE, ctx->zeros, st));
+    OWC_TRY(owc_launch_vision_rope(qkv, 3 * E, pos_hw, w->rope_cos, w->rope_sin, T, H, hd, st));
+    const bf16_t* q = (const bf16_t*)qkv;
+    OWC_TRY(owc_launch_attention(q, 3 * E, hd, q + E, 3 * E, hd, q + 2 * E, 3 * E, hd, attn, E, hd,
+                                 seq_start, nullptr, seq_start, seq_len, nullptr, n_img, H, 1, hd,
+                                 max_len, 0, scale, st));
+    OWC_TRY(owc_launch_gemm_bf16(attn, E, L.proj_w, E, L.proj_b, x, E, x, E, T, E, E, OWC_EPI_RESIDUAL,
+                                 ctx->zeros, st));
+    // x = x + fc2(quick_gelu(fc1(norm2(x))))             (HF:450, :300-301)
+    OWC_TRY(owc_launch_layernorm(x, E, L.ln2_w, L.ln2_b, h, E, T, E, w->ln_eps, st));
+    OWC_TRY(owc_launch_gemm_bf16(h, E, L.fc1_w, E, L.fc1_b, nullptr, 0, mlp, F, T, F, E,
+                                 OWC_EPI_QUICK_GELU, ctx->zeros, st));
+    OWC_TRY(owc_launch_gemm_bf16(mlp, F, L.fc2_w, F, L.fc2_b, x, E, x, E, T, E, F, OWC_EPI_RESIDUAL,
+                                 ctx->zeros, st));
+  }
+  // PatchMerger (HF:288-291): ln_q, view [T/4, 4E], Linear+GELU, Linear
+  const int M = T / w->merge_unit, E4 = E * w->merge_unit;
+  OWC_TRY(owc_launch_layernorm(x, E, w->merger_ln_w, w->merger_ln_b, h, E, T, E, w->ln_eps, st));
+  OWC_TRY(owc_launch_gemm_bf16(h, E4, w->merger_fc1_w, E4, w->merger_fc1_b, nullptr, 0, mlp, E4, M, E4,
+                               E4, OWC_EPI_GELU_ERF, ctx->zeros, st));
+  OWC_TRY(owc_launch_gemm_bf16(mlp, E4, w->merger_fc2_w, E4, w->merger_fc2_b, nullptr, 0, out,
+                               w->out_dim, M, w->out_dim, E4, OWC_EPI_NONE, ctx->zeros, st));
+  return OWC_OK;
+}
+
+size_t owc_llm_workspace_bytes(const owc_llm_weights* w, int T, int n_seq) {
+  if (!w || T <= 0 || n_seq <= 0) return 0;
+  const size_t t = (size_t)T, d = (size_t)w->d_model;
+  const size_t qkv = (size_t)(w->n_q_heads + 2 * w->n_kv_heads) * w->head_dim;
+  size_t b = 0;
+  b += align256(t * d * 2) * 2;                                   // x, h
+  b += align256(t * qkv * 2);                                     // qkv
+  b += align256(t * (size_t)w->n_q_heads * w->head_dim * 2);      // attn
+  b += align256(t * (size_t)w->d_ff * 2);                         // mlp
+  b += align256((size_t)n_seq * d * 2);                           // last-token hidden
+  b += align256((size_t)n_seq * (size_t)w->vocab * 2);            // logits
+  return b + 1024;
+}
+
+static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* cache, void* x,
+                      void* h, void* qkv, void* attn, void* mlp, const int32_t* pos3,
+                      int64_t pos_stride, const int32_t* tok_slot, const int32_t* tok_idx,
+                      const int32_t* q_start, const int32_t* o_start, const int32_t* k_start,
+                      const int32_t* k_len, const int32_t* q_len, int n_seq, int T, int max_q_len,
+                      bool decode, hipStream_t st) {
+  const int d = w->d_model, Hq = w->n_q_heads, Hkv = w->n_kv_heads, hd = w->head_dim, F = w->d_ff;
+  const int NQKV = (Hq + 2 * Hkv) * hd;
+  const int G = Hq / Hkv;
+  const float scale = 1.0f / sqrtf((float)hd);
+  const size_t layer_elems = (size_t)cache->n_slots * Hkv * cache->s_max * hd;
+  for (int i = 0; i < w->n_layers; ++i) {
+    const owc_llm_layer& L = w->layers[i];
+    bf16_t* kc = (bf16_t*)cache->k + (size_t)i * layer_elems;
+    bf16_t* vc = (bf16_t*)cache->v + (size_t)i * layer_elems;
+    // self-attention block (HF:601-614)
+    OWC_TRY(owc_launch_rmsnorm(x, d, L.ln1_w, h, d, T, d, w->rms_eps, nullptr, st));
+    OWC_TRY(owc_launch_gemm_bf16(h, d, L.qkv_w, d, L.qkv_b, nullptr, 0, qkv, NQKV, T, NQKV, d,
+                                 OWC_EPI_NONE, ctx->zeros, st));
+    OWC_TRY(owc_launch_mrope_kv(qkv, NQKV, pos3, pos_stride, w->rope_cos, w->rope_sin, kc, vc, tok_slot,
+                                tok_idx, T, Hq, Hkv, cache->s_max, w->mrope_sec0, w->mrope_sec1, st));
+    if (!decode) {
+      OWC_TRY(owc_launch_attention(qkv, NQKV, hd, kc, hd, (long)cache->s_max * hd, vc, hd,
+                                   (long)cache->s_max * hd, attn, (long)Hq * hd, hd, q_start, nullptr,
+                                   k_start, k_len, nullptr, n_seq, Hq, G, hd, max_q_len, 1, scale, st));
+    } else {
+      // one query row per q head: map the G heads of a kv group onto the "rows" of the kernel
+      OWC_TRY(owc_launch_attention(qkv, hd, (long)G * hd, kc, hd, (long)cache->s_max * hd, vc, hd,
+                                   (long)cache->s_max * hd, attn, hd, (long)G * hd, q_start, o_start,
+                                   k_start, k_len, q_len, n_seq, Hkv, 1, hd, G, 0, scale, st));
+    }
+    OWC_TRY(owc_launch_gemm_bf16(attn, (long)Hq * hd, L.o_w, (long)Hq * hd, nullptr, x, d, x, d, T, d,
+                                 Hq * hd, OWC_EPI_RESIDUAL, ctx->zeros, st));
+    // MLP block (HF:617-620, :464-466)
+    OWC_TRY(owc_launch_rmsnorm(x, d, L.ln2_w, h, d, T, d, w->rms_eps, nullptr, st));
+    OWC_TRY(owc_launch_gemm_bf16(h, d, L.gateup_w, d, nullptr, nullptr, 0, mlp, F, T, 2 * F, d,
+                                 OWC_EPI_SWIGLU, ctx->zeros, st));
+    OWC_TRY(owc_launch_gemm_bf16(mlp, F, L.down_w, F, nullptr, x, d, x, d, T, d, F, OWC_EPI_RESIDUAL,
+                                 ctx->zeros, st));
+  }
+  return OWC_OK;
+}
+
+int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* cache,
+                    const int32_t* ids, const int32_t* img_index, const void* img_embeds,
+                    const int32_t* pos3, const int32_t* tok_slot, const int32_t* tok_idx,
+                    const int32_t* seq_start, const int32_t* seq_len, const int32_t* k_start,
+                    const int32_t* last_index, int n_seq, int T, int max_len, int32_t* next_tok,
+                    void* logits_out, void* workspace, size_t ws_bytes, void* stream) {
+  if (!ctx || !w || !cache || !ids || !pos3 || !tok_slot || !tok_idx || !seq_start || !seq_len ||
+      !k_start || !last_index || !next_tok || !workspace)
+    return OWC_ERR_ARG;
+  if (w->head_dim != 128) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_llm_prefill: head_dim must be 128");
+  if (ws_bytes < owc_llm_workspace_bytes(w, T, n_seq)) OWC_FAIL(ctx, OWC_ERR_WORKSPACE, "owc_llm_prefill: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int d = w->d_model;
+  Carver cv(workspace, ws_bytes);
+  void* x = cv.take((size_t)T * d * 2);
+  void* h = cv.take((size_t)T * d * 2);
+  void* qkv = cv.take((size_t)T * (w->n_q_heads + 2 * w->n_kv_heads) * w->head_dim * 2);
+  void* attn = cv.take((size_t)T * w->n_q_heads * w->head_dim * 2);
+  void* mlp = cv.take((size_t)T * w->d_ff * 2);
+  void* last = cv.take((size_t)n_seq * d * 2);
+  void* logits = cv.take((size_t)n_seq * w->vocab * 2);
+  if (logits_out) logits = logits_out;
+
+  OWC_TRY(owc_launch_embed(ids, img_index, w->embed, img_embeds, x, T, d, st));
+  OWC_TRY(llm_layers(ctx, w, cache, x, h, qkv, attn, mlp, pos3, T, tok_slot, tok_idx, seq_start, nullptr,
+                     k_start, seq_len, nullptr, n_seq, T, max_len, false, st));
+  // final norm on the last token of every prompt only, then lm_head + greedy argmax
+  OWC_TRY(owc_launch_rmsnorm(x, d, w->final_norm_w, last, d, n_seq, d, w->rms_eps, last_index, st));
+  OWC_TRY(owc_launch_gemm_bf16(last, d, w->lm_head_w, d, nullptr, nullptr, 0, logits, w->vocab, n_seq,
+                               w->vocab, d, OWC_EPI_NONE, ctx->zeros, st));
+  OWC_TRY(owc_launch_argmax(logits, w->vocab, n_seq, w->vocab, next_tok, st));
+  return OWC_OK;
+}
+
+int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* cache,
+                        int32_t* tok_io, const int32_t* pos, const int32_t* slot,
+                        const int32_t* write_idx, const int32_t* k_start, const int32_t* k_len,
+                        const int32_t* q_start, const int32_t* o_start, const int32_t* q_len,
+                        uint8_t* done, int32_t* out_tokens, int out_stride, int step, int B,
+                        int eos_id0, int eos_id1, int pad_id, void* logits_out, void* workspace,
+                        size_t ws_bytes, void* stream) {
+  if (!ctx || !w || !cache || !tok_io || !pos || !slot || !write_idx || !k_start || !k_len ||
+      !q_start || !o_start || !q_len || !done || !out_tokens || !workspace)
+    return OWC_ERR_ARG;
+  if (ws_bytes < owc_llm_workspace_bytes(w, B, B)) OWC_FAIL(ctx, OWC_ERR_WORKSPACE, "owc_llm_decode_step: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int d = w->d_model;
+  Carver cv(workspace, ws_bytes);
+  void* x = cv.take((size_t)B * d * 2);
+  void* h = cv.take((size_t)B * d * 2);
+  void* qkv = cv.take((size_t)B * (w->n_q_heads + 2 * w->n_kv_heads) * w->head_dim * 2);
+  void* attn = cv.take((size_t)B * w->n_q_heads * w->head_dim * 2);
+  void* mlp = cv.take((size_t)B * w->d_ff * 2);
+  void* last = cv.take((size_t)B * d * 2);
+  void* logits = cv.take((size_t)B * w->vocab * 2);
+  if (logits_out) logits = logits_out;
+
+  OWC_TRY(owc_launch_embed(tok_io, nullptr, w->embed, nullptr, x, B, d, st));
+  // the three mrope streams of a generated token are identical: pos_stride 0 re-reads `pos`
+  OWC_TRY(llm_layers(ctx, w, cache, x, h, qkv, attn, mlp, pos, 0, slot, write_idx, q_start, o_start,
+                     k_start, k_len, q_len, B, B, w->n_q_heads / w->n_kv_heads, true, st));
+  OWC_TRY(owc_launch_rmsnorm(x, d, w->final_norm_w, last, d, B, d, w->rms_eps, nullptr, st));
+  OWC_TRY(owc_launch_gemm_bf16(last, d, w->lm_head_w, d, nullptr, nullptr, 0, logits, w->vocab, B,
+                               w->vocab, d, OWC_EPI_NONE, ctx->zeros, st));
+  OWC_TRY(owc_launch_argmax(logits, w->vocab, B, w->vocab, tok_io, st));
+  OWC_TRY(owc_launch_decode_update(tok_io, done, out_tokens, out_stride, step, B, eos_id0, eos_id1,
+                                   pad_id, st));
+  return OWC_OK;
+}
+
+}  // extern "C"

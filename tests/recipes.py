@@ -1,0 +1,155 @@
+"""Deterministic synthetic weights / inputs shared by the golden generator and the parity tests.
+
+No checkpoint exists offline, so parity is pinned on seeded random weights of the
+real architecture.  Everything here is plain numpy (PCG64 streams keyed by tensor name) so that the
+generator (this container, with HF transformers + the reference importable) and the tests (GPU box,
+neither available) rebuild bit-identical tensors.  Values are rounded to bfloat16 so the same
+tensors are exact in fp32 and bf16 runs.
+"""
+
+from __future__ import annotations
+
+import zlib
+
+import numpy as np
+
+from oracle.np_ops import bf16_round
+from oracle.qwen2vl_np import Cfg, TextCfg, VisionCfg
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.default_rng([seed, zlib.crc32(name.encode())])
+
+
+def tiny_cfg() -> Cfg:
+    """Same structure as Qwen2-VL (GQA, head_dim 128, mrope [16,24,24], vision head_dim 80, patch 14, merge 2)."""
+    return Cfg(
+        vision=VisionCfg(depth=2, embed_dim=160, num_heads=2, mlp_ratio=4.0, hidden_size=256),
+        text=TextCfg(hidden_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+                     intermediate_size=512, vocab_size=512, tie_word_embeddings=False),
+        image_token_id=500,
+    )
+
+
+def qwen2vl_shapes(cfg: Cfg) -> dict[str, tuple]:
+    v, t = cfg.vision, cfg.text
+    E, F = v.embed_dim, int(v.embed_dim * v.mlp_ratio)
+    d, hd = t.hidden_size, t.hidden_size // t.num_attention_heads
+    s: dict[str, tuple] = {"model.visual.patch_embed.proj.weight": (E, v.in_channels, v.temporal_patch_size, v.patch_size, v.patch_size)}
+    for i in range(v.depth):
+        p = f"model.visual.blocks.{i}."
+        s.update({p + "norm1.weight": (E,), p + "norm1.bias": (E,), p + "norm2.weight": (E,), p + "norm2.bias": (E,),
+                  p + "attn.qkv.weight": (3 * E, E), p + "attn.qkv.bias": (3 * E,),
+                  p + "attn.proj.weight": (E, E), p + "attn.proj.bias": (E,),
+                  p + "mlp.fc1.weight": (F, E), p + "mlp.fc1.bias": (F,),
+                  p + "mlp.fc2.weight": (E, F), p + "mlp.fc2.bias": (E,)})
+    E4 = E * v.spatial_merge_size ** 2
+    s.update({"model.visual.merger.ln_q.weight": (E,), "model.visual.merger.ln_q.bias": (E,),
+              "model.visual.merger.mlp.0.weight": (E4, E4), "model.visual.merger.mlp.0.bias": (E4,),
+              "model.visual.merger.mlp.2.weight": (v.hidden_size, E4), "model.visual.merger.mlp.2.bias": (v.hidden_size,)})
+    s["model.language_model.embed_tokens.weight"] = (t.vocab_size, d)
+    for i in range(t.num_hidden_layers):
+        p = f"model.language_model.layers.{i}."
+        s.update({p + "self_attn.q_proj.weight": (t.num_attention_heads * hd, d), p + "self_attn.q_proj.bias": (t.num_attention_heads * hd,),
+                  p + "self_attn.k_proj.weight": (t.num_key_value_heads * hd, d), p + "self_attn.k_proj.bias": (t.num_key_value_heads * hd,),
+                  p + "self_attn.v_proj.weight": (t.num_key_value_heads * hd, d), p + "self_attn.v_proj.bias": (t.num_key_value_heads * hd,),
+                  p + "self_attn.o_proj.weight": (d, t.num_attention_heads * hd),
+                  p + "mlp.gate_proj.weight": (t.intermediate_size, d), p + "mlp.up_proj.weight": (t.intermediate_size, d),
+                  p + "mlp.down_proj.weight": (d, t.intermediate_size),
+                  p + "input_layernorm.weight": (d,), p + "post_attention_layernorm.weight": (d,)})
+    s["model.language_model.norm.weight"] = (d,)
+    if not t.tie_word_embeddings:
+        s["lm_head.weight"] = (t.vocab_size, d)
+    return s
+
+
+def _fill(name: str, shape: tuple, seed: int) -> np.ndarray:
+    r = _rng(seed, name)
+    if name.endswith("bias"):
+        x = 0.05 * r.standard_normal(shape)
+    elif "norm" in name or "ln_q" in name or "LayerNorm" in name:
+        x = 1.0 + 0.1 * r.standard_normal(shape)
+    elif "embed" in name or "embeddings" in name:
+        x = 0.5 * r.standard_normal(shape)
+    else:
+        fan_in = int(np.prod(shape[1:]))
+        x = r.standard_normal(shape) / np.sqrt(fan_in)
+    return bf16_round(x.astype(np.float32))
+
+
+def qwen2vl_weights(cfg: Cfg, seed: int = 1234) -> dict[str, np.ndarray]:
+    return {k: _fill(k, shp, seed) for k, shp in qwen2vl_shapes(cfg).items()}
+
+
+def pixel_values(grid_thw, seed: int = 7) -> np.ndarray:
+    """Synthetic normalised patches [sum(t*h*w), 1176], bf16-representable."""
+    n = int(sum(t * h * w for t, h, w in grid_thw))
+    return bf16_round(_rng(seed, "pixel_values").standard_normal((n, 1176)).astype(np.float32))
+
+
+def prompt_ids(cfg: Cfg, grid_thw, n_text_before=5, n_text_after=9, seed=11) -> np.ndarray:
+    """[text..., <img tokens per image>..., text...] with ids below the special-token range."""
+    r = _rng(seed, "prompt")
+    merge2 = cfg.vision.spatial_merge_size ** 2
+    hi = min(cfg.image_token_id, cfg.text.vocab_size) - 1
+    parts = [r.integers(1, hi, n_text_before)]
+    for t, h, w in grid_thw:
+        parts.append(np.full(t * h * w // merge2, cfg.image_token_id))
+        parts.append(r.integers(1, hi, 2))
+    parts.append(r.integers(1, hi, n_text_after))
+    return np.concatenate(parts).astype(np.int64)
+
+
+# ---------------------------------------------------------------- BERT / MiniLM
+def bert_cfg(kind: str = "tiny") -> dict:
+    if kind == "tiny":
+        return dict(vocab_size=120, hidden_size=64, num_hidden_layers=2, num_attention_heads=2,
+                    intermediate_size=128, max_position_embeddings=64, type_vocab_size=2, layer_norm_eps=1e-12)
+    # sentence-transformers/all-MiniLM-L6-v2 (src/data/pipelines/text/_text.py:161)
+    return dict(vocab_size=30522, hidden_size=384, num_hidden_layers=6, num_attention_heads=12,
+                intermediate_size=1536, max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12)
+
+
+def bert_shapes(c: dict) -> dict[str, tuple]:
+    H, I = c["hidden_size"], c["intermediate_size"]
+    s = {"embeddings.word_embeddings.weight": (c["vocab_size"], H),
+         "embeddings.position_embeddings.weight": (c["max_position_embeddings"], H),
+         "embeddings.token_type_embeddings.weight": (c["type_vocab_size"], H),
+         "embeddings.LayerNorm.weight": (H,), "embeddings.LayerNorm.bias": (H,)}
+    for i in range(c["num_hidden_layers"]):
+        p = f"encoder.layer.{i}."
+        for n in ("query", "key", "value"):
+            s[p + f"attention.self.{n}.weight"] = (H, H)
+            s[p + f"attention.self.{n}.bias"] = (H,)
+        s.update({p + "attention.output.dense.weight": (H, H), p + "attention.output.dense.bias": (H,),
+                  p + "attention.output.LayerNorm.weight": (H,), p + "attention.output.LayerNorm.bias": (H,),
+                  p + "intermediate.dense.weight": (I, H), p + "intermediate.dense.bias": (I,),
+                  p + "output.dense.weight": (H, I), p + "output.dense.bias": (H,),
+                  p + "output.LayerNorm.weight": (H,), p + "output.LayerNorm.bias": (H,)})
+    return s
+
+
+def bert_weights(c: dict, seed: int = 1234) -> dict[str, np.ndarray]:
+    out = {}
+    for k, shp in bert_shapes(c).items():
+        r = _rng(seed, "bert." + k)
+        if k.endswith("LayerNorm.weight"):
+            x = 1.0 + 0.1 * r.standard_normal(shp)
+        elif k.endswith("bias"):
+            x = 0.05 * r.standard_normal(shp)
+        elif "embeddings" in k:
+            x = 0.3 * r.standard_normal(shp)
+        else:
+            x = 2.0 * r.standard_normal(shp) / np.sqrt(shp[1])
+        out[k] = x.astype(np.float32)
+    return out
+
+
+def label_tokens(n: int, L: int, vocab: int, seed: int):
+    """Synthetic tokenised labels: ids [n, L] (0 = pad), mask [n, L]; lengths uniform in [2, L]."""
+    r = _rng(seed, "labels")
+    lens = r.integers(2, L + 1, n)
+    lens[0] = L  # "padding=True" pads to the longest member
+    ids = r.integers(1, vocab, (n, L))
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    return (ids * mask).astype(np.int64), mask

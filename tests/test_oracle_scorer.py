@@ -1,0 +1,51 @@
+"""Pin the numpy scorer oracle against golden vectors produced by the reference's own
+encode_sentence_bert / semantic_similarity (tools/gen_golden.py, CPU fp32 branch)."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import bert_np as B
+from tests import recipes
+
+GOLD = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD / "scorer.npz"), json.loads((GOLD / "scorer.json").read_text())
+
+
+@pytest.mark.parametrize("kind,n,L", [("tiny", 24, 12), ("minilm", 8, 16)])
+def test_embed_and_paired_cosine(gold, kind, n, L):
+    g, _ = gold
+    c = recipes.bert_cfg(kind)
+    w = recipes.bert_weights(c, 1234)
+    ids_r, mask_r = recipes.label_tokens(n, L, c["vocab_size"], seed=21)
+    ids_p, mask_p = recipes.label_tokens(n, L, c["vocab_size"], seed=22)
+    zr = B.sentence_embed(w, c, ids_r, mask_r)
+    zp = B.sentence_embed(w, c, ids_p, mask_p)
+    np.testing.assert_allclose(zr, g[f"{kind}_ref_embeds"], atol=2e-6)
+    np.testing.assert_allclose(zp, g[f"{kind}_pred_embeds"], atol=2e-6)
+    cos = B.paired_cosine(zr, zp)
+    np.testing.assert_allclose(cos, g[f"{kind}_semantic_similarity_none"], atol=2e-6)
+    np.testing.assert_allclose(cos.mean(), g[f"{kind}_semantic_similarity_mean"], atol=2e-6)
+
+
+def test_mean_average(gold):
+    g, meta = gold
+    got = B.mean_average(g["tiny_semantic_similarity_none"])
+    for k, v in meta["tiny_mean_average"].items():
+        assert abs(got[k] - v) < 1e-6
+
+
+def test_topk_contains_paired():
+    r = np.random.default_rng(0)
+    z = r.standard_normal((20, 64)).astype(np.float32)
+    z /= np.linalg.norm(z, axis=-1, keepdims=True)
+    cl = z[:7]
+    val, idx = B.cosine_topk(z, cl, 3)
+    assert (idx[:7, 0] == np.arange(7)).all()
+    np.testing.assert_allclose(val[:7, 0], 1.0, atol=1e-6)
+    assert (np.diff(val, axis=1) <= 0).all()

@@ -1,0 +1,252 @@
+"""Generate tests/golden/*.npz|json by running the REFERENCE (and the HF code it wraps) in this container.
+
+Runs only where /root/reference and transformers are importable (the build container).  Inputs and
+weights come from tests/recipes.py (pure numpy, seeded) so the tests can rebuild them anywhere; only
+inputs + expected outputs are written — never reference source.  Versions are recorded in each file.
+
+  python tools/gen_golden.py
+"""
+
+from __future__ import annotations
+
+import importlib.machinery
+import json
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+GOLD = ROOT / "tests" / "golden"
+REF = Path("/root/reference")
+
+from tests import recipes  # noqa: E402
+
+
+def versions() -> dict:
+    import datasets
+    import transformers
+
+    return {"transformers": transformers.__version__, "torch": torch.__version__, "datasets": datasets.__version__,
+            "numpy": np.__version__, "reference_pins": "transformers==4.47.0 torch==2.5.1 datasets==3.1.0 (uv.lock)"}
+
+
+# ------------------------------------------------------------------ HF Qwen2-VL (third-party arithmetic)
+def hf_qwen(cfg, weights, dtype):
+    from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
+
+    v, t = cfg.vision, cfg.text
+    hcfg = Qwen2VLConfig(
+        text_config=dict(hidden_size=t.hidden_size, num_hidden_layers=t.num_hidden_layers,
+                         num_attention_heads=t.num_attention_heads, num_key_value_heads=t.num_key_value_heads,
+                         intermediate_size=t.intermediate_size, vocab_size=t.vocab_size, rms_norm_eps=t.rms_norm_eps,
+                         max_position_embeddings=4096, tie_word_embeddings=t.tie_word_embeddings,
+                         rope_parameters=dict(rope_type="default", rope_theta=t.rope_theta, mrope_section=list(t.mrope_section))),
+        vision_config=dict(depth=v.depth, embed_dim=v.embed_dim, num_heads=v.num_heads, hidden_size=v.hidden_size,
+                           mlp_ratio=int(v.mlp_ratio), patch_size=v.patch_size, spatial_merge_size=v.spatial_merge_size,
+                           temporal_patch_size=v.temporal_patch_size),
+        image_token_id=cfg.image_token_id, video_token_id=cfg.image_token_id + 1,
+        vision_start_token_id=cfg.image_token_id + 2, vision_end_token_id=cfg.image_token_id + 3,
+        tie_word_embeddings=t.tie_word_embeddings)
+    hcfg._attn_implementation = "eager"
+    m = Qwen2VLForConditionalGeneration(hcfg)
+    sd = {k: torch.from_numpy(a.copy()) for k, a in weights.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("lm_head" in k or "inv_freq" in k for k in missing), (missing, unexpected)
+    return m.to(dtype).eval()
+
+
+def gen_qwen():
+    cfg = recipes.tiny_cfg()
+    w = recipes.qwen2vl_weights(cfg, 1234)
+    out = {}
+    cases = {"a": [(1, 4, 4)], "b": [(1, 6, 4), (1, 4, 8)]}
+    for name, grid in cases.items():
+        pix = recipes.pixel_values(grid, seed=7)
+        ids = recipes.prompt_ids(cfg, grid, seed=11)
+        for dtype, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+            m = hf_qwen(cfg, w, dtype)
+            g = torch.tensor(grid)
+            inp = torch.from_numpy(ids)[None]
+            mm = (inp == cfg.image_token_id).int()
+            with torch.no_grad():
+                vis = m.model.visual(torch.from_numpy(pix).to(dtype), grid_thw=g).pooler_output
+                gen = m.generate(input_ids=inp, attention_mask=torch.ones_like(inp), pixel_values=torch.from_numpy(pix).to(dtype),
+                                 image_grid_thw=g, mm_token_type_ids=mm, do_sample=False, num_beams=1, max_new_tokens=8,
+                                 use_cache=True, eos_token_id=None, pad_token_id=0, output_logits=True,
+                                 return_dict_in_generate=True)
+                pos, delta = m.model.get_rope_index(inp, mm_token_type_ids=mm, image_grid_thw=g)
+            out[f"{name}_{tag}_vit"] = torch.cat(list(vis), 0).float().numpy() if isinstance(vis, (list, tuple)) else vis.float().numpy()
+            out[f"{name}_{tag}_tokens"] = gen.sequences[0, inp.shape[1]:].numpy()
+            out[f"{name}_{tag}_logits"] = torch.stack([l[0] for l in gen.logits]).float().numpy()
+            out[f"{name}_pos3"] = pos[:, 0].numpy()
+            out[f"{name}_delta"] = np.array(int(delta[0, 0]))
+        out[f"{name}_grid"] = np.array(grid)
+        out[f"{name}_ids"] = ids
+    # G5: rope index of the benchmark prompt shape (448x448 -> 256 image tokens, S = 286)
+    big = Cfg448()
+    out["p448_ids"], out["p448_pos3"], out["p448_delta"] = big
+    np.savez_compressed(GOLD / "qwen2vl_tiny.npz", **out)
+    (GOLD / "qwen2vl_tiny.json").write_text(json.dumps({"versions": versions(), "weights_seed": 1234,
+                                                        "cases": {k: v for k, v in cases.items()}}, indent=1))
+    print("qwen golden:", {k: v.shape for k, v in out.items()})
+
+
+def Cfg448():
+    """get_rope_index on a 286-token prompt holding one 32x32-patch image (16x16 merged tokens)."""
+    from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
+
+    cfg = recipes.tiny_cfg()
+    m = hf_qwen(cfg, recipes.qwen2vl_weights(cfg, 1234), torch.float32)
+    r = np.random.default_rng(5)
+    ids = np.concatenate([r.integers(1, 400, 14), np.full(256, cfg.image_token_id), r.integers(1, 400, 16)]).astype(np.int64)
+    inp = torch.from_numpy(ids)[None]
+    pos, delta = m.model.get_rope_index(inp, mm_token_type_ids=(inp == cfg.image_token_id).int(),
+                                        image_grid_thw=torch.tensor([[1, 32, 32]]))
+    return ids, pos[:, 0].numpy(), np.array(int(delta[0, 0]))
+
+
+# ------------------------------------------------------------------ the reference's scorer
+class _Anything:
+    """Permissive stand-in for symbols of packages that are absent offline (never executed on the metric path)."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Anything()
+
+    def __getattr__(self, name):
+        return _Anything()
+
+    def __or__(self, other):
+        return self
+
+    __ror__ = __and__ = __rand__ = __or__
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Anything
+
+
+def import_reference():
+    for name in ("gdown", "pytablewriter", "dotenv", "tenacity", "wandb", "spacy", "sacrebleu", "sacrebleu.metrics"):
+        if name in sys.modules:
+            continue
+        mod = _Stub(name)
+        mod.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        mod.__path__ = []
+        sys.modules[name] = mod
+    ten = sys.modules["tenacity"]
+    ten.retry = lambda *a, **k: (lambda f: f)
+    sys.modules["dotenv"].load_dotenv = lambda *a, **k: None
+    sys.path.insert(0, str(REF))
+    import datasets.arrow_dataset as ad
+
+    col = getattr(ad, "Column", None)
+    if col is not None and not hasattr(col, "unsqueeze"):  # datasets>=4 returns Column at _group.py:537
+        col.unsqueeze = lambda s, d: torch.stack([torch.as_tensor(x) for x in s]).unsqueeze(d)
+    import src.data.metrics as metrics  # noqa: F401
+    import src.data.pipelines.text._text as text_mod
+    import src.utils as utils
+
+    return metrics, text_mod, utils
+
+
+class IdTokenizer:
+    """Stand-in for AutoTokenizer: a label is a string of space-separated token ids (no tokenizer files offline)."""
+
+    def __call__(self, text, padding=True, truncation=True, return_tensors="pt"):
+        rows = [[int(t) for t in s.split()] for s in text]
+        L = max(len(r) for r in rows)
+        ids = torch.tensor([r + [0] * (L - len(r)) for r in rows])
+        mask = torch.tensor([[1] * len(r) + [0] * (L - len(r)) for r in rows])
+
+        class Enc(dict):
+            def to(self, *a, **k):
+                return self
+
+        return Enc(input_ids=ids, attention_mask=mask)
+
+
+def hf_bert(c, w):
+    from transformers import BertConfig, BertModel
+
+    m = BertModel(BertConfig(**c), add_pooling_layer=False)
+    missing, unexpected = m.load_state_dict({k: torch.from_numpy(a.copy()) for k, a in w.items()}, strict=False)
+    assert not unexpected and not [k for k in missing if "position_ids" not in k], (missing, unexpected)
+    return m.eval()
+
+
+def gen_scorer():
+    metrics, text_mod, utils = import_reference()
+    out, meta = {}, {"versions": versions()}
+    for kind, n, L in (("tiny", 24, 12), ("minilm", 8, 16)):
+        c = recipes.bert_cfg(kind)
+        w = recipes.bert_weights(c, 1234)
+        text_mod.sentence_bert_model = hf_bert(c, w)
+        text_mod.sentence_bert_processor = IdTokenizer()
+        ids_r, mask_r = recipes.label_tokens(n, L, c["vocab_size"], seed=21)
+        ids_p, mask_p = recipes.label_tokens(n, L, c["vocab_size"], seed=22)
+        to_text = lambda ids, mask: [" ".join(str(int(t)) for t, m in zip(r, mk) if m) for r, mk in zip(ids, mask)]  # noqa: E731
+        refs, preds = to_text(ids_r, mask_r), to_text(ids_p, mask_p)
+        # the reference's own encode_sentence_bert (CPU fp32 branch, _text.py:165-170)
+        saved = torch.cuda.is_available
+        torch.cuda.is_available = lambda: False
+        try:
+            b = text_mod.encode_sentence_bert({"text": list(refs)}, input_column="text")
+            out[f"{kind}_ref_embeds"] = np.array(b["text_sentence_bert_embeds"], dtype=np.float32)
+            b = text_mod.encode_sentence_bert({"text": list(preds)}, input_column="text")
+            out[f"{kind}_pred_embeds"] = np.array(b["text_sentence_bert_embeds"], dtype=np.float32)
+            items = [(r, [p]) if i % 2 else ([r], p) for i, (r, p) in enumerate(zip(refs, preds))]
+            ss = metrics.get_metric_info("semantic_similarity")
+            out[f"{kind}_semantic_similarity_none"] = np.array(ss.group_fn(ss.builder_fn(items), reduce="none"), dtype=np.float32)
+            out[f"{kind}_semantic_similarity_mean"] = np.array(ss.group_fn(ss.builder_fn(items), reduce="mean"), dtype=np.float32)
+            if kind == "tiny":
+                ma = metrics.get_metric_info("mean_average_semantic_similarity")
+                meta["tiny_mean_average"] = ma.group_fn(ma.builder_fn(items), reduce="mean")
+        finally:
+            torch.cuda.is_available = saved
+    # string metrics + host helpers (exact expected values from the reference's own functions)
+    em = metrics.get_metric_info("exact_match").builder_fn
+    ti = metrics.get_metric_info("textual_inclusion").builder_fn
+    pairs = [("A dog", "a dog"), ("a, dog", "a dog"), ("$5 bill", "5 bill"), ("cat", "a photo of a cat"),
+             ("Golden Retriever.", "golden retriever"), ("", "x"), ("sea  lion", "sea lion"), (" tabby cat ", "Tabby Cat")]
+    meta["string_metrics"] = [
+        {"pred": p, "ref": r,
+         "exact_match": float(em(predictions=[p], references=[r], ignore_case=True, regexes_to_ignore=[",", "\\$"])["exact_match"]),
+         "exact_match_plain": float(em(predictions=[p], references=[r])["exact_match"]),
+         "textual_inclusion": float(ti(predictions=[p], references=[r])["textual_inclusion"])} for p, r in pairs]
+    meta["create_iterator"] = {f"{w_}_{lim}": [[i for i, _ in utils.create_iterator(enumerate(range(10)), r, w_, lim)] for r in range(w_)]
+                               for w_ in (1, 2, 4, 8) for lim in (None, 9)}
+    meta["parse_string_args"] = {s: utils.parse_string_args(s) for s in
+                                 ("", "a=1,b=true,c=False,d=0.5,e=hello", "max_pixels=802816,use_flash_attention_2=false", "x=1e-3,y=-2")}
+    data = [("ctx b", {"max_new_tokens": 64, "until": ["\n"]}), ("ctx aaaa", {"max_new_tokens": 64, "until": ["\n"]}),
+            ("c", {"max_new_tokens": 16}), ("ctx cc", {"max_new_tokens": 64, "until": ["\n"]})]
+    col = utils.Collator(data, lambda x: (-len(x[0]), x[0]), grouping=True)
+    batches = [list(b) for b in col.get_batched(n=2, batch_fn=None)]
+    meta["collator"] = {"batches": [[x[0] for x in b] for b in batches],
+                        "restored": col.get_original([x[0].upper() for b in batches for x in b])}
+    mean = metrics.AGGREGATIONS["mean"].builder_fn if hasattr(metrics, "AGGREGATIONS") else None
+    if mean:
+        meta["mean"] = mean([0.0, 1.0, 1.0, 0.5])
+    np.savez_compressed(GOLD / "scorer.npz", **out)
+    (GOLD / "scorer.json").write_text(json.dumps(meta, indent=1))
+    print("scorer golden:", {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    GOLD.mkdir(parents=True, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["qwen", "scorer"]
+    if "qwen" in which:
+        gen_qwen()
+    if "scorer" in which:
+        gen_scorer()
