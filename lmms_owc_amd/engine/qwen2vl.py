@@ -1,0 +1,385 @@
+"""Qwen2-VL on libowc_hip.so: weight packing + the batched image -> greedy-label engine.
+
+This is the MI355X replacement for what the reference's `Qwen2VL.generate_until`
+(/root/reference/src/models/_qwen2_vl.py:299-337) delegates to
+`Qwen2VLForConditionalGeneration.generate`: vision tower, prompt prefill, greedy decode.
+Unlike the reference (batch size 1, `_base.py:103-104`) it batches images: the vision tower and the
+prefill run over packed variable-length sequences in chunks, decode runs the whole batch per step.
+
+torch is used for device memory, streams and H2D copies only; all arithmetic is in the HIP library.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from . import positions
+
+BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+
+
+@dataclass
+class Qwen2VLDims:
+    # vision tower
+    v_depth: int = 32
+    v_embed: int = 1280
+    v_heads: int = 16
+    v_mlp: int = 5120
+    patch_k: int = 1176
+    merge: int = 2
+    # decoder
+    n_layers: int = 28
+    d_model: int = 3584
+    n_q_heads: int = 28
+    n_kv_heads: int = 4
+    head_dim: int = 128
+    d_ff: int = 18944
+    vocab: int = 152064
+    tie_embeddings: bool = False
+    rms_eps: float = 1e-6
+    rope_theta: float = 1e6
+    mrope_section: tuple = (16, 24, 24)
+    image_token_id: int = 151655
+    max_positions: int = 4096      # rope table length (prompt + generated positions)
+    max_grid: int = 256            # vision rope table length (patches per side)
+
+
+DIMS = {
+    # public config.json values
+    "qwen2-vl-2b": Qwen2VLDims(n_layers=28, d_model=1536, n_q_heads=12, n_kv_heads=2, d_ff=8960, vocab=151936,
+                               tie_embeddings=True),
+    "qwen2-vl-7b": Qwen2VLDims(),
+    "qwen2-vl-72b": Qwen2VLDims(n_layers=80, d_model=8192, n_q_heads=64, n_kv_heads=8, d_ff=29568, vocab=152064),
+}
+
+
+def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """Row layout the SWIGLU GEMM epilogue expects: [g0..g15, u0..u15, g16..g31, u16..u31, ...]."""
+    f, k = gate.shape
+    assert f % 16 == 0
+    return torch.stack([gate.view(f // 16, 16, k), up.view(f // 16, 16, k)], dim=1).reshape(2 * f, k).contiguous()
+
+
+class Qwen2VLWeights:
+    """Device-resident bf16 weights + the ctypes structs the C ABI takes (include/owc.h)."""
+
+    def __init__(self, dims: Qwen2VLDims, device: torch.device):
+        self.dims = dims
+        self.device = device
+        self._keep: list = []  # tensors referenced by raw pointers
+        self.vit = _lib.VitWeights()
+        self.llm = _lib.LlmWeights()
+
+    # -- construction ------------------------------------------------------------------
+    @classmethod
+    def from_state_dict(cls, dims: Qwen2VLDims, sd, device) -> "Qwen2VLWeights":
+        """`sd`: mapping HF parameter name -> tensor/ndarray (e.g. safetensors shards or a recipe)."""
+        self = cls(dims, torch.device(device))
+
+        def get(name):
+            t = sd[name]
+            if isinstance(t, np.ndarray):
+                t = torch.from_numpy(np.ascontiguousarray(t))
+            return t.to(device=self.device, dtype=BF16).contiguous()
+
+        self._build(get)
+        return self
+
+    @classmethod
+    def random(cls, dims: Qwen2VLDims, device, seed: int = 1234) -> "Qwen2VLWeights":
+        """Seeded N(0, 0.02)-style synthetic weights generated directly in HBM (benchmarks: no checkpoint offline)."""
+        self = cls(dims, torch.device(device))
+        gen = torch.Generator(device=self.device)
+        counter = [0]
+
+        def get(name):
+            shape = _param_shape(dims, name)
+            counter[0] += 1
+            gen.manual_seed(seed * 100003 + counter[0])
+            if name.endswith("bias"):
+                t = torch.randn(shape, generator=gen, device=self.device, dtype=F32) * 0.02
+            elif "norm" in name or "ln_q" in name:
+                t = 1.0 + torch.randn(shape, generator=gen, device=self.device, dtype=F32) * 0.02
+            elif "embed_tokens" in name:
+                t = torch.randn(shape, generator=gen, device=self.device, dtype=BF16) * 0.05
+            else:
+                fan_in = int(np.prod(shape[1:]))
+                t = torch.randn(shape, generator=gen, device=self.device, dtype=BF16) * (1.0 / np.sqrt(fan_in))
+            return t.to(BF16).contiguous()
+
+        self._build(get)
+        return self
+
+    def _k(self, t: torch.Tensor) -> int:
+        self._keep.append(t)
+        return t.data_ptr()
+
+    def _build(self, get) -> None:
+        d = self.dims
+        V, T = "model.visual.", "model.language_model."
+        hd_v = d.v_embed // d.v_heads
+        # ---- vision
+        vl = (_lib.VitLayer * d.v_depth)()
+        for i in range(d.v_depth):
+            p = f"{V}blocks.{i}."
+            for f, n in (("ln1_w", "norm1.weight"), ("ln1_b", "norm1.bias"), ("qkv_w", "attn.qkv.weight"),
+                         ("qkv_b", "attn.qkv.bias"), ("proj_w", "attn.proj.weight"), ("proj_b", "attn.proj.bias"),
+                         ("ln2_w", "norm2.weight"), ("ln2_b", "norm2.bias"), ("fc1_w", "mlp.fc1.weight"),
+                         ("fc1_b", "mlp.fc1.bias"), ("fc2_w", "mlp.fc2.weight"), ("fc2_b", "mlp.fc2.bias")):
+                setattr(vl[i], f, self._k(get(p + n)))
+        self._vit_layers = vl
+        v = self.vit
+        v.depth, v.embed_dim, v.num_heads, v.mlp_hidden = d.v_depth, d.v_embed, d.v_heads, d.v_mlp
+        v.patch_k, v.out_dim, v.merge_unit, v.ln_eps = d.patch_k, d.d_model, d.merge ** 2, 1e-6
+        v.patch_w = self._k(get(V + "patch_embed.proj.weight").reshape(d.v_embed, d.patch_k).contiguous())
+        v.layers = C.cast(vl, C.POINTER(_lib.VitLayer))
+        for f, n in (("merger_ln_w", "merger.ln_q.weight"), ("merger_ln_b", "merger.ln_q.bias"),
+                     ("merger_fc1_w", "merger.mlp.0.weight"), ("merger_fc1_b", "merger.mlp.0.bias"),
+                     ("merger_fc2_w", "merger.mlp.2.weight"), ("merger_fc2_b", "merger.mlp.2.bias")):
+            setattr(v, f, self._k(get(V + n)))
+        vc, vs = ops.rope_table(d.max_grid, hd_v // 4, hd_v // 2, 10000.0, False, self.device)
+        v.rope_cos, v.rope_sin, v.rope_positions = self._k(vc), self._k(vs), d.max_grid
+        # ---- decoder
+        ll = (_lib.LlmLayer * d.n_layers)()
+        for i in range(d.n_layers):
+            p = f"{T}layers.{i}."
+            qkv_w = torch.cat([get(p + "self_attn.q_proj.weight"), get(p + "self_attn.k_proj.weight"),
+                               get(p + "self_attn.v_proj.weight")], 0).contiguous()
+            qkv_b = torch.cat([get(p + "self_attn.q_proj.bias"), get(p + "self_attn.k_proj.bias"),
+                               get(p + "self_attn.v_proj.bias")], 0).contiguous()
+            gu = interleave_gate_up(get(p + "mlp.gate_proj.weight"), get(p + "mlp.up_proj.weight"))
+            ll[i].ln1_w = self._k(get(p + "input_layernorm.weight"))
+            ll[i].qkv_w, ll[i].qkv_b = self._k(qkv_w), self._k(qkv_b)
+            ll[i].o_w = self._k(get(p + "self_attn.o_proj.weight"))
+            ll[i].ln2_w = self._k(get(p + "post_attention_layernorm.weight"))
+            ll[i].gateup_w = self._k(gu)
+            ll[i].down_w = self._k(get(p + "mlp.down_proj.weight"))
+        self._llm_layers = ll
+        m = self.llm
+        m.n_layers, m.d_model, m.n_q_heads, m.n_kv_heads = d.n_layers, d.d_model, d.n_q_heads, d.n_kv_heads
+        m.head_dim, m.d_ff, m.vocab = d.head_dim, d.d_ff, d.vocab
+        m.mrope_sec0, m.mrope_sec1, m.rms_eps = d.mrope_section[0], d.mrope_section[1], d.rms_eps
+        self.embed = get(T + "embed_tokens.weight")
+        m.embed = self._k(self.embed)
+        m.layers = C.cast(ll, C.POINTER(_lib.LlmLayer))
+        m.final_norm_w = self._k(get(T + "norm.weight"))
+        m.lm_head_w = m.embed if d.tie_embeddings else self._k(get("lm_head.weight"))
+        lc, ls = ops.rope_table(d.max_positions, d.head_dim // 2, d.head_dim, d.rope_theta, True, self.device)
+        m.rope_cos, m.rope_sin, m.rope_positions = self._k(lc), self._k(ls), d.max_positions
+
+    def nbytes(self) -> int:
+        seen, total = set(), 0
+        for t in self._keep:
+            if t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                total += t.numel() * t.element_size()
+        return total
+
+
+def _param_shape(d: Qwen2VLDims, name: str) -> tuple:
+    E, F, hd = d.v_embed, d.v_mlp, d.head_dim
+    E4 = E * d.merge ** 2
+    tail = name.split(".", 4)[-1] if "blocks." in name or "layers." in name else name
+    table = {
+        "model.visual.patch_embed.proj.weight": (E, d.patch_k),
+        "norm1.weight": (E,), "norm1.bias": (E,), "norm2.weight": (E,), "norm2.bias": (E,),
+        "attn.qkv.weight": (3 * E, E), "attn.qkv.bias": (3 * E,), "attn.proj.weight": (E, E), "attn.proj.bias": (E,),
+        "mlp.fc1.weight": (F, E), "mlp.fc1.bias": (F,), "mlp.fc2.weight": (E, F), "mlp.fc2.bias": (E,),
+        "model.visual.merger.ln_q.weight": (E,), "model.visual.merger.ln_q.bias": (E,),
+        "model.visual.merger.mlp.0.weight": (E4, E4), "model.visual.merger.mlp.0.bias": (E4,),
+        "model.visual.merger.mlp.2.weight": (d.d_model, E4), "model.visual.merger.mlp.2.bias": (d.d_model,),
+        "model.language_model.embed_tokens.weight": (d.vocab, d.d_model),
+        "self_attn.q_proj.weight": (d.n_q_heads * hd, d.d_model), "self_attn.q_proj.bias": (d.n_q_heads * hd,),
+        "self_attn.k_proj.weight": (d.n_kv_heads * hd, d.d_model), "self_attn.k_proj.bias": (d.n_kv_heads * hd,),
+        "self_attn.v_proj.weight": (d.n_kv_heads * hd, d.d_model), "self_attn.v_proj.bias": (d.n_kv_heads * hd,),
+        "self_attn.o_proj.weight": (d.d_model, d.n_q_heads * hd),
+        "mlp.gate_proj.weight": (d.d_ff, d.d_model), "mlp.up_proj.weight": (d.d_ff, d.d_model),
+        "mlp.down_proj.weight": (d.d_model, d.d_ff),
+        "input_layernorm.weight": (d.d_model,), "post_attention_layernorm.weight": (d.d_model,),
+        "model.language_model.norm.weight": (d.d_model,), "lm_head.weight": (d.vocab, d.d_model),
+    }
+    if name in table:
+        return table[name]
+    if "visual.blocks." in name:
+        return table[name.split(".", 4)[-1]]
+    if "language_model.layers." in name:
+        return table[name.split(".", 4)[-1]]
+    raise KeyError(name)
+
+
+class Qwen2VLEngine:
+    """Batched open-world classification forward: pixel_values + prompt ids -> greedy token ids."""
+
+    def __init__(self, weights: Qwen2VLWeights, *, vit_chunk_tokens: int = 65536, prefill_chunk_tokens: int = 20480):
+        self.w = weights
+        self.d = weights.dims
+        self.device = weights.device
+        self.dev_index = self.device.index or 0
+        self.vit_chunk_tokens = vit_chunk_tokens
+        self.prefill_chunk_tokens = prefill_chunk_tokens
+        self._ws: torch.Tensor | None = None
+        self._lib = _lib.load()
+        self._ctx = _lib.ctx(self.dev_index)
+
+    # -- helpers -----------------------------------------------------------------------
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _i32(self, a) -> torch.Tensor:
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.device, non_blocking=True)
+
+    # -- vision tower ------------------------------------------------------------------
+    def encode_images(self, pixel_values: torch.Tensor, grid_thw) -> torch.Tensor:
+        """pixel_values [sum(t*h*w), 1176] bf16 (device) -> merged embeddings [sum/4, d_model] bf16."""
+        assert pixel_values.dtype == BF16 and pixel_values.is_cuda and pixel_values.stride(1) == 1
+        grid = [tuple(int(x) for x in g) for g in grid_thw]
+        lens = [t * h * w for t, h, w in grid]
+        total = sum(lens)
+        assert total == pixel_values.shape[0]
+        mu = self.d.merge ** 2
+        out = torch.empty((total // mu, self.d.d_model), dtype=BF16, device=self.device)
+        i0 = 0
+        while i0 < len(grid):  # chunk whole images
+            i1, tok = i0, 0
+            while i1 < len(grid) and (tok == 0 or tok + lens[i1] <= self.vit_chunk_tokens):
+                tok += lens[i1]
+                i1 += 1
+            row0 = sum(lens[:i0])
+            self._vit_chunk(pixel_values[row0:row0 + tok], grid[i0:i1], lens[i0:i1], out[row0 // mu:(row0 + tok) // mu])
+            i0 = i1
+        return out
+
+    def _vit_chunk(self, pix, grid, lens, out) -> None:
+        T = pix.shape[0]
+        pos_hw = self._i32(positions.vision_pos_hw(grid, self.d.merge))
+        starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+        seq_start, seq_len = self._i32(starts), self._i32(lens)
+        nbytes = self._lib.owc_vit_workspace_bytes(C.byref(self.w.vit), T)
+        ws = self._workspace(nbytes)
+        rc = self._lib.owc_vit_forward(self._ctx, C.byref(self.w.vit), pix.data_ptr(), pix.stride(0), pos_hw.data_ptr(),
+                                       seq_start.data_ptr(), seq_len.data_ptr(), len(grid), T, max(lens), out.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, self.dev_index)
+
+    # -- decoder -----------------------------------------------------------------------
+    def generate(self, prompts: list, img_embeds: torch.Tensor | None, grids_per_prompt: list, max_new_tokens: int,
+                 *, eos_token_id: int = -1, pad_token_id: int = 0, stop_check_every: int = 8,
+                 return_logits: bool = False):
+        """Greedy generation for a batch of prompts.
+
+        prompts[b]: 1-D int array of token ids holding image_token_id placeholders;
+        grids_per_prompt[b]: list of (t, h, w) for that prompt's images, in order;
+        img_embeds: rows for all image tokens of all prompts, in prompt order.
+        Returns int32 [B, max_new_tokens] (pad after EOS) and, optionally, the first-step logits.
+        """
+        d = self.d
+        B = len(prompts)
+        lens = np.array([len(p) for p in prompts], dtype=np.int64)
+        s_max = int(lens.max()) + max_new_tokens
+        Hkv, G = d.n_kv_heads, d.n_q_heads // d.n_kv_heads
+        cache_elems = d.n_layers * B * Hkv * s_max * d.head_dim
+        kc = torch.empty(cache_elems, dtype=BF16, device=self.device)
+        vc = torch.empty(cache_elems, dtype=BF16, device=self.device)
+        cache = _lib.KvCache(kc.data_ptr(), vc.data_ptr(), B, s_max)
+
+        # positions (host integer bookkeeping)
+        pos_list, max_pos = [], np.empty(B, dtype=np.int64)
+        img_index = []
+        img_cursor = 0
+        for b, ids in enumerate(prompts):
+            ids = np.asarray(ids)
+            if grids_per_prompt[b]:
+                p3, _ = positions.mrope_positions(ids, grids_per_prompt[b], d.image_token_id, d.merge)
+            else:
+                p3 = np.tile(np.arange(len(ids), dtype=np.int32)[None], (3, 1))
+            pos_list.append(p3)
+            max_pos[b] = int(p3.max())
+            is_img = ids == d.image_token_id
+            idx = np.full(len(ids), -1, dtype=np.int32)
+            n_img = int(is_img.sum())
+            idx[is_img] = np.arange(img_cursor, img_cursor + n_img, dtype=np.int32)
+            img_cursor += n_img
+            img_index.append(idx)
+        if img_cursor and (img_embeds is None or img_embeds.shape[0] != img_cursor):
+            raise ValueError("image token count does not match the image embeddings")
+        if int(max_pos.max()) + max_new_tokens + 1 > d.max_positions:
+            raise ValueError("prompt + generation exceeds the rope table (raise Qwen2VLDims.max_positions)")
+
+        next_tok = torch.empty(B, dtype=I32, device=self.device)
+        first_logits = torch.empty((B, d.vocab), dtype=BF16, device=self.device) if return_logits else None
+
+        # ---- prefill in chunks of whole prompts
+        b0 = 0
+        while b0 < B:
+            b1, tok = b0, 0
+            while b1 < B and (tok == 0 or tok + lens[b1] <= self.prefill_chunk_tokens):
+                tok += int(lens[b1])
+                b1 += 1
+            self._prefill_chunk(prompts, pos_list, img_index, img_embeds, lens, b0, b1, cache, next_tok, first_logits)
+            b0 = b1
+
+        # ---- greedy decode, whole batch per step
+        out_tokens = torch.empty((B, max_new_tokens), dtype=I32, device=self.device)
+        done = torch.zeros(B, dtype=torch.uint8, device=self.device)
+        eos1 = -1
+        rc = self._lib.owc_decode_update(self._ctx, next_tok.data_ptr(), done.data_ptr(), out_tokens.data_ptr(),
+                                         max_new_tokens, 0, B, eos_token_id, eos1, pad_token_id, _lib.stream_ptr())
+        _lib.check(rc, self.dev_index)
+        if max_new_tokens > 1:
+            steps = np.arange(max_new_tokens - 1, dtype=np.int64)[:, None]
+            pos_all = self._i32(max_pos[None, :] + 1 + steps)      # rope position of the token fed at step j+1
+            widx_all = self._i32(lens[None, :] + steps)            # cache row it is written to
+            klen_all = self._i32(lens[None, :] + steps + 1)
+            ar = np.arange(B, dtype=np.int64)
+            slot = self._i32(ar)
+            k_start = self._i32(ar * Hkv * s_max)
+            q_start = self._i32(ar * (d.n_q_heads + 2 * Hkv))
+            o_start = self._i32(ar * d.n_q_heads)
+            q_len = self._i32(np.full(B, G))
+            nbytes = self._lib.owc_llm_workspace_bytes(C.byref(self.w.llm), B, B)
+            ws = self._workspace(nbytes)
+            for j in range(1, max_new_tokens):
+                rc = self._lib.owc_llm_decode_step(
+                    self._ctx, C.byref(self.w.llm), C.byref(cache), next_tok.data_ptr(), pos_all[j - 1].data_ptr(),
+                    slot.data_ptr(), widx_all[j - 1].data_ptr(), k_start.data_ptr(), klen_all[j - 1].data_ptr(),
+                    q_start.data_ptr(), o_start.data_ptr(), q_len.data_ptr(), done.data_ptr(), out_tokens.data_ptr(),
+                    max_new_tokens, j, B, eos_token_id, eos1, pad_token_id, None, ws.data_ptr(), ws.numel(),
+                    _lib.stream_ptr())
+                _lib.check(rc, self.dev_index)
+                if eos_token_id >= 0 and stop_check_every and j % stop_check_every == 0 and bool(done.all().item()):
+                    out_tokens[:, j + 1:] = pad_token_id
+                    break
+        return (out_tokens, first_logits) if return_logits else out_tokens
+
+    def _prefill_chunk(self, prompts, pos_list, img_index, img_embeds, lens, b0, b1, cache, next_tok, first_logits):
+        d = self.d
+        n = b1 - b0
+        T = int(lens[b0:b1].sum())
+        ids = np.concatenate([np.asarray(prompts[b], dtype=np.int32) for b in range(b0, b1)])
+        pos3 = np.concatenate([pos_list[b] for b in range(b0, b1)], axis=1)
+        iidx = np.concatenate([img_index[b] for b in range(b0, b1)])
+        starts = np.concatenate([[0], np.cumsum(lens[b0:b1])[:-1]])
+        tok_slot = np.repeat(np.arange(b0, b1), lens[b0:b1])
+        tok_idx = np.concatenate([np.arange(int(lens[b]), dtype=np.int32) for b in range(b0, b1)])
+        k_start = np.arange(b0, b1, dtype=np.int64) * d.n_kv_heads * cache.s_max
+        last = starts + lens[b0:b1] - 1
+        t_ids, t_pos3, t_iidx = self._i32(ids), self._i32(pos3), self._i32(iidx)
+        t_slot, t_idx, t_start, t_len = self._i32(tok_slot), self._i32(tok_idx), self._i32(starts), self._i32(lens[b0:b1])
+        t_kstart, t_last = self._i32(k_start), self._i32(last)
+        nbytes = self._lib.owc_llm_workspace_bytes(C.byref(self.w.llm), T, n)
+        ws = self._workspace(nbytes)
+        logits_ptr = first_logits[b0:b1].data_ptr() if first_logits is not None else None
+        rc = self._lib.owc_llm_prefill(
+            self._ctx, C.byref(self.w.llm), C.byref(cache), t_ids.data_ptr(), t_iidx.data_ptr(),
+            _lib.ptr(img_embeds), t_pos3.data_ptr(), t_slot.data_ptr(), t_idx.data_ptr(), t_start.data_ptr(),
+            t_len.data_ptr(), t_kstart.data_ptr(), t_last.data_ptr(), n, T, int(lens[b0:b1].max()),
+            next_tok[b0:b1].data_ptr(), logits_ptr, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, self.dev_index)

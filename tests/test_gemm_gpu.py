@@ -85,4 +85,6 @@ def test_gemm_epilogues(gpu, epi):
         u = np_ops.linear(to_np(a), to_np(wu), bf16=True)
         want = np_ops.bf16_round(np_ops.silu(g, bf16=True) * u)
     torch.cuda.synchronize()
-    assert_bf16_close(to_np(out), want, ulps=4.0, min_exact=0.80, atol=1e-4)
+    # a residual add can cancel: allow one bf16 ulp of the pre-add magnitude as absolute slack
+    atol = 2.0**-7 * float(np.abs(y).max()) if epi == "residual" else 1e-4
+    assert_bf16_close(to_np(out), want, ulps=4.0, min_exact=0.80, atol=atol)

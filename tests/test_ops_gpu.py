@@ -1,0 +1,211 @@
+"""Op-level parity: each HIP kernel (through the C ABI) vs its numpy restatement in oracle/."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ops
+from oracle import qwen2vl_np as Q
+from tests.util import assert_bf16_close, bf16_randn, to_np
+
+pytestmark = pytest.mark.gpu
+I32 = torch.int32
+
+
+def i32(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+
+
+@pytest.mark.parametrize("rows,d", [(5, 160), (300, 1280), (33, 3584), (4, 8192)])
+def test_layernorm_rmsnorm(gpu, rows, d):
+    from lmms_owc_amd import ops
+
+    x = bf16_randn((rows, d), 1, 2.0, gpu)
+    w = (1 + 0.1 * torch.randn(d)).to(torch.bfloat16).to(gpu)
+    b = (0.1 * torch.randn(d)).to(torch.bfloat16).to(gpu)
+    y = ops.layernorm(x, w, b, 1e-6)
+    assert_bf16_close(to_np(y), np_ops.layer_norm(to_np(x), to_np(w), to_np(b), 1e-6, bf16=True), atol=1e-3)
+    y = ops.rmsnorm(x, w, 1e-6)
+    assert_bf16_close(to_np(y), np_ops.rms_norm(to_np(x), to_np(w), 1e-6, bf16=True), atol=1e-3)
+    idx = i32(np.arange(rows - 1, -1, -2), gpu)
+    y = ops.rmsnorm(x, w, 1e-6, row_index=idx)
+    assert_bf16_close(to_np(y), np_ops.rms_norm(to_np(x)[to_np(idx).astype(int)], to_np(w), 1e-6, bf16=True), atol=1e-3)
+
+
+def test_vision_rope(gpu):
+    from lmms_owc_amd import ops
+    from lmms_owc_amd.engine import positions
+
+    H, hd = 2, 80
+    grid = [(1, 6, 4), (1, 4, 8)]
+    T = sum(t * h * w for t, h, w in grid)
+    qkv = bf16_randn((T, 3 * H * hd), 3, 1.0, gpu)
+    ref = to_np(qkv).reshape(T, 3, H, hd)
+    pos = positions.vision_pos_hw(grid)
+    cos, sin = ops.rope_table(64, hd // 4, hd // 2, 10000.0, False, gpu)
+    ops.vision_rope_(qkv, i32(pos, gpu), cos, sin, H, hd)
+    inv = (1.0 / (10000.0 ** (np.arange(0, 40, 2, dtype=np.float32) / np.float32(40)))).astype(np.float32)
+    fr = (pos[:, :, None].astype(np.float32) * inv).reshape(T, -1)
+    emb = np.concatenate([fr, fr], -1)
+    c, s = np.cos(emb)[:, None, :], np.sin(emb)[:, None, :]
+    want = ref.copy()
+    for j in (0, 1):
+        want[:, j] = np_ops.bf16_round(ref[:, j] * c + Q._rotate_half(ref[:, j]) * s)
+    assert_bf16_close(to_np(qkv).reshape(T, 3, H, hd), want, atol=1e-3, min_exact=0.99)
+
+
+def test_mrope_kv_write(gpu):
+    from lmms_owc_amd import ops
+
+    Hq, Hkv, hd, T, s_max, slots = 4, 2, 128, 37, 50, 3
+    qkv = bf16_randn((T, (Hq + 2 * Hkv) * hd), 5, 1.0, gpu)
+    ref = to_np(qkv)
+    r = np.random.default_rng(0)
+    pos3 = r.integers(0, 300, (3, T))
+    slot = r.integers(0, slots, T)
+    # unique (slot, idx) pairs
+    idx = np.array([np.sum(slot[:i] == slot[i]) for i in range(T)])
+    kc = torch.zeros(slots * Hkv * s_max * hd, dtype=torch.bfloat16, device=gpu)
+    vc = torch.zeros_like(kc)
+    cos, sin = ops.rope_table(512, 64, 128, 1e6, True, gpu)
+    ops.mrope_kv_write_(qkv, i32(pos3, gpu), cos, sin, kc, vc, i32(slot, gpu), i32(idx, gpu), Hq, Hkv, s_max, 16, 24)
+    tc = Q.TextCfg()
+    c, s = Q._mrope_cos_sin(pos3, tc, hd, True)
+    x = ref.reshape(T, Hq + 2 * Hkv, hd)
+    rot = lambda a: np_ops.bf16_round(np_ops.bf16_round(a * c[:, None]) + np_ops.bf16_round(Q._rotate_half(a) * s[:, None]))  # noqa: E731
+    q_want, k_want, v_want = rot(x[:, :Hq]), rot(x[:, Hq:Hq + Hkv]), x[:, Hq + Hkv:]
+    got = to_np(qkv).reshape(T, Hq + 2 * Hkv, hd)
+    assert_bf16_close(got[:, :Hq], q_want, atol=1e-3, min_exact=0.98)
+    kcn = to_np(kc).reshape(slots, Hkv, s_max, hd)
+    vcn = to_np(vc).reshape(slots, Hkv, s_max, hd)
+    assert_bf16_close(kcn[slot, :, idx], k_want, atol=1e-3, min_exact=0.98)
+    assert np.array_equal(vcn[slot, :, idx], v_want)
+
+
+def _attn_ref(q, k, v, causal):
+    """[H, Sq, hd] x [H, Sk, hd] -> [H, Sq, hd], fp32 softmax, bf16-rounded output."""
+    return Q._attn(q, k, v, q.shape[-1] ** -0.5, causal, False)
+
+
+@pytest.mark.parametrize("lens", [[16], [1024], [24, 32, 700]])
+def test_attention_vision_varlen(gpu, lens):
+    from lmms_owc_amd import ops
+
+    H, hd = 4, 80
+    T = sum(lens)
+    qkv = bf16_randn((T, 3 * H * hd), 9, 1.0, gpu)
+    out = torch.zeros((T, H * hd), dtype=torch.bfloat16, device=gpu)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    E = H * hd
+    ops.attention(qkv, 3 * E, hd, qkv[:, E:], 3 * E, hd, qkv[:, 2 * E:], 3 * E, hd, out, E, hd, i32(starts, gpu),
+                  i32(starts, gpu), i32(lens, gpu), n_seq=len(lens), n_heads=H, kv_group=1, head_dim=hd,
+                  max_q_len=max(lens), causal=False, scale=hd ** -0.5)
+    x = to_np(qkv).reshape(T, 3, H, hd)
+    want = np.empty((T, H, hd), np.float32)
+    for s0, n in zip(starts, lens):
+        sl = slice(s0, s0 + n)
+        want[sl] = _attn_ref(x[sl, 0].transpose(1, 0, 2), x[sl, 1].transpose(1, 0, 2), x[sl, 2].transpose(1, 0, 2), False).transpose(1, 0, 2)
+    got = to_np(out).reshape(T, H, hd)
+    # P is rounded to bf16 before P.V (as HF eager/flash do): allow ~2 bf16 ulps of the value scale
+    assert np.abs(got - want).max() <= 0.02 * np.abs(want).max() + 1e-3
+    assert np.abs(got - want).mean() <= 2e-3 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("lens", [[7], [286], [130, 64, 257]])
+def test_attention_causal_gqa_cache(gpu, lens):
+    from lmms_owc_amd import ops
+
+    Hq, Hkv, hd, s_max = 6, 2, 128, 300
+    n = len(lens)
+    T = sum(lens)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    q = bf16_randn((T, Hq * hd), 1, 1.0, gpu)
+    kc = bf16_randn((n, Hkv, s_max, hd), 2, 1.0, gpu)
+    vc = bf16_randn((n, Hkv, s_max, hd), 3, 1.0, gpu)
+    out = torch.zeros((T, Hq * hd), dtype=torch.bfloat16, device=gpu)
+    k_start = np.arange(n) * Hkv * s_max
+    ops.attention(q, Hq * hd, hd, kc, hd, s_max * hd, vc, hd, s_max * hd, out, Hq * hd, hd, i32(starts, gpu),
+                  i32(k_start, gpu), i32(lens, gpu), n_seq=n, n_heads=Hq, kv_group=Hq // Hkv, head_dim=hd,
+                  max_q_len=max(lens), causal=True, scale=hd ** -0.5)
+    qn, kn, vn = to_np(q).reshape(T, Hq, hd), to_np(kc), to_np(vc)
+    got = to_np(out).reshape(T, Hq, hd)
+    for b, (s0, L) in enumerate(zip(starts, lens)):
+        kk = np.repeat(kn[b, :, :L], Hq // Hkv, 0)
+        vv = np.repeat(vn[b, :, :L], Hq // Hkv, 0)
+        want = _attn_ref(qn[s0:s0 + L].transpose(1, 0, 2), kk, vv, True).transpose(1, 0, 2)
+        assert np.abs(got[s0:s0 + L] - want).max() <= 0.02 * np.abs(want).max() + 1e-3
+
+
+def test_attention_decode_mapping(gpu):
+    """q_len = G query heads per kv group mapped onto kernel rows (what owc_llm_decode_step does)."""
+    from lmms_owc_amd import ops
+
+    Hq, Hkv, hd, s_max, B = 12, 2, 128, 96, 5
+    G = Hq // Hkv
+    klen = np.array([1, 17, 64, 65, 96])
+    qkv = bf16_randn((B, (Hq + 2 * Hkv) * hd), 4, 1.0, gpu)
+    kc = bf16_randn((B, Hkv, s_max, hd), 5, 1.0, gpu)
+    vc = bf16_randn((B, Hkv, s_max, hd), 6, 1.0, gpu)
+    out = torch.zeros((B, Hq * hd), dtype=torch.bfloat16, device=gpu)
+    ar = np.arange(B)
+    ops.attention(qkv, hd, G * hd, kc, hd, s_max * hd, vc, hd, s_max * hd, out, hd, G * hd, i32(ar * (Hq + 2 * Hkv), gpu),
+                  i32(ar * Hkv * s_max, gpu), i32(klen, gpu), n_seq=B, n_heads=Hkv, kv_group=1, head_dim=hd, max_q_len=G,
+                  causal=False, scale=hd ** -0.5, o_start=i32(ar * Hq, gpu), q_len=i32(np.full(B, G), gpu))
+    qn = to_np(qkv)[:, :Hq * hd].reshape(B, Hq, hd)
+    got = to_np(out).reshape(B, Hq, hd)
+    for b in range(B):
+        kk = np.repeat(to_np(kc)[b, :, :klen[b]], G, 0)
+        vv = np.repeat(to_np(vc)[b, :, :klen[b]], G, 0)
+        want = _attn_ref(qn[b][:, None, :], kk, vv, False)[:, 0]
+        assert np.abs(got[b] - want).max() <= 0.02 * np.abs(want).max() + 1e-3
+
+
+def test_embed_argmax_patchify(gpu):
+    from lmms_owc_amd import ops
+
+    table = bf16_randn((50, 64), 1, 1.0, gpu)
+    img = bf16_randn((6, 64), 2, 1.0, gpu)
+    ids = np.array([3, 7, 49, 49, 49, 0, 49], dtype=np.int32)
+    iidx = np.array([-1, -1, 0, 1, 2, -1, 5], dtype=np.int32)
+    out = ops.embed_tokens(i32(ids, gpu), i32(iidx, gpu), table, img)
+    want = np.where(iidx[:, None] >= 0, to_np(img)[np.maximum(iidx, 0)], to_np(table)[ids])
+    assert np.array_equal(to_np(out), want)
+
+    logits = bf16_randn((9, 1000), 3, 1.0, gpu)
+    logits[2, 10] = 50.0
+    logits[2, 700] = 50.0  # tie -> lowest index
+    got = ops.argmax_bf16(logits)
+    assert np.array_equal(to_np(got).astype(int), np.argmax(to_np(logits), -1))
+
+    g = torch.Generator().manual_seed(0)
+    im = torch.randint(0, 256, (2, 3, 56, 84), generator=g, dtype=torch.uint8)
+    mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+    pv = to_np(ops.patchify_u8(im.to(gpu), mean, std))
+    x = (im.numpy().astype(np.float32) / 255.0 - np.array(mean, np.float32)[None, :, None, None]) / np.array(std, np.float32)[None, :, None, None]
+    gh, gw = 4, 6
+    p = x.reshape(2, 3, gh // 2, 2, 14, gw // 2, 2, 14).transpose(0, 2, 5, 3, 6, 1, 4, 7)  # n, bh, bw, ih, iw, c, py, px
+    p = np.repeat(p[:, :, :, :, :, :, None], 2, axis=6).reshape(2 * gh * gw, 1176)
+    assert_bf16_close(pv, np_ops.bf16_round(p), ulps=1.0, atol=1e-6, min_exact=0.99)
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(100, 384, 384, "none"), (257, 1536, 384, "gelu"), (64, 384, 1536, "res"), (5, 64, 132, "none")])
+def test_gemm_f32(gpu, m, n, k, epi):
+    from lmms_owc_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(m, k, generator=g).to(gpu)
+    w = (torch.randn(n, k, generator=g) / math.sqrt(k)).to(gpu)
+    b = torch.randn(n, generator=g).to(gpu)
+    y = to_np(a).astype(np.float64) @ to_np(w).astype(np.float64).T + to_np(b)
+    if epi == "gelu":
+        out = ops.gemm_f32(a, w, b, epilogue=_lib.EPI_GELU_ERF)
+        want = np_ops.gelu_erf(y.astype(np.float32))
+    elif epi == "res":
+        r = torch.randn(m, n, generator=g).to(gpu)
+        out = ops.gemm_f32(a, w, b, epilogue=_lib.EPI_RESIDUAL, residual=r)
+        want = y + to_np(r)
+    else:
+        out = ops.gemm_f32(a, w, b)
+        want = y
+    np.testing.assert_allclose(to_np(out), want, rtol=1e-5, atol=2e-5)

@@ -1,0 +1,68 @@
+"""Scorer parity on the GPU: fp32 HIP BERT encoder + cosine kernels vs the oracle and the golden
+vectors the REFERENCE's encode_sentence_bert / semantic_similarity produced (tests/golden/scorer.npz).
+Tolerance: 1e-4 on cosine (BASELINE.json north_star), we assert 2e-5."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bert_np as B
+from tests import recipes
+from tests.util import to_np
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+@pytest.mark.parametrize("kind,n,L", [("minilm", 8, 16)])
+def test_embed_matches_reference_golden(gpu, kind, n, L):
+    from lmms_owc_amd.engine.scorer import BertWeights, SentenceScorer
+
+    g = np.load(GOLD / "scorer.npz")
+    c = recipes.bert_cfg(kind)
+    sc = SentenceScorer(BertWeights(c, recipes.bert_weights(c, 1234), gpu))
+    ids_r, mask_r = recipes.label_tokens(n, L, c["vocab_size"], seed=21)
+    ids_p, mask_p = recipes.label_tokens(n, L, c["vocab_size"], seed=22)
+    zr, zp = sc.embed(ids_r, mask_r), sc.embed(ids_p, mask_p)
+    np.testing.assert_allclose(to_np(zr), g[f"{kind}_ref_embeds"], atol=2e-5)
+    np.testing.assert_allclose(to_np(zp), g[f"{kind}_pred_embeds"], atol=2e-5)
+    cos = to_np(sc.paired_cosine(zr, zp))
+    np.testing.assert_allclose(cos, g[f"{kind}_semantic_similarity_none"], atol=2e-5)
+
+
+def test_embed_matches_oracle_ragged(gpu):
+    from lmms_owc_amd.engine.scorer import BertWeights, SentenceScorer
+
+    c = recipes.bert_cfg("minilm")
+    w = recipes.bert_weights(c, 77)
+    sc = SentenceScorer(BertWeights(c, w, gpu), max_batch=100)
+    for n, L in ((1, 2), (257, 9), (64, 33)):
+        ids, mask = recipes.label_tokens(n, L, c["vocab_size"], seed=n)
+        np.testing.assert_allclose(to_np(sc.embed(ids, mask)), B.sentence_embed(w, c, ids, mask), atol=2e-5)
+
+
+@pytest.mark.parametrize("N,C,k", [(1, 3, 1), (100, 37, 5), (513, 397, 5), (64, 1000, 16)])
+def test_cosine_topk(gpu, N, C, k):
+    from lmms_owc_amd.engine.scorer import SentenceScorer
+
+    r = np.random.default_rng(N)
+    z = r.standard_normal((N, 384)).astype(np.float32)
+    z /= np.linalg.norm(z, axis=-1, keepdims=True)
+    cl = r.standard_normal((C, 384)).astype(np.float32)
+    cl /= np.linalg.norm(cl, axis=-1, keepdims=True)
+    cl[0] = z[0]  # an exact hit
+    label = r.integers(0, C, N)
+    kk = min(k, C)
+    tv, ti, paired = SentenceScorer.topk(torch.from_numpy(z).to(gpu), torch.from_numpy(cl).to(gpu), kk,
+                                         torch.from_numpy(label.astype(np.int32)).to(gpu))
+    wv, wi = B.cosine_topk(z, cl, kk)
+    np.testing.assert_allclose(to_np(tv), wv, atol=2e-6)
+    sim = z @ cl.T
+    # indices must agree except where two classes tie within fp32 rounding
+    got_i = to_np(ti).astype(int)
+    np.testing.assert_allclose(np.take_along_axis(sim, got_i, 1), wv, atol=2e-6)
+    assert (got_i == wi).mean() > 0.999
+    np.testing.assert_allclose(to_np(paired), sim[np.arange(N), label], atol=2e-6)
+    assert got_i[0, 0] == 0 and abs(to_np(tv)[0, 0] - 1.0) < 1e-5
