@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the MI355X open-world classification hot path (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic input per GPU:
+  pixel_values [B*1024, 1176] bf16 (B images of 448x448, resident in HBM)
+    -> Qwen2-VL vision tower -> prompt prefill (S = 286) -> 16 greedy decode steps -> token ids on host.
+Reported `value` = images/s over all ranks (weak scaling: per-GPU batch fixed).  The same JSON line carries
+the label-cosine/s of the scorer leg, the MFMA roofline of the dominant kernel (bf16 GEMM, HIP events
+around every launch of the timed region) and the reference's CPU HuggingFace path timed on the host cores.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+         bench.py --gpus 8 --steps 3 --warmup 1
+"""
+
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("TOKENIZERS_PARALLELISM", "false")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+S_TEXT_BEFORE, S_IMG, S_TEXT_AFTER = 14, 256, 16  # 286-token prompt of the 448x448 classification query
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md (never the 2:1-sparsity figure)
+
+
+def flops_per_image(d, new_tokens: int) -> float:
+    """SURVEY.md §8(d) algorithmic FLOPs per 448x448 image (causal attention counted at 1/2)."""
+    P, Dv, Lv, S = 1024, d.v_embed, d.v_depth, S_TEXT_BEFORE + S_IMG + S_TEXT_AFTER
+    f_vit = 2 * P * d.patch_k * Dv + Lv * (8 * P * Dv * Dv + 4 * P * P * Dv + 4 * P * Dv * d.v_mlp) \
+        + 2 * 256 * (4 * Dv) ** 2 + 2 * 256 * 4 * Dv * d.d_model
+    H, KV, hd, dm, ff, L, V = d.n_q_heads, d.n_kv_heads, d.head_dim, d.d_model, d.d_ff, d.n_layers, d.vocab
+    f_pre = L * (2 * S * dm * (H + 2 * KV) * hd + 2 * S * H * hd * dm + 2 * S * S * H * hd + 6 * S * dm * ff) + 2 * dm * V
+    f_dec = sum(L * (2 * dm * (H + 2 * KV) * hd + 2 * H * hd * dm + 4 * (S + i) * H * hd + 6 * dm * ff) + 2 * dm * V
+                for i in range(new_tokens))
+    return float(f_vit + f_pre + f_dec)
+
+
+def cpu_baseline_lmm(model_key: str, new_tokens: int, n_images: int) -> dict:
+    """The reference's CPU path: HF Qwen2VLForConditionalGeneration, batch 1, greedy (src/models/_qwen2_vl.py:308-329)."""
+    from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
+
+    from lmms_owc_amd.engine.qwen2vl import DIMS
+
+    d = DIMS[model_key]
+    threads = min(os.cpu_count() or 1, 128)
+    torch.set_num_threads(threads)
+    cfg = Qwen2VLConfig(
+        text_config=dict(hidden_size=d.d_model, num_hidden_layers=d.n_layers, num_attention_heads=d.n_q_heads,
+                         num_key_value_heads=d.n_kv_heads, intermediate_size=d.d_ff, vocab_size=d.vocab,
+                         rms_norm_eps=d.rms_eps, max_position_embeddings=4096, tie_word_embeddings=d.tie_embeddings,
+                         rope_parameters=dict(rope_type="default", rope_theta=d.rope_theta, mrope_section=list(d.mrope_section))),
+        vision_config=dict(depth=d.v_depth, embed_dim=d.v_embed, num_heads=d.v_heads, hidden_size=d.d_model, mlp_ratio=4,
+                           patch_size=14, spatial_merge_size=2, temporal_patch_size=2),
+        image_token_id=d.image_token_id, video_token_id=d.image_token_id + 1, vision_start_token_id=d.image_token_id - 3,
+        vision_end_token_id=d.image_token_id - 2, tie_word_embeddings=d.tie_embeddings)
+    cfg._attn_implementation = "sdpa"
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        import transformers.initialization as tinit  # noqa: F401
+        ctx = getattr(__import__("transformers.modeling_utils", fromlist=["no_init_weights"]), "no_init_weights", None)
+    except Exception:  # pragma: no cover
+        ctx = None
+    try:
+        if ctx is not None:
+            with ctx():
+                model = Qwen2VLForConditionalGeneration(cfg)
+        else:
+            model = Qwen2VLForConditionalGeneration(cfg)
+    finally:
+        torch.set_default_dtype(prev)
+    model = model.to(torch.bfloat16).eval()
+    g = torch.Generator().manual_seed(1234)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.uniform_(-0.02, 0.02, generator=g)
+    ids = prompt_ids(d.image_token_id)
+    inp = torch.from_numpy(ids.astype(np.int64))[None]
+    mm = (inp == d.image_token_id).int()
+    grid = torch.tensor([[1, 32, 32]])
+    times = []
+    with torch.no_grad():
+        for i in range(n_images):
+            pix = torch.randn(1024, 1176, generator=g).to(torch.bfloat16)
+            t0 = time.perf_counter()
+            model.generate(input_ids=inp, attention_mask=torch.ones_like(inp), pixel_values=pix, image_grid_thw=grid,
+                           mm_token_type_ids=mm, do_sample=False, num_beams=1, max_new_tokens=new_tokens,
+                           min_new_tokens=new_tokens, use_cache=True, pad_token_id=0)
+            times.append(time.perf_counter() - t0)
+    del model
+    best = float(np.mean(times[1:])) if len(times) > 1 else float(times[0])
+    import transformers
+
+    return {"value": 1.0 / best, "unit": "images/s", "cores": threads, "kind": "reference",
+            "sample": f"{n_images} image(s) 448x448, batch 1, bf16, transformers {transformers.__version__} "
+                      f"Qwen2VLForConditionalGeneration.generate on CPU (greedy, {new_tokens} new tokens, random weights); "
+                      f"mean of images after the first; per-image s = {[round(t, 2) for t in times]}"}
+
+
+def cpu_baseline_scorer(n_labels: int, L: int) -> dict:
+    """Reference scorer on CPU fp32: BertModel (MiniLM-L6 config) + mean pool + L2 + paired bmm (_text.py:175-202)."""
+    from transformers import BertConfig, BertModel
+
+    from lmms_owc_amd.engine.scorer import MINILM_L6
+
+    threads = min(os.cpu_count() or 1, 128)
+    torch.set_num_threads(threads)
+    m = BertModel(BertConfig(**MINILM_L6), add_pooling_layer=False).eval()
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(1000, 30000, (n_labels, L), generator=g)
+    mask = torch.ones_like(ids)
+
+    def run():
+        with torch.no_grad():
+            outs = []
+            for i in range(0, n_labels, 1024):  # datasets.map(batch_size=1024), _group.py:524-535
+                h = m(input_ids=ids[i:i + 1024], attention_mask=mask[i:i + 1024])[0]
+                mk = mask[i:i + 1024].unsqueeze(-1).float()
+                z = (h * mk).sum(1) / mk.sum(1).clamp(min=1e-9)
+                outs.append(z / z.norm(p=2, dim=-1, keepdim=True))
+            z = torch.cat(outs)
+            return torch.bmm(z.unsqueeze(1), z.unsqueeze(2)).squeeze()
+
+    run()
+    t0 = time.perf_counter()
+    run()
+    dt = time.perf_counter() - t0
+    return {"value": n_labels / dt, "unit": "labels/s", "cores": threads, "kind": "reference",
+            "sample": f"{n_labels} labels x {L} tokens, HF BertModel fp32 CPU batches of 1024 + paired bmm"}
+
+
+def prompt_ids(image_token_id: int) -> np.ndarray:
+    r = np.random.default_rng(1234)
+    return np.concatenate([r.integers(1000, 150000, S_TEXT_BEFORE), np.full(S_IMG, image_token_id),
+                           r.integers(1000, 150000, S_TEXT_AFTER)]).astype(np.int32)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="7b", choices=["2b", "7b", "72b"])
+    ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
+    ap.add_argument("--new-tokens", type=int, default=16)
+    ap.add_argument("--scorer-labels", type=int, default=65536)
+    ap.add_argument("--scorer-classes", type=int, default=397)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+
+    from lmms_owc_amd import _lib
+    from lmms_owc_amd import build as owc_build
+
+    if rank == 0 or not _lib.lib_path().exists():
+        if local == 0:
+            owc_build.build(verbose=False)
+    if dist is not None:
+        dist.barrier()
+    from lmms_owc_amd.engine.qwen2vl import DIMS, Qwen2VLEngine, Qwen2VLWeights
+    from lmms_owc_amd.engine.scorer import MINILM_L6, BertWeights, SentenceScorer
+
+    key = f"qwen2-vl-{args.model}"
+    dims = DIMS[key]
+    weights = Qwen2VLWeights.random(dims, device, seed=1234)
+    engine = Qwen2VLEngine(weights)
+    B, T = args.batch, args.new_tokens
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    pix = torch.randn((B * 1024, 1176), generator=gen, device=device, dtype=torch.bfloat16)
+    ids = prompt_ids(dims.image_token_id)
+    prompts = [ids] * B
+    grids = [[(1, 32, 32)]] * B
+    flat_grids = [(1, 32, 32)] * B
+
+    def step():
+        emb = engine.encode_images(pix, flat_grids)
+        toks = engine.generate(prompts, emb, grids, T, eos_token_id=-1, pad_token_id=0)
+        return toks.cpu()  # last decoded token ids on the host
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    lib, ctx = _lib.load(), _lib.ctx(local)
+    for _ in range(args.warmup):
+        step()
+    sync()
+    lib.owc_gemm_profile_enable(ctx, 1 if rank == 0 else 0)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    dt = time.perf_counter() - t0
+    ms, fl, n_launch = C.c_double(), C.c_double(), C.c_int64()
+    if rank == 0:
+        _lib.check(lib.owc_gemm_profile_read(ctx, C.byref(ms), C.byref(fl), C.byref(n_launch)), local)
+    lib.owc_gemm_profile_enable(ctx, 0)
+    assert out.shape == (B, T)
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    images_per_s = world * B * args.steps / dt
+
+    # ---- scorer leg: label-cosine/s (embed predictions + cosine top-5 against resident class embeddings)
+    n_lab, L = args.scorer_labels, 16
+    scorer = SentenceScorer(BertWeights.random(MINILM_L6, device, seed=7), max_batch=16384)
+    lg = torch.Generator(device=device).manual_seed(99 + rank)
+    lab_ids = torch.randint(1000, 30000, (n_lab, L), generator=lg, device=device, dtype=torch.int32)
+    lens = torch.randint(2, L + 1, (n_lab,), generator=lg, device=device)
+    lab_mask = (torch.arange(L, device=device)[None, :] < lens[:, None]).to(torch.int32)
+    cls_z = scorer.embed(lab_ids[: args.scorer_classes], lab_mask[: args.scorer_classes])
+    label = torch.randint(0, args.scorer_classes, (n_lab,), generator=lg, device=device, dtype=torch.int32)
+
+    def score():
+        z = scorer.embed(lab_ids, lab_mask)
+        return scorer.topk(z, cls_z, 5, label)
+
+    score()
+    sync()
+    s0 = time.perf_counter()
+    for _ in range(args.steps):
+        tv, ti, paired = score()
+    sync()
+    sdt = torch.tensor([time.perf_counter() - s0], device=device, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
+    labels_per_s = world * n_lab * args.steps / float(sdt.item())
+
+    if rank == 0:
+        f_img = flops_per_image(dims, T)
+        gemm_tflops = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        result = {
+            "metric": "images/sec (whole node) Qwen2-VL-7B open-world classify; label-cosine/sec",
+            "value": images_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Qwen2-VL-{args.model.upper()} open-world classify: {B} synthetic 448x448 images per GPU per step "
+                                   f"(1024 patches -> 256 image tokens), prompt S=286, {T} forced greedy tokens, seeded random "
+                                   "weights of the real architecture; images strided across ranks, no data-path collective",
+                       "images_per_gpu_per_step": B, "prompt_tokens": 286, "new_tokens": T, "parallelism": f"dp{world}"},
+            "label_cosine_per_sec": labels_per_s,
+            "label_cosine_config": {"labels_per_gpu": n_lab, "tokens_per_label": L, "classes": args.scorer_classes, "top_k": 5,
+                                    "encoder": "MiniLM-L6 (BERT 6x384) fp32 on f32-input MFMA"},
+            "model_flops_per_image": f_img,
+            "mfma_frac_end_to_end": images_per_s / world * f_img / (PEAK_BF16_TFLOPS * 1e12),
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel (all epilogues)", "achieved": gemm_tflops,
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tflops / PEAK_BF16_TFLOPS,
+                         "traffic": None, "launches": int(n_launch.value), "kernel_ms_total": ms.value,
+                         "share_of_step_time": ms.value * 1e-3 / (time_or(dt)), "method":
+                             "HIP events around every launch of the timed region on the launch stream; achieved = sum(2MNK) / sum(t)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline_lmm(key, T, args.cpu_images)
+                result["cpu_baseline_label_cosine"] = cpu_baseline_scorer(4096, L)
+            except Exception as e:  # the baseline must never sink the measurement
+                result["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "reference",
+                                          "sample": f"failed: {type(e).__name__}: {e}"}
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def time_or(x: float) -> float:
+    return x if x > 0 else 1.0
+
+
+if __name__ == "__main__":
+    main()

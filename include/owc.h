@@ -55,6 +55,13 @@ int owc_destroy(owc_ctx* ctx);
 const char* owc_last_error(const owc_ctx* ctx);
 int owc_abi_version(void); /* bumped whenever a signature in this header changes */
 
+/* ---- measurement hooks (bench.py roofline leg) ------------------------------------------------ */
+/* When enabled, every owc_gemm_bf16-family launch (also inside the model drivers) is bracketed by a
+ * HIP-event pair on its own stream.  owc_gemm_profile_read (call after synchronising) returns the summed
+ * kernel time, the summed algorithmic FLOPs (2*M*N*K per launch) and the launch count, then resets. */
+int owc_gemm_profile_enable(owc_ctx* ctx, int on);
+int owc_gemm_profile_read(owc_ctx* ctx, double* total_ms, double* total_flops, int64_t* launches);
+
 /* ---- op level (each is one kernel launch; used by the model drivers below and by tests) ------ */
 
 /* C[M,N] = A[M,K] . W[N,K]^T (+bias[N]) with a fused epilogue.  Replaces torch.nn.Linear.forward as

@@ -15,7 +15,7 @@ _lock = threading.Lock()
 _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = range(6)
 
@@ -107,6 +107,8 @@ SIGNATURES: dict[str, tuple] = {
     "owc_bert_embed": (i32, [vp, C.POINTER(BertWeights), vp, vp, i32, i32, vp, vp, sz, vp]),
     "owc_cosine_topk": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "owc_paired_dot": (i32, [vp, vp, vp, i32, i32, vp, vp]),
+    "owc_gemm_profile_enable": (i32, [vp, i32]),
+    "owc_gemm_profile_read": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
 

@@ -13,7 +13,7 @@
 
 extern "C" {
 
-int owc_abi_version(void) { return 2; }
+int owc_abi_version(void) { return 3; }
 
 int owc_init(int device, owc_ctx** out) {
   if (out == nullptr) return OWC_ERR_ARG;
@@ -126,6 +126,20 @@ int owc_decode_update(owc_ctx* ctx, int32_t* next_tok, uint8_t* done, int32_t* o
   if (!ctx || !next_tok || !done || !out_tokens) return OWC_ERR_ARG;
   RET(ctx, "owc_decode_update",
       owc_launch_decode_update(next_tok, done, out_tokens, out_stride, step, B, eos_id0, eos_id1, pad_id, ST(stream)));
+}
+
+int owc_gemm_profile_enable(owc_ctx* ctx, int on) {
+  if (!ctx) return OWC_ERR_ARG;
+  owc_gemm_profile_set(on);
+  return OWC_OK;
+}
+
+int owc_gemm_profile_read(owc_ctx* ctx, double* total_ms, double* total_flops, int64_t* launches) {
+  if (!ctx || !total_ms || !total_flops || !launches) return OWC_ERR_ARG;
+  long n = 0;
+  int rc = owc_gemm_profile_collect(total_ms, total_flops, &n);
+  *launches = n;
+  RET(ctx, "owc_gemm_profile_read", rc);
 }
 
 }  // extern "C"

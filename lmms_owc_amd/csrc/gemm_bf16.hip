@@ -22,8 +22,19 @@
 //  * XCD-aware block->tile map: blocks that share an XCD (bid % 8) walk a contiguous range of
 //    tiles in GROUP_M-major order so A/W panels are reused out of that XCD's L2.
 #include "owc_common.h"
+#include <vector>
 
 namespace {
+
+// ---- optional live profiling of THIS kernel (bench.py roofline leg): one HIP-event pair per launch on
+// the launch stream, summed by owc_gemm_profile_read().  Off by default (zero cost).
+struct GemmProfile {
+  bool on = false;
+  std::vector<hipEvent_t> ev;  // start/stop pairs
+  std::vector<double> flops;
+  size_t used = 0;
+};
+GemmProfile g_prof;
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
@@ -204,9 +215,24 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
       return OWC_ERR_HIP;
     attr_set = true;
   }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_prof.on) {
+    if (g_prof.used + 2 > g_prof.ev.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return OWC_ERR_HIP;
+      g_prof.ev.push_back(a);
+      g_prof.ev.push_back(b);
+    }
+    e0 = g_prof.ev[g_prof.used];
+    e1 = g_prof.ev[g_prof.used + 1];
+    g_prof.used += 2;
+    g_prof.flops.push_back(2.0 * (double)M * (double)N * (double)K);
+    (void)hipEventRecord(e0, s);
+  }
   hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, s,
                      (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
                      (const bf16_t*)R, ldr, C, ldc, M, N, K, zeros, tiles_m, tiles_n);
+  if (e1) (void)hipEventRecord(e1, s);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 
@@ -229,4 +255,30 @@ int owc_launch_gemm_bf16(const void* A, long lda, const void* W, long ldw, const
     case OWC_EPI_F32: return launch<OWC_EPI_F32>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, s);
     default: return OWC_ERR_ARG;
   }
+}
+
+// ---- profiling hooks (C ABI: owc_gemm_profile_enable / owc_gemm_profile_read in api.hip) ----
+void owc_gemm_profile_set(int on) {
+  g_prof.on = on != 0;
+  g_prof.used = 0;
+  g_prof.flops.clear();
+}
+
+// Sums the recorded launches (the caller has synchronised the stream): total kernel milliseconds,
+// total algorithmic FLOPs (2*M*N*K per launch) and the launch count; then resets the recording.
+int owc_gemm_profile_collect(double* total_ms, double* total_flops, long* launches) {
+  double ms = 0.0, fl = 0.0;
+  const size_t n = g_prof.used / 2;
+  for (size_t i = 0; i < n; ++i) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return OWC_ERR_HIP;
+    ms += t;
+    fl += g_prof.flops[i];
+  }
+  *total_ms = ms;
+  *total_flops = fl;
+  *launches = (long)n;
+  g_prof.used = 0;
+  g_prof.flops.clear();
+  return OWC_OK;
 }
