@@ -10,6 +10,11 @@ import ctypes as C
 import threading
 from pathlib import Path
 
+# torch ships its own libamdhip64: it must be the HIP runtime of the process, so import torch BEFORE
+# dlopen-ing libowc_hip.so (whose DT_NEEDED libamdhip64.so.7 then binds to the already loaded runtime).
+# Loading the extension first would put a second HIP runtime in the process (hipSetDevice fails).
+import torch  # noqa: F401
+
 _LIB_PATH = Path(__file__).resolve().parent / "libowc_hip.so"
 _lock = threading.Lock()
 _lib: C.CDLL | None = None
