@@ -55,6 +55,9 @@ DIMS = {
                                tie_embeddings=True),
     "qwen2-vl-7b": Qwen2VLDims(),
     "qwen2-vl-72b": Qwen2VLDims(n_layers=80, d_model=8192, n_q_heads=64, n_kv_heads=8, d_ff=29568, vocab=152064),
+    # structure-preserving miniature for tests / smoke runs (GQA, head_dim 128, vision head_dim 80)
+    "tiny": Qwen2VLDims(v_depth=2, v_embed=160, v_heads=2, v_mlp=640, n_layers=2, d_model=256, n_q_heads=2, n_kv_heads=1,
+                        d_ff=512, vocab=512, tie_embeddings=False, max_positions=2048, max_grid=128),
 }
 
 

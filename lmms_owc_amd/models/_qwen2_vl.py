@@ -1,0 +1,231 @@
+"""`Qwen2VL` model plug-in on the MI355X engine — drop-in for /root/reference/src/models/_qwen2_vl.py.
+
+Same constructor kwargs (`:59-72`), same registry names (`:619-632`), same `generate_until` contract
+(`list[TaskInstance] -> list[str]`, same length and order, `:143-348`), but requests are BATCHED: images of a
+chunk go through the HIP vision tower together, prompts are prefilled packed and decoded as one batch.
+`model_name_or_path="synthetic:<registry-name>"` builds seeded random weights + a byte tokenizer (no
+checkpoint exists offline); a local HF checkpoint directory loads real weights, tokenizer and chat template.
+"""
+
+from __future__ import annotations
+
+import json
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .. import ops, utils
+from ..engine.qwen2vl import DIMS, Qwen2VLDims, Qwen2VLEngine, Qwen2VLWeights
+from . import imageproc
+from ._api import register_model
+from ._base import Model
+
+__all__ = ["Qwen2VL"]
+
+SYSTEM_PROMPT = "You are a helpful assistant."
+
+
+class ByteTokenizer:
+    """Stand-in tokenizer for synthetic runs: UTF-8 bytes + 3, specials above the byte range."""
+
+    name_or_path = "synthetic-bytes"
+    pad_token_id, eos_token_id = 0, 1
+    im_start, im_end, vision_start, vision_end, image_pad = 260, 261, 262, 263, 264
+
+    def encode(self, text: str) -> list[int]:
+        return [b + 3 for b in text.encode("utf-8")]
+
+    def decode(self, ids, skip_special_tokens: bool = True) -> str:
+        if isinstance(ids, int):
+            ids = [ids]
+        return bytes(int(i) - 3 for i in ids if 3 <= int(i) < 259).decode("utf-8", errors="replace")
+
+    def batch_decode(self, rows, skip_special_tokens: bool = True, **_) -> list[str]:
+        return [self.decode(r) for r in rows]
+
+    def chat_ids(self, question: str, n_image_tokens: list[int]) -> list[int]:
+        ids = [self.im_start] + self.encode("system\n" + SYSTEM_PROMPT) + [self.im_end] + self.encode("\n")
+        ids += [self.im_start] + self.encode("user\n")
+        for n in n_image_tokens:
+            ids += [self.vision_start] + [self.image_pad] * n + [self.vision_end]
+        ids += self.encode(question) + [self.im_end] + self.encode("\n") + [self.im_start] + self.encode("assistant\n")
+        return ids
+
+
+class Qwen2VL(Model):
+    def __init__(self, model_name_or_path: str = "Qwen/Qwen2-VL-7B-Instruct", use_cache: bool = True,
+                 use_flash_attention_2: bool | None = False, max_pixels: int = 1024 * 28 * 28,
+                 min_pixels: int = 4 * 28 * 28, batch_size: int = 1, device_map: str = "auto",
+                 dtype: str | torch.dtype = "bfloat16", load_in_8bit: bool = False, load_in_4bit: bool = False,
+                 **kwargs) -> None:
+        self._model_name_or_path = model_name_or_path
+        self._use_cache = use_cache                    # the HIP decoder always uses its KV cache
+        self._use_flash_attention_2 = use_flash_attention_2  # accepted; attention is always the fused HIP kernel
+        self._max_pixels = max_pixels
+        self._min_pixels = min_pixels
+        super().__init__(batch_size=batch_size, device_map=device_map, dtype=dtype, load_in_8bit=load_in_8bit,
+                         load_in_4bit=load_in_4bit, distributed_types=["FSDP", "MULTI_GPU"], **kwargs)
+
+    # ------------------------------------------------------------------ loading
+    def load_model(self) -> None:
+        name = self._model_name_or_path
+        if name.startswith("synthetic:"):
+            key = name.split(":", 1)[1]
+            dims = DIMS[key]
+            tok = ByteTokenizer()
+            dims = Qwen2VLDims(**{**dims.__dict__, "image_token_id": tok.image_pad})
+            weights = Qwen2VLWeights.random(dims, self._device, seed=1234)
+            self._tokenizer = tok
+        else:
+            path = Path(name)
+            if not path.is_dir():
+                from huggingface_hub import snapshot_download
+
+                path = Path(snapshot_download(name))
+            dims = dims_from_hf_config(json.loads((path / "config.json").read_text()))
+            weights = Qwen2VLWeights.from_state_dict(dims, LazyCheckpoint(path), self._device)
+            from transformers import AutoTokenizer
+
+            self._tokenizer = AutoTokenizer.from_pretrained(str(path))
+            self.chat_template = getattr(self._tokenizer, "chat_template", None)
+        self._dims = dims
+        self._model = Qwen2VLEngine(weights)
+        self._processor = self._tokenizer
+
+    def loglikelihood(self, requests: list) -> list[tuple[float, bool]]:
+        raise NotImplementedError("Loglikelihood is not implemented for Qwen2_VL")  # as the reference (:141)
+
+    def generate_until_multi_round(self, requests: list) -> list[str]:
+        raise NotImplementedError("multi-round generation is outside the accelerated path (SURVEY.md §8f)")
+
+    # ------------------------------------------------------------------ prompt building
+    def _prompt_ids(self, context: str, n_image_tokens: list[int]) -> np.ndarray:
+        tok = self._tokenizer
+        if isinstance(tok, ByteTokenizer):
+            return np.asarray(tok.chat_ids(context, n_image_tokens), dtype=np.int32)
+        content = [{"type": "image"} for _ in n_image_tokens] + [{"type": "text", "text": context}]
+        messages = [{"role": "system", "content": SYSTEM_PROMPT}, {"role": "user", "content": content}]
+        text = tok.apply_chat_template(messages, tokenize=False, add_generation_prompt=True)
+        ids = tok.encode(text)
+        # expand every single <|image_pad|> placeholder to the image's token count (HF processor behaviour)
+        out, it = [], iter(n_image_tokens)
+        for t in ids:
+            if t == self._dims.image_token_id:
+                out.extend([t] * next(it))
+            else:
+                out.append(t)
+        return np.asarray(out, dtype=np.int32)
+
+    # ------------------------------------------------------------------ the hot loop
+    def generate_until(self, requests: list) -> list[str]:
+        res: list[str] = []
+
+        def _collate(x):
+            return -len(self._tokenizer.encode(x[0])), x[0]
+
+        reordered = utils.Collator([reg.args for reg in requests], _collate, grouping=True)
+        for chunk in reordered.get_batched(n=self.batch_size, batch_fn=None):
+            contexts, all_gen_kwargs, doc_to_visual, doc_ids, tasks, splits = zip(*chunk, strict=True)
+            task, split = tasks[0], splits[0]
+            gen_kwargs = dict(all_gen_kwargs[0])
+            gen_kwargs.pop("until", None)  # popped and unused in the reference's single-round mode (:211-219)
+            max_new = int(gen_kwargs.get("max_new_tokens", 128))
+            if gen_kwargs.get("temperature", 0) not in (0, 0.0) or gen_kwargs.get("num_beams", 1) != 1:
+                raise NotImplementedError("the HIP decoder implements greedy decoding (temperature 0, 1 beam)")
+
+            images, grids_per_prompt, prompts = [], [], []
+            for ctx, did in zip(contexts, doc_ids):
+                visuals = doc_to_visual[0](self.task_dict[task][split][did])
+                arrs = [imageproc.prepare_image(v, self._min_pixels, self._max_pixels) for v in visuals]
+                grids = [(1, a.shape[1] // 14, a.shape[2] // 14) for a in arrs]
+                images += arrs
+                grids_per_prompt.append(grids)
+                n_tok = [g[1] * g[2] // 4 for g in grids]
+                prompts.append(self._prompt_ids(ctx.replace("<image>", ""), n_tok))
+
+            emb = None
+            if images:
+                pix = self._pixel_values(images)
+                emb = self._model.encode_images(pix, [g for gs in grids_per_prompt for g in gs])
+            tok = self._tokenizer
+            pad = tok.pad_token_id if tok.pad_token_id is not None else 0
+            out = self._model.generate(prompts, emb, grids_per_prompt, max_new, eos_token_id=tok.eos_token_id,
+                                       pad_token_id=pad).cpu().numpy()
+            rows = []
+            for r in out:
+                stop = np.flatnonzero(r == tok.eos_token_id)
+                rows.append(r[: stop[0]] if len(stop) else r)
+            answers = tok.batch_decode(rows, skip_special_tokens=True, clean_up_tokenization_spaces=False)
+            for ans, ctx in zip(answers, contexts):
+                res.append(ans)
+                self.cache_hook.add_partial("generate_until", (ctx, gen_kwargs), ans)
+        return reordered.get_original(res)
+
+    def _pixel_values(self, images: list[np.ndarray]) -> torch.Tensor:
+        """uint8 CHW arrays (sides % 28 == 0) -> packed pixel_values rows on the GPU; same-size images share a launch."""
+        rows = sum((a.shape[1] // 14) * (a.shape[2] // 14) for a in images)
+        pix = torch.empty((rows, 1176), dtype=torch.bfloat16, device=self._device)
+        r0, i = 0, 0
+        while i < len(images):
+            j = i
+            while j < len(images) and images[j].shape == images[i].shape:
+                j += 1
+            batch = torch.from_numpy(np.stack(images[i:j])).to(self._device, non_blocking=True)
+            n = (j - i) * (images[i].shape[1] // 14) * (images[i].shape[2] // 14)
+            ops.patchify_u8(batch, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD, out=pix[r0:r0 + n])
+            r0 += n
+            i = j
+        return pix
+
+
+def dims_from_hf_config(cfg: dict) -> Qwen2VLDims:
+    t = cfg.get("text_config", cfg)
+    v = cfg["vision_config"]
+    rope = t.get("rope_parameters") or t.get("rope_scaling") or {}
+    return Qwen2VLDims(
+        v_depth=v["depth"], v_embed=v["embed_dim"], v_heads=v["num_heads"], v_mlp=int(v["embed_dim"] * v.get("mlp_ratio", 4)),
+        patch_k=v.get("in_channels", v.get("in_chans", 3)) * v.get("temporal_patch_size", 2) * v.get("patch_size", 14) ** 2,
+        merge=v.get("spatial_merge_size", 2), n_layers=t["num_hidden_layers"], d_model=t["hidden_size"],
+        n_q_heads=t["num_attention_heads"], n_kv_heads=t["num_key_value_heads"],
+        head_dim=t["hidden_size"] // t["num_attention_heads"], d_ff=t["intermediate_size"], vocab=t["vocab_size"],
+        tie_embeddings=bool(cfg.get("tie_word_embeddings", t.get("tie_word_embeddings", False))),
+        rms_eps=t.get("rms_norm_eps", 1e-6), rope_theta=rope.get("rope_theta", t.get("rope_theta", 1e6)),
+        mrope_section=tuple(rope.get("mrope_section", (16, 24, 24))), image_token_id=cfg.get("image_token_id", 151655))
+
+
+class LazyCheckpoint:
+    """name -> tensor over safetensors shards; accepts both the 4.47 (`visual.`, `model.layers.`) and the
+    5.x (`model.visual.`, `model.language_model.layers.`) parameter naming."""
+
+    def __init__(self, path: Path) -> None:
+        from safetensors import safe_open
+
+        self._files = {}
+        for f in sorted(path.glob("*.safetensors")):
+            h = safe_open(str(f), framework="pt", device="cpu")
+            for k in h.keys():
+                self._files[k] = h
+        if not self._files:
+            raise FileNotFoundError(f"no safetensors shards under {path}")
+
+    def __getitem__(self, name: str):
+        for cand in (name, name.replace("model.visual.", "visual."), name.replace("model.language_model.", "model.")):
+            if cand in self._files:
+                return self._files[cand].get_tensor(cand)
+        raise KeyError(name)
+
+
+@register_model("qwen2-vl-7b")
+def qwen2_vl_7b(**model_kwargs) -> Qwen2VL:
+    return Qwen2VL(model_kwargs.pop("model_name_or_path", "Qwen/Qwen2-VL-7B-Instruct"), **model_kwargs)
+
+
+@register_model("qwen2-vl-2b")
+def qwen2_vl_2b(**model_kwargs) -> Qwen2VL:
+    return Qwen2VL(model_kwargs.pop("model_name_or_path", "Qwen/Qwen2-VL-2B-Instruct"), **model_kwargs)
+
+
+@register_model("qwen2-vl-72b")
+def qwen2_vl_72b(**model_kwargs) -> Qwen2VL:
+    return Qwen2VL(model_kwargs.pop("model_name_or_path", "Qwen/Qwen2-VL-72B-Instruct"), **model_kwargs)

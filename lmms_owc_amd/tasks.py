@@ -1,0 +1,189 @@
+"""The slice of the reference's task layer that the open-world classification loop touches:
+
+* `TaskInstance` (src/data/tasks/_base.py:29-55) — request tuple
+  `(context, gen_kwargs, doc_to_visual, doc_id, task, split)` (src/data/tasks/_manager.py:895-902);
+* `build_all_requests` sharding through `create_iterator` (src/data/tasks/_base.py:363-368);
+* `process_results`, generate_until branch (src/data/tasks/_manager.py:938-942, :1030-1090): strip the
+  response, call `fn(references=[gold], predictions=[pred], **kw)` and fall back to storing `[gold, [pred]]`
+  for passthrough metrics;
+* the `take_first` filter (src/data/filters/_selection.py:36-52).
+
+Task definitions are small YAML files (prompt, generation kwargs, metric list) mirroring
+src/data/tasks/_classification/*/base.yaml + assets/_default_template_yaml; documents come from a JSONL
+manifest, a `datasets.load_from_disk` directory, or a seeded synthetic generator (no dataset exists offline).
+"""
+
+from __future__ import annotations
+
+import json
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Any
+
+import numpy as np
+import yaml
+
+from . import utils
+from .metrics import get_metric_info
+
+CONFIG_DIR = Path(__file__).resolve().parent / "task_configs"
+
+
+@dataclass
+class TaskInstance:
+    request_type: str
+    arguments: tuple
+    idx: int
+    doc: dict | None = None
+    metadata: dict = field(default_factory=dict)
+    resps: list = field(default_factory=list)
+    filtered_resps: dict = field(default_factory=dict)
+    task_name: str | None = None
+    doc_id: int | None = None
+
+    @property
+    def args(self) -> tuple:
+        return self.arguments if isinstance(self.arguments, tuple) else (self.arguments,)
+
+
+DEFAULT_METRICS = [
+    {"metric": "exact_match", "aggregation": "mean", "higher_is_better": True, "ignore_case": True,
+     "ignore_punctuation": False, "regexes_to_ignore": [",", "\\$"]},
+    {"metric": "semantic_similarity", "aggregation": "semantic_similarity", "higher_is_better": True},
+    {"metric": "textual_inclusion", "aggregation": "mean", "higher_is_better": True},
+]
+
+
+class ClassificationTask:
+    """`output_type: generate_until`, `test_split: test` open-world classification task."""
+
+    OUTPUT_TYPE = "generate_until"
+
+    def __init__(self, name: str, docs: list[dict], prompt: str = "What type of object is in this photo?",
+                 pre_prompt: str = "", post_prompt: str = "", generation_kwargs: dict | None = None,
+                 metric_list: list[dict] | None = None, split: str = "test") -> None:
+        self.task_name = name
+        self.split = split
+        self.docs = docs
+        self.prompt, self.pre_prompt, self.post_prompt = prompt, pre_prompt, post_prompt
+        self.generation_kwargs = dict(generation_kwargs or {"max_new_tokens": 64, "do_sample": False})
+        self.metric_list = metric_list or DEFAULT_METRICS
+        self._metric_fn, self._metric_kwargs, self._agg, self._higher = {}, {}, {}, {}
+        for m in self.metric_list:
+            m = dict(m)
+            name_ = m.pop("metric")
+            info = get_metric_info(name_)
+            self._metric_fn[name_] = info.builder_fn
+            self._agg[name_] = info.group_fn
+            self._higher[name_] = m.pop("higher_is_better", info.higher_is_better)
+            m.pop("aggregation", None)
+            self._metric_kwargs[name_] = m
+        self.instances: list[TaskInstance] = []
+
+    # ---- document accessors (…/_caltech101_utils.py:75-94)
+    @property
+    def dataset(self) -> dict:
+        return {self.split: self.docs}
+
+    def doc_to_text(self, doc: dict) -> str:
+        return f"{self.pre_prompt}{self.prompt}{self.post_prompt}"
+
+    @staticmethod
+    def doc_to_target(doc: dict) -> str:
+        return str(doc["target"]).replace("_", " ")
+
+    @staticmethod
+    def doc_to_visual(doc: dict) -> list:
+        v = doc["visual"]
+        if isinstance(v, (str, Path)):
+            from PIL import Image
+
+            return [Image.open(v).convert("RGB")]
+        return [v.convert("RGB")]
+
+    # ---- request construction with the reference's strided shard
+    def build_all_requests(self, *, limit: int | None = None, rank: int = 0, world_size: int = 1) -> None:
+        self.instances = []
+        it = utils.create_iterator(enumerate(self.docs), rank, world_size, limit)
+        for doc_id, doc in it:
+            args = (self.doc_to_text(doc), dict(self.generation_kwargs), self.doc_to_visual, doc_id, self.task_name, self.split)
+            self.instances.append(TaskInstance("generate_until", args, idx=0, doc=doc, task_name=self.task_name, doc_id=doc_id))
+
+    def apply_filters(self) -> None:
+        for inst in self.instances:  # default ensemble ("none", [take_first])
+            inst.filtered_resps["none"] = inst.resps[0]
+
+    def process_results(self, doc: dict, results: list) -> dict:
+        if isinstance(results, list) and results and isinstance(results[0], list):
+            results = results[0]
+        result = [r.strip() for r in results]
+        gold = [self.doc_to_target(doc)]
+        out = {}
+        for metric, fn in self._metric_fn.items():
+            try:
+                score = fn(references=gold, predictions=result, **self._metric_kwargs[metric])
+            except TypeError:  # passthrough metric: keep the pair for the batched aggregation
+                score = fn([gold, result])
+            if isinstance(score, dict):
+                score = score[metric]
+            out[metric] = score
+        return out
+
+    def aggregation(self) -> dict:
+        return dict(self._agg)
+
+    def higher_is_better(self) -> dict:
+        return dict(self._higher)
+
+
+def load_task(name: str, *, data_root: str | Path = "data", include_path: str | Path | None = None) -> ClassificationTask:
+    """`name` is a YAML task config (task_configs/ or --include_path) or `synthetic:<n>:<H>x<W>[:<classes>]`."""
+    if name.startswith("synthetic"):
+        return synthetic_task(name)
+    for base in ([Path(include_path)] if include_path else []) + [CONFIG_DIR]:
+        f = base / f"{name}.yaml"
+        if f.exists():
+            cfg = yaml.safe_load(f.read_text())
+            break
+    else:
+        raise KeyError(f"unknown task '{name}' (no {name}.yaml under {CONFIG_DIR} or --include_path)")
+    msk = (cfg.get("model_specific_kwargs") or {}).get("default", {})
+    docs = load_docs(Path(cfg.get("dataset_path", Path(data_root) / name)), cfg.get("test_split", "test"))
+    return ClassificationTask(cfg.get("task", name), docs, prompt=msk.get("prompt", "What type of object is in this photo?"),
+                              pre_prompt=msk.get("pre_prompt", ""), post_prompt=msk.get("post_prompt", ""),
+                              generation_kwargs=cfg.get("generation_kwargs"), metric_list=cfg.get("metric_list"),
+                              split=cfg.get("test_split", "test"))
+
+
+def load_docs(path: Path, split: str) -> list[dict]:
+    manifest = path / f"{split}.jsonl"
+    if manifest.exists():
+        docs = [json.loads(line) for line in manifest.read_text().splitlines() if line.strip()]
+        for d in docs:
+            if isinstance(d["visual"], str) and not Path(d["visual"]).is_absolute():
+                d["visual"] = str(path / d["visual"])
+        return docs
+    if (path / "dataset_dict.json").exists() or (path / split).exists():
+        import datasets
+
+        ds = datasets.load_from_disk(str(path))
+        ds = ds[split] if isinstance(ds, datasets.DatasetDict) else ds
+        return [dict(r) for r in ds]
+    raise FileNotFoundError(f"no {split}.jsonl manifest or saved `datasets` directory under {path}")
+
+
+def synthetic_task(spec: str) -> ClassificationTask:
+    """`synthetic:<n>:<H>x<W>:<classes>` — seeded uint8 images + class names (benchmarks / tests)."""
+    from PIL import Image
+
+    parts = spec.split(":")
+    n = int(parts[1]) if len(parts) > 1 else 16
+    h, w = (int(x) for x in parts[2].split("x")) if len(parts) > 2 else (448, 448)
+    c = int(parts[3]) if len(parts) > 3 else 10
+    rng = np.random.default_rng(1234)
+    names = [f"class_{i}" for i in range(c)]
+    docs = []
+    for i in range(n):
+        arr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        docs.append({"visual": Image.fromarray(arr, "RGB"), "target": names[i % c]})
+    return ClassificationTask("synthetic", docs, generation_kwargs={"max_new_tokens": 8, "do_sample": False})

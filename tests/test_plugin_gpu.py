@@ -1,0 +1,89 @@
+"""End-to-end drop-in path on the GPU: model registry -> batched generate_until -> evaluate loop ->
+samples JSONL -> eval_metrics.py offline scorer (sentence encoder on the HIP scorer)."""
+import json
+import re
+from argparse import Namespace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class HashTokenizer:
+    """Word -> id by crc32 (no tokenizer files offline); pad-to-longest like AutoTokenizer(padding=True)."""
+
+    def __call__(self, text, padding=True, truncation=True, return_tensors="np"):
+        import zlib
+
+        rows = [[101] + [1000 + zlib.crc32(w.encode()) % 20000 for w in re.findall(r"\w+", t.lower())][:30] + [102] for t in text]
+        L = max(len(r) for r in rows)
+        ids = np.array([r + [0] * (L - len(r)) for r in rows], dtype=np.int64)
+        mask = np.array([[1] * len(r) + [0] * (L - len(r)) for r in rows], dtype=np.int64)
+        return {"input_ids": ids, "attention_mask": mask}
+
+
+@pytest.fixture(scope="module")
+def scorer(gpu):
+    from lmms_owc_amd.engine.scorer import MINILM_L6, BertWeights, SentenceScorer
+    from lmms_owc_amd.pipelines import text
+
+    sc = SentenceScorer(BertWeights.random(MINILM_L6, gpu, seed=3))
+    text.set_sentence_bert(sc, HashTokenizer())
+    return sc
+
+
+def test_generate_until_batch_invariant_and_ordered(gpu):
+    from lmms_owc_amd.models import get_model
+    from lmms_owc_amd.tasks import load_task
+
+    task = load_task("synthetic:7:56x84:3")
+    task.build_all_requests(limit=None, rank=0, world_size=1)
+    outs = []
+    for bs in (1, 4):
+        lm = get_model("custom-model", model_type="qwen2-vl", model_name_or_path="synthetic:tiny", batch_size=bs)
+        lm.task_dict[task.task_name] = task.dataset
+        outs.append(lm.generate_until(task.instances))
+    assert len(outs[0]) == 7 and outs[0] == outs[1]
+    with pytest.raises(ValueError):
+        get_model("custom-model", model_type="qwen2-vl", model_name_or_path="synthetic:tiny", bogus=1)
+
+
+def test_evaluate_then_offline_metrics(gpu, scorer, tmp_path, capsys):
+    import eval_metrics
+    from lmms_owc_amd.engine.evaluate import simple_evaluate
+    from lmms_owc_amd.engine.tracker import EngineTracker
+    from lmms_owc_amd.pipelines.text import encode_sentence_bert
+
+    res = simple_evaluate(model="custom-model", model_args="model_type=qwen2-vl,model_name_or_path=synthetic:tiny",
+                          tasks=["synthetic:6:84x56:3"], batch_size=4, limit=5)
+    r = res["results"]["synthetic:6:84x56:3"]
+    assert set(r) >= {"exact_match,none", "semantic_similarity,none", "textual_inclusion,none", "exact_match_stderr,none"}
+    assert -1.0 <= r["semantic_similarity,none"] <= 1.0 and r["semantic_similarity_stderr,none"] == "N/A"
+    samples = res["samples"]["synthetic:6:84x56:3"]
+    assert [s["doc_id"] for s in samples] == [0, 1, 2, 3, 4]
+    out_dir = tmp_path / "logs" / "schedule" / "synthetic" / "tiny-model"
+    tr = EngineTracker(output_path=str(out_dir))
+    tr.log_experiment_args(model_args="")
+    tr.save_results_aggregated({k: v for k, v in res.items() if k != "samples"}, res["samples"], "2026-01-01T00:00:00")
+    f = tr.save_results_samples("synthetic", samples)
+    rec = json.loads(f.read_text().splitlines()[0])
+    assert list(rec)[:6] == ["doc_id", "doc", "target", "arguments", "resps", "filtered_resps"] and "input" in rec
+    # offline re-scoring rewrites the JSONL in place with per-sample columns and prints the table
+    out = eval_metrics.main(Namespace(input=str(tmp_path / "logs" / "schedule"), metrics="semantic_similarity,textual_inclusion,mean_average_semantic_similarity",
+                                      seed=1234, log_level="WARNING"))
+    rec = json.loads(f.read_text().splitlines()[0])
+    assert "semantic_similarity" in rec and "semantic_similarity@0.5" in rec
+    per_sample = [json.loads(l)["semantic_similarity"] for l in f.read_text().splitlines()]
+    assert abs(np.mean(per_sample) - out["synthetic"]["tiny-model"]["semantic_similarity"]) < 1e-6
+    assert "tiny-model" in capsys.readouterr().out
+    # the hook contract of encode_sentence_bert: adds a list[list[float]] column of unit vectors
+    b = encode_sentence_bert({"reference": ["sea lion", "a dog"]}, input_column="reference")
+    z = np.array(b["reference_sentence_bert_embeds"])
+    assert z.shape == (2, 384) and np.allclose(np.linalg.norm(z, axis=1), 1.0, atol=1e-5)
+    # paired cosine of identical strings is 1
+    from lmms_owc_amd.metrics import get_metric_info
+
+    ss = get_metric_info("semantic_similarity")
+    vals = ss.group_fn(ss.builder_fn([("sea lion", ["x", "sea lion"]), (["golden retriever"], "golden retriever")]), reduce="none")
+    assert np.allclose(vals, 1.0, atol=1e-5)
