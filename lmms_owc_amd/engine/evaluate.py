@@ -42,7 +42,8 @@ def simple_evaluate(model: str, model_args: str | dict = "", tasks: list[str] | 
     torch.manual_seed(torch_random_seed)
     task_dict: dict[str, ClassificationTask] = dict(task_objects or {})
     for name in tasks or []:
-        task_dict[name] = load_task(name, data_root=data_root, include_path=include_path)
+        t = load_task(name, data_root=data_root, include_path=include_path)
+        task_dict[t.task_name] = t  # requests carry task.task_name (tasks/_manager.py:895-902)
     if isinstance(model_args, str):
         model_args = utils.parse_string_args(model_args)
     lm = model_object if model_object is not None else get_model(model, batch_size=batch_size, **model_args)
@@ -52,8 +53,8 @@ def simple_evaluate(model: str, model_args: str | dict = "", tasks: list[str] | 
         gk = utils.parse_string_args(gen_kwargs) if isinstance(gen_kwargs, str) else dict(gen_kwargs)
         for t in task_dict.values():
             t.generation_kwargs.update(gk)
-    for name, t in task_dict.items():
-        lm.task_dict[name] = t.dataset
+    for t in task_dict.values():
+        lm.task_dict[t.task_name] = t.dataset
     results = evaluate(lm, task_dict, limit=limit, log_samples=log_samples)
     if results is not None:
         results["config"] = {"model": model if isinstance(model, str) else type(lm).__name__, "model_args": model_args,

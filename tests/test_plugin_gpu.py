@@ -57,10 +57,10 @@ def test_evaluate_then_offline_metrics(gpu, scorer, tmp_path, capsys):
 
     res = simple_evaluate(model="custom-model", model_args="model_type=qwen2-vl,model_name_or_path=synthetic:tiny",
                           tasks=["synthetic:6:84x56:3"], batch_size=4, limit=5)
-    r = res["results"]["synthetic:6:84x56:3"]
+    r = res["results"]["synthetic"]
     assert set(r) >= {"exact_match,none", "semantic_similarity,none", "textual_inclusion,none", "exact_match_stderr,none"}
     assert -1.0 <= r["semantic_similarity,none"] <= 1.0 and r["semantic_similarity_stderr,none"] == "N/A"
-    samples = res["samples"]["synthetic:6:84x56:3"]
+    samples = res["samples"]["synthetic"]
     assert [s["doc_id"] for s in samples] == [0, 1, 2, 3, 4]
     out_dir = tmp_path / "logs" / "schedule" / "synthetic" / "tiny-model"
     tr = EngineTracker(output_path=str(out_dir))
