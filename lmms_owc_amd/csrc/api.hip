@@ -2,6 +2,7 @@
 // The model-level entries live in qwen2vl.hip / bert.hip.
 #include "../../include/owc.h"
 #include "owc_internal.h"
+#include <cstdlib>
 
 #define ST(s) ((hipStream_t)(s))
 #define RET(ctx, name, rc)                                                        \
@@ -25,6 +26,8 @@ int owc_init(int device, owc_ctx** out) {
     delete ctx;
     return OWC_ERR_HIP;
   }
+  if (const char* e = getenv("OWC_GEMM_BIG_MIN_M")) owc_gemm_set_big_min_m(atoi(e));  // tuning / A-B knob
+  if (const char* e = getenv("OWC_GEMM_DBG")) owc_gemm_set_dbg(atoi(e));                // timing-only experiments
   *out = ctx;
   return OWC_OK;
 }

@@ -35,6 +35,8 @@ struct GemmProfile {
   size_t used = 0;
 };
 GemmProfile g_prof;
+int g_gemm_dbg = 0;       // experiment knob (OWC_GEMM_DBG): 1 = skip DMA, 2 = skip MFMA — results are garbage
+int g_big_min_m = 1024;  // M at and above which the 256x128 3-stage kernel is used (OWC_GEMM_BIG_MIN_M)
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
@@ -43,6 +45,92 @@ constexpr int GROUP_M = 8;
 __device__ __forceinline__ float act_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// ---- epilogue: lane owns row m = ..+fr, 4 consecutive columns n = ..+fq*4+{0..3} per tile ----
+// Loads (bias, residual) are issued unconditionally from clamped addresses so they batch; only the
+// stores are predicated on the ragged edges.
+template <int EPI, int MT>
+__device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mrow0, int ncol0, int fr, int fq,
+                                              const bf16_t* __restrict__ bias, const bf16_t* R, long ldr,
+                                              void* Cv, long ldc, int M, int N) {
+  if constexpr (EPI == OWC_EPI_SWIGLU) {
+    bf16_t* C = (bf16_t*)Cv;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mrow0 + mt * 16 + fr;
+#pragma unroll
+      for (int nt = 0; nt < 4; nt += 2) {
+        const int nb = ncol0 + nt * 16;  // gate rows nb.., up rows nb+16..
+        const int f = (nb >> 1) + fq * 4;
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = rbf(acc[nt][mt][e]);
+          const float u = rbf(acc[nt + 1][mt][e]);
+          o[e] = f2bf(rbf(act_silu(g)) * u);
+        }
+        if (m < M && nb + 16 + fq * 4 < N) *(bf16x4*)(C + (long)m * ldc + f) = o;
+      }
+    }
+  } else {
+    float bv[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = min(ncol0 + nt * 16 + fq * 4, N - 4);
+      if (bias != nullptr) {
+        const bf16x4 b = *(const bf16x4*)(bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[nt][e] = bf2f(b[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[nt][e] = 0.f;
+      }
+    }
+    // all residual tiles are read before the first store (R may alias C: in-place x += f(x))
+    bf16x4 rr[MT][4];
+    if constexpr (EPI == OWC_EPI_RESIDUAL) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const long mc = min(mrow0 + mt * 16 + fr, M - 1);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          rr[mt][nt] = *(const bf16x4*)(R + mc * ldr + min(ncol0 + nt * 16 + fq * 4, N - 4));
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mrow0 + mt * 16 + fr;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = ncol0 + nt * 16 + fq * 4;
+        const bool ok = (m < M) && (n < N);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][e] + bv[nt][e];
+        if constexpr (EPI == OWC_EPI_F32) {
+          if (ok) *(f32x4*)((float*)Cv + (long)m * ldc + n) = (f32x4){v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
+          if constexpr (EPI == OWC_EPI_QUICK_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_quick_gelu(v[e]);
+          } else if constexpr (EPI == OWC_EPI_GELU_ERF) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_gelu_erf(v[e]);
+          } else if constexpr (EPI == OWC_EPI_RESIDUAL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bf2f(rr[mt][nt][e]);
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+          if (ok) *(bf16x4*)((bf16_t*)Cv + (long)m * ldc + n) = o;
+        }
+      }
+    }
+  }
+}
 
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
@@ -142,76 +230,164 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns row m = ..+fr, 4 consecutive columns n = ..+fq*4+{0..3} per tile ----
+  gemm_epilogue<EPI, 4>(acc, m0 + wm * 64, n0 + wn * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Large-M variant: 256x256x64 block tile, 512 threads = 8 waves (2 along M x 4 along N), 128x64 per wave
+// (8x4 accumulator tiles = 128 VGPRs).  Why: with 128-wide tiles the kernel is bound by the L2 -> LDS
+// DMA rate of a CU (measured: the DMA stream alone takes as long as the MFMAs); a 256x256 tile halves
+// the operand bytes per FLOP.  Structure per K-tile (64 MFMAs per wave) — 4 phases of 16 MFMAs, each
+// (64 rows of the wave tile) x (all 64 columns) x (one 32-deep k-step), walked (rows, k) = (0,0) (1,0)
+// (1,1) (0,1) so that every phase consumes fragment blocks that were fetched from LDS during an EARLIER
+// phase (software pipeline over 4 register blocks of 4 fragments, 64 VGPRs).  One raw s_barrier per
+// K-tile, after phase 3: it publishes stage kt+1 (whose first fragments are prefetched under phase 4) and
+// frees stage kt's LDS buffer, into which the DMA of stage kt+2 is issued right away (a full K-tile of
+// lead time).  LDS: 2 stages x 64 KiB, one block of 8 waves per CU.
+// Requires K % 64 == 0 (no K tail; other shapes use the 128x128 kernel above).
+// ------------------------------------------------------------------------------------------------
+constexpr int BT = 256;
+constexpr int OP_BYTES = BT * BK * 2;        // 32 KiB per operand per stage
+constexpr int STAGE_BYTES = 2 * OP_BYTES;    // 64 KiB
+constexpr int GROUP_M2 = 4;
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
+    const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
+    const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv, long ldc, int M, int N, int K,
+    int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+
+  const int nblk = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int width = GROUP_M2 * tiles_n;
+  const int group = lid / width;
+  const int first_m = group * GROUP_M2;
+  const int gsize = min(tiles_m - first_m, GROUP_M2);
+  const int tm = first_m + (lid % width) % gsize;
+  const int tn = (lid % width) / gsize;
+  const int m0 = tm * BT, n0 = tn * BT;
+
+  // DMA sources: wave w stages rows [32w, 32w+32) of both operand tiles (4 pieces of 8 rows each);
+  // per-lane 32-bit byte offsets from the tile's (uniform) base pointer, rows clamped at the ragged edge.
+  const char* abase = (const char*)(A + (long)m0 * lda);
+  const char* wbase = (const char*)(W + (long)n0 * ldw);
+  unsigned aoff[4], woff[4];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wm * 64 + mt * 16 + fr;
-    if (m >= M) continue;
-    if constexpr (EPI == OWC_EPI_SWIGLU) {
-      bf16_t* C = (bf16_t*)Cv;
-#pragma unroll
-      for (int nt = 0; nt < 4; nt += 2) {
-        const int nb = n0 + wn * 64 + nt * 16;  // gate rows nb.., up rows nb+16..
-        if (nb + 16 + fq * 4 >= N) continue;
-        const int f = (nb >> 1) + fq * 4;
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float g = rbf(acc[nt][mt][e]);
-          const float u = rbf(acc[nt + 1][mt][e]);
-          o[e] = f2bf(rbf(act_silu(g)) * u);
-        }
-        *(bf16x4*)(C + (long)m * ldc + f) = o;
-      }
-    } else {
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wn * 64 + nt * 16 + fq * 4;
-        if (n >= N) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][e];
-        if (bias != nullptr) {
-          const bf16x4 b = *(const bf16x4*)(bias + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bf2f(b[e]);
-        }
-        if constexpr (EPI == OWC_EPI_F32) {
-          float* C = (float*)Cv;
-          *(f32x4*)(C + (long)m * ldc + n) = (f32x4){v[0], v[1], v[2], v[3]};
-        } else {
-          bf16_t* C = (bf16_t*)Cv;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
-          if constexpr (EPI == OWC_EPI_QUICK_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_quick_gelu(v[e]);
-          } else if constexpr (EPI == OWC_EPI_GELU_ERF) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_gelu_erf(v[e]);
-          } else if constexpr (EPI == OWC_EPI_RESIDUAL) {
-            const bf16x4 rr = *(const bf16x4*)(R + (long)m * ldr + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bf2f(rr[e]);
-          }
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-          *(bf16x4*)(C + (long)m * ldc + n) = o;
-        }
-      }
-    }
+  for (int j = 0; j < 4; ++j) {
+    const int row = 32 * w + 8 * j + (l >> 3);
+    const int c = (l & 7) ^ ((row >> 1) & 7);
+    aoff[j] = (unsigned)((long)min(row, M - 1 - m0) * lda * 2 + c * 16);
+    woff[j] = (unsigned)((long)min(row, N - 1 - n0) * ldw * 2 + c * 16);
   }
+  const int nk = K / BK;
+
+  auto stage = [&](int buf, int kt) {
+    char* la = lds + buf * STAGE_BYTES + w * 4096;
+    char* lw = la + OP_BYTES;
+    const long kb = (long)kt * (BK * 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      glds16(abase + kb + aoff[j], la + j * 1024);
+      glds16(wbase + kb + woff[j], lw + j * 1024);
+    }
+  };
+
+  const int wr = w >> 2, wc = w & 3;
+  const int fr = l & 15, fq = l >> 4;
+  const int swz = (fr >> 1) & 7;
+  // byte offsets (inside a stage) of this lane's fragment rows; k-step ks adds the chunk term
+  const int rowA = (wr * 128 + fr) * 128;
+  const int rowW = OP_BYTES + (wc * 64 + fr) * 128;
+  const int ch0 = ((0 + fq) ^ swz) << 4, ch1 = ((4 + fq) ^ swz) << 4;
+
+  f32x4 acc[4][8];  // [nt][mt]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // Fragment registers hold 4 blocks of 4 fragments: xa/ya = A blocks (4 m tiles of one half, one k-step),
+  // wk0/wk1 = the 4 W fragments (n tiles) of k-step 0 / 1.  64 VGPRs, each block is refilled from LDS
+  // while a phase that does not use it runs.
+  bf16x8 xa[4], ya[4], wk0[4], wk1[4];
+
+  auto read_a = [&](bf16x8 (&dst)[4], const char* sbase, int half, int ch) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dst[t] = *(const bf16x8*)(sbase + rowA + (half * 4 + t) * 2048 + ch);
+  };
+  auto read_w = [&](bf16x8 (&dst)[4], const char* sbase, int ch) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dst[t] = *(const bf16x8*)(sbase + rowW + t * 2048 + ch);
+  };
+  // 16 MFMAs: rows half mh of the wave tile, all 4 n tiles, one 32-deep k-step
+  auto phase = [&](const bf16x8 (&af)[4], const bf16x8 (&wf)[4], int mh) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        acc[n][mh * 4 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], af[m], acc[n][mh * 4 + m], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  stage(0, 0);
+  if (nk > 1) {
+    stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // stage 0 landed (stage 1's 8 pieces may fly)
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  read_a(xa, lds, 0, ch0);
+  read_w(wk0, lds, ch0);
+
+  // Per K-tile, phases walk (m half, k-step) = (0,0) (1,0) (1,1) (0,1): consecutive phases share either the
+  // W block or nothing but always need exactly what was fetched one phase earlier.
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* cur = lds + (kt & 1) * STAGE_BYTES;
+    const char* nxt = lds + ((kt + 1) & 1) * STAGE_BYTES;
+    read_a(ya, cur, 1, ch0);   // for phase 2
+    phase(xa, wk0, 0);         // phase 1: rows 0-63,  k-step 0
+    read_a(xa, cur, 1, ch1);   // for phase 3
+    read_w(wk1, cur, ch1);
+    phase(ya, wk0, 1);         // phase 2: rows 64-127, k-step 0
+    read_a(ya, cur, 0, ch1);   // for phase 4
+    phase(xa, wk1, 1);         // phase 3: rows 64-127, k-step 1
+    // every LDS read of stage kt by this wave has completed (lgkmcnt(0), issued >= one phase ago) and its DMA
+    // pieces of stage kt+1 have landed (issued a whole K-tile ago); the barrier publishes stage kt+1 and proves
+    // stage kt's buffer is no longer read by anyone.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kt + 2 < nk) stage(kt & 1, kt + 2);
+    read_a(xa, nxt, 0, ch0);   // next tile, phase 1
+    read_w(wk0, nxt, ch0);
+    phase(ya, wk1, 0);         // phase 4: rows 0-63,  k-step 1
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  gemm_epilogue<EPI, 8>(acc, m0 + wr * 128, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N);
 }
 
 template <int EPI>
 int launch(const void* A, long lda, const void* W, long ldw, const void* bias, const void* R,
            long ldr, void* C, long ldc, int M, int N, int K, const void* zeros, hipStream_t s) {
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const bool big = M >= g_big_min_m && N >= BT && (K % BK) == 0;
+  const int tiles_m = big ? (M + BT - 1) / BT : (M + BM - 1) / BM;
+  const int tiles_n = big ? (N + BT - 1) / BT : (N + BN - 1) / BN;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<EPI>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<EPI>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES) != hipSuccess)
       return OWC_ERR_HIP;
     attr_set = true;
   }
@@ -229,9 +405,14 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
     g_prof.flops.push_back(2.0 * (double)M * (double)N * (double)K);
     (void)hipEventRecord(e0, s);
   }
-  hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, s,
-                     (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
-                     (const bf16_t*)R, ldr, C, ldc, M, N, K, zeros, tiles_m, tiles_n);
+  if (big)
+    hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), 2 * STAGE_BYTES, s,
+                       (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
+                       (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n);
+  else
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, s,
+                       (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
+                       (const bf16_t*)R, ldr, C, ldc, M, N, K, zeros, tiles_m, tiles_n);
   if (e1) (void)hipEventRecord(e1, s);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
@@ -282,3 +463,6 @@ int owc_gemm_profile_collect(double* total_ms, double* total_flops, long* launch
   g_prof.flops.clear();
   return OWC_OK;
 }
+
+void owc_gemm_set_big_min_m(int m) { g_big_min_m = m; }
+void owc_gemm_set_dbg(int v) { g_gemm_dbg = v; }

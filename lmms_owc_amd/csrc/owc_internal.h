@@ -63,3 +63,5 @@ int owc_launch_gemm_f32(const float* A, long lda, const float* W, long ldw, cons
                         const void* zeros, hipStream_t s);
 void owc_gemm_profile_set(int on);
 int owc_gemm_profile_collect(double* total_ms, double* total_flops, long* launches);
+void owc_gemm_set_big_min_m(int m);
+void owc_gemm_set_dbg(int v);

@@ -27,7 +27,10 @@ SHAPES = [
 
 def main():
     dev = torch.device("cuda:0")
+    only = sys.argv[1] if len(sys.argv) > 1 else None
     for name, m, n, k in SHAPES:
+        if only and name != only:
+            continue
         a = torch.randn(m, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
         out = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
