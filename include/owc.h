@@ -66,7 +66,7 @@ int owc_gemm_profile_read(owc_ctx* ctx, double* total_ms, double* total_flops, i
 
 /* C[M,N] = A[M,K] . W[N,K]^T (+bias[N]) with a fused epilogue.  Replaces torch.nn.Linear.forward as
  * called from HF:268-275 (patch-embed conv == GEMM), :349-350, :296-301, :281-291, :501-504, :460-466.
- * K % 8 == 0, lda % 8 == 0, ldw % 8 == 0, N % 4 == 0, ldc % 4 == 0. */
+ * K % 8 == 0, lda % 8 == 0, ldw % 8 == 0; bf16 outputs: N % 8 == 0, ldc % 8 == 0 (16-byte stores). */
 int owc_gemm_bf16(owc_ctx* ctx, const void* A, int64_t lda, const void* W, int64_t ldw,
                   const void* bias, const void* residual, int64_t ldr, void* C, int64_t ldc,
                   int M, int N, int K, int epilogue, void* stream);

@@ -17,6 +17,8 @@ SHAPES = [
     ("7b.o", 18304, 3584, 3584),
     ("7b.gateup", 18304, 37888, 3584),
     ("7b.down", 18304, 3584, 18944),
+    ("vit.qkv.x8", 32768, 4096, 1280),
+    ("vit.qkv.k5120", 32768, 4096, 5120),
     ("sq4096", 4096, 4096, 4096),
     ("sq8192", 8192, 8192, 8192),
     ("7b.decode.qkv", 512, 4608, 3584),
