@@ -218,7 +218,7 @@ def _param_shape(d: Qwen2VLDims, name: str) -> tuple:
 class Qwen2VLEngine:
     """Batched open-world classification forward: pixel_values + prompt ids -> greedy token ids."""
 
-    def __init__(self, weights: Qwen2VLWeights, *, vit_chunk_tokens: int = 65536, prefill_chunk_tokens: int = 20480):
+    def __init__(self, weights: Qwen2VLWeights, *, vit_chunk_tokens: int = 65536, prefill_chunk_tokens: int = 32768):
         self.w = weights
         self.d = weights.dims
         self.device = weights.device
