@@ -153,7 +153,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="7b", choices=["2b", "7b", "72b"])
-    ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=2048, help="images per GPU per step")
     ap.add_argument("--new-tokens", type=int, default=16)
     ap.add_argument("--scorer-labels", type=int, default=65536)
     ap.add_argument("--scorer-classes", type=int, default=397)

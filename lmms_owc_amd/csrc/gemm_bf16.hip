@@ -36,6 +36,7 @@ struct GemmProfile {
 };
 GemmProfile g_prof;
 int g_gemm_dbg = 0;       // experiment knob (OWC_GEMM_DBG): 1 = skip DMA, 2 = skip MFMA — results are garbage
+int g_big_min_tiles = 192;  // fewer 256x256 tiles than this -> use the 128x128 kernel
 int g_big_min_m = 1024;  // M at and above which the 256x128 3-stage kernel is used (OWC_GEMM_BIG_MIN_M)
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -404,7 +405,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
 template <int EPI>
 int launch(const void* A, long lda, const void* W, long ldw, const void* bias, const void* R,
            long ldr, void* C, long ldc, int M, int N, int K, const void* zeros, hipStream_t s) {
-  const bool big = M >= g_big_min_m && N >= BT && (K % BK) == 0;
+  // 256x256 tiles need enough of them to fill the 256 CUs (one block per CU); otherwise 128x128 (2 per CU)
+  const bool big = M >= g_big_min_m && N >= BT && (K % BK) == 0 &&
+                   (long)((M + BT - 1) / BT) * ((N + BT - 1) / BT) >= g_big_min_tiles;
   const int tiles_m = big ? (M + BT - 1) / BT : (M + BM - 1) / BM;
   const int tiles_n = big ? (N + BT - 1) / BT : (N + BN - 1) / BN;
   static bool attr_set = false;

@@ -21,6 +21,12 @@ SHAPES = [
     ("vit.qkv.k5120", 32768, 4096, 5120),
     ("sq4096", 4096, 4096, 4096),
     ("sq8192", 8192, 8192, 8192),
+    ("7b.dec2k.qkv", 2048, 4608, 3584),
+    ("7b.dec2k.o", 2048, 3584, 3584),
+    ("7b.dec2k.gateup", 2048, 37888, 3584),
+    ("7b.dec2k.down", 2048, 3584, 18944),
+    ("7b.dec4k.qkv", 4096, 4608, 3584),
+    ("7b.dec4k.down", 4096, 3584, 18944),
     ("7b.decode.qkv", 512, 4608, 3584),
     ("7b.decode.gateup", 512, 37888, 3584),
     ("7b.decode.down", 512, 3584, 18944),
