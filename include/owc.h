@@ -136,6 +136,9 @@ int owc_patchify_u8(owc_ctx* ctx, const uint8_t* images, void* pixel_values, int
 
 /* ---- model level: Qwen2-VL vision tower ----------------------------------------------------- */
 typedef struct owc_vit_layer {
+  /* qkv_w / qkv_b: inside every q and k head the rows are PAIR-INTERLEAVED, new[2j] = old[j],
+   * new[2j+1] = old[j + head_dim/2] (q.k is invariant to it), so the rotary pairs of HF:225-236 are
+   * adjacent output columns and the rotation is fused into the projection's epilogue. */
   const void *ln1_w, *ln1_b, *qkv_w, *qkv_b, *proj_w, *proj_b;
   const void *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
 } owc_vit_layer;

@@ -34,7 +34,7 @@ struct Cfg {
 };
 
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     const bf16_t* __restrict__ Q, long q_ts, long q_hs, const bf16_t* __restrict__ K, long k_ts,
     long k_hs, const bf16_t* __restrict__ V, long v_ts, long v_hs, bf16_t* __restrict__ O, long o_ts,
     long o_hs, const int* __restrict__ q_start, const int* __restrict__ o_start,
@@ -90,20 +90,43 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
   const bf16_t* Kb = K + (long)hk * k_hs;
   const bf16_t* Vb = V + (long)hk * v_hs;
 
+  // per-piece DMA source offsets (bytes from the sequence's first K/V row), hoisted out of the tile loop
+  constexpr int NPW = (2 * C::NP + 3) / 4;  // pieces per wave
+  unsigned poff[NPW];
+  int pkey[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int p = w + 4 * i;
+    const bool isv = p >= C::NP;
+    const int pp = isv ? p - C::NP : p;
+    const int ci = pp * 64 + l;
+    const int key = ci / C::CPR;
+    const int pos = ci - key * C::CPR;
+    const int c = C::SWZ ? (pos ^ ((key & 7) << 1)) : pos;
+    pkey[i] = key;
+    poff[i] = (unsigned)((long)key * (isv ? v_ts : k_ts) * 2 + c * 16);
+  }
+  const char* Kseq = (const char*)(Kb + ks0 * k_ts);
+  const char* Vseq = (const char*)(Vb + ks0 * v_ts);
+
   auto stage = [&](int buf, int t) {
     char* base = lds + buf * (2 * C::TILE);
+    const bool full = (t * KB + KB) <= L;  // wave-uniform: no row clamping needed
 #pragma unroll
-    for (int i = 0; i < (2 * C::NP + 3) / 4; ++i) {
+    for (int i = 0; i < NPW; ++i) {
       const int p = w + 4 * i;  // wave-uniform piece id
       if (p < 2 * C::NP) {
         const bool isv = p >= C::NP;
         const int pp = isv ? p - C::NP : p;
-        const int ci = pp * 64 + l;
-        const int key = ci / C::CPR;
-        const int pos = ci - key * C::CPR;
-        const int c = C::SWZ ? (pos ^ ((key & 7) << 1)) : pos;
-        const long tok = ks0 + min(t * KB + key, L - 1);
-        const bf16_t* src = isv ? (Vb + tok * v_ts + c * 8) : (Kb + tok * k_ts + c * 8);
+        const long ts2 = (isv ? v_ts : k_ts) * 2;
+        const char* sq = isv ? Vseq : Kseq;
+        const char* src;
+        if (full) {
+          src = sq + (long)t * KB * ts2 + poff[i];
+        } else {
+          const int key = pkey[i];
+          src = sq + (long)min(t * KB + key, L - 1) * ts2 + (poff[i] - (unsigned)((long)key * ts2));
+        }
         glds16(src, base + (isv ? C::TILE : 0) + pp * 1024);
       }
     }
@@ -162,42 +185,44 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
     bf16x8 pf[2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      float x[4][4];
+      // raw scores; the softmax scale (and log2 e) is folded into the exp2 argument by one fma per element
       float mx = -1e30f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = s[kt][qt][r] * scale_log2e;
           if (edge) {
             const int key = t * KB + kt * 16 + g * 4 + r;
-            if (key >= L || (CAUSAL && key > qrow[qt])) v = -1e30f;
+            if (key >= L || (CAUSAL && key > qrow[qt])) s[kt][qt][r] = -1e30f;
           }
-          x[kt][r] = v;
-          mx = fmaxf(mx, v);
+          mx = fmaxf(mx, s[kt][qt][r]);
         }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mnew = fmaxf(mrun[qt], mx);
-      const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+      const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * scale_log2e);
+      const float neg = -mnew * scale_log2e;
       mrun[qt] = mnew;
       float sum = 0.f;
+      float x[4][4];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          // a fully masked entry stays at -1e30 - mnew -> exp2 -> 0
-          const float p = __builtin_amdgcn_exp2f(x[kt][r] - mnew);
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], scale_log2e, neg));
           x[kt][r] = p;
           sum += p;
         }
       lrun[qt] = lrun[qt] * alpha + sum;
+      // the running max rarely moves after the first tiles: skip the O rescale when no lane needs it
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-      for (int d = 0; d < C::DT; ++d) {
-        o[d][qt][0] *= alpha;
-        o[d][qt][1] *= alpha;
-        o[d][qt][2] *= alpha;
-        o[d][qt][3] *= alpha;
+        for (int d = 0; d < C::DT; ++d) {
+          o[d][qt][0] *= alpha;
+          o[d][qt][1] *= alpha;
+          o[d][qt][2] *= alpha;
+          o[d][qt][3] *= alpha;
+        }
       }
 #pragma unroll
       for (int sx = 0; sx < 2; ++sx) {

@@ -12,7 +12,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 constexpr int NORM_MAXC = 16;  // chunks of 8 per lane -> rows up to 8192
 
-template <bool RMS>
+template <bool RMS, int NORM_C>  // NORM_C = chunks per lane this instantiation covers (d <= 512 * NORM_C)
 __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ X, long ldx,
                                                    const bf16_t* __restrict__ Wt,
                                                    const bf16_t* __restrict__ Bs,
@@ -24,10 +24,10 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ X,
   const long src_row = row_index ? (long)row_index[row] : (long)row;
   const bf16_t* x = X + src_row * ldx;
   const int nch = d >> 3;
-  bf16x8 c[NORM_MAXC];
+  bf16x8 c[NORM_C];
   float sum = 0.f, sq = 0.f;
 #pragma unroll
-  for (int i = 0; i < NORM_MAXC; ++i) {
+  for (int i = 0; i < NORM_C; ++i) {
     const int ch = i * 64 + l;
     if (ch < nch) {
       c[i] = *(const bf16x8*)(x + ch * 8);
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ X,
     mean = sum * inv_d;
     float var = 0.f;
 #pragma unroll
-    for (int i = 0; i < NORM_MAXC; ++i) {
+    for (int i = 0; i < NORM_C; ++i) {
       const int ch = i * 64 + l;
       if (ch < nch) {
 #pragma unroll
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ X,
   }
   bf16_t* y = Y + (long)row * ldy;
 #pragma unroll
-  for (int i = 0; i < NORM_MAXC; ++i) {
+  for (int i = 0; i < NORM_C; ++i) {
     const int ch = i * 64 + l;
     if (ch < nch) {
       const bf16x8 wv = *(const bf16x8*)(Wt + ch * 8);
@@ -316,16 +316,22 @@ __global__ __launch_bounds__(256) void patchify_kernel(const uint8_t* __restrict
 int owc_launch_layernorm(const void* X, long ldx, const void* W, const void* B, void* Y, long ldy,
                          int rows, int d, float eps, hipStream_t st) {
   if ((d & 7) || d > NORM_MAXC * 512 || (ldx & 7) || (ldy & 7) || rows <= 0) return OWC_ERR_SHAPE;
-  hipLaunchKernelGGL(norm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, (const bf16_t*)X, ldx,
-                     (const bf16_t*)W, (const bf16_t*)B, (bf16_t*)Y, ldy, rows, d, eps, (const int*)nullptr);
+#define OWC_LN(C_)                                                                                         \
+  hipLaunchKernelGGL((norm_kernel<false, C_>), dim3((rows + 3) / 4), dim3(256), 0, st, (const bf16_t*)X, ldx, \
+                     (const bf16_t*)W, (const bf16_t*)B, (bf16_t*)Y, ldy, rows, d, eps, (const int*)nullptr)
+  if (d <= 1536) OWC_LN(3); else if (d <= 4096) OWC_LN(8); else OWC_LN(16);
+#undef OWC_LN
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 
 int owc_launch_rmsnorm(const void* X, long ldx, const void* W, void* Y, long ldy, int rows, int d,
                        float eps, const int* row_index, hipStream_t st) {
   if ((d & 7) || d > NORM_MAXC * 512 || (ldx & 7) || (ldy & 7) || rows <= 0) return OWC_ERR_SHAPE;
-  hipLaunchKernelGGL(norm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, st, (const bf16_t*)X, ldx,
-                     (const bf16_t*)W, (const bf16_t*)nullptr, (bf16_t*)Y, ldy, rows, d, eps, row_index);
+#define OWC_RMS(C_)                                                                                       \
+  hipLaunchKernelGGL((norm_kernel<true, C_>), dim3((rows + 3) / 4), dim3(256), 0, st, (const bf16_t*)X, ldx, \
+                     (const bf16_t*)W, (const bf16_t*)nullptr, (bf16_t*)Y, ldy, rows, d, eps, row_index)
+  if (d <= 1536) OWC_RMS(3); else if (d <= 4096) OWC_RMS(8); else OWC_RMS(16);
+#undef OWC_RMS
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 

@@ -62,7 +62,7 @@ __device__ __forceinline__ void swap16(float& x, float& y) {
 template <int EPI, int MT>
 __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mrow0, int ncol0, int fr, int fq,
                                               const bf16_t* __restrict__ bias, const bf16_t* R, long ldr,
-                                              void* Cv, long ldc, int M, int N) {
+                                              void* Cv, long ldc, int M, int N, const owc_gemm_aux& aux) {
   if constexpr (EPI == OWC_EPI_F32) {
     float* C = (float*)Cv;
 #pragma unroll
@@ -138,6 +138,24 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + bv[e]);
+        if constexpr (EPI == OWC_EPI_VROPE) {
+          // apply_rotary_pos_emb_vision (HF:225-236) on pair-interleaved columns: (2j, 2j+1) hold the
+          // original (j, j + head_dim/2); angle j uses the row's h position for j < head_dim/4, else w.
+          if (n < aux.rope_cols) {
+            const int quarter = aux.head_dim >> 2;
+            const int j0 = (n % aux.head_dim) >> 1;  // multiple of 4, never straddles `quarter`
+            const int2 hw = *(const int2*)(aux.pos_hw + 2 * (long)min(m, M - 1));
+            const int ti = (j0 < quarter) ? hw.x * quarter + j0 : hw.y * quarter + (j0 - quarter);
+            const f32x4 c4 = *(const f32x4*)(aux.cos_t + ti);
+            const f32x4 s4 = *(const f32x4*)(aux.sin_t + ti);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x1 = v[2 * e], x2 = v[2 * e + 1];
+              v[2 * e] = x1 * c4[e] - x2 * s4[e];
+              v[2 * e + 1] = x2 * c4[e] + x1 * s4[e];
+            }
+          }
+        }
         if constexpr (EPI == OWC_EPI_QUICK_GELU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = act_quick_gelu(v[e]);
@@ -161,7 +179,7 @@ template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
     const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
     const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv,
-    long ldc, int M, int N, int K, const void* __restrict__ zeros, int tiles_m, int tiles_n) {
+    long ldc, int M, int N, int K, const void* __restrict__ zeros, int tiles_m, int tiles_n, owc_gemm_aux aux) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   // [buf][A|W][128 rows][128 B]
   const int tid = threadIdx.x;
@@ -255,7 +273,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
     __syncthreads();
   }
 
-  gemm_epilogue<EPI, 4>(acc, m0 + wm * 64, n0 + wn * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N);
+  gemm_epilogue<EPI, 4>(acc, m0 + wm * 64, n0 + wn * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
 }
 
 
@@ -281,7 +299,7 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
     const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
     const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv, long ldc, int M, int N, int K,
-    int tiles_m, int tiles_n, int dbg) {
+    int tiles_m, int tiles_n, int dbg, owc_gemm_aux aux) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -399,12 +417,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   if (dbg & 4) { if (acc[0][0][0] == 123.456f) ((float*)Cv)[0] = 1.f; return; }  // timing experiment: no epilogue
-  gemm_epilogue<EPI, 8>(acc, m0 + wr * 128, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N);
+  gemm_epilogue<EPI, 8>(acc, m0 + wr * 128, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
 }
 
 template <int EPI>
 int launch(const void* A, long lda, const void* W, long ldw, const void* bias, const void* R,
-           long ldr, void* C, long ldc, int M, int N, int K, const void* zeros, hipStream_t s) {
+           long ldr, void* C, long ldc, int M, int N, int K, const void* zeros, hipStream_t s,
+           const owc_gemm_aux& aux) {
   // 256x256 tiles need enough of them to fill the 256 CUs (one block per CU); otherwise 128x128 (2 per CU)
   const bool big = M >= g_big_min_m && N >= BT && (K % BK) == 0 &&
                    (long)((M + BT - 1) / BT) * ((N + BT - 1) / BT) >= g_big_min_tiles;
@@ -436,11 +455,11 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
   if (big)
     hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), 2 * STAGE_BYTES, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
-                       (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, g_gemm_dbg);
+                       (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, g_gemm_dbg, aux);
   else
     hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
-                       (const bf16_t*)R, ldr, C, ldc, M, N, K, zeros, tiles_m, tiles_n);
+                       (const bf16_t*)R, ldr, C, ldc, M, N, K, zeros, tiles_m, tiles_n, aux);
   if (e1) (void)hipEventRecord(e1, s);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
@@ -448,24 +467,38 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
 }  // namespace
 
 // Internal entry used by the C ABI (api.cpp) and by the model drivers.
-int owc_launch_gemm_bf16(const void* A, long lda, const void* W, long ldw, const void* bias,
-                         const void* R, long ldr, void* C, long ldc, int M, int N, int K, int epi,
-                         const void* zeros, hipStream_t s) {
+int owc_launch_gemm_bf16_aux(const void* A, long lda, const void* W, long ldw, const void* bias,
+                             const void* R, long ldr, void* C, long ldc, int M, int N, int K, int epi,
+                             const void* zeros, hipStream_t s, const owc_gemm_aux* auxp) {
   if (M <= 0 || N <= 0 || K <= 0) return OWC_ERR_SHAPE;
   if ((K & 7) || (lda & 7) || (ldw & 7) || (N & 3) || (ldc & 3)) return OWC_ERR_SHAPE;
   if (epi != OWC_EPI_F32 && epi != OWC_EPI_SWIGLU && ((N & 7) || (ldc & 7))) return OWC_ERR_SHAPE;  // 16-byte stores
   if (epi == OWC_EPI_SWIGLU && (ldc & 7)) return OWC_ERR_SHAPE;
   if (epi == OWC_EPI_SWIGLU && (N & 31)) return OWC_ERR_SHAPE;
   if (epi == OWC_EPI_RESIDUAL && (R == nullptr || (ldr & 7))) return OWC_ERR_ARG;
+  owc_gemm_aux aux = {nullptr, nullptr, nullptr, 0, 8};
+  if (epi == OWC_EPI_VROPE) {
+    if (!auxp || !auxp->pos_hw || !auxp->cos_t || !auxp->sin_t || (auxp->head_dim % 16) || (auxp->rope_cols % 8))
+      return OWC_ERR_ARG;
+    aux = *auxp;
+  }
   switch (epi) {
-    case OWC_EPI_NONE: return launch<OWC_EPI_NONE>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, s);
-    case OWC_EPI_QUICK_GELU: return launch<OWC_EPI_QUICK_GELU>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, s);
-    case OWC_EPI_GELU_ERF: return launch<OWC_EPI_GELU_ERF>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, s);
-    case OWC_EPI_RESIDUAL: return launch<OWC_EPI_RESIDUAL>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, s);
-    case OWC_EPI_SWIGLU: return launch<OWC_EPI_SWIGLU>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, s);
-    case OWC_EPI_F32: return launch<OWC_EPI_F32>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, s);
+    case OWC_EPI_NONE: return launch<OWC_EPI_NONE>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, s, aux);
+    case OWC_EPI_QUICK_GELU: return launch<OWC_EPI_QUICK_GELU>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, s, aux);
+    case OWC_EPI_GELU_ERF: return launch<OWC_EPI_GELU_ERF>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, s, aux);
+    case OWC_EPI_RESIDUAL: return launch<OWC_EPI_RESIDUAL>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, s, aux);
+    case OWC_EPI_SWIGLU: return launch<OWC_EPI_SWIGLU>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, s, aux);
+    case OWC_EPI_F32: return launch<OWC_EPI_F32>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, s, aux);
+    case OWC_EPI_VROPE: return launch<OWC_EPI_VROPE>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, s, aux);
     default: return OWC_ERR_ARG;
   }
+}
+
+int owc_launch_gemm_bf16(const void* A, long lda, const void* W, long ldw, const void* bias,
+                         const void* R, long ldr, void* C, long ldc, int M, int N, int K, int epi,
+                         const void* zeros, hipStream_t s) {
+  if (epi == OWC_EPI_VROPE) return OWC_ERR_ARG;  // needs the aux operands
+  return owc_launch_gemm_bf16_aux(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, epi, zeros, s, nullptr);
 }
 
 // ---- profiling hooks (C ABI: owc_gemm_profile_enable / owc_gemm_profile_read in api.hip) ----

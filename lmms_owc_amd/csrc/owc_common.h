@@ -47,6 +47,16 @@ enum {
   OWC_EPI_RESIDUAL = 3,    // C = bf16(res + bf16(acc + bias))
   OWC_EPI_SWIGLU = 4,      // interleaved gate/up rows: C[m][f] = bf16(bf16(silu(g)) * u)
   OWC_EPI_F32 = 5,         // C (fp32) = acc + bias   (no rounding)
+  OWC_EPI_VROPE = 6,       // vision qkv: bf16(acc + bias), then 2-D RoPE on pair-interleaved q/k columns
+};
+
+// Extra operands of the fused-RoPE epilogue (vision qkv projection).
+struct owc_gemm_aux {
+  const int* pos_hw;     // [M][2] patch (h, w)
+  const float* cos_t;    // [positions][head_dim/4]
+  const float* sin_t;
+  int rope_cols;         // columns < rope_cols (q and k blocks) are rotated
+  int head_dim;
 };
 
 #define OWC_OK 0

@@ -54,6 +54,7 @@ int owc_vit_forward(owc_ctx* ctx, const owc_vit_weights* w, const void* pixel_va
   void* qkv = cv.take((size_t)T * E * 3 * 2);
   void* mlp = cv.take((size_t)T * F * 2);
   const float scale = 1.0f / sqrtf((float)hd);
+  const owc_gemm_aux aux = {pos_hw, w->rope_cos, w->rope_sin, 2 * E, hd};
 
   // patch embed: Conv3d(kernel == stride) == GEMM [T, patch_k] x [E, patch_k]^T, no bias (HF:268-275)
   OWC_TRY(owc_launch_gemm_bf16(pixel_values, ld_pix, w->patch_w, w->patch_k, nullptr, nullptr, 0, x, E,
@@ -62,9 +63,9 @@ int owc_vit_forward(owc_ctx* ctx, const owc_vit_weights* w, const void* pixel_va
     const owc_vit_layer& L = w->layers[i];
     // x = x + proj(attn(rope(qkv(norm1(x)))))            (HF:442-449, :356-422)
     OWC_TRY(owc_launch_layernorm(x, E, L.ln1_w, L.ln1_b, h, E, T, E, w->ln_eps, st));
-    OWC_TRY(owc_launch_gemm_bf16(h, E, L.qkv_w, E, L.qkv_b, nullptr, 0, qkv, 3 * E, T, 3 * E, E,
-                                 OWC_EPI_NONE, ctx->zeros, st));
-    OWC_TRY(owc_launch_vision_rope(qkv, 3 * E, pos_hw, w->rope_cos, w->rope_sin, T, H, hd, st));
+    // qkv projection with the 2-D RoPE fused into the epilogue (q/k rows of qkv_w are pair-interleaved)
+    OWC_TRY(owc_launch_gemm_bf16_aux(h, E, L.qkv_w, E, L.qkv_b, nullptr, 0, qkv, 3 * E, T, 3 * E, E,
+                                     OWC_EPI_VROPE, ctx->zeros, st, &aux));
     const bf16_t* q = (const bf16_t*)qkv;
     OWC_TRY(owc_launch_attention(q, 3 * E, hd, q + E, 3 * E, hd, q + 2 * E, 3 * E, hd, attn, E, hd,
                                  seq_start, nullptr, seq_start, seq_len, nullptr, n_img, H, 1, hd,

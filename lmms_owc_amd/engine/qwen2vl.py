@@ -61,6 +61,16 @@ DIMS = {
 }
 
 
+def vision_qkv_row_permutation(embed: int, heads: int) -> torch.Tensor:
+    """Row order of the fused vision qkv weight that owc_vit_forward expects: inside every q and k head the
+    rotary partners (j, j + hd/2) become adjacent rows (2j, 2j+1); v rows are untouched."""
+    hd = embed // heads
+    j = torch.arange(hd // 2)
+    head = torch.stack([j, j + hd // 2], dim=1).reshape(-1)            # [0, hd/2, 1, hd/2+1, ...]
+    qk = (torch.arange(2 * heads)[:, None] * hd + head[None, :]).reshape(-1)
+    return torch.cat([qk, torch.arange(2 * embed, 3 * embed)])
+
+
 def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     """Row layout the SWIGLU GEMM epilogue expects: [g0..g15, u0..u15, g16..g31, u16..u31, ...]."""
     f, k = gate.shape
@@ -128,10 +138,13 @@ class Qwen2VLWeights:
         hd_v = d.v_embed // d.v_heads
         # ---- vision
         vl = (_lib.VitLayer * d.v_depth)()
+        perm = vision_qkv_row_permutation(d.v_embed, d.v_heads).to(self.device)
         for i in range(d.v_depth):
             p = f"{V}blocks.{i}."
-            for f, n in (("ln1_w", "norm1.weight"), ("ln1_b", "norm1.bias"), ("qkv_w", "attn.qkv.weight"),
-                         ("qkv_b", "attn.qkv.bias"), ("proj_w", "attn.proj.weight"), ("proj_b", "attn.proj.bias"),
+            vl[i].qkv_w = self._k(get(p + "attn.qkv.weight").index_select(0, perm).contiguous())
+            vl[i].qkv_b = self._k(get(p + "attn.qkv.bias").index_select(0, perm).contiguous())
+            for f, n in (("ln1_w", "norm1.weight"), ("ln1_b", "norm1.bias"),
+                         ("proj_w", "attn.proj.weight"), ("proj_b", "attn.proj.bias"),
                          ("ln2_w", "norm2.weight"), ("ln2_b", "norm2.bias"), ("fc1_w", "mlp.fc1.weight"),
                          ("fc1_b", "mlp.fc1.bias"), ("fc2_w", "mlp.fc2.weight"), ("fc2_b", "mlp.fc2.bias")):
                 setattr(vl[i], f, self._k(get(p + n)))

@@ -1,0 +1,56 @@
+"""Time owc_attention_bf16 on the Qwen2-VL shapes."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from lmms_owc_amd import ops  # noqa: E402
+
+
+def i32(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+
+
+def main():
+    dev = torch.device("cuda:0")
+    # vision: 64 images x 1024 tokens, 16 heads x 80
+    n, L, H, hd = 64, 1024, 16, 80
+    T, E = n * L, H * hd
+    qkv = torch.randn(T, 3 * E, device=dev).to(torch.bfloat16)
+    out = torch.empty(T, E, device=dev, dtype=torch.bfloat16)
+    starts, lens = i32(np.arange(n) * L, dev), i32(np.full(n, L), dev)
+
+    def vit():
+        ops.attention(qkv, 3 * E, hd, qkv[:, E:], 3 * E, hd, qkv[:, 2 * E:], 3 * E, hd, out, E, hd, starts, starts, lens,
+                      n_seq=n, n_heads=H, kv_group=1, head_dim=hd, max_q_len=L, causal=False, scale=hd ** -0.5)
+
+    # decoder prefill: 114 prompts x 286, 28 q heads / 4 kv heads x 128
+    nb, S, Hq, Hkv, smax = 114, 286, 28, 4, 302
+    q = torch.randn(nb * S, (Hq + 2 * Hkv) * 128, device=dev).to(torch.bfloat16)
+    kc = torch.randn(nb, Hkv, smax, 128, device=dev).to(torch.bfloat16)
+    vc = torch.randn(nb, Hkv, smax, 128, device=dev).to(torch.bfloat16)
+    o2 = torch.empty(nb * S, Hq * 128, device=dev, dtype=torch.bfloat16)
+    st2, kst2, ln2 = i32(np.arange(nb) * S, dev), i32(np.arange(nb) * Hkv * smax, dev), i32(np.full(nb, S), dev)
+
+    def prefill():
+        ops.attention(q, (Hq + 2 * Hkv) * 128, 128, kc, 128, smax * 128, vc, 128, smax * 128, o2, Hq * 128, 128, st2, kst2, ln2,
+                      n_seq=nb, n_heads=Hq, kv_group=Hq // Hkv, head_dim=128, max_q_len=S, causal=True, scale=128 ** -0.5)
+
+    for name, fn, flops in (("vit hd80 64x1024", vit, 4.0 * n * H * L * L * hd), ("prefill hd128 114x286 causal", prefill, 2.0 * nb * Hq * S * S * 128)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        print(f"{name:32s} {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
