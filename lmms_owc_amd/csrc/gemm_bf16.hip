@@ -409,7 +409,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
     // pieces of stage kt+1 have landed (issued a whole K-tile ago); the barrier publishes stage kt+1 and proves
     // stage kt's buffer is no longer read by anyone.
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (kt + 2 < nk) stage(kt & 1, kt + 2);
+    if (kt + 2 < nk && !(dbg & 1)) stage(kt & 1, kt + 2);
     read_a(xa, nxt, 0, ch0);   // next tile, phase 1
     read_w(wk0, nxt, ch0);
     phase(ya, wk1, 0);         // phase 4: rows 0-63,  k-step 1
