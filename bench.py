@@ -158,7 +158,7 @@ def main() -> None:
     ap.add_argument("--scorer-labels", type=int, default=65536)
     ap.add_argument("--scorer-classes", type=int, default=397)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=1)
+    ap.add_argument("--cpu-images", type=int, default=2)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -36,6 +36,7 @@ struct GemmProfile {
 };
 GemmProfile g_prof;
 int g_gemm_dbg = 0;       // experiment knob (OWC_GEMM_DBG): 1 = skip DMA, 2 = skip MFMA — results are garbage
+int g_persistent_blocks = 0;  // 0 = one block per tile (default; measured equal); 256 = persistent, one block per CU
 int g_big_min_tiles = 192;  // fewer 256x256 tiles than this -> use the 128x128 kernel
 int g_big_min_m = 1024;  // M at and above which the 256x128 3-stage kernel is used (OWC_GEMM_BIG_MIN_M)
 
@@ -59,7 +60,7 @@ __device__ __forceinline__ void swap16(float& x, float& y) {
   y = __uint_as_float(r[1]);
 }
 
-template <int EPI, int MT>
+template <int EPI, int MT, bool FULL = false>
 __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mrow0, int ncol0, int fr, int fq,
                                               const bf16_t* __restrict__ bias, const bf16_t* R, long ldr,
                                               void* Cv, long ldc, int M, int N, const owc_gemm_aux& aux) {
@@ -77,7 +78,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += bf2f(b[e]);
         }
-        if (m < M && n < N) *(f32x4*)(C + (long)m * ldc + n) = v;
+        if (FULL || (m < M && n < N)) *(f32x4*)(C + (long)m * ldc + n) = v;
       }
     }
   } else if constexpr (EPI == OWC_EPI_SWIGLU) {
@@ -101,7 +102,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
         o[e] = f2bf(o0[e]);
         o[4 + e] = f2bf(o1[e]);
       }
-      if (m < M && f < nout) *(bf16x8*)(C + (long)m * ldc + f) = o;
+      if (FULL || (m < M && f < nout)) *(bf16x8*)(C + (long)m * ldc + f) = o;
     }
   } else {
     bf16_t* C = (bf16_t*)Cv;
@@ -169,7 +170,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-        if (m < M && n < N) *(bf16x8*)(C + (long)m * ldc + n) = o;
+        if (FULL || (m < M && n < N)) *(bf16x8*)(C + (long)m * ldc + n) = o;
       }
     }
   }
@@ -306,31 +307,35 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
   const int l = tid & 63;
 
   const int nblk = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
-  const int q = nblk >> 3, r = nblk & 7;
-  const int xcd = bid & 7, idx = bid >> 3;
-  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  const int width = GROUP_M2 * tiles_n;
-  const int group = lid / width;
-  const int first_m = group * GROUP_M2;
-  const int gsize = min(tiles_m - first_m, GROUP_M2);
-  const int tm = first_m + (lid % width) % gsize;
-  const int tn = (lid % width) / gsize;
-  const int m0 = tm * BT, n0 = tn * BT;
-
-  // DMA sources: wave w stages rows [32w, 32w+32) of both operand tiles (4 pieces of 8 rows each);
-  // per-lane 32-bit byte offsets from the tile's (uniform) base pointer, rows clamped at the ragged edge.
-  const char* abase = (const char*)(A + (long)m0 * lda);
-  const char* wbase = (const char*)(W + (long)n0 * ldw);
-  unsigned aoff[4], woff[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = 32 * w + 8 * j + (l >> 3);
-    const int c = (l & 7) ^ ((row >> 1) & 7);
-    aoff[j] = (unsigned)((long)min(row, M - 1 - m0) * lda * 2 + c * 16);
-    woff[j] = (unsigned)((long)min(row, N - 1 - n0) * ldw * 2 + c * 16);
-  }
   const int nk = K / BK;
+
+  // tile id -> (m0, n0): the blocks of one XCD (id & 7) walk a contiguous, GROUP_M-major range of tiles.  A block
+  // visits ids blockIdx.x, + gridDim.x, ... (grid = all tiles, or one block per CU when persistent).
+  int m0 = 0, n0 = 0;
+  const char *abase = nullptr, *wbase = nullptr;
+  unsigned aoff[4], woff[4];
+  auto setup = [&](int bid) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int width = GROUP_M2 * tiles_n;
+    const int group = lid / width;
+    const int first_m = group * GROUP_M2;
+    const int gsize = min(tiles_m - first_m, GROUP_M2);
+    m0 = (first_m + (lid % width) % gsize) * BT;
+    n0 = ((lid % width) / gsize) * BT;
+    // DMA sources: wave w stages rows [32w, 32w+32) of both operand tiles (4 pieces of 8 rows each);
+    // per-lane 32-bit byte offsets from the tile's (uniform) base pointer, rows clamped at the ragged edge.
+    abase = (const char*)(A + (long)m0 * lda);
+    wbase = (const char*)(W + (long)n0 * ldw);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = 32 * w + 8 * j + (l >> 3);
+      const int c = (l & 7) ^ ((row >> 1) & 7);
+      aoff[j] = (unsigned)((long)min(row, M - 1 - m0) * lda * 2 + c * 16);
+      woff[j] = (unsigned)((long)min(row, N - 1 - n0) * ldw * 2 + c * 16);
+    }
+  };
 
   auto stage = [&](int buf, int kt) {
     char* la = lds + buf * STAGE_BYTES + w * 4096;
@@ -352,10 +357,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
   const int ch0 = ((0 + fq) ^ swz) << 4, ch1 = ((4 + fq) ^ swz) << 4;
 
   f32x4 acc[4][8];  // [nt][mt]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // Fragment registers hold 4 blocks of 4 fragments: xa/ya = A blocks (4 m tiles of one half, one k-step),
   // wk0/wk1 = the 4 W fragments (n tiles) of k-step 0 / 1.  64 VGPRs, each block is refilled from LDS
@@ -383,41 +384,86 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  // global stores one thread issues in a FULL-tile epilogue (counted waits below rely on it)
+  constexpr int NST = (EPI == OWC_EPI_SWIGLU) ? 8 : (EPI == OWC_EPI_F32 ? 32 : 16);
+
+  int tile = blockIdx.x;
+  setup(tile);
   stage(0, 0);
-  if (nk > 1) {
-    stage(1, 1);
-    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // stage 0 landed (stage 1's 8 pieces may fly)
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  }
-  read_a(xa, lds, 0, ch0);
-  read_w(wk0, lds, ch0);
+  if (nk > 1) stage(1, 1);
+  bool carry = false;  // true: the previous tile's NST epilogue stores may still be in flight (younger than the DMA)
 
-  // Per K-tile, phases walk (m half, k-step) = (0,0) (1,0) (1,1) (0,1): consecutive phases share either the
-  // W block or nothing but always need exactly what was fetched one phase earlier.
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* cur = lds + (kt & 1) * STAGE_BYTES;
-    const char* nxt = lds + ((kt + 1) & 1) * STAGE_BYTES;
-    read_a(ya, cur, 1, ch0);   // for phase 2
-    phase(xa, wk0, 0);         // phase 1: rows 0-63,  k-step 0
-    read_a(xa, cur, 1, ch1);   // for phase 3
-    read_w(wk1, cur, ch1);
-    phase(ya, wk0, 1);         // phase 2: rows 64-127, k-step 0
-    read_a(ya, cur, 0, ch1);   // for phase 4
-    phase(xa, wk1, 1);         // phase 3: rows 64-127, k-step 1
-    // every LDS read of stage kt by this wave has completed (lgkmcnt(0), issued >= one phase ago) and its DMA
-    // pieces of stage kt+1 have landed (issued a whole K-tile ago); the barrier publishes stage kt+1 and proves
-    // stage kt's buffer is no longer read by anyone.
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (kt + 2 < nk && !(dbg & 1)) stage(kt & 1, kt + 2);
-    read_a(xa, nxt, 0, ch0);   // next tile, phase 1
-    read_w(wk0, nxt, ch0);
-    phase(ya, wk1, 0);         // phase 4: rows 0-63,  k-step 1
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (;;) {
+    // wait until stage 0 has landed; allowed to stay outstanding (all YOUNGER than stage 0): stage 1's 8 pieces
+    // and, on a follow-up tile, the previous tile's store tail.
+    if (carry) {
+      if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NST + 8) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NST) : "memory");
+    } else {
+      if (nk > 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    read_a(xa, lds, 0, ch0);
+    read_w(wk0, lds, ch0);
 
-  if (dbg & 4) { if (acc[0][0][0] == 123.456f) ((float*)Cv)[0] = 1.f; return; }  // timing experiment: no epilogue
-  gemm_epilogue<EPI, 8>(acc, m0 + wr * 128, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
+    // Per K-tile, phases walk (m half, k-step) = (0,0) (1,0) (1,1) (0,1): every phase consumes fragment blocks
+    // that were fetched from LDS one phase earlier.
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* cur = lds + (kt & 1) * STAGE_BYTES;
+      const char* nxt = lds + ((kt + 1) & 1) * STAGE_BYTES;
+      read_a(ya, cur, 1, ch0);   // for phase 2
+      phase(xa, wk0, 0);         // phase 1: rows 0-63,  k-step 0
+      read_a(xa, cur, 1, ch1);   // for phase 3
+      read_w(wk1, cur, ch1);
+      phase(ya, wk0, 1);         // phase 2: rows 64-127, k-step 0
+      read_a(ya, cur, 0, ch1);   // for phase 4
+      phase(xa, wk1, 1);         // phase 3: rows 64-127, k-step 1
+      // every LDS read of stage kt by this wave has completed (lgkmcnt(0), issued >= one phase ago) and its DMA
+      // pieces of stage kt+1 have landed (issued a whole K-tile ago); the barrier publishes stage kt+1 and proves
+      // stage kt's buffer is no longer read by anyone.  On the first K-tile of a follow-up tile the previous
+      // tile's stores (younger than stage 1) may keep flying.
+      if (carry && kt == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (kt + 2 < nk && !(dbg & 1)) stage(kt & 1, kt + 2);
+      if (kt + 1 < nk) {
+        read_a(xa, nxt, 0, ch0);  // next K-tile, phase 1
+        read_w(wk0, nxt, ch0);
+      }
+      phase(ya, wk1, 0);         // phase 4: rows 0-63,  k-step 1
+    }
+
+    // ---- tile done.  Both LDS stages are free (every wave's last LDS read preceded the last barrier), so the
+    // NEXT tile's first two stages are put in flight BEFORE this tile's epilogue: DMA latency and store tail
+    // hide behind each other, and the stores then drain under the next tile's first K-tile.
+    const int out_m0 = m0, out_n0 = n0;
+    const int next = tile + (int)gridDim.x;
+    const bool more = next < nblk;
+    if (more) {
+      setup(next);
+      stage(0, 0);
+      if (nk > 1) stage(1, 1);
+    }
+    // pin the issue order DMA -> epilogue loads/stores: the counted waits assume the stores are YOUNGER
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (dbg & 4) {
+      if (acc[0][0][0] == 123.456f) ((float*)Cv)[0] = 1.f;  // timing experiment: no epilogue
+      carry = false;
+    } else if (out_m0 + BT <= M && out_n0 + BT <= N) {
+      gemm_epilogue<EPI, 8, true>(acc, out_m0 + wr * 128, out_n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
+      carry = true;
+    } else {
+      gemm_epilogue<EPI, 8, false>(acc, out_m0 + wr * 128, out_n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
+      if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // predicated stores: count unknown, drain
+      carry = false;
+    }
+    if (!more) break;
+    tile = next;
+  }
 }
 
 template <int EPI>
@@ -453,8 +499,10 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
     (void)hipEventRecord(e0, s);
   }
   if (big)
-    hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), 2 * STAGE_BYTES, s,
-                       (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
+    // g_persistent_blocks > 0: one resident block per CU walks the tiles (epilogue overlapped with the next tile)
+    hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>,
+                       dim3(g_persistent_blocks > 0 ? min(tiles_m * tiles_n, g_persistent_blocks) : tiles_m * tiles_n),
+                       dim3(512), 2 * STAGE_BYTES, s, (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
                        (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, g_gemm_dbg, aux);
   else
     hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, s,
@@ -529,3 +577,4 @@ int owc_gemm_profile_collect(double* total_ms, double* total_flops, long* launch
 
 void owc_gemm_set_big_min_m(int m) { g_big_min_m = m; }
 void owc_gemm_set_dbg(int v) { g_gemm_dbg = v; }
+void owc_gemm_set_persistent(int v) { g_persistent_blocks = v; }

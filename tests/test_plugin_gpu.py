@@ -87,3 +87,19 @@ def test_evaluate_then_offline_metrics(gpu, scorer, tmp_path, capsys):
     ss = get_metric_info("semantic_similarity")
     vals = ss.group_fn(ss.builder_fn([("sea lion", ["x", "sea lion"]), (["golden retriever"], "golden retriever")]), reduce="none")
     assert np.allclose(vals, 1.0, atol=1e-5)
+
+
+def test_eval_model_cli_end_to_end(gpu, scorer, tmp_path, capsys):
+    """eval_model.py with the reference's flag names: writes {date}_results.json + {date}_samples_{task}.jsonl."""
+    import eval_model
+
+    out = tmp_path / "logs" / "schedule" / "synthetic" / "qwen2-vl-tiny"
+    eval_model.main(["--model", "custom-model", "--model_args", "model_type=qwen2-vl,model_name_or_path=synthetic:tiny",
+                     "--tasks", "synthetic:5:56x56:2", "--batch_size", "3", "--limit", "4", "--log_samples",
+                     "--output_path", str(out), "--verbosity", "DEBUG", "--gen_kwargs", "max_new_tokens=4"])
+    files = sorted(p.name for p in out.iterdir())
+    assert any(f.endswith("_results.json") for f in files) and any("_samples_synthetic.jsonl" in f for f in files)
+    res = json.loads(next(out.glob("*_results.json")).read_text())
+    assert "synthetic" in res["results"] and "total_evaluation_time_seconds" in res
+    assert len(next(out.glob("*_samples_*.jsonl")).read_text().splitlines()) == 4
+    assert "| synthetic |" in capsys.readouterr().out
