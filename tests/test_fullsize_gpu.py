@@ -1,0 +1,87 @@
+"""Parity at BASELINE's full widths: a 2-block slice of the real vision tower (1280 x 16 heads x 5120) over
+16 images of 448x448 (16384 patch rows: the 256x256 GEMM, fused-RoPE epilogue and hd-80 attention at their
+production shapes) and a 2-layer slice of the Qwen2-VL-2B decoder (1536 / 12 q / 2 kv heads / 8960, S = 286)
+against the bf16 numpy oracle, plus size-independent properties on the full 2B model."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import qwen2vl_np as Q
+from tests import recipes
+from tests.util import to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _dims(**kw):
+    from lmms_owc_amd.engine.qwen2vl import Qwen2VLDims
+
+    base = dict(v_depth=2, v_embed=1280, v_heads=16, v_mlp=5120, n_layers=2, d_model=1536, n_q_heads=12, n_kv_heads=2,
+                d_ff=8960, vocab=4096, tie_embeddings=False, image_token_id=4000, max_positions=1024, max_grid=64)
+    base.update(kw)
+    return Qwen2VLDims(**base)
+
+
+@pytest.fixture(scope="module")
+def slice_model(gpu):
+    from lmms_owc_amd.engine.qwen2vl import Qwen2VLEngine, Qwen2VLWeights
+
+    cfg = Q.Cfg(vision=Q.VisionCfg(depth=2, embed_dim=1280, num_heads=16, mlp_ratio=4.0, hidden_size=1536),
+                text=Q.TextCfg(hidden_size=1536, num_hidden_layers=2, num_attention_heads=12, num_key_value_heads=2,
+                               intermediate_size=8960, vocab_size=4096, tie_word_embeddings=False), image_token_id=4000)
+    w = recipes.qwen2vl_weights(cfg, 4321)
+    eng = Qwen2VLEngine(Qwen2VLWeights.from_state_dict(_dims(), w, gpu))
+    return cfg, w, eng
+
+
+def test_vision_slice_full_width(slice_model, gpu):
+    cfg, w, eng = slice_model
+    grid = [(1, 32, 32)] * 16
+    pix = recipes.pixel_values(grid, 3)
+    out = to_np(eng.encode_images(torch.from_numpy(pix).to(torch.bfloat16).to(gpu), grid))
+    # the oracle on 2 of the 16 images (numpy time); images are independent
+    for i in (0, 15):
+        ref = Q.vit_forward(w, cfg, pix[i * 1024:(i + 1) * 1024], grid[:1], bf16=True)
+        got = out[i * 256:(i + 1) * 256]
+        assert np.abs(got - ref).max() <= 0.03 * np.abs(ref).max(), (i, np.abs(got - ref).max(), np.abs(ref).max())
+        assert np.abs(got - ref).mean() <= 0.004 * np.abs(ref).max()
+
+
+def test_decoder_slice_full_width(slice_model, gpu):
+    cfg, w, eng = slice_model
+    grid = [(1, 32, 32)]
+    pix = recipes.pixel_values(grid, 5)
+    r = np.random.default_rng(9)
+    ids = np.concatenate([r.integers(1, 3900, 14), np.full(256, cfg.image_token_id), r.integers(1, 3900, 16)])
+    emb = eng.encode_images(torch.from_numpy(pix).to(torch.bfloat16).to(gpu), grid)
+    toks, logits = eng.generate([ids], emb, [grid], 3, return_logits=True)
+    o_toks, o_logits = Q.generate(w, cfg, ids, pix, grid, 3, bf16=True, return_logits=True)
+    got = to_np(logits)[0]
+    assert np.abs(got - o_logits[0]).max() <= 0.03 * np.abs(o_logits[0]).max()
+    top2 = np.sort(o_logits[0])[-2:]
+    if top2[1] - top2[0] > 0.06 * np.abs(o_logits[0]).max():
+        assert int(toks[0, 0]) == int(o_toks[0])
+
+
+def test_full_2b_properties(gpu):
+    """Full Qwen2-VL-2B (random weights): batch invariance + determinism of greedy tokens, finite logits."""
+    from lmms_owc_amd.engine.qwen2vl import DIMS, Qwen2VLEngine, Qwen2VLWeights
+
+    d = DIMS["qwen2-vl-2b"]
+    eng = Qwen2VLEngine(Qwen2VLWeights.random(d, gpu, seed=5))
+    g = torch.Generator(device=gpu).manual_seed(1)
+    n = 6
+    pix = torch.randn((n * 1024, 1176), generator=g, device=gpu, dtype=torch.bfloat16)
+    r = np.random.default_rng(2)
+    ids = [np.concatenate([r.integers(1000, 150000, 10 + i), np.full(256, d.image_token_id), r.integers(1000, 150000, 12)])
+           for i in range(n)]
+    grids = [[(1, 32, 32)]] * n
+    emb = eng.encode_images(pix, [(1, 32, 32)] * n)
+    assert bool(torch.isfinite(emb.float()).all())
+    batch, logits = eng.generate(ids, emb, grids, 6, return_logits=True)
+    assert bool(torch.isfinite(logits.float()).all())
+    again = eng.generate(ids, emb, grids, 6)
+    assert torch.equal(batch, again)  # deterministic
+    for b in (0, n - 1):
+        single = eng.generate([ids[b]], emb[b * 256:(b + 1) * 256].contiguous(), [grids[b]], 6)
+        assert torch.equal(single[0], batch[b]), (b, single[0].tolist(), batch[b].tolist())

@@ -18,6 +18,10 @@ SHAPES = [
     (1024, 3840, 1280),
     (513, 2048, 8960),
     (64, 1280, 5120),
+    # >= 192 tiles of 256x256 and K % 64 == 0 -> the 256x256 quadrant-pipelined kernel (full and ragged tiles)
+    (4096, 3072, 1280),
+    (4000, 3080, 1344),
+    (3700, 4096, 64),
 ]
 
 
@@ -87,4 +91,41 @@ def test_gemm_epilogues(gpu, epi):
     torch.cuda.synchronize()
     # a residual add can cancel: allow one bf16 ulp of the pre-add magnitude as absolute slack
     atol = 2.0**-7 * float(np.abs(y).max()) if epi == "residual" else 1e-4
+    assert_bf16_close(to_np(out), want, ulps=4.0, min_exact=0.80, atol=atol)
+
+
+@pytest.mark.parametrize("epi", ["quick_gelu", "residual", "swiglu"])
+def test_gemm_epilogues_large_kernel(gpu, epi):
+    """Same epilogues on the 256x256 kernel (M, N ragged against the tile, in-place residual as the model uses it)."""
+    from lmms_owc_amd import _lib, ops
+
+    m, n, k = 3900, 4104, 512
+    a = bf16_randn((m, k), 14, device=gpu)
+    b = bf16_randn((n,), 16, device=gpu)
+    if epi == "swiglu":
+        n = 8192
+        f = n // 2
+        wg = bf16_randn((f, k), 18, 0.06, device=gpu)
+        wu = bf16_randn((f, k), 19, 0.06, device=gpu)
+        wi = torch.stack([wg.view(f // 16, 16, k), wu.view(f // 16, 16, k)], dim=1).reshape(n, k).contiguous()
+        out = ops.gemm_bf16(a, wi, None, epilogue=_lib.EPI_SWIGLU)
+        g = np_ops.linear(to_np(a), to_np(wg), bf16=True)
+        u = np_ops.linear(to_np(a), to_np(wu), bf16=True)
+        want = np_ops.bf16_round(np_ops.silu(g, bf16=True) * u)
+        atol = 2.0**-7 * float(np.abs(u).max())  # silu(g)*u: one ulp of either factor, scaled by the other
+    else:
+        w = bf16_randn((n, k), 15, 0.06, device=gpu)
+        y = _oracle(a, w, b)
+        if epi == "quick_gelu":
+            out = ops.gemm_bf16(a, w, b, epilogue=_lib.EPI_QUICK_GELU)
+            want = np_ops.quick_gelu(y, bf16=True)
+            # the activation maps a 1-ulp difference of its INPUT (accumulation order) to up to ~1.1 input ulps of
+            # output, which is many output ulps where gelu(x) ~ 0: allow one input ulp of absolute slack
+            atol = 2.0**-7 * float(np.abs(y).max())
+        else:
+            r = bf16_randn((m, n), 17, device=gpu)
+            want = np_ops.bf16_round(to_np(r) + y)
+            out = ops.gemm_bf16(a, w, b, epilogue=_lib.EPI_RESIDUAL, residual=r, out=r)  # in place: x += f(x)
+            atol = 2.0**-7 * float(np.abs(y).max())
+    torch.cuda.synchronize()
     assert_bf16_close(to_np(out), want, ulps=4.0, min_exact=0.80, atol=atol)
