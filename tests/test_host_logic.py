@@ -130,3 +130,27 @@ def test_evaluate_two_ranks_equals_one(tmp_path):
         outs.append(json.loads(out.read_text()))
     assert outs[0] == outs[1]
     assert [s["doc_id"] for s in outs[0]["samples"]] == list(range(9))
+
+
+def test_image_preprocessing_matches_hf_golden():
+    """smart_resize + bicubic resize (host) + rescale/normalise/patchify restated in numpy == HF's
+    Qwen2VLImageProcessor on a 450x300 image (golden G6, tools/gen_golden.py)."""
+    import numpy as np
+    from PIL import Image
+
+    from lmms_owc_amd.models import imageproc
+
+    g = np.load(ROOT / "tests" / "golden" / "image_proc.npz")
+    yy, xx = np.mgrid[0:300, 0:450]
+    img = np.stack([(xx * 255 // 449), (yy * 255 // 299), ((xx + yy) * 255 // 748)], -1).astype(np.uint8)
+    arr = imageproc.prepare_image(Image.fromarray(img, "RGB"), 4 * 28 * 28, 1024 * 28 * 28, jpeg=False)
+    gh, gw = arr.shape[1] // 14, arr.shape[2] // 14
+    assert [1, gh, gw] == g["grid"][0].tolist()
+    x = (arr.astype(np.float32) / 255.0 - np.array(imageproc.OPENAI_CLIP_MEAN, np.float32)[:, None, None]) / \
+        np.array(imageproc.OPENAI_CLIP_STD, np.float32)[:, None, None]
+    p = x.reshape(3, gh // 2, 2, 14, gw // 2, 2, 14).transpose(1, 4, 2, 5, 0, 3, 6)
+    p = np.repeat(p[:, :, :, :, :, None], 2, axis=5).reshape(gh * gw, 1176)
+    assert list(p.shape) == g["shape"].tolist()
+    np.testing.assert_allclose(p[::37, ::29], g["sample"], atol=1e-6)
+    np.testing.assert_allclose(p[:2], g["first_rows"], atol=1e-6)
+    np.testing.assert_allclose(p.sum(1), g["row_sums"], rtol=1e-5, atol=1e-3)

@@ -241,11 +241,33 @@ def gen_scorer():
     print("scorer golden:", {k: v.shape for k, v in out.items()})
 
 
+def gradient_image(h=300, w=450):
+    """Deterministic RGB test image (no dataset offline): three linear ramps."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    return np.stack([(xx * 255 // (w - 1)), (yy * 255 // (h - 1)), ((xx + yy) * 255 // (h + w - 2))], -1).astype(np.uint8)
+
+
+def gen_image():
+    """G6: HF Qwen2VLImageProcessor (PIL backend) on a 450x300 image: smart_resize + bicubic + normalise + patchify."""
+    from PIL import Image
+    from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil
+
+    proc = Qwen2VLImageProcessorPil(min_pixels=4 * 28 * 28, max_pixels=1024 * 28 * 28)  # the wrapper's defaults (_qwen2_vl.py:64-65)
+    out = proc(images=[Image.fromarray(gradient_image(), "RGB")], return_tensors="np")
+    pv = out["pixel_values"].astype(np.float32)
+    np.savez_compressed(GOLD / "image_proc.npz", grid=out["image_grid_thw"], sample=pv[::37, ::29], row_sums=pv.sum(1),
+                        first_rows=pv[:2], shape=np.array(pv.shape))
+    (GOLD / "image_proc.json").write_text(json.dumps({"versions": versions(), "image": "gradient_image(300, 450)"}, indent=1))
+    print("image golden:", pv.shape, out["image_grid_thw"].tolist())
+
+
 if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["qwen", "scorer"]
+    which = sys.argv[1:] or ["qwen", "scorer", "image"]
+    if "image" in which:
+        gen_image()
     if "qwen" in which:
         gen_qwen()
     if "scorer" in which:
