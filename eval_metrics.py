@@ -22,7 +22,7 @@ from lmms_owc_amd.metrics import get_metric_info
 
 log = logging.getLogger("eval_metrics")
 
-SAVE_INTERMEDIATE = ["mean_average_semantic_similarity", "semantic_similarity"]
+SAVE_INTERMEDIATE = ["concept_semantic_similarity", "mean_average_semantic_similarity", "semantic_similarity"]
 
 
 def main(args: Namespace) -> dict:
@@ -50,6 +50,11 @@ def main(args: Namespace) -> dict:
             elif info.name in SAVE_INTERMEDIATE:
                 output = info.group_fn(info.builder_fn([(str(r), p) for r, p in items]), reduce="none")
                 extra = {}
+                if info.name == "concept_semantic_similarity":  # (concepts, similarities) per sample (:94-104)
+                    concepts, sims = zip(*output, strict=True)
+                    output = [float(np.max(row)) for row in sims]
+                    extra["last_resp_concepts"] = list(concepts)
+                    extra["last_resp_concepts_similarities"] = list(sims)
                 if info.name == "mean_average_semantic_similarity":
                     avg = output.pop("semantic_similarity@avg")
                     extra.update(output)

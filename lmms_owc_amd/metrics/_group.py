@@ -64,3 +64,37 @@ def mean_average_semantic_similarity(items: list, reduce: Literal["none", "mean"
         outputs[f"semantic_similarity@{thr}"] = (cos >= thr).int().tolist()
     outputs["semantic_similarity@avg"] = torch.tensor(list(outputs.values()), dtype=torch.float32).mean(dim=0).tolist()
     return outputs
+
+
+SKIP_WORDS = [  # same groups as the reference (_group.py:207-236)
+    "1", "2", "3", "4", "5", "6", "7", "8", "9", "10", "one", "two", "three", "four", "five", "six", "seven", "eight",
+    "nine", "ten", "*", "a", "the", "image", "object", "photo", "type", "this photo", "it", "they", "them", "that",
+    "this", "those", "which", "who", "whom", "whose", "where", "when", "what", "why", "how", "some",
+]
+
+
+@register_aggregation("concept_semantic_similarity")
+def concept_semantic_similarity(items: list, reduce: Literal["none", "max", "mean", "median", "min"] = "max"):
+    """Similarity between the ground truth and every concept (noun chunk) of the prediction, the whole prediction
+    included; reduced per sample (max by default) and averaged.  Same contract as the reference
+    (_group.py:176-334); concepts come from the pluggable extractor, the embedding of the UNIQUE strings and the
+    pairing run on the GPU scorer."""
+    import numpy as np
+    import torch
+
+    from ..pipelines.text import embed_texts_unique, extract_concepts, get_scorer
+
+    if reduce not in ("none", "max", "mean", "median", "min"):
+        raise ValueError(f'Unknown `reduce` value for `concept_semantic_similarity` metric. Expected "none", "max", '
+                         f'"mean", "median", or "min", but got "{reduce}"')
+    refs, preds = _unwrap(items)
+    concepts = [c + [p] for c, p in zip(extract_concepts(preds, SKIP_WORDS), preds, strict=True)]
+    flat_refs = [r for r, cs in zip(refs, concepts) for _ in cs]
+    flat_concepts = [c for cs in concepts for c in cs]
+    sims = get_scorer().paired_cosine(embed_texts_unique(flat_refs), embed_texts_unique(flat_concepts)).cpu().numpy()
+    bounds = np.cumsum([0] + [len(cs) for cs in concepts])
+    rows = [sims[a:b] for a, b in zip(bounds[:-1], bounds[1:])]
+    if reduce == "none":
+        return list(zip(concepts, [r.tolist() for r in rows], strict=True))
+    fn = {"max": np.max, "mean": np.mean, "median": lambda r: torch.from_numpy(r).median().item(), "min": np.min}[reduce]
+    return float(np.mean([fn(r) for r in rows]))

@@ -46,3 +46,8 @@ def semantic_similarity(items: list) -> list:
 @register_metric(group_fn_name="mean_average_semantic_similarity", higher_is_better=True, output_types=["generate_until"])
 def mean_average_semantic_similarity(items: list) -> list:
     return items
+
+
+@register_metric(group_fn_name="concept_semantic_similarity", higher_is_better=True, output_types=["generate_until"])
+def concept_semantic_similarity(items: list) -> list:
+    return items

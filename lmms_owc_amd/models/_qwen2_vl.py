@@ -90,6 +90,9 @@ class Qwen2VL(Model):
             self._tokenizer = AutoTokenizer.from_pretrained(str(path))
             self.chat_template = getattr(self._tokenizer, "chat_template", None)
         self._dims = dims
+        from concurrent.futures import ThreadPoolExecutor
+
+        self._pool = ThreadPoolExecutor(max_workers=8)
         self._model = Qwen2VLEngine(weights)
         self._processor = self._tokenizer
 
@@ -135,9 +138,14 @@ class Qwen2VL(Model):
                 raise NotImplementedError("the HIP decoder implements greedy decoding (temperature 0, 1 beam)")
 
             images, grids_per_prompt, prompts = [], [], []
-            for ctx, did in zip(contexts, doc_ids):
-                visuals = doc_to_visual[0](self.task_dict[task][split][did])
-                arrs = [imageproc.prepare_image(v, self._min_pixels, self._max_pixels) for v in visuals]
+            # JPEG round trip + bicubic resize are host work (PIL releases the GIL): a small thread pool keeps one
+            # rank's preparation rate above the GPU's image rate
+            visuals_per_doc = [doc_to_visual[0](self.task_dict[task][split][did]) for did in doc_ids]
+            flat = [v for vs in visuals_per_doc for v in vs]
+            prepared = iter(list(self._pool.map(
+                lambda v: imageproc.prepare_image(v, self._min_pixels, self._max_pixels), flat)))
+            for ctx, visuals in zip(contexts, visuals_per_doc):
+                arrs = [next(prepared) for _ in visuals]
                 grids = [(1, a.shape[1] // 14, a.shape[2] // 14) for a in arrs]
                 images += arrs
                 grids_per_prompt.append(grids)

@@ -97,6 +97,44 @@ def embed_texts_unique(texts: list[str]) -> torch.Tensor:
     return z.index_select(0, idx).contiguous()
 
 
+# ---- concept extraction hook (reference: concept_extraction_spacy, _text.py:18-140) -----------------------
+concept_extractor = None  # callable(list[str], skip_words: list[str]) -> list[list[str]]
+
+
+def set_concept_extractor(fn) -> None:
+    """Plug the noun-chunk extractor used by `concept_semantic_similarity` (spaCy en_core_web_lg in the
+    reference; the CPU NLP pipeline itself is outside the accelerated path)."""
+    global concept_extractor
+    concept_extractor = fn
+
+
+def extract_concepts(texts: list[str], skip_words: list[str]) -> list[list[str]]:
+    global concept_extractor
+    if concept_extractor is None:
+        try:
+            import spacy
+
+            nlp = spacy.load("en_core_web_lg")
+        except Exception as e:  # spaCy / the model are not installed offline
+            raise RuntimeError("concept_semantic_similarity needs a concept extractor: install spaCy + en_core_web_lg "
+                               "or call lmms_owc_amd.pipelines.text.set_concept_extractor(fn)") from e
+
+        def _spacy(batch, skip):
+            out = []
+            for doc in nlp.pipe(batch):
+                chunks = []
+                for ch in doc.noun_chunks:
+                    words = [t.text for t in ch if t.text.lower() not in skip]  # remove_prefix_words / skip words
+                    text = " ".join(words).strip()
+                    if text and text.lower() not in skip and text not in chunks:
+                        chunks.append(text)
+                out.append(chunks)
+            return out
+
+        concept_extractor = _spacy
+    return concept_extractor(texts, skip_words)
+
+
 def encode_sentence_bert(batch: dict, rank: int | None = None, **kwargs) -> dict:
     input_column = kwargs.pop("input_column", "text")
     output_column = kwargs.pop("output_column", f"{input_column}_sentence_bert_embeds")

@@ -103,3 +103,27 @@ def test_eval_model_cli_end_to_end(gpu, scorer, tmp_path, capsys):
     assert "synthetic" in res["results"] and "total_evaluation_time_seconds" in res
     assert len(next(out.glob("*_samples_*.jsonl")).read_text().splitlines()) == 4
     assert "| synthetic |" in capsys.readouterr().out
+
+
+def test_concept_semantic_similarity(gpu, scorer):
+    """Contract of the reference's concept_semantic_similarity with a plugged-in extractor."""
+    from lmms_owc_amd.metrics import get_metric_info
+    from lmms_owc_amd.pipelines import text
+
+    def bigrams(batch, skip):  # stand-in for spaCy noun chunks: every sliding word pair
+        out = []
+        for t in batch:
+            w = re.findall(r"[a-z]+", t.lower())
+            out.append([f"{a} {b}" for a, b in zip(w, w[1:]) if f"{a} {b}" not in skip])
+        return out
+
+    text.set_concept_extractor(bigrams)
+    info = get_metric_info("concept_semantic_similarity")
+    items = [("sea lion", ["it is a sea lion on a rock"]), (["golden retriever"], "a photo of a golden retriever dog")]
+    rows = info.group_fn(info.builder_fn(items), reduce="none")
+    assert rows[0][0][-1] == "it is a sea lion on a rock" and len(rows[0][0]) == len(rows[0][1])
+    assert any(abs(v - 1.0) < 1e-5 for v in rows[0][1])  # the chunk "sea lion" matches the reference exactly
+    mx = info.group_fn(info.builder_fn(items), reduce="max")
+    mn = info.group_fn(info.builder_fn(items), reduce="min")
+    assert mn <= info.group_fn(info.builder_fn(items), reduce="mean") <= mx <= 1.0 + 1e-5
+    assert abs(mx - np.mean([max(r[1]) for r in rows])) < 1e-6
