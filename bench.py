@@ -42,8 +42,9 @@ def flops_per_image(d, new_tokens: int) -> float:
         + 2 * 256 * (4 * Dv) ** 2 + 2 * 256 * 4 * Dv * d.d_model
     H, KV, hd, dm, ff, L, V = d.n_q_heads, d.n_kv_heads, d.head_dim, d.d_model, d.d_ff, d.n_layers, d.vocab
     f_pre = L * (2 * S * dm * (H + 2 * KV) * hd + 2 * S * H * hd * dm + 2 * S * S * H * hd + 6 * S * dm * ff) + 2 * dm * V
+    # the first new token comes out of the prefill logits: T new tokens need T - 1 single-token forwards
     f_dec = sum(L * (2 * dm * (H + 2 * KV) * hd + 2 * H * hd * dm + 4 * (S + i) * H * hd + 6 * dm * ff) + 2 * dm * V
-                for i in range(new_tokens))
+                for i in range(new_tokens - 1))
     return float(f_vit + f_pre + f_dec)
 
 
