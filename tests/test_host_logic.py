@@ -132,6 +132,24 @@ def test_evaluate_two_ranks_equals_one(tmp_path):
     assert [s["doc_id"] for s in outs[0]["samples"]] == list(range(9))
 
 
+def test_evaluate_rank_with_empty_shard(tmp_path):
+    """limit=1 on two ranks: rank 1 owns no document (the reference pads by re-running a request; here the shard is
+    simply empty) and the gathered result equals the single-rank one."""
+    worker = ROOT / "tests" / "dist_worker.py"
+    outs = []
+    for world in (1, 2):
+        out = tmp_path / f"e{world}.json"
+        procs = []
+        for rank in range(world):
+            env = {**__import__("os").environ, "RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
+                   "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(29631 + world), "OWC_TEST_LIMIT": "1"}
+            procs.append(subprocess.Popen([sys.executable, str(worker), str(out)], env=env, cwd=str(ROOT)))
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+        outs.append(json.loads(out.read_text()))
+    assert outs[0] == outs[1] and len(outs[0]["samples"]) == 1
+
+
 def test_image_preprocessing_matches_hf_golden():
     """smart_resize + bicubic resize (host) + rescale/normalise/patchify restated in numpy == HF's
     Qwen2VLImageProcessor on a 450x300 image (golden G6, tools/gen_golden.py)."""
@@ -154,3 +172,24 @@ def test_image_preprocessing_matches_hf_golden():
     np.testing.assert_allclose(p[::37, ::29], g["sample"], atol=1e-6)
     np.testing.assert_allclose(p[:2], g["first_rows"], atol=1e-6)
     np.testing.assert_allclose(p.sum(1), g["row_sums"], rtol=1e-5, atol=1e-3)
+
+
+def test_checkpoint_readers_cpu(tmp_path):
+    """LazyCheckpoint resolves both parameter-name generations over sharded safetensors; dims come from config.json."""
+    import numpy as np
+
+    from lmms_owc_amd.models._qwen2_vl import LazyCheckpoint, dims_from_hf_config
+    from tests import ckpt_util
+
+    for legacy in (False, True):
+        d = tmp_path / f"ckpt{int(legacy)}"
+        info = ckpt_util.write_qwen2vl_checkpoint(d, legacy_names=legacy)
+        ck = LazyCheckpoint(d)
+        for name in ("model.visual.blocks.1.attn.qkv.weight", "model.language_model.layers.0.mlp.up_proj.weight", "lm_head.weight"):
+            assert np.array_equal(ck[name].float().numpy(), info["weights"][name])
+        dims = dims_from_hf_config(json.loads((d / "config.json").read_text()))
+        assert (dims.v_depth, dims.v_embed, dims.v_heads, dims.v_mlp, dims.patch_k) == (2, 160, 2, 640, 1176)
+        assert (dims.n_layers, dims.d_model, dims.n_q_heads, dims.n_kv_heads, dims.head_dim, dims.d_ff, dims.vocab) == (2, 256, 2, 1, 128, 512, 512)
+        assert dims.mrope_section == (16, 24, 24) and dims.image_token_id == 500 and not dims.tie_embeddings
+    with pytest.raises(KeyError):
+        ck["model.visual.nope"]

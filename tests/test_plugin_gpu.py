@@ -45,6 +45,7 @@ def test_generate_until_batch_invariant_and_ordered(gpu):
         lm.task_dict[task.task_name] = task.dataset
         outs.append(lm.generate_until(task.instances))
     assert len(outs[0]) == 7 and outs[0] == outs[1]
+    assert lm.generate_until([]) == []  # empty shard
     with pytest.raises(ValueError):
         get_model("custom-model", model_type="qwen2-vl", model_name_or_path="synthetic:tiny", bogus=1)
 
@@ -127,3 +128,60 @@ def test_concept_semantic_similarity(gpu, scorer):
     mn = info.group_fn(info.builder_fn(items), reduce="min")
     assert mn <= info.group_fn(info.builder_fn(items), reduce="mean") <= mx <= 1.0 + 1e-5
     assert abs(mx - np.mean([max(r[1]) for r in rows])) < 1e-6
+
+
+def test_real_checkpoint_loading_path(gpu, tmp_path):
+    """An on-disk HF-style checkpoint (config.json, sharded safetensors, fast tokenizer with a chat template) goes
+    through the same loader a real Qwen2-VL directory would; generation must equal the engine fed directly."""
+    import torch
+
+    from lmms_owc_amd.engine.qwen2vl import Qwen2VLEngine, Qwen2VLWeights
+    from lmms_owc_amd.models import get_model
+    from lmms_owc_amd.models._qwen2_vl import dims_from_hf_config
+    from lmms_owc_amd.tasks import load_task
+    from tests import ckpt_util
+
+    d = tmp_path / "Qwen2-VL-tiny"
+    info = ckpt_util.write_qwen2vl_checkpoint(d, legacy_names=True)
+    lm = get_model("custom-model", model_type="qwen2-vl", model_name_or_path=str(d), batch_size=2)
+    assert lm.eot_token_id == info["specials"]["<|im_end|>"] and lm.chat_template
+    task = load_task("synthetic:3:56x56:2")
+    task.build_all_requests(limit=None, rank=0, world_size=1)
+    lm.task_dict[task.task_name] = task.dataset
+    out = lm.generate_until(task.instances)
+    assert len(out) == 3 and all(isinstance(x, str) for x in out)
+    # prompt built through the tokenizer's chat template: specials + one image_pad run of the right length
+    ids = lm._prompt_ids("What type of object is in this photo?", [4])
+    s = info["specials"]
+    assert (ids == s["<|image_pad|>"]).sum() == 4 and ids[0] == s["<|im_start|>"] and (ids == s["<|vision_start|>"]).sum() == 1
+    # same weights fed directly
+    dims = dims_from_hf_config(json.loads((d / "config.json").read_text()))
+    eng = Qwen2VLEngine(Qwen2VLWeights.from_state_dict(dims, info["weights"], gpu))
+    from lmms_owc_amd import ops
+    from lmms_owc_amd.models import imageproc
+
+    img = imageproc.prepare_image(task.docs[0]["visual"], 4 * 28 * 28, 1024 * 28 * 28)
+    pix = ops.patchify_u8(torch.from_numpy(img[None]).to(gpu), imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD)
+    emb = eng.encode_images(pix, [(1, 4, 4)])
+    toks = eng.generate([ids], emb, [[(1, 4, 4)]], 8, eos_token_id=s["<|im_end|>"], pad_token_id=s["<|endoftext|>"]).cpu().numpy()[0]
+    stop = np.flatnonzero(toks == s["<|im_end|>"])
+    direct = lm.tokenizer.batch_decode([toks[: stop[0]] if len(stop) else toks], skip_special_tokens=True)[0]
+    single = lm.generate_until([task.instances[0]])
+    assert single[0] == direct
+
+
+def test_sentence_encoder_loads_from_directory(gpu, tmp_path, monkeypatch):
+    from lmms_owc_amd.pipelines import text
+    from oracle import bert_np
+    from tests import ckpt_util
+
+    d = tmp_path / "minilm"
+    info = ckpt_util.write_bert_checkpoint(d)
+    monkeypatch.setenv("OWC_SENTENCE_BERT_PATH", str(d))
+    monkeypatch.setattr(text, "sentence_bert_model", None)
+    monkeypatch.setattr(text, "sentence_bert_processor", None)
+    out = text.encode_sentence_bert({"text": ["sea lion", "what type of dog is this ?"]})
+    z = np.array(out["text_sentence_bert_embeds"], dtype=np.float32)
+    enc = text.sentence_bert_processor(["sea lion", "what type of dog is this ?"], padding=True, truncation=True, return_tensors="np")
+    want = bert_np.sentence_embed(info["weights"], info["cfg"], np.asarray(enc["input_ids"]), np.asarray(enc["attention_mask"]))
+    np.testing.assert_allclose(z, want, atol=2e-5)
