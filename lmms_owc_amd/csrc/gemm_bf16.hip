@@ -36,7 +36,6 @@ struct GemmProfile {
 };
 GemmProfile g_prof;
 int g_gemm_dbg = 0;       // experiment knob (OWC_GEMM_DBG): 1 = skip DMA, 2 = skip MFMA — results are garbage
-int g_persistent_blocks = 0;  // 0 = one block per tile (default; measured equal); 256 = persistent, one block per CU
 int g_big_min_tiles = 192;  // fewer 256x256 tiles than this -> use the 128x128 kernel
 int g_big_min_m = 1024;  // M at and above which the 256x128 3-stage kernel is used (OWC_GEMM_BIG_MIN_M)
 
@@ -309,8 +308,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
   const int nblk = tiles_m * tiles_n;
   const int nk = K / BK;
 
-  // tile id -> (m0, n0): the blocks of one XCD (id & 7) walk a contiguous, GROUP_M-major range of tiles.  A block
-  // visits ids blockIdx.x, + gridDim.x, ... (grid = all tiles, or one block per CU when persistent).
+  // tile id -> (m0, n0): the blocks of one XCD (id & 7) walk a contiguous, GROUP_M-major range of tiles.
   int m0 = 0, n0 = 0;
   const char *abase = nullptr, *wbase = nullptr;
   unsigned aoff[4], woff[4];
@@ -346,6 +344,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
       glds16(abase + kb + aoff[j], la + j * 1024);
       glds16(wbase + kb + woff[j], lw + j * 1024);
     }
+  };
+  // one A piece + one W piece (j = 0..3) of a stage: issued BETWEEN the MFMAs of a phase, where their issue cost
+  // (~60 cycles per LDS-DMA instruction) hides under the matrix pipe instead of in front of it
+  auto stage_piece = [&](int buf, int kt, int j) {
+    char* la = lds + buf * STAGE_BYTES + w * 4096;
+    const long kb = (long)kt * (BK * 2);
+    glds16(abase + kb + aoff[j], la + j * 1024);
+    glds16(wbase + kb + woff[j], la + OP_BYTES + j * 1024);
   };
 
   const int wr = w >> 2, wc = w & 3;
@@ -384,86 +390,68 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // global stores one thread issues in a FULL-tile epilogue (counted waits below rely on it)
-  constexpr int NST = (EPI == OWC_EPI_SWIGLU) ? 8 : (EPI == OWC_EPI_F32 ? 32 : 16);
-
-  int tile = blockIdx.x;
-  setup(tile);
-  stage(0, 0);
-  if (nk > 1) stage(1, 1);
-  bool carry = false;  // true: the previous tile's NST epilogue stores may still be in flight (younger than the DMA)
-
-  for (;;) {
-    // wait until stage 0 has landed; allowed to stay outstanding (all YOUNGER than stage 0): stage 1's 8 pieces
-    // and, on a follow-up tile, the previous tile's store tail.
-    if (carry) {
-      if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NST + 8) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NST) : "memory");
-    } else {
-      if (nk > 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    read_a(xa, lds, 0, ch0);
-    read_w(wk0, lds, ch0);
-
-    // Per K-tile, phases walk (m half, k-step) = (0,0) (1,0) (1,1) (0,1): every phase consumes fragment blocks
-    // that were fetched from LDS one phase earlier.
-    for (int kt = 0; kt < nk; ++kt) {
-      const char* cur = lds + (kt & 1) * STAGE_BYTES;
-      const char* nxt = lds + ((kt + 1) & 1) * STAGE_BYTES;
-      read_a(ya, cur, 1, ch0);   // for phase 2
-      phase(xa, wk0, 0);         // phase 1: rows 0-63,  k-step 0
-      read_a(xa, cur, 1, ch1);   // for phase 3
-      read_w(wk1, cur, ch1);
-      phase(ya, wk0, 1);         // phase 2: rows 64-127, k-step 0
-      read_a(ya, cur, 0, ch1);   // for phase 4
-      phase(xa, wk1, 1);         // phase 3: rows 64-127, k-step 1
-      // every LDS read of stage kt by this wave has completed (lgkmcnt(0), issued >= one phase ago) and its DMA
-      // pieces of stage kt+1 have landed (issued a whole K-tile ago); the barrier publishes stage kt+1 and proves
-      // stage kt's buffer is no longer read by anyone.  On the first K-tile of a follow-up tile the previous
-      // tile's stores (younger than stage 1) may keep flying.
-      if (carry && kt == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NST) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (kt + 2 < nk && !(dbg & 1)) stage(kt & 1, kt + 2);
-      if (kt + 1 < nk) {
-        read_a(xa, nxt, 0, ch0);  // next K-tile, phase 1
-        read_w(wk0, nxt, ch0);
-      }
-      phase(ya, wk1, 0);         // phase 4: rows 0-63,  k-step 1
-    }
-
-    // ---- tile done.  Both LDS stages are free (every wave's last LDS read preceded the last barrier), so the
-    // NEXT tile's first two stages are put in flight BEFORE this tile's epilogue: DMA latency and store tail
-    // hide behind each other, and the stores then drain under the next tile's first K-tile.
-    const int out_m0 = m0, out_n0 = n0;
-    const int next = tile + (int)gridDim.x;
-    const bool more = next < nblk;
-    if (more) {
-      setup(next);
-      stage(0, 0);
-      if (nk > 1) stage(1, 1);
-    }
-    // pin the issue order DMA -> epilogue loads/stores: the counted waits assume the stores are YOUNGER
-    asm volatile("" ::: "memory");
+  // phase 4 variant: the same 16 MFMAs in 4 groups of 4 with one DMA piece pair after each group: the issue cost of
+  // an LDS-DMA instruction (~60 cycles) hides under the matrix pipe instead of idling both waves of the SIMD
+  auto phase_dma = [&](const bf16x8 (&af)[4], const bf16x8 (&wf)[4], int mh, int buf, int kt2, bool issue) {
     __builtin_amdgcn_sched_barrier(0);
-    if (dbg & 4) {
-      if (acc[0][0][0] == 123.456f) ((float*)Cv)[0] = 1.f;  // timing experiment: no epilogue
-      carry = false;
-    } else if (out_m0 + BT <= M && out_n0 + BT <= N) {
-      gemm_epilogue<EPI, 8, true>(acc, out_m0 + wr * 128, out_n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
-      carry = true;
-    } else {
-      gemm_epilogue<EPI, 8, false>(acc, out_m0 + wr * 128, out_n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
-      if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // predicated stores: count unknown, drain
-      carry = false;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        acc[n][mh * 4 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], af[m], acc[n][mh * 4 + m], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (issue) stage_piece(buf, kt2, n);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (!more) break;
-    tile = next;
+  };
+
+  setup(blockIdx.x);
+  stage(0, 0);
+  if (nk > 1) {
+    stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");  // stage 0 landed (stage 1's 8 pieces may fly)
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  read_a(xa, lds, 0, ch0);
+  read_w(wk0, lds, ch0);
+
+  // Per K-tile, phases walk (m half, k-step) = (0,0) (1,0) (1,1) (0,1): every phase consumes fragment blocks
+  // that were fetched from LDS one phase earlier.
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* cur = lds + (kt & 1) * STAGE_BYTES;
+    const char* nxt = lds + ((kt + 1) & 1) * STAGE_BYTES;
+    read_a(ya, cur, 1, ch0);   // for phase 2
+    phase(xa, wk0, 0);         // phase 1: rows 0-63,  k-step 0
+    read_a(xa, cur, 1, ch1);   // for phase 3
+    read_w(wk1, cur, ch1);
+    phase(ya, wk0, 1);         // phase 2: rows 64-127, k-step 0
+    read_a(ya, cur, 0, ch1);   // for phase 4
+    phase(xa, wk1, 1);         // phase 3: rows 64-127, k-step 1
+    // every LDS read of stage kt by this wave has completed (lgkmcnt(0), issued >= one phase ago) and its DMA
+    // pieces of stage kt+1 have landed (issued a whole K-tile ago); the barrier publishes stage kt+1 and proves
+    // stage kt's buffer is no longer read by anyone.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kt + 1 < nk) {
+      read_a(xa, nxt, 0, ch0);  // next K-tile, phase 1
+      read_w(wk0, nxt, ch0);
+    }
+    // phase 4: rows 0-63, k-step 1 — with the DMA of stage kt+2 (into stage kt's buffer, free since the barrier)
+    // interleaved between its MFMA groups
+    phase_dma(ya, wk1, 0, kt & 1, kt + 2, kt + 2 < nk && !(dbg & 1));
+  }
+
+  if (dbg & 4) {  // timing experiment: no epilogue
+    if (acc[0][0][0] == 123.456f) ((float*)Cv)[0] = 1.f;
+    return;
+  }
+  gemm_epilogue<EPI, 8>(acc, m0 + wr * 128, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
 }
 
 template <int EPI>
@@ -499,10 +487,8 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
     (void)hipEventRecord(e0, s);
   }
   if (big)
-    // g_persistent_blocks > 0: one resident block per CU walks the tiles (epilogue overlapped with the next tile)
-    hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>,
-                       dim3(g_persistent_blocks > 0 ? min(tiles_m * tiles_n, g_persistent_blocks) : tiles_m * tiles_n),
-                       dim3(512), 2 * STAGE_BYTES, s, (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
+    hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), 2 * STAGE_BYTES, s,
+                       (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
                        (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, g_gemm_dbg, aux);
   else
     hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, s,
@@ -577,4 +563,3 @@ int owc_gemm_profile_collect(double* total_ms, double* total_flops, long* launch
 
 void owc_gemm_set_big_min_m(int m) { g_big_min_m = m; }
 void owc_gemm_set_dbg(int v) { g_gemm_dbg = v; }
-void owc_gemm_set_persistent(int v) { g_persistent_blocks = v; }
