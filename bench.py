@@ -232,6 +232,25 @@ def main() -> None:
     dt = float(tmax.item())
     images_per_s = world * B * args.steps / dt
 
+    # ---- PCIe-inclusive leg (never `value`): the same step fed from host uint8 images (what the boundary hands over in a
+    # real run): pinned H2D copy + GPU rescale/normalise/patchify + the step above
+    from lmms_owc_amd import ops as owc_ops
+    from lmms_owc_amd.models import imageproc
+
+    host_u8 = torch.randint(0, 256, (B, 3, 448, 448), dtype=torch.uint8).pin_memory()
+    sync()
+    p0 = time.perf_counter()
+    dev_u8 = host_u8.to(device, non_blocking=True)
+    pix_h = owc_ops.patchify_u8(dev_u8, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD)
+    emb_h = engine.encode_images(pix_h, flat_grids)
+    engine.generate(prompts, emb_h, grids, T, eos_token_id=-1, pad_token_id=0).cpu()
+    sync()
+    pcie_dt = torch.tensor([time.perf_counter() - p0], device=device, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(pcie_dt, op=dist.ReduceOp.MAX)
+    pcie_images_per_s = world * B / float(pcie_dt.item())
+    del host_u8, dev_u8, pix_h, emb_h
+
     # ---- scorer leg: label-cosine/s (embed predictions + cosine top-5 against resident class embeddings)
     n_lab, L = args.scorer_labels, 16
     scorer = SentenceScorer(BertWeights.random(MINILM_L6, device, seed=7), max_batch=16384)
@@ -269,6 +288,7 @@ def main() -> None:
                                    f"(1024 patches -> 256 image tokens), prompt S=286, {T} forced greedy tokens, seeded random "
                                    "weights of the real architecture; images strided across ranks, no data-path collective",
                        "images_per_gpu_per_step": B, "prompt_tokens": 286, "new_tokens": T, "parallelism": f"dp{world}"},
+            "images_per_s_from_host_uint8": pcie_images_per_s,  # PCIe-inclusive (H2D + GPU patchify + step), not `value`
             "label_cosine_per_sec": labels_per_s,
             "label_cosine_config": {"labels_per_gpu": n_lab, "tokens_per_label": L, "classes": args.scorer_classes, "top_k": 5,
                                     "encoder": "MiniLM-L6 (BERT 6x384) fp32 on f32-input MFMA"},
