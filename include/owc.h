@@ -189,17 +189,23 @@ typedef struct owc_kv_cache {
 
 size_t owc_llm_workspace_bytes(const owc_llm_weights* w, int T, int n_seq);
 
-/* Prefill of `n_seq` packed prompts (T tokens in total), HF:1144-1205 + :762-846 + lm_head:
+/* Prefill of packed prompts (T token rows in total), HF:1144-1205 + :762-846 + lm_head.
  *   ids/img_index/tok_slot/tok_idx: int32[T]; pos3: int32[3][T] from get_rope_index (HF:914-1019);
- *   seq_start/seq_len/k_start: int32[n_seq] (k_start[b] = slot * n_kv_heads * s_max);
- *   last_index: int32[n_seq] = packed index of each prompt's last token.
- * Writes the KV cache and next_tok[n_seq] = argmax of the last position's logits.
- * `logits_out` (optional, [n_seq, vocab] bf16) receives those logits. */
+ *   the token rows form `n_seq` attention segments: segment s covers rows [seq_start[s], +q_len[s]) and attends,
+ *   causally, the keys [0, seq_len[s]) of the cache slot at k_start[s] (= slot * n_kv_heads * s_max); its rows
+ *   are the LAST q_len[s] positions of that key range (q_len == NULL -> q_len = seq_len, the plain case).
+ *   Shared-prefix mode (every prompt of a classification task starts with the same system/question tokens): the
+ *   prefix is computed ONCE as segment n_seq-1 (tok_slot = -1 on its rows: the K/V rows are written to all slots
+ *   [bcast_first_slot, +bcast_n_slots)), the other segments hold only the per-image suffixes.
+ *   last_index: int32[n_out] = row of each prompt's last token (n_out = number of real prompts <= n_seq).
+ * Writes the KV cache and next_tok[n_out] = argmax of the last position's logits.
+ * `logits_out` (optional, [n_out, vocab] bf16) receives those logits. */
 int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* cache,
                     const int32_t* ids, const int32_t* img_index, const void* img_embeds,
                     const int32_t* pos3, const int32_t* tok_slot, const int32_t* tok_idx,
-                    const int32_t* seq_start, const int32_t* seq_len, const int32_t* k_start,
-                    const int32_t* last_index, int n_seq, int T, int max_len, int32_t* next_tok,
+                    const int32_t* seq_start, const int32_t* seq_len, const int32_t* q_len,
+                    const int32_t* k_start, const int32_t* last_index, int n_seq, int n_out, int T,
+                    int max_len, int bcast_first_slot, int bcast_n_slots, int32_t* next_tok,
                     void* logits_out, void* workspace, size_t ws_bytes, void* stream);
 
 /* One greedy decode step for B sequences (HF GenerationMixin loop body, one token each):

@@ -20,7 +20,7 @@ _lock = threading.Lock()
 _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = range(6)
 
@@ -103,8 +103,8 @@ SIGNATURES: dict[str, tuple] = {
     "owc_vit_workspace_bytes": (sz, [C.POINTER(VitWeights), i32]),
     "owc_vit_forward": (i32, [vp, C.POINTER(VitWeights), vp, i64, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]),
     "owc_llm_workspace_bytes": (sz, [C.POINTER(LlmWeights), i32, i32]),
-    "owc_llm_prefill": (i32, [vp, C.POINTER(LlmWeights), C.POINTER(KvCache), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                              i32, i32, i32, vp, vp, vp, sz, vp]),
+    "owc_llm_prefill": (i32, [vp, C.POINTER(LlmWeights), C.POINTER(KvCache), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                              i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "owc_llm_decode_step": (i32, [vp, C.POINTER(LlmWeights), C.POINTER(KvCache), vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                   vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
     "owc_decode_update": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

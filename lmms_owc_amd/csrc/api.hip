@@ -14,7 +14,7 @@
 
 extern "C" {
 
-int owc_abi_version(void) { return 3; }
+int owc_abi_version(void) { return 4; }
 
 int owc_init(int device, owc_ctx** out) {
   if (out == nullptr) return OWC_ERR_ARG;
@@ -89,7 +89,7 @@ int owc_mrope_kv_write(owc_ctx* ctx, void* qkv, int64_t ld, const int32_t* pos3,
     return OWC_ERR_ARG;
   RET(ctx, "owc_mrope_kv_write",
       owc_launch_mrope_kv(qkv, ld, pos3, pos_stride, cos_t, sin_t, k_cache, v_cache, tok_slot, tok_idx, T,
-                          n_q_heads, n_kv_heads, s_max, mrope_sec0, mrope_sec1, ST(stream)));
+                          n_q_heads, n_kv_heads, s_max, mrope_sec0, mrope_sec1, 0, 0, ST(stream)));
 }
 
 int owc_attention_bf16(owc_ctx* ctx, const void* Q, int64_t q_ts, int64_t q_hs, const void* K,

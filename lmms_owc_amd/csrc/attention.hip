@@ -66,7 +66,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
   const long qs = q_start[b], ks0 = k_start[b];
   const long os = o_start ? (long)o_start[b] : qs;
 
-  const int kmax = CAUSAL ? min(L, qb * QB + QB) : L;
+  // causal: query row i sits at absolute position coff + i (coff = L - Lq > 0 when a shared prefix's keys
+  // precede the rows handled here) and sees keys <= coff + i
+  const int coff = L - Lq;
+  const int kmax = CAUSAL ? min(L, qb * QB + QB + coff) : L;
   const int ntiles = (kmax + KB - 1) / KB;
 
   // ---- Q fragments (B operand): lane = query column fr, 8 consecutive d per k-step ----
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     }
 
     // ---- online softmax (lane = query column; keys 16kt + 4g + r) ----
-    const bool edge = (t * KB + KB > L) || (CAUSAL && (t * KB + KB - 1 > qb * QB + w * 32));
+    const bool edge = (t * KB + KB > L) || (CAUSAL && (t * KB + KB - 1 > qb * QB + w * 32 + coff));
     bf16x8 pf[2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
         for (int r = 0; r < 4; ++r) {
           if (edge) {
             const int key = t * KB + kt * 16 + g * 4 + r;
-            if (key >= L || (CAUSAL && key > qrow[qt])) s[kt][qt][r] = -1e30f;
+            if (key >= L || (CAUSAL && key > qrow[qt] + coff)) s[kt][qt][r] = -1e30f;
           }
           mx = fmaxf(mx, s[kt][qt][r]);
         }

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void mrope_kv_kernel(
     bf16_t* __restrict__ qkv, long ld, const int* __restrict__ pos3, long pos_stride,
     const float* __restrict__ cos_t, const float* __restrict__ sin_t, bf16_t* __restrict__ kc,
     bf16_t* __restrict__ vc, const int* __restrict__ tok_slot, const int* __restrict__ tok_idx,
-    int T, int n_q, int n_kv, int s_max, int sec0, int sec1) {
+    int T, int n_q, int n_kv, int s_max, int sec0, int sec1, int bcast_first, int bcast_n) {
   // thread = (token, head among q+2kv, group of 4 dims in [0,64))
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int n_h = n_q + 2 * n_kv;
@@ -166,9 +166,14 @@ __global__ __launch_bounds__(256) void mrope_kv_kernel(
   const bf16x4 b = *(const bf16x4*)(p + i0 + 64);
   if (h >= n_q + n_kv) {  // v: straight copy into the cache
     const int kvh = h - n_q - n_kv;
-    bf16_t* dst = vc + (((long)tok_slot[t] * n_kv + kvh) * s_max + tok_idx[t]) * 128;
-    *(bf16x4*)(dst + i0) = a;
-    *(bf16x4*)(dst + i0 + 64) = b;
+    // tok_slot < 0: a shared-prefix token, its K/V row goes to every slot of [bcast_first, bcast_first + bcast_n)
+    const int s0 = tok_slot[t] < 0 ? bcast_first : tok_slot[t];
+    const int ns = tok_slot[t] < 0 ? bcast_n : 1;
+    for (int sl = s0; sl < s0 + ns; ++sl) {
+      bf16_t* dst = vc + (((long)sl * n_kv + kvh) * s_max + tok_idx[t]) * 128;
+      *(bf16x4*)(dst + i0) = a;
+      *(bf16x4*)(dst + i0 + 64) = b;
+    }
     return;
   }
   bf16x4 oa, ob;
@@ -187,9 +192,13 @@ __global__ __launch_bounds__(256) void mrope_kv_kernel(
     *(bf16x4*)(p + i0 + 64) = ob;
   } else {
     const int kvh = h - n_q;
-    bf16_t* dst = kc + (((long)tok_slot[t] * n_kv + kvh) * s_max + tok_idx[t]) * 128;
-    *(bf16x4*)(dst + i0) = oa;
-    *(bf16x4*)(dst + i0 + 64) = ob;
+    const int s0 = tok_slot[t] < 0 ? bcast_first : tok_slot[t];
+    const int ns = tok_slot[t] < 0 ? bcast_n : 1;
+    for (int sl = s0; sl < s0 + ns; ++sl) {
+      bf16_t* dst = kc + (((long)sl * n_kv + kvh) * s_max + tok_idx[t]) * 128;
+      *(bf16x4*)(dst + i0) = oa;
+      *(bf16x4*)(dst + i0 + 64) = ob;
+    }
   }
 }
 
@@ -356,12 +365,12 @@ int owc_launch_vision_rope(void* qkv, long ld, const int* pos_hw, const float* c
 int owc_launch_mrope_kv(void* qkv, long ld, const int* pos3, long pos_stride, const float* cos_t,
                         const float* sin_t, void* kc, void* vc, const int* tok_slot,
                         const int* tok_idx, int T, int n_q, int n_kv, int s_max, int sec0, int sec1,
-                        hipStream_t st) {
+                        int bcast_first, int bcast_n, hipStream_t st) {
   if (T <= 0 || (ld & 3)) return OWC_ERR_SHAPE;
   const long total = (long)T * (n_q + 2 * n_kv) * 16;
   hipLaunchKernelGGL(mrope_kv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                      (bf16_t*)qkv, ld, pos3, pos_stride, cos_t, sin_t, (bf16_t*)kc, (bf16_t*)vc,
-                     tok_slot, tok_idx, T, n_q, n_kv, s_max, sec0, sec1);
+                     tok_slot, tok_idx, T, n_q, n_kv, s_max, sec0, sec1, bcast_first, bcast_n);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 

@@ -50,7 +50,7 @@ int owc_launch_vision_rope(void* qkv, long ld, const int* pos_hw, const float* c
 int owc_launch_mrope_kv(void* qkv, long ld, const int* pos3, long pos_stride, const float* cos_t,
                         const float* sin_t, void* kc, void* vc, const int* tok_slot,
                         const int* tok_idx, int T, int n_q, int n_kv, int s_max, int sec0, int sec1,
-                        hipStream_t st);
+                        int bcast_first, int bcast_n, hipStream_t st);
 int owc_launch_embed(const int* ids, const int* img_index, const void* table, const void* img,
                      void* out, int T, int d, hipStream_t st);
 int owc_launch_argmax(const void* logits, long ld, int rows, int V, int* out, hipStream_t st);

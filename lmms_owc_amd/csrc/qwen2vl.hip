@@ -108,7 +108,7 @@ static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache
                       int64_t pos_stride, const int32_t* tok_slot, const int32_t* tok_idx,
                       const int32_t* q_start, const int32_t* o_start, const int32_t* k_start,
                       const int32_t* k_len, const int32_t* q_len, int n_seq, int T, int max_q_len,
-                      bool decode, hipStream_t st) {
+                      bool decode, int bcast_first, int bcast_n, hipStream_t st) {
   const int d = w->d_model, Hq = w->n_q_heads, Hkv = w->n_kv_heads, hd = w->head_dim, F = w->d_ff;
   const int NQKV = (Hq + 2 * Hkv) * hd;
   const int G = Hq / Hkv;
@@ -123,11 +123,11 @@ static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache
     OWC_TRY(owc_launch_gemm_bf16(h, d, L.qkv_w, d, L.qkv_b, nullptr, 0, qkv, NQKV, T, NQKV, d,
                                  OWC_EPI_NONE, ctx->zeros, st));
     OWC_TRY(owc_launch_mrope_kv(qkv, NQKV, pos3, pos_stride, w->rope_cos, w->rope_sin, kc, vc, tok_slot,
-                                tok_idx, T, Hq, Hkv, cache->s_max, w->mrope_sec0, w->mrope_sec1, st));
+                                tok_idx, T, Hq, Hkv, cache->s_max, w->mrope_sec0, w->mrope_sec1, bcast_first, bcast_n, st));
     if (!decode) {
       OWC_TRY(owc_launch_attention(qkv, NQKV, hd, kc, hd, (long)cache->s_max * hd, vc, hd,
                                    (long)cache->s_max * hd, attn, (long)Hq * hd, hd, q_start, nullptr,
-                                   k_start, k_len, nullptr, n_seq, Hq, G, hd, max_q_len, 1, scale, st));
+                                   k_start, k_len, q_len, n_seq, Hq, G, hd, max_q_len, 1, scale, st));
     } else {
       // one query row per q head: map the G heads of a kv group onto the "rows" of the kernel
       OWC_TRY(owc_launch_attention(qkv, hd, (long)G * hd, kc, hd, (long)cache->s_max * hd, vc, hd,
@@ -149,12 +149,14 @@ static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache
 int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* cache,
                     const int32_t* ids, const int32_t* img_index, const void* img_embeds,
                     const int32_t* pos3, const int32_t* tok_slot, const int32_t* tok_idx,
-                    const int32_t* seq_start, const int32_t* seq_len, const int32_t* k_start,
-                    const int32_t* last_index, int n_seq, int T, int max_len, int32_t* next_tok,
+                    const int32_t* seq_start, const int32_t* seq_len, const int32_t* q_len,
+                    const int32_t* k_start, const int32_t* last_index, int n_seq, int n_out, int T,
+                    int max_len, int bcast_first_slot, int bcast_n_slots, int32_t* next_tok,
                     void* logits_out, void* workspace, size_t ws_bytes, void* stream) {
   if (!ctx || !w || !cache || !ids || !pos3 || !tok_slot || !tok_idx || !seq_start || !seq_len ||
       !k_start || !last_index || !next_tok || !workspace)
     return OWC_ERR_ARG;
+  if (n_out <= 0 || n_out > n_seq) OWC_FAIL(ctx, OWC_ERR_ARG, "owc_llm_prefill: 0 < n_out <= n_seq");
   if (w->head_dim != 128) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_llm_prefill: head_dim must be 128");
   if (ws_bytes < owc_llm_workspace_bytes(w, T, n_seq)) OWC_FAIL(ctx, OWC_ERR_WORKSPACE, "owc_llm_prefill: workspace too small");
   hipStream_t st = (hipStream_t)stream;
@@ -171,12 +173,12 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
 
   OWC_TRY(owc_launch_embed(ids, img_index, w->embed, img_embeds, x, T, d, st));
   OWC_TRY(llm_layers(ctx, w, cache, x, h, qkv, attn, mlp, pos3, T, tok_slot, tok_idx, seq_start, nullptr,
-                     k_start, seq_len, nullptr, n_seq, T, max_len, false, st));
+                     k_start, seq_len, q_len, n_seq, T, max_len, false, bcast_first_slot, bcast_n_slots, st));
   // final norm on the last token of every prompt only, then lm_head + greedy argmax
-  OWC_TRY(owc_launch_rmsnorm(x, d, w->final_norm_w, last, d, n_seq, d, w->rms_eps, last_index, st));
-  OWC_TRY(owc_launch_gemm_bf16(last, d, w->lm_head_w, d, nullptr, nullptr, 0, logits, w->vocab, n_seq,
+  OWC_TRY(owc_launch_rmsnorm(x, d, w->final_norm_w, last, d, n_out, d, w->rms_eps, last_index, st));
+  OWC_TRY(owc_launch_gemm_bf16(last, d, w->lm_head_w, d, nullptr, nullptr, 0, logits, w->vocab, n_out,
                                w->vocab, d, OWC_EPI_NONE, ctx->zeros, st));
-  OWC_TRY(owc_launch_argmax(logits, w->vocab, n_seq, w->vocab, next_tok, st));
+  OWC_TRY(owc_launch_argmax(logits, w->vocab, n_out, w->vocab, next_tok, st));
   return OWC_OK;
 }
 
@@ -206,7 +208,7 @@ int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cac
   OWC_TRY(owc_launch_embed(tok_io, nullptr, w->embed, nullptr, x, B, d, st));
   // the three mrope streams of a generated token are identical: pos_stride 0 re-reads `pos`
   OWC_TRY(llm_layers(ctx, w, cache, x, h, qkv, attn, mlp, pos, 0, slot, write_idx, q_start, o_start,
-                     k_start, k_len, q_len, B, B, w->n_q_heads / w->n_kv_heads, true, st));
+                     k_start, k_len, q_len, B, B, w->n_q_heads / w->n_kv_heads, true, 0, 0, st));
   OWC_TRY(owc_launch_rmsnorm(x, d, w->final_norm_w, last, d, B, d, w->rms_eps, nullptr, st));
   OWC_TRY(owc_launch_gemm_bf16(last, d, w->lm_head_w, d, nullptr, nullptr, 0, logits, w->vocab, B,
                                w->vocab, d, OWC_EPI_NONE, ctx->zeros, st));

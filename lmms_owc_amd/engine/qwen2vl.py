@@ -231,7 +231,10 @@ def _param_shape(d: Qwen2VLDims, name: str) -> tuple:
 class Qwen2VLEngine:
     """Batched open-world classification forward: pixel_values + prompt ids -> greedy token ids."""
 
-    def __init__(self, weights: Qwen2VLWeights, *, vit_chunk_tokens: int = 65536, prefill_chunk_tokens: int = 32768):
+    def __init__(self, weights: Qwen2VLWeights, *, vit_chunk_tokens: int = 65536, prefill_chunk_tokens: int = 32768,
+                 share_prefix: bool = True, min_shared_prefix: int = 4):
+        self.share_prefix = share_prefix            # prefill the prompts' common leading text tokens once per chunk
+        self.min_shared_prefix = min_shared_prefix
         self.w = weights
         self.d = weights.dims
         self.device = weights.device
@@ -375,27 +378,61 @@ class Qwen2VLEngine:
                     break
         return (out_tokens, first_logits) if return_logits else out_tokens
 
+    def _common_prefix(self, prompts, b0: int, b1: int) -> int:
+        """Length of the leading run of text tokens shared by every prompt of the chunk (system prompt, question
+        preamble, <|vision_start|>): identical ids at identical positions give identical hidden states in every
+        layer under causal attention, so they are prefilled once."""
+        if not self.share_prefix or b1 - b0 < 2:
+            return 0
+        first = np.asarray(prompts[b0])
+        p = int(min(len(prompts[b]) for b in range(b0, b1))) - 1  # every prompt keeps >= 1 own token
+        img = np.flatnonzero(first[:p] == self.d.image_token_id)
+        if len(img):
+            p = int(img[0])
+        for b in range(b0 + 1, b1):
+            if p <= 0:
+                break
+            neq = np.flatnonzero(np.asarray(prompts[b][:p]) != first[:p])
+            if len(neq):
+                p = int(neq[0])
+        return p if p >= self.min_shared_prefix else 0
+
     def _prefill_chunk(self, prompts, pos_list, img_index, img_embeds, lens, b0, b1, cache, next_tok, first_logits):
         d = self.d
         n = b1 - b0
-        T = int(lens[b0:b1].sum())
-        ids = np.concatenate([np.asarray(prompts[b], dtype=np.int32) for b in range(b0, b1)])
-        pos3 = np.concatenate([pos_list[b] for b in range(b0, b1)], axis=1)
-        iidx = np.concatenate([img_index[b] for b in range(b0, b1)])
-        starts = np.concatenate([[0], np.cumsum(lens[b0:b1])[:-1]])
-        tok_slot = np.repeat(np.arange(b0, b1), lens[b0:b1])
-        tok_idx = np.concatenate([np.arange(int(lens[b]), dtype=np.int32) for b in range(b0, b1)])
+        P = self._common_prefix(prompts, b0, b1)
+        sl = lens[b0:b1] - P                       # rows each prompt contributes
+        ids = [np.asarray(prompts[b], dtype=np.int32)[P:] for b in range(b0, b1)]
+        pos3 = [pos_list[b][:, P:] for b in range(b0, b1)]
+        iidx = [img_index[b][P:] for b in range(b0, b1)]
+        tok_slot = [np.full(int(sl[i]), b0 + i, dtype=np.int32) for i in range(n)]
+        tok_idx = [np.arange(P, int(lens[b0 + i]), dtype=np.int32) for i in range(n)]
+        starts = np.concatenate([[0], np.cumsum(sl)[:-1]])
+        q_len, k_len = sl.copy(), lens[b0:b1].copy()
         k_start = np.arange(b0, b1, dtype=np.int64) * d.n_kv_heads * cache.s_max
-        last = starts + lens[b0:b1] - 1
-        t_ids, t_pos3, t_iidx = self._i32(ids), self._i32(pos3), self._i32(iidx)
-        t_slot, t_idx, t_start, t_len = self._i32(tok_slot), self._i32(tok_idx), self._i32(starts), self._i32(lens[b0:b1])
+        last = starts + sl - 1
+        if P:  # the shared prefix rides along as one extra segment at the end of the packed rows
+            ids.append(np.asarray(prompts[b0], dtype=np.int32)[:P])
+            pos3.append(pos_list[b0][:, :P])
+            iidx.append(np.full(P, -1, dtype=np.int32))
+            tok_slot.append(np.full(P, -1, dtype=np.int32))   # -1: K/V rows are written to every slot of the chunk
+            tok_idx.append(np.arange(P, dtype=np.int32))
+            starts = np.concatenate([starts, [int(sl.sum())]])
+            q_len, k_len = np.concatenate([q_len, [P]]), np.concatenate([k_len, [P]])
+            k_start = np.concatenate([k_start, [k_start[0]]])
+        T = int(sum(len(x) for x in ids))
+        t_ids, t_pos3, t_iidx = self._i32(np.concatenate(ids)), self._i32(np.concatenate(pos3, axis=1)), self._i32(np.concatenate(iidx))
+        t_slot, t_idx = self._i32(np.concatenate(tok_slot)), self._i32(np.concatenate(tok_idx))
+        t_start, t_klen, t_qlen = self._i32(starts), self._i32(k_len), self._i32(q_len)
         t_kstart, t_last = self._i32(k_start), self._i32(last)
-        nbytes = self._lib.owc_llm_workspace_bytes(C.byref(self.w.llm), T, n)
+        n_seq = len(starts)
+        nbytes = self._lib.owc_llm_workspace_bytes(C.byref(self.w.llm), T, n_seq)
         ws = self._workspace(nbytes)
         logits_ptr = first_logits[b0:b1].data_ptr() if first_logits is not None else None
         rc = self._lib.owc_llm_prefill(
             self._ctx, C.byref(self.w.llm), C.byref(cache), t_ids.data_ptr(), t_iidx.data_ptr(),
             _lib.ptr(img_embeds), t_pos3.data_ptr(), t_slot.data_ptr(), t_idx.data_ptr(), t_start.data_ptr(),
-            t_len.data_ptr(), t_kstart.data_ptr(), t_last.data_ptr(), n, T, int(lens[b0:b1].max()),
-            next_tok[b0:b1].data_ptr(), logits_ptr, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+            t_klen.data_ptr(), t_qlen.data_ptr(), t_kstart.data_ptr(), t_last.data_ptr(), n_seq, n, T,
+            int(q_len.max()), b0, n, next_tok[b0:b1].data_ptr(), logits_ptr, ws.data_ptr(), ws.numel(),
+            _lib.stream_ptr())
         _lib.check(rc, self.dev_index)

@@ -101,3 +101,31 @@ def test_eos_pads_rest(setup, gpu):
     first = int(np.flatnonzero(free == eos)[0])
     got = to_np(eng.generate([ids], emb, [grid], 6, eos_token_id=eos, pad_token_id=0, stop_check_every=1))[0].astype(int)
     assert np.array_equal(got[:first + 1], free[:first + 1]) and (got[first + 1:] == 0).all()
+
+
+def test_shared_prefix_is_bit_identical(setup, gpu):
+    """Prefilling the prompts' common leading tokens once (shared-prefix segment + K/V broadcast) must give exactly
+    the tokens and first-step logits of the plain per-prompt prefill."""
+    from lmms_owc_amd.engine.qwen2vl import Qwen2VLEngine
+
+    cfg, w, eng, g = setup
+    plain = Qwen2VLEngine(eng.w, vit_chunk_tokens=64, prefill_chunk_tokens=4096, share_prefix=False)
+    shared = Qwen2VLEngine(eng.w, vit_chunk_tokens=64, prefill_chunk_tokens=4096, share_prefix=True, min_shared_prefix=2)
+    r = np.random.default_rng(3)
+    head = r.integers(1, 400, 7)
+    prompts, grids, pixs = [], [], []
+    for i, grid in enumerate([[(1, 4, 4)], [(1, 6, 4)], [(1, 4, 8)], [(1, 4, 4)]]):
+        n_img = grid[0][1] * grid[0][2] // 4
+        prompts.append(np.concatenate([head, np.full(n_img, cfg.image_token_id), r.integers(1, 400, 3 + i)]))
+        grids.append(grid)
+        pixs.append(recipes.pixel_values(grid, 20 + i))
+    pix = torch.from_numpy(np.concatenate(pixs)).to(torch.bfloat16).to(gpu)
+    emb = eng.encode_images(pix, [gg for gs in grids for gg in gs])
+    assert shared._common_prefix(prompts, 0, 4) == 7
+    a, la = plain.generate(prompts, emb, grids, 6, return_logits=True)
+    b, lb = shared.generate(prompts, emb, grids, 6, return_logits=True)
+    assert torch.equal(a, b) and torch.equal(la, lb)
+    # two chunks (the prefix is shared per chunk) and a chunk of one prompt (no sharing) agree as well
+    shared2 = Qwen2VLEngine(eng.w, vit_chunk_tokens=64, prefill_chunk_tokens=40, share_prefix=True, min_shared_prefix=2)
+    c = shared2.generate(prompts, emb, grids, 6)
+    assert torch.equal(a, c)
