@@ -335,12 +335,14 @@ class Qwen2VLEngine:
         next_tok = torch.empty(B, dtype=I32, device=self.device)
         first_logits = torch.empty((B, d.vocab), dtype=BF16, device=self.device) if return_logits else None
 
-        # ---- prefill in chunks of whole prompts
+        # ---- prefill in chunks of whole prompts (chunk size counted in packed ROWS: with a shared prefix every
+        # prompt contributes len - P rows, so more prompts fit the same GEMM M)
+        p_all = self._common_prefix(prompts, 0, B)
         b0 = 0
         while b0 < B:
-            b1, tok = b0, 0
-            while b1 < B and (tok == 0 or tok + lens[b1] <= self.prefill_chunk_tokens):
-                tok += int(lens[b1])
+            b1, rows = b0, p_all
+            while b1 < B and (b1 == b0 or rows + lens[b1] - p_all <= self.prefill_chunk_tokens):
+                rows += int(lens[b1]) - p_all
                 b1 += 1
             self._prefill_chunk(prompts, pos_list, img_index, img_embeds, lens, b0, b1, cache, next_tok, first_logits)
             b0 = b1
