@@ -151,34 +151,34 @@ __global__ __launch_bounds__(256) void mrope_kv_kernel(
     const float* __restrict__ cos_t, const float* __restrict__ sin_t, bf16_t* __restrict__ kc,
     bf16_t* __restrict__ vc, const int* __restrict__ tok_slot, const int* __restrict__ tok_idx,
     int T, int n_q, int n_kv, int s_max, int sec0, int sec1, int bcast_first, int bcast_n) {
-  // thread = (token, head among q+2kv, group of 4 dims in [0,64))
+  // thread = (token, head among q+2kv, group of 8 dims in [0,64)): two 16-byte accesses per half
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int n_h = n_q + 2 * n_kv;
-  const long total = (long)T * n_h * 16;
+  const long total = (long)T * n_h * 8;
   if (idx >= total) return;
-  const int qd = idx & 15;
-  long r = idx >> 4;
+  const int od = idx & 7;
+  long r = idx >> 3;
   const int h = r % n_h;
   const int t = r / n_h;
-  const int i0 = qd * 4;
+  const int i0 = od * 8;
   bf16_t* p = qkv + (long)t * ld + (long)h * 128;
-  const bf16x4 a = *(const bf16x4*)(p + i0);
-  const bf16x4 b = *(const bf16x4*)(p + i0 + 64);
+  const bf16x8 a = *(const bf16x8*)(p + i0);
+  const bf16x8 b = *(const bf16x8*)(p + i0 + 64);
+  // tok_slot < 0: a shared-prefix token, its K/V row goes to every slot of [bcast_first, bcast_first + bcast_n)
+  const int s0 = tok_slot[t] < 0 ? bcast_first : tok_slot[t];
+  const int ns = tok_slot[t] < 0 ? bcast_n : 1;
   if (h >= n_q + n_kv) {  // v: straight copy into the cache
     const int kvh = h - n_q - n_kv;
-    // tok_slot < 0: a shared-prefix token, its K/V row goes to every slot of [bcast_first, bcast_first + bcast_n)
-    const int s0 = tok_slot[t] < 0 ? bcast_first : tok_slot[t];
-    const int ns = tok_slot[t] < 0 ? bcast_n : 1;
     for (int sl = s0; sl < s0 + ns; ++sl) {
       bf16_t* dst = vc + (((long)sl * n_kv + kvh) * s_max + tok_idx[t]) * 128;
-      *(bf16x4*)(dst + i0) = a;
-      *(bf16x4*)(dst + i0 + 64) = b;
+      *(bf16x8*)(dst + i0) = a;
+      *(bf16x8*)(dst + i0 + 64) = b;
     }
     return;
   }
-  bf16x4 oa, ob;
+  bf16x8 oa, ob;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
+  for (int e = 0; e < 8; ++e) {
     const int i = i0 + e;
     const int stream = (i < sec0) ? 0 : ((i < sec0 + sec1) ? 1 : 2);
     const int pos = pos3[stream * pos_stride + t];
@@ -188,16 +188,14 @@ __global__ __launch_bounds__(256) void mrope_kv_kernel(
     ob[e] = f2bf(rbf(x2 * c) + rbf(x1 * s));
   }
   if (h < n_q) {
-    *(bf16x4*)(p + i0) = oa;
-    *(bf16x4*)(p + i0 + 64) = ob;
+    *(bf16x8*)(p + i0) = oa;
+    *(bf16x8*)(p + i0 + 64) = ob;
   } else {
     const int kvh = h - n_q;
-    const int s0 = tok_slot[t] < 0 ? bcast_first : tok_slot[t];
-    const int ns = tok_slot[t] < 0 ? bcast_n : 1;
     for (int sl = s0; sl < s0 + ns; ++sl) {
       bf16_t* dst = kc + (((long)sl * n_kv + kvh) * s_max + tok_idx[t]) * 128;
-      *(bf16x4*)(dst + i0) = oa;
-      *(bf16x4*)(dst + i0 + 64) = ob;
+      *(bf16x8*)(dst + i0) = oa;
+      *(bf16x8*)(dst + i0 + 64) = ob;
     }
   }
 }
@@ -366,8 +364,8 @@ int owc_launch_mrope_kv(void* qkv, long ld, const int* pos3, long pos_stride, co
                         const float* sin_t, void* kc, void* vc, const int* tok_slot,
                         const int* tok_idx, int T, int n_q, int n_kv, int s_max, int sec0, int sec1,
                         int bcast_first, int bcast_n, hipStream_t st) {
-  if (T <= 0 || (ld & 3)) return OWC_ERR_SHAPE;
-  const long total = (long)T * (n_q + 2 * n_kv) * 16;
+  if (T <= 0 || (ld & 7)) return OWC_ERR_SHAPE;
+  const long total = (long)T * (n_q + 2 * n_kv) * 8;
   hipLaunchKernelGGL(mrope_kv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                      (bf16_t*)qkv, ld, pos3, pos_stride, cos_t, sin_t, (bf16_t*)kc, (bf16_t*)vc,
                      tok_slot, tok_idx, T, n_q, n_kv, s_max, sec0, sec1, bcast_first, bcast_n);

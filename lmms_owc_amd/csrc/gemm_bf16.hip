@@ -43,9 +43,10 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 constexpr int GROUP_M = 8;
 
-__device__ __forceinline__ float act_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+// v_rcp_f32 (1 ulp) instead of an IEEE division: the result is rounded to bf16 right after
+__device__ __forceinline__ float act_quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float act_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // ---- epilogue ----
 // After the MFMAs a lane owns, per 16x16 tile, 4 consecutive columns of one row (8 bytes of bf16).  The
