@@ -28,6 +28,7 @@ int owc_init(int device, owc_ctx** out) {
   }
   if (const char* e = getenv("OWC_GEMM_BIG_MIN_M")) owc_gemm_set_big_min_m(atoi(e));  // tuning / A-B knob
   if (const char* e = getenv("OWC_GEMM_DBG")) owc_gemm_set_dbg(atoi(e));                // timing-only experiments
+  if (const char* e = getenv("OWC_ATTN_DBG")) owc_attn_set_dbg(atoi(e));
   *out = ctx;
   return OWC_OK;
 }

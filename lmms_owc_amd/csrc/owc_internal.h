@@ -68,3 +68,4 @@ void owc_gemm_set_dbg(int v);
 int owc_launch_gemm_bf16_aux(const void* A, long lda, const void* W, long ldw, const void* bias,
                              const void* R, long ldr, void* C, long ldc, int M, int N, int K, int epi,
                              const void* zeros, hipStream_t s, const owc_gemm_aux* aux);
+void owc_attn_set_dbg(int v);
