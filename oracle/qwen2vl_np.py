@@ -202,9 +202,10 @@ def llm_forward(w: dict, cfg: Cfg, x: np.ndarray, pos3: np.ndarray, cache: KVCac
     for i in range(tc.num_hidden_layers):
         p = f"{T}layers.{i}."
         h = ops.rms_norm(x, w[p + "input_layernorm.weight"], tc.rms_norm_eps, bf16=bf16)
-        q = ops.linear(h, w[p + "self_attn.q_proj.weight"], w[p + "self_attn.q_proj.bias"], bf16=bf16)
-        k = ops.linear(h, w[p + "self_attn.k_proj.weight"], w[p + "self_attn.k_proj.bias"], bf16=bf16)
-        v = ops.linear(h, w[p + "self_attn.v_proj.weight"], w[p + "self_attn.v_proj.bias"], bf16=bf16)
+        # Qwen2 has q/k/v biases, Llama-family decoders (LLaVA) do not
+        q = ops.linear(h, w[p + "self_attn.q_proj.weight"], w.get(p + "self_attn.q_proj.bias"), bf16=bf16)
+        k = ops.linear(h, w[p + "self_attn.k_proj.weight"], w.get(p + "self_attn.k_proj.bias"), bf16=bf16)
+        v = ops.linear(h, w[p + "self_attn.v_proj.weight"], w.get(p + "self_attn.v_proj.bias"), bf16=bf16)
         S = x.shape[0]
         q = q.reshape(S, Hq, hd).transpose(1, 0, 2)
         k = k.reshape(S, Hkv, hd).transpose(1, 0, 2)

@@ -153,3 +153,59 @@ def label_tokens(n: int, L: int, vocab: int, seed: int):
     ids = r.integers(1, vocab, (n, L))
     mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
     return (ids * mask).astype(np.int64), mask
+
+
+# ---------------------------------------------------------------- LLaVA (CLIP ViT + projector + Llama decoder)
+def tiny_llava_cfg():
+    from oracle.llava_np import ClipCfg, LlavaCfg
+
+    return LlavaCfg(vision=ClipCfg(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2,
+                                   image_size=56, patch_size=14, layer_norm_eps=1e-5),
+                    text=TextCfg(hidden_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+                                 intermediate_size=512, vocab_size=512, rms_norm_eps=1e-5, rope_theta=10000.0,
+                                 tie_word_embeddings=False),
+                    image_token_id=500, vision_feature_layer=-2)
+
+
+def llava_shapes(cfg) -> dict[str, tuple]:
+    v, t = cfg.vision, cfg.text
+    E, F, d = v.hidden_size, v.intermediate_size, t.hidden_size
+    hd = d // t.num_attention_heads
+    g = v.image_size // v.patch_size
+    VT = "model.vision_tower."
+    s = {VT + "embeddings.class_embedding": (E,), VT + "embeddings.patch_embedding.weight": (E, 3, v.patch_size, v.patch_size),
+         VT + "embeddings.position_embedding.weight": (g * g + 1, E), VT + "pre_layrnorm.weight": (E,), VT + "pre_layrnorm.bias": (E,)}
+    for i in range(v.num_hidden_layers):
+        p = f"{VT}encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[p + f"self_attn.{n}.weight"] = (E, E)
+            s[p + f"self_attn.{n}.bias"] = (E,)
+        s.update({p + "layer_norm1.weight": (E,), p + "layer_norm1.bias": (E,), p + "layer_norm2.weight": (E,), p + "layer_norm2.bias": (E,),
+                  p + "mlp.fc1.weight": (F, E), p + "mlp.fc1.bias": (F,), p + "mlp.fc2.weight": (E, F), p + "mlp.fc2.bias": (E,)})
+    P = "model.multi_modal_projector."
+    s.update({P + "linear_1.weight": (d, E), P + "linear_1.bias": (d,), P + "linear_2.weight": (d, d), P + "linear_2.bias": (d,)})
+    s["model.language_model.embed_tokens.weight"] = (t.vocab_size, d)
+    for i in range(t.num_hidden_layers):
+        p = f"model.language_model.layers.{i}."
+        s.update({p + "self_attn.q_proj.weight": (t.num_attention_heads * hd, d), p + "self_attn.k_proj.weight": (t.num_key_value_heads * hd, d),
+                  p + "self_attn.v_proj.weight": (t.num_key_value_heads * hd, d), p + "self_attn.o_proj.weight": (d, t.num_attention_heads * hd),
+                  p + "mlp.gate_proj.weight": (t.intermediate_size, d), p + "mlp.up_proj.weight": (t.intermediate_size, d),
+                  p + "mlp.down_proj.weight": (d, t.intermediate_size), p + "input_layernorm.weight": (d,),
+                  p + "post_attention_layernorm.weight": (d,)})
+    s["model.language_model.norm.weight"] = (d,)
+    s["lm_head.weight"] = (t.vocab_size, d)
+    return s
+
+
+def llava_weights(cfg, seed: int = 1234) -> dict[str, np.ndarray]:
+    out = {}
+    for k, shp in llava_shapes(cfg).items():
+        if k.endswith("class_embedding") or "position_embedding" in k:
+            out[k] = bf16_round((0.3 * _rng(seed, k).standard_normal(shp)).astype(np.float32))
+        else:
+            out[k] = _fill(k, shp, seed)
+    return out
+
+
+def clip_pixels(n: int, size: int, seed: int = 31) -> np.ndarray:
+    return bf16_round(_rng(seed, "clip_pixels").standard_normal((n, 3, size, size)).astype(np.float32))

@@ -1,0 +1,41 @@
+"""Pin the LLaVA numpy oracle (oracle/llava_np.py) against golden vectors produced by HF transformers'
+LlavaForConditionalGeneration (tools/gen_golden.py gen_llava) — the model class the reference drives in
+`src/models/_llava_hf.py:365-376`."""
+
+import numpy as np
+
+from oracle import llava_np as L
+from tests import recipes
+from pathlib import Path
+
+GOLDEN = Path(__file__).parent / "golden"
+
+
+def _setup():
+    g = np.load(GOLDEN / "llava_tiny.npz")
+    cfg = recipes.tiny_llava_cfg()
+    return g, cfg, recipes.llava_weights(cfg, 1234), recipes.clip_pixels(2, cfg.vision.image_size)
+
+
+def test_clip_features_fp32_match_hf():
+    g, cfg, w, pix = _setup()
+    feats = L.project(w, L.clip_features(w, cfg, pix), bf16=False).reshape(-1, cfg.text.hidden_size)
+    np.testing.assert_allclose(feats, g["f32_feats"], rtol=2e-4, atol=2e-4)
+
+
+def test_generate_fp32_matches_hf():
+    g, cfg, w, pix = _setup()
+    toks, logits = L.generate(w, cfg, g["ids"], pix, 8, return_logits=True)
+    assert toks.tolist() == g["f32_tokens"].tolist()
+    np.testing.assert_allclose(logits, g["f32_logits"], rtol=3e-4, atol=3e-4)
+
+
+def test_generate_bf16_matches_hf():
+    g, cfg, w, pix = _setup()
+    feats = L.project(w, L.clip_features(w, cfg, pix, bf16=True), bf16=True).reshape(-1, cfg.text.hidden_size)
+    # bf16: same rounding points, different fp32 accumulation order -> a few ulps on isolated elements
+    err = np.abs(feats - g["bf16_feats"])
+    assert np.quantile(err, 0.99) <= 2.0 ** -6 * np.abs(g["bf16_feats"]).max()
+    toks, logits = L.generate(w, cfg, g["ids"], pix, 8, bf16=True, return_logits=True)
+    assert toks.tolist() == g["bf16_tokens"].tolist()
+    assert np.abs(logits - g["bf16_logits"]).max() <= 0.05 * np.abs(g["bf16_logits"]).max()

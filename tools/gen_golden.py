@@ -241,6 +241,51 @@ def gen_scorer():
     print("scorer golden:", {k: v.shape for k, v in out.items()})
 
 
+def gen_llava():
+    """HF LlavaForConditionalGeneration (CLIP tower + projector + Llama decoder) on a tiny config, fp32 and bf16."""
+    from transformers import CLIPVisionConfig, LlamaConfig, LlavaConfig, LlavaForConditionalGeneration
+
+    cfg = recipes.tiny_llava_cfg()
+    w = recipes.llava_weights(cfg, 1234)
+    v, t = cfg.vision, cfg.text
+    hcfg = LlavaConfig(
+        vision_config=CLIPVisionConfig(hidden_size=v.hidden_size, intermediate_size=v.intermediate_size,
+                                       num_hidden_layers=v.num_hidden_layers, num_attention_heads=v.num_attention_heads,
+                                       image_size=v.image_size, patch_size=v.patch_size, hidden_act="quick_gelu",
+                                       layer_norm_eps=v.layer_norm_eps, projection_dim=64),
+        text_config=LlamaConfig(hidden_size=t.hidden_size, intermediate_size=t.intermediate_size, num_hidden_layers=t.num_hidden_layers,
+                                num_attention_heads=t.num_attention_heads, num_key_value_heads=t.num_key_value_heads,
+                                vocab_size=t.vocab_size, rms_norm_eps=t.rms_norm_eps, max_position_embeddings=1024,
+                                rope_theta=t.rope_theta, tie_word_embeddings=False),
+        image_token_id=cfg.image_token_id, vision_feature_layer=cfg.vision_feature_layer,
+        vision_feature_select_strategy="default", projector_hidden_act="gelu", image_seq_length=16)
+    hcfg._attn_implementation = "eager"
+    out = {}
+    r = np.random.default_rng(17)
+    pix = recipes.clip_pixels(2, v.image_size)
+    ids = np.concatenate([r.integers(1, 400, 6), np.full(16, cfg.image_token_id), r.integers(1, 400, 3),
+                          np.full(16, cfg.image_token_id), r.integers(1, 400, 7)]).astype(np.int64)
+    for dtype, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        m = LlavaForConditionalGeneration(hcfg)
+        missing, unexpected = m.load_state_dict({k: torch.from_numpy(a.copy()) for k, a in w.items()}, strict=False)
+        assert not unexpected and all("post_layernorm" in k or "position_ids" in k for k in missing), (missing, unexpected)
+        m = m.to(dtype).eval()
+        inp = torch.from_numpy(ids)[None]
+        with torch.no_grad():
+            feats = m.get_image_features(torch.from_numpy(pix).to(dtype), vision_feature_layer=cfg.vision_feature_layer,
+                                         vision_feature_select_strategy="default").pooler_output
+            gen = m.generate(input_ids=inp, attention_mask=torch.ones_like(inp), pixel_values=torch.from_numpy(pix).to(dtype),
+                             do_sample=False, num_beams=1, max_new_tokens=8, use_cache=True, eos_token_id=None, pad_token_id=0,
+                             output_logits=True, return_dict_in_generate=True)
+        out[f"{tag}_feats"] = torch.cat(list(feats), 0).float().numpy()
+        out[f"{tag}_tokens"] = gen.sequences[0, inp.shape[1]:].numpy()
+        out[f"{tag}_logits"] = torch.stack([l[0] for l in gen.logits]).float().numpy()
+    out["ids"] = ids
+    np.savez_compressed(GOLD / "llava_tiny.npz", **out)
+    (GOLD / "llava_tiny.json").write_text(json.dumps({"versions": versions(), "weights_seed": 1234}, indent=1))
+    print("llava golden:", {k: v.shape for k, v in out.items()})
+
+
 def gradient_image(h=300, w=450):
     """Deterministic RGB test image (no dataset offline): three linear ramps."""
     yy, xx = np.mgrid[0:h, 0:w]
@@ -265,9 +310,11 @@ if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["qwen", "scorer", "image"]
+    which = sys.argv[1:] or ["qwen", "scorer", "image", "llava"]
     if "image" in which:
         gen_image()
+    if "llava" in which:
+        gen_llava()
     if "qwen" in which:
         gen_qwen()
     if "scorer" in which:
