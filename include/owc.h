@@ -163,6 +163,36 @@ int owc_vit_forward(owc_ctx* ctx, const owc_vit_weights* w, const void* pixel_va
                     int n_img, int T, int max_len, void* out, void* workspace, size_t ws_bytes,
                     void* stream);
 
+/* ---- model level: LLaVA image branch (CLIP ViT + projector) -------------------------------- */
+/* Replaces LlavaModel.get_image_features (HF modeling_llava.py:144-189) as reached from the reference's
+ * src/models/_llava_hf.py:365-376 (`self.model.generate(**inputs)`), config #4 of BASELINE.json. */
+typedef struct owc_clip_weights {
+  int32_t n_layers;   /* encoder layers to RUN = num_hidden_layers + 1 + vision_feature_layer (-2 -> L-1) */
+  int32_t embed_dim, num_heads, mlp_hidden;
+  int32_t patch_k;    /* 3*14*14 = 588 zero-padded to a multiple of 8 (640 keeps K % 64 == 0) */
+  int32_t tokens;     /* 1 + (image_size/14)^2 per image (CLS first) */
+  int32_t out_dim;    /* projector width = decoder d_model */
+  float ln_eps;
+  const void* patch_w;            /* [embed_dim, patch_k], zero in the padded columns */
+  const void* pos_cls;            /* [tokens, embed_dim]: position_embedding, row 0 += class_embedding */
+  const void *pre_ln_w, *pre_ln_b;
+  const owc_vit_layer* layers;    /* HOST array; qkv_w = cat(q_proj, k_proj, v_proj) rows, NOT interleaved */
+  const void *proj1_w, *proj1_b, *proj2_w, *proj2_b; /* multi_modal_projector.linear_1 / linear_2 */
+} owc_clip_weights;
+
+size_t owc_clip_workspace_bytes(const owc_clip_weights* w, int n_img);
+
+/* patches [n_img * (tokens-1), patch_k] bf16 -> out [n_img * tokens, out_dim] bf16: the projected
+ * hidden_states[vision_feature_layer] of every token, CLS row included (row n*tokens); the "default"
+ * feature-select strategy is the caller skipping that row when it builds owc_llm_prefill's img_index. */
+int owc_clip_forward(owc_ctx* ctx, const owc_clip_weights* w, const void* patches, int64_t ld_patches,
+                     int n_img, void* out, void* workspace, size_t ws_bytes, void* stream);
+
+/* uint8 [n,3,S,S] (resized + cropped on the host) -> patches [n*(S/14)^2, ld] bf16, columns (c, py, px),
+ * [588, patch_k) zeroed (HF image_processing_clip.py: rescale 1/255, normalise; Conv2d patch order). */
+int owc_clip_patchify_u8(owc_ctx* ctx, const uint8_t* images, void* patches, int64_t ld, int patch_k, int n,
+                         int S, const float* mean_host, const float* std_host, void* stream);
+
 /* ---- model level: Qwen2-VL decoder ---------------------------------------------------------- */
 typedef struct owc_llm_layer {
   const void *ln1_w, *qkv_w, *qkv_b, *o_w, *ln2_w, *gateup_w, *down_w;

@@ -20,7 +20,7 @@ _lock = threading.Lock()
 _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = range(6)
 
@@ -46,6 +46,15 @@ class VitWeights(C.Structure):
         ("merger_ln_w", vp), ("merger_ln_b", vp), ("merger_fc1_w", vp), ("merger_fc1_b", vp),
         ("merger_fc2_w", vp), ("merger_fc2_b", vp),
         ("rope_cos", vp), ("rope_sin", vp), ("rope_positions", C.c_int32),
+    ]
+
+
+class ClipWeights(C.Structure):
+    _fields_ = [
+        ("n_layers", C.c_int32), ("embed_dim", C.c_int32), ("num_heads", C.c_int32), ("mlp_hidden", C.c_int32),
+        ("patch_k", C.c_int32), ("tokens", C.c_int32), ("out_dim", C.c_int32), ("ln_eps", f32),
+        ("patch_w", vp), ("pos_cls", vp), ("pre_ln_w", vp), ("pre_ln_b", vp), ("layers", C.POINTER(VitLayer)),
+        ("proj1_w", vp), ("proj1_b", vp), ("proj2_w", vp), ("proj2_b", vp),
     ]
 
 
@@ -102,6 +111,9 @@ SIGNATURES: dict[str, tuple] = {
     "owc_patchify_u8": (i32, [vp, vp, vp, i64, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp]),
     "owc_vit_workspace_bytes": (sz, [C.POINTER(VitWeights), i32]),
     "owc_vit_forward": (i32, [vp, C.POINTER(VitWeights), vp, i64, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]),
+    "owc_clip_workspace_bytes": (sz, [C.POINTER(ClipWeights), i32]),
+    "owc_clip_forward": (i32, [vp, C.POINTER(ClipWeights), vp, i64, i32, vp, vp, sz, vp]),
+    "owc_clip_patchify_u8": (i32, [vp, vp, vp, i64, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp]),
     "owc_llm_workspace_bytes": (sz, [C.POINTER(LlmWeights), i32, i32]),
     "owc_llm_prefill": (i32, [vp, C.POINTER(LlmWeights), C.POINTER(KvCache), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                               i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),

@@ -14,7 +14,7 @@
 
 extern "C" {
 
-int owc_abi_version(void) { return 4; }
+int owc_abi_version(void) { return 5; }
 
 int owc_init(int device, owc_ctx** out) {
   if (out == nullptr) return OWC_ERR_ARG;

@@ -318,7 +318,88 @@ __global__ __launch_bounds__(256) void patchify_kernel(const uint8_t* __restrict
   }
 }
 
+// CLIP ViT front end (HF modeling_clip.py CLIPVisionEmbeddings / image_processing_clip.py):
+//   uint8 [n,3,S,S] -> rows [n*(S/14)^2, ldo] bf16, row = flattened Conv2d patch (c, py, px), columns
+//   [588, kpad) zeroed so the patch GEMM can run on a K padded to the MFMA tile.
+__global__ __launch_bounds__(256) void clip_patchify_kernel(const uint8_t* __restrict__ img,
+                                                            bf16_t* __restrict__ out, long ldo, int kpad,
+                                                            int n_img, int S, float m0, float m1, float m2,
+                                                            float s0, float s1, float s2) {
+  const int g = S / 14, P = g * g;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (img, patch, c, py) -> 14 px
+  const long total = (long)n_img * P * 3 * 14;
+  if (idx >= total) return;
+  const int py = idx % 14;
+  long r = idx / 14;
+  const int c = r % 3;
+  r /= 3;
+  const int pi = r % P;
+  const int n = r / P;
+  const int gy = pi / g, gx = pi % g;
+  const uint8_t* src = img + (((long)n * 3 + c) * S + (gy * 14 + py)) * S + gx * 14;
+  const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+  const float stdv = c == 0 ? s0 : (c == 1 ? s1 : s2);
+  bf16_t* row = out + ((long)n * P + pi) * ldo;
+  bf16_t* dst = row + c * 196 + py * 14;
+#pragma unroll
+  for (int px = 0; px < 14; ++px) dst[px] = f2bf(((float)src[px] * (1.0f / 255.0f) - mean) / stdv);
+  if (c == 2 && py == 13)
+    for (int k = 588; k < kpad; ++k) row[k] = f2bf(0.f);
+}
+
+// embeddings = cat([class_embedding, patch_embeds]) + position_embedding  (modeling_clip.py CLIPVisionEmbeddings.forward)
+// pos_cls row 0 already holds bf16(class_embedding + position_embedding[0]).
+__global__ __launch_bounds__(256) void clip_embed_kernel(const bf16_t* __restrict__ pe,
+                                                         const bf16_t* __restrict__ pos_cls,
+                                                         bf16_t* __restrict__ x, int n_img, int tokens, int E) {
+  const int nch = E >> 3;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n_img * tokens * nch) return;
+  const int ch = idx % nch;
+  const long row = idx / nch;
+  const int t = row % tokens;
+  const long n = row / tokens;
+  bf16x8 p = *(const bf16x8*)(pos_cls + (long)t * E + ch * 8);
+  if (t > 0) {
+    const bf16x8 v = *(const bf16x8*)(pe + (n * (tokens - 1) + (t - 1)) * E + ch * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) p[e] = f2bf(bf2f(v[e]) + bf2f(p[e]));
+  }
+  *(bf16x8*)(x + row * E + ch * 8) = p;
+}
+
+__global__ void seq_iota_kernel(int* __restrict__ start, int* __restrict__ len, int n, int L) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    start[i] = i * L;
+    len[i] = L;
+  }
+}
+
 }  // namespace
+
+int owc_launch_clip_patchify(const uint8_t* img, void* out, long ldo, int kpad, int n_img, int S,
+                             const float* mean, const float* stdv, hipStream_t st) {
+  if (n_img <= 0 || S % 14 || kpad < 588 || ldo < kpad) return OWC_ERR_SHAPE;
+  const long total = (long)n_img * (S / 14) * (S / 14) * 3 * 14;
+  hipLaunchKernelGGL(clip_patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img,
+                     (bf16_t*)out, ldo, kpad, n_img, S, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2]);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_clip_embed(const void* pe, const void* pos_cls, void* x, int n_img, int tokens, int E,
+                          hipStream_t st) {
+  if (n_img <= 0 || tokens < 2 || (E & 7)) return OWC_ERR_SHAPE;
+  const long total = (long)n_img * tokens * (E >> 3);
+  hipLaunchKernelGGL(clip_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                     (const bf16_t*)pe, (const bf16_t*)pos_cls, (bf16_t*)x, n_img, tokens, E);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_seq_iota(int* start, int* len, int n, int L, hipStream_t st) {
+  hipLaunchKernelGGL(seq_iota_kernel, dim3((n + 255) / 256), dim3(256), 0, st, start, len, n, L);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
 
 int owc_launch_layernorm(const void* X, long ldx, const void* W, const void* B, void* Y, long ldy,
                          int rows, int d, float eps, hipStream_t st) {

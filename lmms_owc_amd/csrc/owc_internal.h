@@ -69,3 +69,25 @@ int owc_launch_gemm_bf16_aux(const void* A, long lda, const void* W, long ldw, c
                              const void* R, long ldr, void* C, long ldc, int M, int N, int K, int epi,
                              const void* zeros, hipStream_t s, const owc_gemm_aux* aux);
 void owc_attn_set_dbg(int v);
+int owc_launch_clip_patchify(const uint8_t* img, void* out, long ldo, int kpad, int n_img, int S,
+                             const float* mean, const float* stdv, hipStream_t st);
+int owc_launch_clip_embed(const void* pe, const void* pos_cls, void* x, int n_img, int tokens, int E,
+                          hipStream_t st);
+int owc_launch_seq_iota(int* start, int* len, int n, int L, hipStream_t st);
+
+// ---- host-side driver helpers ----
+#include "../../include/owc.h"
+inline size_t owc_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+struct Carver {  // bump allocator over a caller-provided workspace
+  char* base;
+  size_t off = 0, cap;
+  Carver(void* p, size_t c) : base((char*)p), cap(c) {}
+  void* take(size_t bytes) {
+    void* r = base + off;
+    off += owc_align256(bytes);
+    return r;
+  }
+};
+int owc_vit_layers(owc_ctx* ctx, const owc_vit_layer* layers, int n_layers, void* x, void* h, void* attn,
+                   void* qkv, void* mlp, int T, int E, int H, int F, float eps, const int32_t* seq_start,
+                   const int32_t* seq_len, int n_img, int max_len, const owc_gemm_aux* aux, hipStream_t st);

@@ -7,23 +7,39 @@
 #include "../../include/owc.h"
 #include "owc_internal.h"
 
-namespace {
-
-inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-
-struct Carver {
-  char* base;
-  size_t off = 0, cap;
-  Carver(void* p, size_t c) : base((char*)p), cap(c) {}
-  void* take(size_t bytes) {
-    void* r = base + off;
-    off += align256(bytes);
-    return r;
+// Pre-LN transformer encoder layers shared by the Qwen2-VL vision tower (aux != NULL: 2-D RoPE fused into
+// the qkv epilogue, HF:442-450) and the CLIP tower of LLaVA (aux == NULL; modeling_clip.py CLIPEncoderLayer).
+int owc_vit_layers(owc_ctx* ctx, const owc_vit_layer* layers, int n_layers, void* x, void* h, void* attn,
+                   void* qkv, void* mlp, int T, int E, int H, int F, float eps, const int32_t* seq_start,
+                   const int32_t* seq_len, int n_img, int max_len, const owc_gemm_aux* aux, hipStream_t st) {
+  const int hd = E / H;
+  const float scale = 1.0f / sqrtf((float)hd);
+  for (int i = 0; i < n_layers; ++i) {
+    const owc_vit_layer& L = layers[i];
+    // x = x + proj(attn(rope(qkv(norm1(x)))))
+    OWC_TRY(owc_launch_layernorm(x, E, L.ln1_w, L.ln1_b, h, E, T, E, eps, st));
+    if (aux) {  // q/k rows of qkv_w are pair-interleaved, rotation in the epilogue
+      OWC_TRY(owc_launch_gemm_bf16_aux(h, E, L.qkv_w, E, L.qkv_b, nullptr, 0, qkv, 3 * E, T, 3 * E, E,
+                                       OWC_EPI_VROPE, ctx->zeros, st, aux));
+    } else {
+      OWC_TRY(owc_launch_gemm_bf16(h, E, L.qkv_w, E, L.qkv_b, nullptr, 0, qkv, 3 * E, T, 3 * E, E,
+                                   OWC_EPI_NONE, ctx->zeros, st));
+    }
+    const bf16_t* q = (const bf16_t*)qkv;
+    OWC_TRY(owc_launch_attention(q, 3 * E, hd, q + E, 3 * E, hd, q + 2 * E, 3 * E, hd, attn, E, hd,
+                                 seq_start, nullptr, seq_start, seq_len, nullptr, n_img, H, 1, hd,
+                                 max_len, 0, scale, st));
+    OWC_TRY(owc_launch_gemm_bf16(attn, E, L.proj_w, E, L.proj_b, x, E, x, E, T, E, E, OWC_EPI_RESIDUAL,
+                                 ctx->zeros, st));
+    // x = x + fc2(quick_gelu(fc1(norm2(x))))
+    OWC_TRY(owc_launch_layernorm(x, E, L.ln2_w, L.ln2_b, h, E, T, E, eps, st));
+    OWC_TRY(owc_launch_gemm_bf16(h, E, L.fc1_w, E, L.fc1_b, nullptr, 0, mlp, F, T, F, E,
+                                 OWC_EPI_QUICK_GELU, ctx->zeros, st));
+    OWC_TRY(owc_launch_gemm_bf16(mlp, F, L.fc2_w, F, L.fc2_b, x, E, x, E, T, E, F, OWC_EPI_RESIDUAL,
+                                 ctx->zeros, st));
   }
-  bool ok() const { return off <= cap; }
-};
-
-}  // namespace
+  return OWC_OK;
+}
 
 extern "C" {
 
@@ -31,9 +47,9 @@ size_t owc_vit_workspace_bytes(const owc_vit_weights* w, int T) {
   if (!w || T <= 0) return 0;
   const size_t e = (size_t)w->embed_dim, t = (size_t)T;
   size_t b = 0;
-  b += align256(t * e * 2) * 3;                 // x, h, attn
-  b += align256(t * e * 3 * 2);                 // qkv
-  b += align256(t * (size_t)w->mlp_hidden * 2); // mlp hidden (also merger hidden)
+  b += owc_align256(t * e * 2) * 3;                 // x, h, attn
+  b += owc_align256(t * e * 3 * 2);                 // qkv
+  b += owc_align256(t * (size_t)w->mlp_hidden * 2); // mlp hidden (also merger hidden)
   return b + 1024;
 }
 
@@ -53,32 +69,13 @@ int owc_vit_forward(owc_ctx* ctx, const owc_vit_weights* w, const void* pixel_va
   void* attn = cv.take((size_t)T * E * 2);
   void* qkv = cv.take((size_t)T * E * 3 * 2);
   void* mlp = cv.take((size_t)T * F * 2);
-  const float scale = 1.0f / sqrtf((float)hd);
   const owc_gemm_aux aux = {pos_hw, w->rope_cos, w->rope_sin, 2 * E, hd};
 
   // patch embed: Conv3d(kernel == stride) == GEMM [T, patch_k] x [E, patch_k]^T, no bias (HF:268-275)
   OWC_TRY(owc_launch_gemm_bf16(pixel_values, ld_pix, w->patch_w, w->patch_k, nullptr, nullptr, 0, x, E,
                                T, E, w->patch_k, OWC_EPI_NONE, ctx->zeros, st));
-  for (int i = 0; i < w->depth; ++i) {
-    const owc_vit_layer& L = w->layers[i];
-    // x = x + proj(attn(rope(qkv(norm1(x)))))            (HF:442-449, :356-422)
-    OWC_TRY(owc_launch_layernorm(x, E, L.ln1_w, L.ln1_b, h, E, T, E, w->ln_eps, st));
-    // qkv projection with the 2-D RoPE fused into the epilogue (q/k rows of qkv_w are pair-interleaved)
-    OWC_TRY(owc_launch_gemm_bf16_aux(h, E, L.qkv_w, E, L.qkv_b, nullptr, 0, qkv, 3 * E, T, 3 * E, E,
-                                     OWC_EPI_VROPE, ctx->zeros, st, &aux));
-    const bf16_t* q = (const bf16_t*)qkv;
-    OWC_TRY(owc_launch_attention(q, 3 * E, hd, q + E, 3 * E, hd, q + 2 * E, 3 * E, hd, attn, E, hd,
-                                 seq_start, nullptr, seq_start, seq_len, nullptr, n_img, H, 1, hd,
-                                 max_len, 0, scale, st));
-    OWC_TRY(owc_launch_gemm_bf16(attn, E, L.proj_w, E, L.proj_b, x, E, x, E, T, E, E, OWC_EPI_RESIDUAL,
-                                 ctx->zeros, st));
-    // x = x + fc2(quick_gelu(fc1(norm2(x))))             (HF:450, :300-301)
-    OWC_TRY(owc_launch_layernorm(x, E, L.ln2_w, L.ln2_b, h, E, T, E, w->ln_eps, st));
-    OWC_TRY(owc_launch_gemm_bf16(h, E, L.fc1_w, E, L.fc1_b, nullptr, 0, mlp, F, T, F, E,
-                                 OWC_EPI_QUICK_GELU, ctx->zeros, st));
-    OWC_TRY(owc_launch_gemm_bf16(mlp, F, L.fc2_w, F, L.fc2_b, x, E, x, E, T, E, F, OWC_EPI_RESIDUAL,
-                                 ctx->zeros, st));
-  }
+  OWC_TRY(owc_vit_layers(ctx, w->layers, w->depth, x, h, attn, qkv, mlp, T, E, H, F, w->ln_eps, seq_start,
+                         seq_len, n_img, max_len, &aux, st));
   // PatchMerger (HF:288-291): ln_q, view [T/4, 4E], Linear+GELU, Linear
   const int M = T / w->merge_unit, E4 = E * w->merge_unit;
   OWC_TRY(owc_launch_layernorm(x, E, w->merger_ln_w, w->merger_ln_b, h, E, T, E, w->ln_eps, st));
@@ -94,12 +91,12 @@ size_t owc_llm_workspace_bytes(const owc_llm_weights* w, int T, int n_seq) {
   const size_t t = (size_t)T, d = (size_t)w->d_model;
   const size_t qkv = (size_t)(w->n_q_heads + 2 * w->n_kv_heads) * w->head_dim;
   size_t b = 0;
-  b += align256(t * d * 2) * 2;                                   // x, h
-  b += align256(t * qkv * 2);                                     // qkv
-  b += align256(t * (size_t)w->n_q_heads * w->head_dim * 2);      // attn
-  b += align256(t * (size_t)w->d_ff * 2);                         // mlp
-  b += align256((size_t)n_seq * d * 2);                           // last-token hidden
-  b += align256((size_t)n_seq * (size_t)w->vocab * 2);            // logits
+  b += owc_align256(t * d * 2) * 2;                                   // x, h
+  b += owc_align256(t * qkv * 2);                                     // qkv
+  b += owc_align256(t * (size_t)w->n_q_heads * w->head_dim * 2);      // attn
+  b += owc_align256(t * (size_t)w->d_ff * 2);                         // mlp
+  b += owc_align256((size_t)n_seq * d * 2);                           // last-token hidden
+  b += owc_align256((size_t)n_seq * (size_t)w->vocab * 2);            // logits
   return b + 1024;
 }
 

@@ -161,16 +161,23 @@ class Qwen2VLWeights:
         vc, vs = ops.rope_table(d.max_grid, hd_v // 4, hd_v // 2, 10000.0, False, self.device)
         v.rope_cos, v.rope_sin, v.rope_positions = self._k(vc), self._k(vs), d.max_grid
         # ---- decoder
+        self._build_llm(get, T, qkv_bias=True)
+
+    def _build_llm(self, get, T: str, *, qkv_bias: bool) -> None:
+        """Decoder weights -> owc_llm_weights.  `T`: HF prefix of the text model; Llama-family decoders
+        (LLaVA) have no q/k/v biases (qkv_b stays NULL)."""
+        d = self.dims
         ll = (_lib.LlmLayer * d.n_layers)()
         for i in range(d.n_layers):
             p = f"{T}layers.{i}."
             qkv_w = torch.cat([get(p + "self_attn.q_proj.weight"), get(p + "self_attn.k_proj.weight"),
                                get(p + "self_attn.v_proj.weight")], 0).contiguous()
-            qkv_b = torch.cat([get(p + "self_attn.q_proj.bias"), get(p + "self_attn.k_proj.bias"),
-                               get(p + "self_attn.v_proj.bias")], 0).contiguous()
             gu = interleave_gate_up(get(p + "mlp.gate_proj.weight"), get(p + "mlp.up_proj.weight"))
             ll[i].ln1_w = self._k(get(p + "input_layernorm.weight"))
-            ll[i].qkv_w, ll[i].qkv_b = self._k(qkv_w), self._k(qkv_b)
+            ll[i].qkv_w = self._k(qkv_w)
+            if qkv_bias:
+                ll[i].qkv_b = self._k(torch.cat([get(p + "self_attn.q_proj.bias"), get(p + "self_attn.k_proj.bias"),
+                                                 get(p + "self_attn.v_proj.bias")], 0).contiguous())
             ll[i].o_w = self._k(get(p + "self_attn.o_proj.weight"))
             ll[i].ln2_w = self._k(get(p + "post_attention_layernorm.weight"))
             ll[i].gateup_w = self._k(gu)
@@ -291,12 +298,14 @@ class Qwen2VLEngine:
     # -- decoder -----------------------------------------------------------------------
     def generate(self, prompts: list, img_embeds: torch.Tensor | None, grids_per_prompt: list, max_new_tokens: int,
                  *, eos_token_id: int = -1, pad_token_id: int = 0, stop_check_every: int = 8,
-                 return_logits: bool = False):
+                 return_logits: bool = False, img_rows: list | None = None):
         """Greedy generation for a batch of prompts.
 
         prompts[b]: 1-D int array of token ids holding image_token_id placeholders;
         grids_per_prompt[b]: list of (t, h, w) for that prompt's images, in order;
-        img_embeds: rows for all image tokens of all prompts, in prompt order.
+        img_embeds: rows for all image tokens of all prompts, in prompt order;
+        img_rows[b] (optional): explicit row of `img_embeds` for every image token of prompt b (engines whose
+        feature buffer is not already in token order, e.g. LLaVA's CLS-skipping / anyres packing).
         Returns int32 [B, max_new_tokens] (pad after EOS) and, optionally, the first-step logits.
         """
         d = self.d
@@ -324,10 +333,16 @@ class Qwen2VLEngine:
             is_img = ids == d.image_token_id
             idx = np.full(len(ids), -1, dtype=np.int32)
             n_img = int(is_img.sum())
-            idx[is_img] = np.arange(img_cursor, img_cursor + n_img, dtype=np.int32)
+            if img_rows is not None:
+                rows = np.asarray(img_rows[b], dtype=np.int32)
+                if len(rows) != n_img or (n_img and (img_embeds is None or rows.min() < 0 or rows.max() >= img_embeds.shape[0])):
+                    raise ValueError("image token count does not match the image feature rows")
+                idx[is_img] = rows
+            else:
+                idx[is_img] = np.arange(img_cursor, img_cursor + n_img, dtype=np.int32)
             img_cursor += n_img
             img_index.append(idx)
-        if img_cursor and (img_embeds is None or img_embeds.shape[0] != img_cursor):
+        if img_rows is None and img_cursor and (img_embeds is None or img_embeds.shape[0] != img_cursor):
             raise ValueError("image token count does not match the image embeddings")
         if int(max_pos.max()) + max_new_tokens + 1 > d.max_positions:
             raise ValueError("prompt + generation exceeds the rope table (raise Qwen2VLDims.max_positions)")

@@ -1,0 +1,119 @@
+"""LLaVA parity on the GPU: HIP engine (through the C ABI: owc_clip_forward, owc_llm_prefill/decode) vs the numpy
+oracle and the golden vectors HF's LlavaForConditionalGeneration produced for the same seeded weights
+(tests/golden/llava_tiny.npz).  Tiny config with the real structure: CLIP head_dim 64, CLS + position embedding,
+pre-LN, feature layer -2, GELU projector, GQA decoder with head_dim 128 and 1-D RoPE.
+
+Tolerance (stated): same bf16 rounding points, different fp32 accumulation order: max |diff| <= 3-5 % of max |ref|;
+greedy tokens must match wherever the reference's top-2 margin exceeds that bound.
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import llava_np as L
+from oracle import np_ops
+from tests import recipes
+from tests.util import assert_bf16_close, to_np
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+BF16 = torch.bfloat16
+
+
+def _patches(pix: np.ndarray, patch_k: int) -> np.ndarray:
+    n, _, S, _ = pix.shape
+    g = S // 14
+    p = pix.reshape(n, 3, g, 14, g, 14).transpose(0, 2, 4, 1, 3, 5).reshape(n * g * g, 588)
+    return np.concatenate([p, np.zeros((p.shape[0], patch_k - 588), np.float32)], 1)
+
+
+@pytest.fixture(scope="module")
+def setup(gpu):
+    from lmms_owc_amd.engine.llava import DIMS, LlavaEngine, LlavaWeights
+
+    cfg = recipes.tiny_llava_cfg()
+    w = recipes.llava_weights(cfg, 1234)
+    eng = LlavaEngine(LlavaWeights.from_state_dict(DIMS["tiny"], w, gpu), clip_chunk_views=1, prefill_chunk_tokens=64)
+    return cfg, w, eng, np.load(GOLD / "llava_tiny.npz")
+
+
+def _close(got, ref, frac):
+    assert np.abs(got - ref).max() <= frac * np.abs(ref).max(), (np.abs(got - ref).max(), np.abs(ref).max())
+
+
+def _feats(eng, pix, gpu):
+    return eng.encode_views(torch.from_numpy(_patches(pix, eng.d.patch_k)).to(BF16).to(gpu))
+
+
+def test_clip_features_match_oracle_and_hf(setup, gpu):
+    cfg, w, eng, g = setup
+    pix = recipes.clip_pixels(2, cfg.vision.image_size)
+    out = to_np(_feats(eng, pix, gpu)).reshape(2, eng.d.tokens, -1)[:, 1:].reshape(-1, cfg.text.hidden_size)
+    want = L.project(w, L.clip_features(w, cfg, pix, bf16=True), bf16=True).reshape(-1, cfg.text.hidden_size)
+    _close(out, want, 0.03)
+    _close(out, g["bf16_feats"], 0.04)
+    _close(out, g["f32_feats"], 0.05)
+
+
+def test_generate_matches_oracle_and_hf(setup, gpu):
+    cfg, w, eng, g = setup
+    pix = recipes.clip_pixels(2, cfg.vision.image_size)
+    ids = g["ids"]
+    rows = np.concatenate(eng.feature_rows([1, 1]))
+    toks, logits = eng.generate_from_features([ids], _feats(eng, pix, gpu), [rows], 8, return_logits=True)
+    toks, logits = to_np(toks)[0].astype(int), to_np(logits)[0]
+    o_toks, o_logits = L.generate(w, cfg, ids, pix, 8, bf16=True, return_logits=True)
+    _close(logits, o_logits[0], 0.03)
+    _close(logits, g["bf16_logits"][0], 0.05)
+    _close(logits, g["f32_logits"][0], 0.05)
+    ref = g["f32_logits"]
+    for j in range(8):
+        top2 = np.sort(ref[j])[-2:]
+        if top2[1] - top2[0] > 0.06 * np.abs(ref[j]).max():
+            assert toks[j] == g["f32_tokens"][j], (j, toks, g["f32_tokens"])
+        else:
+            break
+
+
+def test_batched_equals_single(setup, gpu):
+    """Packed varlen prefill + batched decode + shared text prefix must not change any prompt's tokens."""
+    cfg, w, eng, g = setup
+    r = np.random.default_rng(5)
+    pix = recipes.clip_pixels(3, cfg.vision.image_size, seed=77)
+    feats = _feats(eng, pix, gpu)
+    head = r.integers(1, 400, 6)
+    prompts, rows = [], []
+    per_view = eng.feature_rows([1, 1, 1])
+    for b in range(3):
+        prompts.append(np.concatenate([head, np.full(16, cfg.image_token_id), r.integers(1, 400, 3 + 2 * b)]).astype(np.int64))
+        rows.append(per_view[b])
+    batched = to_np(eng.generate_from_features(prompts, feats, rows, 6))
+    for b in range(3):
+        single = to_np(eng.generate_from_features([prompts[b]], feats, [rows[b]], 6))
+        assert np.array_equal(batched[b], single[0]), b
+    # text-only prompt (no image rows at all) also runs
+    t = to_np(eng.generate_from_features([r.integers(1, 400, 9)], None, [np.zeros(0, np.int64)], 3))
+    assert t.shape == (1, 3)
+
+
+def test_clip_patchify_u8_matches_numpy(setup, gpu):
+    cfg, w, eng, g = setup
+    gen = torch.Generator().manual_seed(0)
+    S = cfg.vision.image_size
+    im = torch.randint(0, 256, (3, 3, S, S), generator=gen, dtype=torch.uint8)
+    mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+    got = to_np(eng.patchify(im.to(gpu), mean, std))
+    x = (im.numpy().astype(np.float32) / 255.0 - np.array(mean, np.float32)[None, :, None, None]) / np.array(std, np.float32)[None, :, None, None]
+    want = _patches(x, eng.d.patch_k)
+    assert np.all(got[:, 588:] == 0)
+    assert_bf16_close(got, np_ops.bf16_round(want), ulps=1.0, atol=1e-6, min_exact=0.99)
+
+
+def test_wrong_row_count_is_an_error(setup, gpu):
+    cfg, w, eng, g = setup
+    feats = _feats(eng, recipes.clip_pixels(1, cfg.vision.image_size), gpu)
+    ids = np.concatenate([[5, 6], np.full(16, cfg.image_token_id), [7]])
+    with pytest.raises(ValueError):
+        eng.generate_from_features([ids], feats, [np.arange(15)], 2)
