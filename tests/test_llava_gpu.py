@@ -117,3 +117,40 @@ def test_wrong_row_count_is_an_error(setup, gpu):
     ids = np.concatenate([[5, 6], np.full(16, cfg.image_token_id), [7]])
     with pytest.raises(ValueError):
         eng.generate_from_features([ids], feats, [np.arange(15)], 2)
+
+
+# ---------------------------------------------------------------- LLaVA-NeXT (anyres tiling, unpad, image_newline)
+@pytest.fixture(scope="module")
+def setup_next(gpu):
+    from lmms_owc_amd.engine.llava import DIMS, LlavaEngine, LlavaWeights
+
+    cfg = recipes.tiny_llava_next_cfg()
+    w = recipes.llava_weights(cfg, 1234)
+    eng = LlavaEngine(LlavaWeights.from_state_dict(DIMS["tiny-next"], w, gpu), clip_chunk_views=3)
+    return cfg, w, eng, np.load(GOLD / "llava_next_tiny.npz")
+
+
+def test_next_generate_matches_oracle_and_hf(setup_next, gpu):
+    cfg, w, eng, g = setup_next
+    views, sizes = g["views"].tolist(), g["image_sizes"].tolist()
+    pix = recipes.clip_pixels(sum(views), cfg.vision.image_size, seed=41)
+    feats = _feats(eng, pix, gpu)
+    rows = eng.feature_rows(views, sizes)
+    assert [len(r) for r in rows] == g["n_tok"].tolist()
+    packed = to_np(feats)[np.concatenate(rows)]
+    _close(packed, g["bf16_feats"], 0.04)
+    _close(packed, g["f32_feats"], 0.05)
+    ids = g["ids"]
+    toks, logits = eng.generate_from_features([ids], feats, [np.concatenate(rows)], 8, return_logits=True)
+    toks, logits = to_np(toks)[0].astype(int), to_np(logits)[0]
+    o_toks, o_logits = L.generate(w, cfg, ids, pix, 8, bf16=True, return_logits=True, image_sizes=sizes, views_per_image=views)
+    _close(logits, o_logits[0], 0.03)
+    _close(logits, g["bf16_logits"][0], 0.05)
+    _close(logits, g["f32_logits"][0], 0.05)
+    ref = g["f32_logits"]
+    for j in range(8):
+        top2 = np.sort(ref[j])[-2:]
+        if top2[1] - top2[0] > 0.06 * np.abs(ref[j]).max():
+            assert toks[j] == g["f32_tokens"][j], (j, toks, g["f32_tokens"])
+        else:
+            break

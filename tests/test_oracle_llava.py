@@ -39,3 +39,37 @@ def test_generate_bf16_matches_hf():
     toks, logits = L.generate(w, cfg, g["ids"], pix, 8, bf16=True, return_logits=True)
     assert toks.tolist() == g["bf16_tokens"].tolist()
     assert np.abs(logits - g["bf16_logits"]).max() <= 0.05 * np.abs(g["bf16_logits"]).max()
+
+
+# ---------------------------------------------------------------- LLaVA-NeXT (anyres)
+def _setup_next():
+    g = np.load(GOLDEN / "llava_next_tiny.npz")
+    cfg = recipes.tiny_llava_next_cfg()
+    return g, cfg, recipes.llava_weights(cfg, 1234), recipes.clip_pixels(int(g["views"].sum()), cfg.vision.image_size, seed=41)
+
+
+def test_next_generate_fp32_matches_hf():
+    g, cfg, w, pix = _setup_next()
+    toks, logits = L.generate(w, cfg, g["ids"], pix, 8, return_logits=True, image_sizes=g["image_sizes"].tolist(),
+                              views_per_image=g["views"].tolist())
+    assert toks.tolist() == g["f32_tokens"].tolist()
+    np.testing.assert_allclose(logits, g["f32_logits"], rtol=3e-4, atol=3e-4)
+
+
+def test_next_packed_features_match_hf():
+    g, cfg, w, pix = _setup_next()
+    feats = L.project(w, L.clip_features(w, cfg, pix), bf16=False)
+    packed, v0 = [], 0
+    for nv, size in zip(g["views"].tolist(), g["image_sizes"].tolist()):
+        packed.append(L.pack_anyres(w, cfg, feats[v0:v0 + nv], size))
+        v0 += nv
+    assert [len(p) for p in packed] == g["n_tok"].tolist()
+    np.testing.assert_allclose(np.concatenate(packed), g["f32_feats"], rtol=2e-4, atol=2e-4)
+
+
+def test_next_generate_bf16_matches_hf():
+    g, cfg, w, pix = _setup_next()
+    toks, logits = L.generate(w, cfg, g["ids"], pix, 8, bf16=True, return_logits=True, image_sizes=g["image_sizes"].tolist(),
+                              views_per_image=g["views"].tolist())
+    assert toks.tolist() == g["bf16_tokens"].tolist()
+    assert np.abs(logits - g["bf16_logits"]).max() <= 0.05 * np.abs(g["bf16_logits"]).max()

@@ -12,6 +12,7 @@ from __future__ import annotations
 import importlib.machinery
 import json
 import sys
+import zlib
 import types
 from pathlib import Path
 
@@ -286,6 +287,84 @@ def gen_llava():
     print("llava golden:", {k: v.shape for k, v in out.items()})
 
 
+NEXT_SIZES = [(90, 160), (200, 100)]  # (h, w) of the two synthetic images: a wide one and a tall one
+
+
+def gen_llava_next():
+    """HF LlavaNextForConditionalGeneration (anyres tiling + unpad + image_newline) on a tiny config, fp32 and bf16;
+    plus the feature ORDER pack_image_features produces for a sweep of image sizes (integer golden)."""
+    from transformers import CLIPVisionConfig, LlamaConfig, LlavaNextConfig, LlavaNextForConditionalGeneration
+    from transformers.models.llava_next.modeling_llava_next import image_size_to_num_patches
+
+    cfg = recipes.tiny_llava_next_cfg()
+    w = recipes.llava_weights(cfg, 1234)
+    v, t = cfg.vision, cfg.text
+    pin = [list(p) for p in cfg.image_grid_pinpoints]
+    hcfg = LlavaNextConfig(
+        vision_config=CLIPVisionConfig(hidden_size=v.hidden_size, intermediate_size=v.intermediate_size,
+                                       num_hidden_layers=v.num_hidden_layers, num_attention_heads=v.num_attention_heads,
+                                       image_size=v.image_size, patch_size=v.patch_size, hidden_act="quick_gelu",
+                                       layer_norm_eps=v.layer_norm_eps, projection_dim=64),
+        text_config=LlamaConfig(hidden_size=t.hidden_size, intermediate_size=t.intermediate_size, num_hidden_layers=t.num_hidden_layers,
+                                num_attention_heads=t.num_attention_heads, num_key_value_heads=t.num_key_value_heads,
+                                vocab_size=t.vocab_size, rms_norm_eps=t.rms_norm_eps, max_position_embeddings=1024,
+                                rope_theta=t.rope_theta, tie_word_embeddings=False),
+        image_token_id=cfg.image_token_id, vision_feature_layer=cfg.vision_feature_layer,
+        vision_feature_select_strategy="default", projector_hidden_act="gelu", image_grid_pinpoints=pin, image_seq_length=16)
+    hcfg._attn_implementation = "eager"
+    out = {}
+    S = v.image_size
+    views = [image_size_to_num_patches(list(sz), pin, S) for sz in NEXT_SIZES]
+    pix = recipes.clip_pixels(sum(views), S, seed=41)
+    padded = np.zeros((len(views), max(views), 3, S, S), np.float32)
+    v0 = 0
+    for i, nv in enumerate(views):
+        padded[i, :nv] = pix[v0:v0 + nv]
+        v0 += nv
+    r = np.random.default_rng(19)
+    for dtype, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        m = LlavaNextForConditionalGeneration(hcfg)
+        missing, unexpected = m.load_state_dict({k: torch.from_numpy(a.copy()) for k, a in w.items()}, strict=False)
+        assert not unexpected and all("post_layernorm" in k or "position_ids" in k for k in missing), (missing, unexpected)
+        m = m.to(dtype).eval()
+        with torch.no_grad():
+            feats = m.get_image_features(torch.from_numpy(padded).to(dtype), torch.tensor(NEXT_SIZES),
+                                         vision_feature_layer=cfg.vision_feature_layer,
+                                         vision_feature_select_strategy="default").pooler_output
+            n_tok = [int(f.shape[0]) for f in feats]
+            if "ids" not in out:
+                out["ids"] = np.concatenate([r.integers(1, 400, 5), np.full(n_tok[0], cfg.image_token_id), r.integers(1, 400, 2),
+                                             np.full(n_tok[1], cfg.image_token_id), r.integers(1, 400, 6)]).astype(np.int64)
+            inp = torch.from_numpy(out["ids"])[None]
+            gen = m.generate(input_ids=inp, attention_mask=torch.ones_like(inp), pixel_values=torch.from_numpy(padded).to(dtype),
+                             image_sizes=torch.tensor(NEXT_SIZES), do_sample=False, num_beams=1, max_new_tokens=8, use_cache=True,
+                             eos_token_id=None, pad_token_id=0, output_logits=True, return_dict_in_generate=True)
+        out[f"{tag}_feats"] = torch.cat(list(feats), 0).float().numpy()
+        out[f"{tag}_tokens"] = gen.sequences[0, inp.shape[1]:].numpy()
+        out[f"{tag}_logits"] = torch.stack([l[0] for l in gen.logits]).float().numpy()
+    out["views"] = np.array(views)
+    out["n_tok"] = np.array(n_tok)
+    out["image_sizes"] = np.array(NEXT_SIZES)
+    # integer golden: order in which pack_image_features reads (view, patch) for many sizes, real geometry (g = 24)
+    from transformers import LlavaNextProcessor  # noqa: F401  (import check only)
+
+    real = LlavaNextConfig()
+    real_pin = [[336, 672], [672, 336], [672, 672], [1008, 336], [336, 1008]]
+    mm = LlavaNextForConditionalGeneration(hcfg).model  # only used for its pack_image_features method
+    mm.config.vision_config.image_size, mm.config.vision_config.patch_size, mm.config.image_grid_pinpoints = 336, 14, real_pin
+    order = {}
+    for (h, w_) in [(480, 640), (640, 480), (336, 336), (500, 500), (1000, 300), (300, 1000), (333, 999), (768, 1024), (37, 1200), (1080, 1920)]:
+        nv = image_size_to_num_patches([h, w_], real_pin, 336)
+        f = (torch.arange(nv)[:, None] * 577 + 1 + torch.arange(576)[None]).float()[..., None]  # value = row in a view-major [nv*577] buffer
+        packed, _ = mm.pack_image_features([f], torch.tensor([[h, w_]]), "default", image_newline=torch.tensor([-1.0]))
+        idx = packed[0][:, 0].long().numpy()
+        order[f"{h}x{w_}"] = {"views": int(nv), "n": int(len(idx)), "crc": int(zlib.crc32(idx.astype(np.int64).tobytes())),
+                              "head": idx[576:576 + 30].tolist()}
+    np.savez_compressed(GOLD / "llava_next_tiny.npz", **out)
+    (GOLD / "llava_next_tiny.json").write_text(json.dumps({"versions": versions(), "weights_seed": 1234, "pack_order_real_geometry": order}, indent=1))
+    print("llava-next golden:", {k: v.shape for k, v in out.items()}, views, n_tok)
+
+
 def gradient_image(h=300, w=450):
     """Deterministic RGB test image (no dataset offline): three linear ramps."""
     yy, xx = np.mgrid[0:h, 0:w]
@@ -310,11 +389,13 @@ if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["qwen", "scorer", "image", "llava"]
+    which = sys.argv[1:] or ["qwen", "scorer", "image", "llava", "llava_next"]
     if "image" in which:
         gen_image()
     if "llava" in which:
         gen_llava()
+    if "llava_next" in which:
+        gen_llava_next()
     if "qwen" in which:
         gen_qwen()
     if "scorer" in which:
