@@ -4,12 +4,14 @@ from collections.abc import Callable
 
 from ._api import MODELS, get_model, get_model_builder, get_model_info, get_models_info, register_model
 from ._base import Model
+from ._llava_hf import LLaVA
 from ._qwen2_vl import Qwen2VL
 
-__all__ = ["MODELS", "Model", "Qwen2VL", "register_model", "get_model", "get_model_builder", "get_model_info",
+__all__ = ["MODELS", "Model", "LLaVA", "Qwen2VL", "register_model", "get_model", "get_model_builder", "get_model_info",
            "get_models_info"]
 
-MODEL_TYPES: dict[str, Callable] = {"qwen2-vl": Qwen2VL}
+# same keys as the reference's `custom-model` map (src/models/__init__.py) for the families on this path
+MODEL_TYPES: dict[str, Callable] = {"llava": LLaVA, "qwen2-vl": Qwen2VL}
 
 
 @register_model("custom-model")

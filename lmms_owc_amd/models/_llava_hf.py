@@ -1,0 +1,258 @@
+"""`LLaVA` model plug-in on the MI355X engine — drop-in for /root/reference/src/models/_llava_hf.py.
+
+Same constructor kwargs (`:64-76`), same registry names (`:586-615`) and the same `generate_until` contract
+(`:260-392`: prepend `<image>` tokens when the context has none, chat template with the Vicuna fallback, greedy
+decode until the tokenizer's EOS, `list[TaskInstance] -> list[str]` in request order), covering both families the
+reference's `load_model` maps (`:130-147`): LLaVA-1.5 (one 336x336 CLIP view) and LLaVA-NeXT / 1.6 (anyres tiling).
+Requests are BATCHED (the reference runs batch size 1): every view of a chunk goes through the HIP CLIP tower
+together, prompts are prefilled packed, decode runs the whole batch per step.
+`model_name_or_path="synthetic:<name>"` (names of engine/llava.py DIMS) builds seeded random weights + a byte
+tokenizer; a local HF checkpoint directory loads real weights, tokenizer and chat template.
+"""
+
+from __future__ import annotations
+
+import json
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .. import utils
+from ..engine import anyres
+from ..engine.llava import DIMS, NEXT_PINPOINTS, LlavaDims, LlavaEngine, LlavaWeights
+from . import imageproc
+from ._api import register_model
+from ._base import Model
+from ._qwen2_vl import ByteTokenizer, LazyCheckpoint
+
+__all__ = ["LLaVA"]
+
+DEFAULT_IMAGE_TOKEN = "<image>"  # noqa: S105
+_VICUNA_SYSTEM = ("A chat between a curious user and an artificial intelligence assistant. The assistant gives helpful, "
+                  "detailed, and polite answers to the user's questions.")
+
+
+def vicuna_prompt(messages: list[dict], eos_token: str = "</s>", add_generation_prompt: bool = True) -> str:
+    """Text the reference's fallback chat template (`_llava_hf.py:23`) renders: system preamble before the first
+    turn, `USER: ... ` / ` ASSISTANT: ...</s>` turns, and a trailing `ASSISTANT:` generation prompt."""
+    out = []
+    for i, m in enumerate(messages):
+        if i == 0:
+            out.append(f"{_VICUNA_SYSTEM} USER: {m['content']} ")
+        elif m["role"] == "user":
+            out.append(f"USER: {m['content']} ")
+        else:
+            out.append(f" ASSISTANT: {m['content']}{eos_token}")
+    if add_generation_prompt:
+        out.append("ASSISTANT:")
+    return "".join(out)
+
+
+class LlavaByteTokenizer(ByteTokenizer):
+    """Synthetic-run tokenizer: UTF-8 bytes + 3, BOS = 2, `<image>` = one special id above the byte range."""
+
+    bos_token_id, image_token_id = 2, 264
+    eos_token, chat_template = "</s>", None
+
+    def encode(self, text: str, add_special_tokens: bool = False) -> list[int]:
+        ids = [self.bos_token_id] if add_special_tokens else []
+        for i, part in enumerate(text.split(DEFAULT_IMAGE_TOKEN)):
+            if i:
+                ids.append(self.image_token_id)
+            ids += [b + 3 for b in part.encode("utf-8")]
+        return ids
+
+
+class LLaVA(Model):
+    def __init__(self, model_name_or_path: str = "llava-hf/llava-1.5-7b-hf", attn_implementation: str | None = None,
+                 chat_template: str | None = None, use_cache: bool = True, batch_size: int = 1, device_map: str = "auto",
+                 dtype: str | torch.dtype = "bfloat16", load_in_8bit: bool = False, load_in_4bit: bool = False,
+                 **kwargs) -> None:
+        self._model_name_or_path = model_name_or_path
+        self._attn_implementation = attn_implementation  # accepted; attention is always the fused HIP kernel
+        self._chat_template = chat_template
+        self._use_cache = use_cache                      # the HIP decoder always uses its KV cache
+        super().__init__(batch_size=batch_size, device_map=device_map, dtype=dtype, load_in_8bit=load_in_8bit,
+                         load_in_4bit=load_in_4bit, distributed_types=["FSDP", "MULTI_GPU", "DEEPSPEED"], **kwargs)
+
+    # ------------------------------------------------------------------ loading
+    def load_model(self) -> None:
+        name = self._model_name_or_path
+        if name.startswith("synthetic:"):
+            tok = LlavaByteTokenizer()
+            dims = LlavaDims(**{**DIMS[name.split(":", 1)[1]].__dict__, "image_token_id": tok.image_token_id})
+            weights = LlavaWeights.random(dims, self._device, seed=1234)
+            self._tokenizer = tok
+        else:
+            path = Path(name)
+            if not path.is_dir():
+                from huggingface_hub import snapshot_download
+
+                path = Path(snapshot_download(name))
+            dims = dims_from_hf_config(json.loads((path / "config.json").read_text()))
+            weights = LlavaWeights.from_state_dict(dims, LlavaCheckpoint(path), self._device)
+            from transformers import AutoTokenizer
+
+            self._tokenizer = AutoTokenizer.from_pretrained(str(path))
+            self._tokenizer.padding_side = "left"  # as the reference (:163); prompts are packed, never padded, here
+        self._dims = dims
+        from concurrent.futures import ThreadPoolExecutor
+
+        self._pool = ThreadPoolExecutor(max_workers=8)
+        self._model = LlavaEngine(weights)
+        self._processor = self._tokenizer
+
+    def loglikelihood(self, requests: list) -> list[tuple[float, bool]]:
+        raise NotImplementedError("loglikelihood is outside the accelerated path (SURVEY.md §8f: generation only)")
+
+    def generate_until_multi_round(self, requests: list) -> list[str]:
+        raise NotImplementedError("multi-round generation is outside the accelerated path (SURVEY.md §8f)")
+
+    # ------------------------------------------------------------------ prompt building
+    def _render(self, context: str) -> str:
+        tok = self._tokenizer
+        messages = [{"role": "user", "content": context}]
+        template = self._chat_template if self._chat_template is not None else getattr(tok, "chat_template", None)
+        if template is None:
+            return vicuna_prompt(messages, getattr(tok, "eos_token", "</s>") or "</s>")
+        if isinstance(tok, ByteTokenizer):
+            from jinja2.sandbox import ImmutableSandboxedEnvironment
+
+            env = ImmutableSandboxedEnvironment(trim_blocks=True, lstrip_blocks=True)
+            return env.from_string(template).render(messages=messages, add_generation_prompt=True, eos_token=tok.eos_token)
+        tok.chat_template = template
+        return tok.apply_chat_template(messages, tokenize=False, add_generation_prompt=True)
+
+    def _prompt_ids(self, context: str, n_image_tokens: list[int]) -> np.ndarray:
+        """Rendered prompt -> ids with every `<image>` placeholder expanded to that image's feature count
+        (what LlavaProcessor / LlavaNextProcessor do on the text before tokenising)."""
+        ids = self._tokenizer.encode(self._render(context), add_special_tokens=True)
+        out, it = [], iter(n_image_tokens)
+        for t in ids:
+            if t == self._dims.image_token_id:
+                out.extend([t] * next(it))
+            else:
+                out.append(t)
+        if next(it, None) is not None:
+            raise ValueError("fewer <image> placeholders in the prompt than images in the request")
+        return np.asarray(out, dtype=np.int32)
+
+    def _views(self, img):
+        d = self._dims
+        if d.grid_pinpoints:
+            return imageproc.anyres_views(img, d.grid_pinpoints, d.image_size)
+        return imageproc.clip_view(img, d.image_size)[None], (img.size[1], img.size[0])
+
+    # ------------------------------------------------------------------ the hot loop
+    def generate_until(self, requests: list) -> list[str]:
+        res: list[str] = []
+        d, eng, tok = self._dims, self._model, self._tokenizer
+
+        def _collate(x):
+            return -len(tok.encode(x[0], add_special_tokens=False)), x[0]
+
+        reordered = utils.Collator([reg.args for reg in requests], _collate, grouping=True)
+        for chunk in reordered.get_batched(n=self.batch_size, batch_fn=None):
+            contexts, all_gen_kwargs, doc_to_visual, doc_ids, tasks, splits = zip(*chunk, strict=True)
+            task, split = tasks[0], splits[0]
+            gen_kwargs = dict(all_gen_kwargs[0])
+            gen_kwargs.pop("until", None)  # read and never applied by the reference (:310-320)
+            max_new = int(gen_kwargs.get("max_new_tokens", 1024))
+            if gen_kwargs.get("temperature", 0) not in (0, 0.0) or gen_kwargs.get("num_beams", 1) != 1:
+                raise NotImplementedError("the HIP decoder implements greedy decoding (temperature 0, 1 beam)")
+
+            visuals_per_doc = [doc_to_visual[0](self.task_dict[task][split][did]) for did in doc_ids]
+            flat = [v for vs in visuals_per_doc for v in vs]
+            prepared = list(self._pool.map(self._views, flat))  # PIL resampling releases the GIL
+            views_per_image = [p[0].shape[0] for p in prepared]
+            sizes = [p[1] for p in prepared]
+            feats, rows = None, []
+            if prepared:
+                u8 = torch.from_numpy(np.concatenate([p[0] for p in prepared])).to(self._device, non_blocking=True)
+                feats = eng.encode_views(eng.patchify(u8, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD))
+                rows = eng.feature_rows(views_per_image, sizes)
+            prompts, rows_per_prompt, cur = [], [], 0
+            for ctx, visuals in zip(contexts, visuals_per_doc):
+                mine = rows[cur:cur + len(visuals)]
+                cur += len(visuals)
+                if DEFAULT_IMAGE_TOKEN not in ctx:  # e.g. classification prompts carry no image token (:324-327)
+                    ctx = f"{' '.join([DEFAULT_IMAGE_TOKEN] * len(visuals))}\n{ctx}"
+                prompts.append(self._prompt_ids(ctx, [len(r) for r in mine]))
+                rows_per_prompt.append(np.concatenate(mine) if mine else np.zeros(0, np.int64))
+
+            eos = tok.eos_token_id
+            out = eng.generate_from_features(prompts, feats, rows_per_prompt, max_new, eos_token_id=eos, pad_token_id=eos).cpu().numpy()
+            outs = []
+            for r in out:
+                stop = np.flatnonzero(r == eos)
+                outs.append(r[: stop[0]] if len(stop) else r)
+            answers = tok.batch_decode(outs, skip_special_tokens=True)
+            for ans, ctx in zip(answers, contexts):
+                res.append(ans)
+                self.cache_hook.add_partial("generate_until", (ctx, gen_kwargs), ans)
+        return reordered.get_original(res)
+
+
+def dims_from_hf_config(cfg: dict) -> LlavaDims:
+    """config.json of a llava-hf checkpoint (model_type `llava` or `llava_next`) -> engine dims."""
+    if cfg.get("model_type", "llava") not in ("llava", "llava_next"):
+        raise ValueError(f"unsupported LLaVA model_type {cfg.get('model_type')!r} (llava, llava_next)")
+    t, v = cfg.get("text_config", {}), cfg.get("vision_config", {})
+    if cfg.get("vision_feature_select_strategy", "default") != "default":
+        raise ValueError("only vision_feature_select_strategy='default' is implemented")
+    if v.get("patch_size", 14) != 14 or v.get("hidden_act", "quick_gelu") != "quick_gelu":
+        raise ValueError("the CLIP tower must be a ViT-*/14 with quick_gelu")
+    heads = t.get("num_attention_heads", 32)
+    hidden = t.get("hidden_size", 4096)
+    rope = t.get("rope_parameters") or {}
+    pin = cfg.get("image_grid_pinpoints")
+    if cfg.get("model_type") == "llava_next" and not pin:
+        pin = NEXT_PINPOINTS
+    return LlavaDims(
+        v_layers=v.get("num_hidden_layers", 24), v_embed=v.get("hidden_size", 1024), v_heads=v.get("num_attention_heads", 16),
+        v_mlp=v.get("intermediate_size", 4096), image_size=v.get("image_size", 336), feature_layer=cfg.get("vision_feature_layer", -2),
+        v_ln_eps=v.get("layer_norm_eps", 1e-5), n_layers=t.get("num_hidden_layers", 32), d_model=hidden, n_q_heads=heads,
+        n_kv_heads=t.get("num_key_value_heads", heads), head_dim=t.get("head_dim") or hidden // heads,
+        d_ff=t.get("intermediate_size", 11008), vocab=t.get("vocab_size", 32064),
+        tie_embeddings=bool(cfg.get("tie_word_embeddings", False)), rms_eps=t.get("rms_norm_eps", 1e-5),
+        rope_theta=rope.get("rope_theta", t.get("rope_theta", 10000.0)), image_token_id=cfg.get("image_token_index", cfg.get("image_token_id", 32000)),
+        max_positions=8192 if pin else 4096, grid_pinpoints=tuple(tuple(p) for p in pin) if pin else None)
+
+
+class LlavaCheckpoint(LazyCheckpoint):
+    """Accepts the 4.47 (`vision_tower.vision_model.`, `language_model.model.`, `multi_modal_projector.`,
+    `image_newline`, `language_model.lm_head.`) and the 5.x (`model.vision_tower.`, `model.language_model.`) naming."""
+
+    def __getitem__(self, name: str):
+        legacy = (name.replace("model.vision_tower.", "vision_tower.vision_model.")
+                  .replace("model.language_model.", "language_model.model.")
+                  .replace("model.multi_modal_projector.", "multi_modal_projector.")
+                  .replace("model.image_newline", "image_newline"))
+        if name == "lm_head.weight":
+            legacy = "language_model.lm_head.weight"
+        mid = name.replace("model.vision_tower.", "model.vision_tower.vision_model.")
+        for cand in (name, mid, legacy):
+            if cand in self._files:
+                return self._files[cand].get_tensor(cand)
+        raise KeyError(name)
+
+
+@register_model("llava-next-mistral-7b")
+def llava_next_mistral_7b(**model_kwargs) -> LLaVA:
+    return LLaVA(model_kwargs.pop("model_name_or_path", "llava-hf/llava-v1.6-mistral-7b-hf"), **model_kwargs)
+
+
+@register_model("llava-next-vicuna-7b")
+def llava_next_vicuna_7b(**model_kwargs) -> LLaVA:
+    return LLaVA(model_kwargs.pop("model_name_or_path", "llava-hf/llava-v1.6-vicuna-7b-hf"), **model_kwargs)
+
+
+@register_model("llava-1.5-13b")
+def llava_15_13b(**model_kwargs) -> LLaVA:
+    return LLaVA(model_kwargs.pop("model_name_or_path", "llava-hf/llava-1.5-13b-hf"), **model_kwargs)
+
+
+@register_model("llava-1.5-7b")
+def llava_15_7b(**model_kwargs) -> LLaVA:
+    return LLaVA(model_kwargs.pop("model_name_or_path", "llava-hf/llava-1.5-7b-hf"), **model_kwargs)

@@ -63,3 +63,51 @@ def prepare_image(img, min_pixels: int, max_pixels: int, jpeg: bool = True) -> n
     if (h2, w2) != (h1, w1):
         img = img.resize((w2, h2), Image.BICUBIC)
     return np.ascontiguousarray(np.asarray(img, dtype=np.uint8).transpose(2, 0, 1))
+
+
+# --------------------------------------------------------------------------------------------------
+# LLaVA (CLIP image processor).  Restates the resampling / cropping / tiling decisions of HF
+# CLIPImageProcessor (image_processing_clip.py: resize shortest edge -> center crop) and
+# LlavaNextImageProcessor (image_processing_llava_next.py: select_best_resolution, _resize_for_patching,
+# _pad_for_patching, divide_to_patches, base view) which the reference reaches through
+# `self.processor(images=visuals, text=text)` (/root/reference/src/models/_llava_hf.py:347).  Everything stays
+# uint8; rescale + normalise + patch layout are `owc_clip_patchify_u8` on the GPU.
+def clip_view(img, size: int = 336) -> np.ndarray:
+    """PIL image -> uint8 [3, size, size]: shortest edge to `size` (bicubic), then center crop."""
+    from PIL import Image
+
+    img = img.convert("RGB")
+    w, h = img.size
+    short, long = (w, h) if w <= h else (h, w)
+    new_short, new_long = size, int(size * long / short)
+    nw, nh = (new_short, new_long) if w <= h else (new_long, new_short)
+    if (nw, nh) != (w, h):
+        img = img.resize((nw, nh), Image.BICUBIC)
+    a = np.asarray(img, dtype=np.uint8)
+    top, left = (nh - size) // 2, (nw - size) // 2
+    return np.ascontiguousarray(a[top:top + size, left:left + size].transpose(2, 0, 1))
+
+
+def anyres_views(img, pinpoints, tile: int = 336) -> tuple[np.ndarray, tuple[int, int]]:
+    """PIL image -> (uint8 [1 + nh*nw, 3, tile, tile], (height, width)): view 0 is the whole image squashed to
+    tile x tile, the rest are the row-major tiles of the aspect-preserving resize, zero-padded to the pinpoint."""
+    from PIL import Image
+
+    from ..engine.anyres import select_best_resolution
+
+    img = img.convert("RGB")
+    w, h = img.size
+    th, tw = select_best_resolution((h, w), pinpoints)
+    sw, sh = tw / w, th / h
+    if sw < sh:
+        nw, nh = tw, min(math.ceil(h * sw), th)
+    else:
+        nh, nw = th, min(math.ceil(w * sh), tw)
+    resized = np.asarray(img.resize((nw, nh), Image.BICUBIC), dtype=np.uint8)
+    canvas = np.zeros((th, tw, 3), dtype=np.uint8)
+    py, px = (th - nh) // 2, (tw - nw) // 2
+    canvas[py:py + nh, px:px + nw] = resized
+    base = np.asarray(img.resize((tile, tile), Image.BICUBIC), dtype=np.uint8)
+    tiles = canvas.reshape(th // tile, tile, tw // tile, tile, 3).transpose(0, 2, 1, 3, 4).reshape(-1, tile, tile, 3)
+    views = np.concatenate([base[None], tiles], 0).transpose(0, 3, 1, 2)
+    return np.ascontiguousarray(views), (h, w)

@@ -216,3 +216,77 @@ def test_anyres_packing_order_matches_hf_golden():
         assert len(rows) == want["n"], key
         assert rows[576:576 + 30].tolist() == want["head"], key
         assert zlib.crc32(rows.astype(np.int64).tobytes()) == want["crc"], key
+
+
+def test_llava_image_prep_matches_hf_golden():
+    """imageproc.clip_view / anyres_views (uint8) followed by the CLIP rescale + normalise reproduce HF
+    CLIPImageProcessor / LlavaNextImageProcessor pixel_values on a wide and a tall gradient image."""
+    import numpy as np
+    from PIL import Image
+
+    from lmms_owc_amd.engine.llava import NEXT_PINPOINTS
+    from lmms_owc_amd.models import imageproc
+
+    g = np.load(ROOT / "tests" / "golden" / "llava_image_proc.npz")
+    mean = np.array(imageproc.OPENAI_CLIP_MEAN, np.float32)[:, None, None]
+    std = np.array(imageproc.OPENAI_CLIP_STD, np.float32)[:, None, None]
+    for tag, (h, w) in {"wide": (300, 450), "tall": (500, 220)}.items():
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([(xx * 255 // (w - 1)), (yy * 255 // (h - 1)), ((xx + yy) * 255 // (w + h - 2))], -1).astype(np.uint8)
+        im = Image.fromarray(img, "RGB")
+        x = (imageproc.clip_view(im, 336).astype(np.float32) / 255.0 - mean) / std
+        np.testing.assert_allclose(x[:, ::7, ::11], g[f"clip_{tag}_sample"], atol=1e-6)
+        np.testing.assert_allclose(x.sum(-1), g[f"clip_{tag}_sums"], rtol=1e-5, atol=1e-3)
+        views, size = imageproc.anyres_views(im, NEXT_PINPOINTS, 336)
+        assert list(size) == g[f"next_{tag}_size"].tolist() == [h, w]
+        x = (views.astype(np.float32) / 255.0 - mean[None]) / std[None]
+        assert x.shape[0] == g[f"next_{tag}_sample"].shape[0]
+        np.testing.assert_allclose(x[:, :, ::7, ::11], g[f"next_{tag}_sample"], atol=1e-6)
+        np.testing.assert_allclose(x.sum(-1), g[f"next_{tag}_sums"], rtol=1e-5, atol=1e-3)
+
+
+def test_llava_prompt_and_tokenizer_cpu():
+    """The Vicuna fallback prompt equals what the reference's chat template renders (golden generated from
+    /root/reference/src/models/_llava_hf.py:23); the synthetic tokenizer maps <image> to one id and round-trips text."""
+    from lmms_owc_amd.models._llava_hf import LlavaByteTokenizer, vicuna_prompt
+
+    gold = json.loads((ROOT / "tests" / "golden" / "llava_prompt.json").read_text())
+    assert len(gold["cases"]) >= 6
+    for c in gold["cases"]:
+        assert vicuna_prompt(c["messages"], c["eos_token"], c["add_generation_prompt"]) == c["text"]
+    tok = LlavaByteTokenizer()
+    ids = tok.encode("<image> <image>\nhi", add_special_tokens=True)
+    assert ids[0] == tok.bos_token_id and ids.count(tok.image_token_id) == 2
+    assert tok.decode(ids) == " \nhi"
+    assert tok.encode("hi") == [ord("h") + 3, ord("i") + 3]
+
+
+def test_llava_checkpoint_readers_cpu(tmp_path):
+    """LlavaCheckpoint resolves both parameter-name generations; dims come from config.json (llava and llava_next)."""
+    import numpy as np
+
+    from lmms_owc_amd.models._llava_hf import LlavaCheckpoint, dims_from_hf_config
+    from tests import ckpt_util
+
+    for legacy, nxt in ((False, False), (True, True)):
+        d = tmp_path / f"llava{int(legacy)}"
+        info = ckpt_util.write_llava_checkpoint(d, legacy_names=legacy, next_=nxt)
+        ck = LlavaCheckpoint(d)
+        names = ["model.vision_tower.embeddings.class_embedding", "model.vision_tower.encoder.layers.1.self_attn.q_proj.bias",
+                 "model.multi_modal_projector.linear_2.weight", "model.language_model.layers.0.mlp.up_proj.weight", "lm_head.weight"]
+        if nxt:
+            names.append("model.image_newline")
+        for name in names:
+            assert np.array_equal(ck[name].float().numpy(), info["weights"][name]), name
+        dims = dims_from_hf_config(json.loads((d / "config.json").read_text()))
+        assert (dims.v_layers, dims.v_embed, dims.v_heads, dims.v_mlp, dims.image_size, dims.tokens, dims.v_run_layers) == (3, 128, 2, 256, 56, 17, 2)
+        assert (dims.n_layers, dims.d_model, dims.n_q_heads, dims.n_kv_heads, dims.head_dim, dims.d_ff, dims.vocab) == (2, 256, 2, 1, 128, 512, 512)
+        assert dims.image_token_id == 500 and (dims.grid_pinpoints is not None) == nxt
+
+
+def test_llava_registry_names_match_reference():
+    from lmms_owc_amd.models import MODEL_TYPES, get_models_info
+
+    names = {m.name for m in get_models_info()}
+    assert {"llava-next-mistral-7b", "llava-next-vicuna-7b", "llava-1.5-13b", "llava-1.5-7b", "custom-model"} <= names
+    assert set(MODEL_TYPES) == {"llava", "qwen2-vl"}

@@ -185,3 +185,58 @@ def test_sentence_encoder_loads_from_directory(gpu, tmp_path, monkeypatch):
     enc = text.sentence_bert_processor(["sea lion", "what type of dog is this ?"], padding=True, truncation=True, return_tensors="np")
     want = bert_np.sentence_embed(info["weights"], info["cfg"], np.asarray(enc["input_ids"]), np.asarray(enc["attention_mask"]))
     np.testing.assert_allclose(z, want, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny-next"])
+def test_llava_generate_until_batch_invariant_and_ordered(gpu, name):
+    """LLaVA plug-in (1.5 and NeXT/anyres): batching must not change any answer; answers come back in request order."""
+    from lmms_owc_amd.models import get_model
+    from lmms_owc_amd.tasks import load_task
+
+    task = load_task("synthetic:6:70x120:3")   # non-square images: anyres picks a 2-tile canvas, 1.5 crops
+    task.build_all_requests(limit=None, rank=0, world_size=1)
+    outs = []
+    for bs in (1, 4):
+        lm = get_model("custom-model", model_type="llava", model_name_or_path=f"synthetic:{name}", batch_size=bs)
+        lm.task_dict[task.task_name] = task.dataset
+        outs.append(lm.generate_until(task.instances))
+    assert len(outs[0]) == 6 and outs[0] == outs[1]
+    assert lm.generate_until([]) == []
+
+
+@pytest.mark.parametrize("nxt", [False, True])
+def test_llava_real_checkpoint_loading_path(gpu, tmp_path, nxt):
+    """An on-disk llava-hf style checkpoint (legacy 4.47 names, fast tokenizer without a chat template -> Vicuna
+    fallback) through the real loader; generation must equal the engine fed directly with the same weights."""
+    import torch
+
+    from lmms_owc_amd.engine.llava import LlavaEngine, LlavaWeights
+    from lmms_owc_amd.models import get_model, imageproc
+    from lmms_owc_amd.models._llava_hf import dims_from_hf_config
+    from lmms_owc_amd.tasks import load_task
+    from tests import ckpt_util
+
+    d = tmp_path / "llava-tiny"
+    info = ckpt_util.write_llava_checkpoint(d, legacy_names=True, next_=nxt)
+    lm = get_model("custom-model", model_type="llava", model_name_or_path=str(d), batch_size=2)
+    assert lm.eot_token_id == 2
+    task = load_task("synthetic:3:70x120:2")
+    task.build_all_requests(limit=None, rank=0, world_size=1)
+    lm.task_dict[task.task_name] = task.dataset
+    out = lm.generate_until(task.instances)
+    assert len(out) == 3 and all(isinstance(x, str) for x in out)
+    dims = dims_from_hf_config(json.loads((d / "config.json").read_text()))
+    eng = LlavaEngine(LlavaWeights.from_state_dict(dims, info["weights"], gpu))
+    views, size = lm._views(task.docs[0]["visual"])
+    feats = eng.encode_views(eng.patchify(torch.from_numpy(views).to(gpu), imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD))
+    rows = eng.feature_rows([views.shape[0]], [size])
+    n_tok = len(rows[0])
+    assert (n_tok == 16) == (not nxt)
+    ctx = task.instances[0].args[0]
+    ids = lm._prompt_ids(f"<image>\n{ctx}", [n_tok])
+    assert ids[0] == 1 and (ids == info["image_token"]).sum() == n_tok   # BOS + expanded placeholder run
+    toks = eng.generate_from_features([ids], feats, [rows[0]], int(task.instances[0].args[1].get("max_new_tokens", 8)),
+                                      eos_token_id=2, pad_token_id=2).cpu().numpy()[0]
+    stop = np.flatnonzero(toks == 2)
+    direct = lm.tokenizer.batch_decode([toks[: stop[0]] if len(stop) else toks], skip_special_tokens=True)[0]
+    assert lm.generate_until([task.instances[0]])[0] == direct

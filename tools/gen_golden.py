@@ -385,15 +385,66 @@ def gen_image():
     print("image golden:", pv.shape, out["image_grid_thw"].tolist())
 
 
+PROMPT_CASES = [
+    [{"role": "user", "content": "<image>\nWhat type of object is in this image?"}],
+    [{"role": "user", "content": "<image> <image>\nCompare."}, {"role": "assistant", "content": "Both are cats."},
+     {"role": "user", "content": "Which breed?"}],
+    [{"role": "user", "content": "no image here"}],
+]
+
+
+def gen_llava_prompt():
+    """Text the reference's fallback chat template renders (the template string is read from the reference at
+    generation time, /root/reference/src/models/_llava_hf.py:23, and rendered the way HF apply_chat_template does)."""
+    import ast
+
+    from jinja2.sandbox import ImmutableSandboxedEnvironment
+
+    src = Path("/root/reference/src/models/_llava_hf.py").read_text()
+    node = next(n for n in ast.parse(src).body if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "VICUNA_CHAT_TEMPLATE")
+    template = ast.literal_eval(node.value)
+    env = ImmutableSandboxedEnvironment(trim_blocks=True, lstrip_blocks=True)
+    cases = []
+    for msgs in PROMPT_CASES:
+        for gen in (True, False):
+            cases.append({"messages": msgs, "add_generation_prompt": gen, "eos_token": "</s>",
+                          "text": env.from_string(template).render(messages=msgs, add_generation_prompt=gen, eos_token="</s>")})
+    (GOLD / "llava_prompt.json").write_text(json.dumps({"source": "_llava_hf.py:23 rendered with jinja2 (trim_blocks, lstrip_blocks)", "cases": cases}, indent=1))
+    print("llava prompt golden:", len(cases), "cases;", cases[0]["text"][:80])
+
+
+def gen_llava_image():
+    """HF CLIPImageProcessor (LLaVA-1.5) and LlavaNextImageProcessor (PIL backends) on the gradient image."""
+    from PIL import Image
+    from transformers.models.clip.image_processing_pil_clip import CLIPImageProcessorPil
+    from transformers.models.llava_next.image_processing_pil_llava_next import LlavaNextImageProcessorPil
+
+    out = {}
+    kw = dict(size={"shortest_edge": 336}, crop_size={"height": 336, "width": 336}, resample=3)
+    for tag, (h, w) in {"wide": (300, 450), "tall": (500, 220)}.items():
+        im = Image.fromarray(gradient_image(h, w), "RGB")
+        pv = CLIPImageProcessorPil(**kw)(images=[im], return_tensors="np")["pixel_values"][0].astype(np.float32)
+        out[f"clip_{tag}_sample"], out[f"clip_{tag}_sums"] = pv[:, ::7, ::11], pv.sum(-1)
+        o = LlavaNextImageProcessorPil(**kw)(images=[im], return_tensors="np")
+        pv = o["pixel_values"][0].astype(np.float32)
+        out[f"next_{tag}_sample"], out[f"next_{tag}_sums"], out[f"next_{tag}_size"] = pv[:, :, ::7, ::11], pv.sum(-1), np.asarray(o["image_sizes"][0])
+    np.savez_compressed(GOLD / "llava_image_proc.npz", **out)
+    print("llava image golden:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["qwen", "scorer", "image", "llava", "llava_next"]
+    which = sys.argv[1:] or ["qwen", "scorer", "image", "llava", "llava_next", "llava_image", "llava_prompt"]
     if "image" in which:
         gen_image()
     if "llava" in which:
         gen_llava()
+    if "llava_prompt" in which:
+        gen_llava_prompt()
+    if "llava_image" in which:
+        gen_llava_image()
     if "llava_next" in which:
         gen_llava_next()
     if "qwen" in which:
