@@ -85,3 +85,51 @@ def test_full_2b_properties(gpu):
     for b in (0, n - 1):
         single = eng.generate([ids[b]], emb[b * 256:(b + 1) * 256].contiguous(), [grids[b]], 6)
         assert torch.equal(single[0], batch[b]), (b, single[0].tolist(), batch[b].tolist())
+
+
+# ---------------------------------------------------------------- LLaVA at CLIP-L/336 + Llama-7B widths
+def test_llava_clip_slice_full_width(gpu):
+    """2 encoder layers of the real CLIP ViT-L/14-336 geometry (1024 x 16 heads x 4096, 577 tokens per view, 4 views
+    so the 256x256 GEMM and the head_dim-64 attention run at production shapes) + the 1024 -> 4096 projector, against
+    the bf16 numpy oracle."""
+    from lmms_owc_amd.engine.llava import LlavaDims, LlavaEngine, LlavaWeights
+    from oracle import llava_np as L
+
+    cfg = L.LlavaCfg(vision=L.ClipCfg(num_hidden_layers=3), text=Q.TextCfg(hidden_size=4096, num_hidden_layers=1, num_attention_heads=32,
+                                                                           num_key_value_heads=32, intermediate_size=1024, vocab_size=1024,
+                                                                           rms_norm_eps=1e-5, rope_theta=10000.0, tie_word_embeddings=False),
+                     image_token_id=1000)
+    w = recipes.llava_weights(cfg, 777)
+    dims = LlavaDims(v_layers=3, n_layers=1, d_ff=1024, vocab=1024, image_token_id=1000, max_positions=1024)
+    eng = LlavaEngine(LlavaWeights.from_state_dict(dims, w, gpu))
+    pix = recipes.clip_pixels(4, 336, seed=3)
+    p = pix.reshape(4, 3, 24, 14, 24, 14).transpose(0, 2, 4, 1, 3, 5).reshape(4 * 576, 588)
+    p = np.concatenate([p, np.zeros((p.shape[0], dims.patch_k - 588), np.float32)], 1)
+    out = to_np(eng.encode_views(torch.from_numpy(p).to(torch.bfloat16).to(gpu))).reshape(4, 577, 4096)[:, 1:]
+    for i in (0, 3):  # views are independent; the oracle on two of them (numpy time)
+        ref = L.project(w, L.clip_features(w, cfg, pix[i:i + 1], bf16=True), bf16=True)[0]
+        assert np.abs(out[i] - ref).max() <= 0.03 * np.abs(ref).max(), (i, np.abs(out[i] - ref).max(), np.abs(ref).max())
+        assert np.abs(out[i] - ref).mean() <= 0.004 * np.abs(ref).max()
+
+
+def test_full_llava_15_7b_properties(gpu):
+    """Full LLaVA-1.5-7B (random weights): batch invariance + determinism of greedy tokens, finite features."""
+    from lmms_owc_amd.engine.llava import DIMS, LlavaEngine, LlavaWeights
+
+    d = DIMS["llava-1.5-7b"]
+    eng = LlavaEngine(LlavaWeights.random(d, gpu, seed=5))
+    g = torch.Generator(device=gpu).manual_seed(1)
+    n = 5
+    u8 = torch.randint(0, 256, (n, 3, 336, 336), generator=g, device=gpu, dtype=torch.uint8)
+    feats = eng.encode_views(eng.patchify(u8, (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)))
+    assert feats.shape == (n * 577, 4096) and bool(torch.isfinite(feats.float()).all())
+    rows = eng.feature_rows([1] * n)
+    r = np.random.default_rng(2)
+    head = r.integers(1000, 30000, 20)
+    ids = [np.concatenate([head, np.full(576, d.image_token_id), r.integers(1000, 30000, 8 + i)]) for i in range(n)]
+    a = to_np(eng.generate_from_features(ids, feats, rows, 6))
+    b = to_np(eng.generate_from_features(ids, feats, rows, 6))
+    assert np.array_equal(a, b)
+    for i in (0, n - 1):
+        s = to_np(eng.generate_from_features([ids[i]], feats, [rows[i]], 6))
+        assert np.array_equal(s[0], a[i]), i
