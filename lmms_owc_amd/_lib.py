@@ -20,7 +20,7 @@ _lock = threading.Lock()
 _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = range(6)
 
@@ -94,6 +94,7 @@ class BertWeights(C.Structure):
 # name -> (restype, argtypes); every symbol include/owc.h declares
 SIGNATURES: dict[str, tuple] = {
     "owc_abi_version": (i32, []),
+    "owc_tuning_set": (i32, [C.c_char_p, i32]),
     "owc_init": (i32, [i32, C.POINTER(vp)]),
     "owc_destroy": (i32, [vp]),
     "owc_last_error": (C.c_char_p, [vp]),

@@ -2,6 +2,7 @@
 // The model-level entries live in qwen2vl.hip / bert.hip.
 #include "../../include/owc.h"
 #include "owc_internal.h"
+#include <string.h>
 #include <cstdlib>
 
 #define ST(s) ((hipStream_t)(s))
@@ -14,7 +15,16 @@
 
 extern "C" {
 
-int owc_abi_version(void) { return 5; }
+int owc_abi_version(void) { return 6; }
+
+int owc_tuning_set(const char* name, int value) {
+  if (!name) return OWC_ERR_ARG;
+  if (!strcmp(name, "gemm_big_min_m")) owc_gemm_set_big_min_m(value);
+  else if (!strcmp(name, "gemm_dbg")) owc_gemm_set_dbg(value);
+  else if (!strcmp(name, "attn_dbg")) owc_attn_set_dbg(value);
+  else return OWC_ERR_ARG;
+  return OWC_OK;
+}
 
 int owc_init(int device, owc_ctx** out) {
   if (out == nullptr) return OWC_ERR_ARG;

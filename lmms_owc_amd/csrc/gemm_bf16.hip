@@ -35,7 +35,8 @@ struct GemmProfile {
   size_t used = 0;
 };
 GemmProfile g_prof;
-int g_gemm_dbg = 0;       // experiment knob (OWC_GEMM_DBG): 1 = skip DMA, 2 = skip MFMA — results are garbage
+int g_gemm_dbg = 0;       // timing-experiment knob (OWC_GEMM_DBG / owc_tuning_set "gemm_dbg"), results are garbage unless 0 or 512:
+                          // 1 no DMA, 2 DMA re-reads K-tiles 0/1 (all L2 hits), 4 no epilogue, 512 direct (un-staged) epilogue stores
 int g_big_min_tiles = 192;  // fewer 256x256 tiles than this -> use the 128x128 kernel
 int g_big_min_m = 1024;  // M at and above which the 256x128 3-stage kernel is used (OWC_GEMM_BIG_MIN_M)
 
@@ -60,10 +61,15 @@ __device__ __forceinline__ void swap16(float& x, float& y) {
   y = __uint_as_float(r[1]);
 }
 
+// `ctile` != NULL: instead of going to memory, the finished bf16 values are parked in a block-wide LDS image of the output
+// tile (row pitch `cpitch` bytes, 16-byte chunks XOR-swizzled by row & 7, block-local origin (lrow0, lcol0)) and
+// store_ctile() writes them out as whole rows.  Why: a lane group of the MFMA layout only covers 64 contiguous bytes of
+// a row, and half-line writes measurably slow the whole kernel (ablation: full-line pattern +2..8 %).
 template <int EPI, int MT, bool FULL = false>
 __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mrow0, int ncol0, int fr, int fq,
                                               const bf16_t* __restrict__ bias, const bf16_t* R, long ldr,
-                                              void* Cv, long ldc, int M, int N, const owc_gemm_aux& aux) {
+                                              void* Cv, long ldc, int M, int N, const owc_gemm_aux& aux,
+                                              char* ctile = nullptr, int cpitch = 0, int lrow0 = 0, int lcol0 = 0) {
   if constexpr (EPI == OWC_EPI_F32) {
     float* C = (float*)Cv;
 #pragma unroll
@@ -102,7 +108,12 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
         o[e] = f2bf(o0[e]);
         o[4 + e] = f2bf(o1[e]);
       }
-      if (FULL || (m < M && f < nout)) *(bf16x8*)(C + (long)m * ldc + f) = o;
+      if (ctile) {
+        const int lr = lrow0 + mt * 16 + fr, lc = (lcol0 >> 1) + odd * 16 + (fq >> 1) * 8;
+        *(bf16x8*)(ctile + lr * cpitch + (((lc >> 3) ^ (lr & 7)) << 4)) = o;
+      } else if (FULL || (m < M && f < nout)) {
+        *(bf16x8*)(C + (long)m * ldc + f) = o;
+      }
     }
   } else {
     bf16_t* C = (bf16_t*)Cv;
@@ -170,9 +181,33 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-        if (FULL || (m < M && n < N)) *(bf16x8*)(C + (long)m * ldc + n) = o;
+        if (ctile) {
+          const int lr = lrow0 + mt * 16 + fr, lc = lcol0 + (2 * p + odd) * 16 + (fq >> 1) * 8;
+          *(bf16x8*)(ctile + lr * cpitch + (((lc >> 3) ^ (lr & 7)) << 4)) = o;
+        } else if (FULL || (m < M && n < N)) {
+          *(bf16x8*)(C + (long)m * ldc + n) = o;
+        }
       }
     }
+  }
+}
+
+// Second half of the LDS-staged epilogue: the block's output tile (rows x cols bf16, pitch = cols * 2 bytes) leaves LDS as
+// whole rows - a wave-instruction covers 64 lanes x 16 B = 1 KiB of consecutive row segments.
+template <int WAVES>
+__device__ __forceinline__ void store_ctile(const char* ctile, int rows, int cols, bf16_t* C, long ldc, int m0, int n0,
+                                            int M, int Ncols, int w, int l) {
+  const int lpr = cols >> 3;            // lanes per row (16-byte chunks)
+  const int rpi = 64 / lpr;             // rows per wave-instruction
+  const int rows_per_wave = rows / WAVES;
+  const int c = l % lpr;
+  const int r_in = l / lpr;
+  const int n = n0 + c * 8;
+#pragma unroll 4
+  for (int it = 0; it < rows_per_wave / rpi; ++it) {
+    const int r = w * rows_per_wave + it * rpi + r_in;
+    const bf16x8 v = *(const bf16x8*)(ctile + r * (cols * 2) + ((c ^ (r & 7)) << 4));
+    if (m0 + r < M && n < Ncols) *(bf16x8*)(C + (long)(m0 + r) * ldc + n) = v;
   }
 }
 
@@ -445,15 +480,31 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
     }
     // phase 4: rows 0-63, k-step 1 — with the DMA of stage kt+2 (into stage kt's buffer, free since the barrier)
     // interleaved between its MFMA groups
-    phase_dma(ya, wk1, 0, kt & 1, kt + 2, kt + 2 < nk && !(dbg & 1));
+    phase_dma(ya, wk1, 0, kt & 1, (dbg & 2) ? (kt & 1) : kt + 2, kt + 2 < nk && !(dbg & 1));  // dbg 2: re-read K-tiles 0/1 (all L2 hits)
   }
 
   if (dbg & 4) {  // timing experiment: no epilogue
     if (acc[0][0][0] == 123.456f) ((float*)Cv)[0] = 1.f;
     return;
   }
-  gemm_epilogue<EPI, 8>(acc, m0 + wr * 128, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
+  if constexpr (EPI == OWC_EPI_F32) {
+    gemm_epilogue<EPI, 8>(acc, m0 + wr * 128, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
+  } else {
+    // LDS is quiescent here (every wave passed the last K-tile's barrier with lgkmcnt(0); no DMA is pending): the two
+    // stage buffers become the 256 x 256 (SWIGLU: 256 x 128) bf16 image of the output tile
+    if (dbg & 512) {
+      gemm_epilogue<EPI, 8>(acc, m0 + wr * 128, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
+      return;
+    }
+    constexpr int CCOLS = EPI == OWC_EPI_SWIGLU ? BT / 2 : BT;
+    gemm_epilogue<EPI, 8>(acc, m0 + wr * 128, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux, lds, CCOLS * 2,
+                          wr * 128, wc * 64);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    store_ctile<8>(lds, BT, CCOLS, (bf16_t*)Cv, ldc, m0, EPI == OWC_EPI_SWIGLU ? (n0 >> 1) : n0, M,
+                   EPI == OWC_EPI_SWIGLU ? (N >> 1) : N, w, l);
+  }
 }
+
 
 template <int EPI>
 int launch(const void* A, long lda, const void* W, long ldw, const void* bias, const void* R,
@@ -517,6 +568,7 @@ int owc_launch_gemm_bf16_aux(const void* A, long lda, const void* W, long ldw, c
       return OWC_ERR_ARG;
     aux = *auxp;
   }
+
   switch (epi) {
     case OWC_EPI_NONE: return launch<OWC_EPI_NONE>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, s, aux);
     case OWC_EPI_QUICK_GELU: return launch<OWC_EPI_QUICK_GELU>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, s, aux);

@@ -33,9 +33,68 @@ SHAPES = [
 ]
 
 
+def ab(dev, only, knob=b"gemm_big_min_m"):
+    """Interleaved A/B of one owc_tuning_set knob (0 vs 1) in ONE process (median / best of 7 rounds each)."""
+    import statistics
+
+    lib = _lib.load()
+    for name, m, n, k in SHAPES:
+        if only and name != only:
+            continue
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+        out = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+        res = {0: [], 1: []}
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for rnd in range(8):
+            for v in (0, 1):
+                lib.owc_tuning_set(knob, v)
+                for _ in range(2):
+                    ops.gemm_bf16(a, w, out=out)
+                e0.record()
+                for _ in range(10):
+                    ops.gemm_bf16(a, w, out=out)
+                e1.record()
+                torch.cuda.synchronize()
+                if rnd:
+                    res[v].append(2.0 * m * n * k / (e0.elapsed_time(e1) / 10) / 1e9)
+        lib.owc_tuning_set(knob, 0)
+        print(f"{name:18s} M={m:6d} N={n:6d} K={k:6d}  [{knob.decode()}] off med {statistics.median(res[0]):7.1f} max {max(res[0]):7.1f} | "
+              f"on med {statistics.median(res[1]):7.1f} max {max(res[1]):7.1f}  ratio {statistics.median(res[1]) / statistics.median(res[0]):.3f}", flush=True)
+
+
 def main():
     dev = torch.device("cuda:0")
-    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if "--dbg" in sys.argv:  # timing experiments (--vals=0,512,4): 0 normal, 1 no DMA, 2 DMA re-reads K-tiles 0/1 (L2 hits), 4 no epilogue, 512 direct epilogue stores
+        lib = _lib.load()
+        only = next((a for a in sys.argv[1:] if not a.startswith("--")), None)
+        for name, m, n, k in SHAPES:
+            if only and name != only:
+                continue
+            a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+            w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+            out = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            res = {}
+            for rnd in range(4):
+                for v in [int(x) for x in next((a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('--vals=')), '0,4').split(',')]:
+                    lib.owc_tuning_set(b"gemm_dbg", v)
+                    for _ in range(2):
+                        ops.gemm_bf16(a, w, out=out)
+                    e0.record()
+                    for _ in range(10):
+                        ops.gemm_bf16(a, w, out=out)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if rnd:
+                        res.setdefault(v, []).append(2.0 * m * n * k / (e0.elapsed_time(e1) / 10) / 1e9)
+            lib.owc_tuning_set(b"gemm_dbg", 0)
+            print(f"{name:18s} " + "  ".join(f"dbg{v}: {sorted(r)[len(r) // 2]:7.1f}" for v, r in res.items()), flush=True)
+        return
+    if "--ab" in sys.argv:
+        knob = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--knob=")), "gemm_dbg")
+        return ab(dev, next((a for a in sys.argv[1:] if not a.startswith("--")), None), knob.encode())
+    only = next((a for a in sys.argv[1:] if not a.startswith("--")), None)
     for name, m, n, k in SHAPES:
         if only and name != only:
             continue
@@ -54,7 +113,20 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
         tf = 2.0 * m * n * k / ms / 1e9
-        print(f"{name:18s} M={m:6d} N={n:6d} K={k:6d}  {ms:8.3f} ms  {tf:8.1f} TFLOP/s", flush=True)
+        line = f"{name:18s} M={m:6d} N={n:6d} K={k:6d}  {ms:8.3f} ms  {tf:8.1f} TFLOP/s"
+        if "--yardstick" in sys.argv:
+            # vendor library (hipBLASLt through torch) on the same operands: a yardstick for the headroom, never on the product path
+            for _ in range(3):
+                torch.matmul(a, w.t(), out=out)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(iters):
+                torch.matmul(a, w.t(), out=out)
+            e1.record()
+            torch.cuda.synchronize()
+            ms2 = e0.elapsed_time(e1) / iters
+            line += f"   | torch.matmul {ms2:8.3f} ms {2.0 * m * n * k / ms2 / 1e9:8.1f} TFLOP/s"
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
