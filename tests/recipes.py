@@ -9,6 +9,7 @@ tensors are exact in fp32 and bf16 runs.
 
 from __future__ import annotations
 
+import json
 import zlib
 
 import numpy as np
@@ -220,3 +221,25 @@ def llava_weights(cfg, seed: int = 1234) -> dict[str, np.ndarray]:
 
 def clip_pixels(n: int, size: int, seed: int = 31) -> np.ndarray:
     return bf16_round(_rng(seed, "clip_pixels").standard_normal((n, 3, size, size)).astype(np.float32))
+
+
+# ---------------------------------------------------------------- eval_ranking.py inputs
+def ranking_runs(root, n_docs: int = 30):
+    """Synthetic `logs/schedule/{task}/{model}/*_samples_*.jsonl` runs; answers/targets are strings of token ids
+    (IdTokenizer) so the same files feed the reference on CPU and the HIP scorer on the GPU box."""
+    r = np.random.default_rng(77)
+    vocab = bert_cfg("tiny")["vocab_size"]
+    targets = [" ".join(str(int(t)) for t in r.integers(3, vocab, r.integers(2, 5))) for _ in range(n_docs)]
+    for mi, model in enumerate(("model-a", "model-b", "model-c")):
+        d = root / "toytask" / model
+        d.mkdir(parents=True, exist_ok=True)
+        rows = []
+        for doc_id, tgt in enumerate(targets):
+            toks = tgt.split()
+            if r.random() < 0.35 + 0.2 * mi:   # model-c copies the target most often
+                ans = tgt
+            else:
+                ans = " ".join(toks[:1] + [str(int(t)) for t in r.integers(3, vocab, r.integers(1, 6))])
+            rows.append({"doc_id": doc_id, "filtered_resps": [ans], "target": tgt})
+        (d / f"2026_samples_toytask.jsonl").write_text("\n".join(json.dumps(x) for x in rows) + "\n")
+    return targets

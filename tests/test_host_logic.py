@@ -290,3 +290,50 @@ def test_llava_registry_names_match_reference():
     names = {m.name for m in get_models_info()}
     assert {"llava-next-mistral-7b", "llava-next-vicuna-7b", "llava-1.5-13b", "llava-1.5-7b", "custom-model"} <= names
     assert set(MODEL_TYPES) == {"llava", "qwen2-vl"}
+
+
+def test_eval_ranking_host_logic_matches_reference(tmp_path, monkeypatch, capsys):
+    """Game sampling, Elo updates (zero-sum and plain) and the bootstrap median reproduce what the reference's own
+    eval_ranking.main printed (tests/golden/ranking.json) when fed the same per-game outcomes (the GPU test replaces
+    those with the HIP scorer's)."""
+    import eval_ranking
+    from tests import recipes
+
+    gold = json.loads((ROOT / "tests" / "golden" / "ranking.json").read_text())["cases"]
+    recipes.ranking_runs(tmp_path)
+    for tag, kw in {"default": {}, "no_zero_sum": {"disable_zero_sum": True, "k_factor": 32}}.items():
+        scores = gold[tag]["scores"]
+        monkeypatch.setattr(eval_ranking, "semantic_outcomes", lambda games, s=scores: (len(games) == len(s)) and list(s))
+        args = eval_ranking.build_parser().parse_args(["-i", str(tmp_path), "-c", "semantic_similarity", "-b", "10", "-n", "200",
+                                                       "-k", str(kw.get("k_factor", 16)), "--log-level", "WARNING"]
+                                                      + (["--disable-zero-sum"] if kw.get("disable_zero_sum") else []))
+        eval_ranking.main(args)
+        assert capsys.readouterr().out == gold[tag]["stdout"], tag
+    with pytest.raises(NotImplementedError):
+        eval_ranking.main(eval_ranking.build_parser().parse_args(["-i", str(tmp_path), "-c", "llama_score", "-n", "5", "-b", "2"]))
+
+
+def test_imagenet1k_task_config_loads_from_manifest(tmp_path):
+    """Config #4's task (absent from the reference) is a plain classification YAML over a jsonl manifest."""
+    import numpy as np
+    import yaml
+    from PIL import Image
+
+    from lmms_owc_amd import tasks
+
+    cfg = yaml.safe_load((ROOT / "lmms_owc_amd" / "task_configs" / "imagenet1k.yaml").read_text())
+    d = tmp_path / "imagenet1k"
+    d.mkdir()
+    rows = []
+    for i, name in enumerate(["tench", "great white shark", "sea lion"]):
+        Image.fromarray(np.full((40, 50, 3), 30 * i, np.uint8), "RGB").save(d / f"{i}.png")
+        rows.append({"visual": f"{i}.png", "target": name})
+    (d / "val.jsonl").write_text("\n".join(json.dumps(r) for r in rows))
+    cfg["dataset_path"] = str(d)
+    inc = tmp_path / "inc"
+    inc.mkdir()
+    (inc / "imagenet1k.yaml").write_text(yaml.safe_dump(cfg))
+    t = tasks.load_task("imagenet1k", include_path=inc)
+    t.build_all_requests(limit=None, rank=1, world_size=2)
+    assert t.task_name == "imagenet1k" and len(t.docs) == 3 and [i.doc_id for i in t.instances] == [1]
+    assert t.instances[0].args[0] == "What type of object is in this photo?" and t.instances[0].args[1]["max_new_tokens"] == 64

@@ -240,3 +240,31 @@ def test_llava_real_checkpoint_loading_path(gpu, tmp_path, nxt):
     stop = np.flatnonzero(toks == 2)
     direct = lm.tokenizer.batch_decode([toks[: stop[0]] if len(stop) else toks], skip_special_tokens=True)[0]
     assert lm.generate_until([task.instances[0]])[0] == direct
+
+
+class IdTokenizer:
+    """A text is a string of space-separated token ids (what tools/gen_golden.py fed the reference's scorer)."""
+
+    def __call__(self, text, padding=True, truncation=True, return_tensors="np"):
+        rows = [[int(t) for t in s.split()] for s in text]
+        L = max(len(r) for r in rows)
+        return {"input_ids": np.array([r + [0] * (L - len(r)) for r in rows], dtype=np.int64),
+                "attention_mask": np.array([[1] * len(r) + [0] * (L - len(r)) for r in rows], dtype=np.int64)}
+
+
+def test_eval_ranking_cli_matches_reference(gpu, tmp_path, capsys):
+    """eval_ranking.py end to end on the HIP scorer: every game outcome (win / draw / loss at the 0.05 threshold) and both
+    printed Elo tables equal what the reference's own script produced on CPU fp32 for the same runs and BERT weights."""
+    import eval_ranking
+    from lmms_owc_amd.engine.scorer import BertWeights, SentenceScorer
+    from lmms_owc_amd.pipelines import text
+    from tests import recipes
+
+    gold = json.loads((__import__("pathlib").Path(__file__).parent / "golden" / "ranking.json").read_text())["cases"]
+    c = recipes.bert_cfg("tiny")
+    text.set_sentence_bert(SentenceScorer(BertWeights(c, recipes.bert_weights(c, 1234), gpu)), IdTokenizer())
+    recipes.ranking_runs(tmp_path)
+    res = eval_ranking.main(eval_ranking.build_parser().parse_args(["-i", str(tmp_path), "-c", "semantic_similarity", "-b", "10", "-n", "200",
+                                                                    "--log-level", "WARNING"]))
+    assert res["toytask"]["scores"] == gold["default"]["scores"]
+    assert capsys.readouterr().out == gold["default"]["stdout"]

@@ -10,6 +10,7 @@ inputs + expected outputs are written — never reference source.  Versions are 
 from __future__ import annotations
 
 import importlib.machinery
+import importlib.util
 import json
 import sys
 import zlib
@@ -385,6 +386,55 @@ def gen_image():
     print("image golden:", pv.shape, out["image_grid_thw"].tolist())
 
 
+def gen_ranking():
+    """Runs the reference's own eval_ranking.main (criterion semantic_similarity, CPU fp32 BERT with seeded weights) on
+    synthetic runs and records what it printed plus the per-game outcomes."""
+    import contextlib
+    import io
+    import tempfile
+    from argparse import Namespace
+
+    metrics, text_mod, utils = import_reference()
+    c = recipes.bert_cfg("tiny")
+    text_mod.sentence_bert_model = hf_bert(c, recipes.bert_weights(c, 1234))
+    text_mod.sentence_bert_processor = IdTokenizer()
+    import src.data.pipelines.text as text_pkg
+
+    text_pkg.encode_sentence_bert = text_mod.encode_sentence_bert
+    spec = importlib.util.spec_from_file_location("ref_eval_ranking", str(REF / "eval_ranking.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    captured = {}
+    orig_counter = mod.Counter
+
+    def spy_counter(x=()):
+        x = list(x)
+        if x and all(v in (0, 0.5, 1, 0.0, 1.0) for v in x):
+            captured["scores"] = [float(v) for v in x]
+        return orig_counter(x)
+
+    mod.Counter = spy_counter
+    saved = torch.cuda.is_available
+    torch.cuda.is_available = lambda: False
+    out = {}
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            recipes.ranking_runs(Path(td))
+            for tag, kw in {"default": {}, "no_zero_sum": {"disable_zero_sum": True, "k_factor": 32}}.items():
+                args = Namespace(input=td, criterion="semantic_similarity", initial_rating=1000, k_factor=kw.get("k_factor", 16),
+                                 num_rounds=10, num_samples=200, disable_zero_sum=kw.get("disable_zero_sum", False), seed=1234,
+                                 log_level="WARNING")
+                buf = io.StringIO()
+                with contextlib.redirect_stdout(buf):
+                    mod.main(args)
+                out[tag] = {"stdout": buf.getvalue(), "scores": captured["scores"]}
+    finally:
+        torch.cuda.is_available = saved
+    (GOLD / "ranking.json").write_text(json.dumps({"source": "eval_ranking.py main() of the reference, datasets " + __import__("datasets").__version__,
+                                                    "versions": versions(), "cases": out}, indent=1))
+    print("ranking golden:\n" + out["default"]["stdout"])
+
+
 PROMPT_CASES = [
     [{"role": "user", "content": "<image>\nWhat type of object is in this image?"}],
     [{"role": "user", "content": "<image> <image>\nCompare."}, {"role": "assistant", "content": "Both are cats."},
@@ -436,11 +486,13 @@ if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["qwen", "scorer", "image", "llava", "llava_next", "llava_image", "llava_prompt"]
+    which = sys.argv[1:] or ["qwen", "scorer", "image", "llava", "llava_next", "llava_image", "llava_prompt", "ranking"]
     if "image" in which:
         gen_image()
     if "llava" in which:
         gen_llava()
+    if "ranking" in which:
+        gen_ranking()
     if "llava_prompt" in which:
         gen_llava_prompt()
     if "llava_image" in which:
