@@ -124,6 +124,21 @@ int owc_attention_bf16(owc_ctx* ctx, const void* Q, int64_t q_ts, int64_t q_hs, 
                        const int32_t* q_len, int n_seq, int n_heads, int kv_group, int head_dim,
                        int max_q_len, int causal, float scale, void* stream);
 
+/* ---- fp8 (OCP e4m3fn) decoder projections: BASELINE.json config #5 (Qwen2-VL-72B fp8 MFMA decode).  No reference
+ * counterpart (the reference's reduced-precision loader is bitsandbytes, src/models/_base.py:116-121); the arithmetic is
+ * defined by oracle/fp8_np.py.
+ * q[r][c] = rne_e4m3(x[r][c] / scale[r]), scale[r] = max|x[r]| / 448 (1 for a zero row); x bf16 [rows, cols], cols % 8 == 0.
+ * Per token for activations, per output channel for weights. */
+int owc_quantize_rows_fp8(owc_ctx* ctx, const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int rows,
+                          int cols, void* stream);
+
+/* C[M,N] bf16 = epilogue((A8[M,K] . W8[N,K]^T) * a_scale[m] * w_scale[n] + bias) on v_mfma_scale_f32_16x16x128_f8f6f4.
+ * K % 128 == 0, lda / ldw in bytes and % 16 == 0; epilogue in {OWC_EPI_NONE, OWC_EPI_RESIDUAL, OWC_EPI_SWIGLU}
+ * (SWIGLU: W rows and w_scale interleaved gate/up per 16 like owc_gemm_bf16). */
+int owc_gemm_fp8(owc_ctx* ctx, const void* A, int64_t lda, const float* a_scale, const void* W, int64_t ldw,
+                 const float* w_scale, const void* bias, const void* R, int64_t ldr, void* C, int64_t ldc, int M, int N,
+                 int K, int epilogue, void* stream);
+
 /* inputs_embeds = embed_tokens(ids) with image rows scattered in (HF:1160-1168):
  * out[t] = img_index[t] >= 0 ? img_embeds[img_index[t]] : table[ids[t]]   (img_index may be NULL). */
 int owc_embed_tokens(owc_ctx* ctx, const int32_t* ids, const int32_t* img_index, const void* table,

@@ -20,7 +20,7 @@ _lock = threading.Lock()
 _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = range(6)
 
@@ -107,6 +107,8 @@ SIGNATURES: dict[str, tuple] = {
     "owc_mrope_kv_write": (i32, [vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "owc_attention_bf16": (i32, [vp, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, vp,
                                  i32, i32, i32, i32, i32, i32, f32, vp]),
+    "owc_quantize_rows_fp8": (i32, [vp, vp, i64, vp, i64, vp, i32, i32, vp]),
+    "owc_gemm_fp8": (i32, [vp, vp, i64, vp, vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "owc_embed_tokens": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "owc_argmax_bf16": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "owc_patchify_u8": (i32, [vp, vp, vp, i64, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp]),

@@ -15,7 +15,7 @@
 
 extern "C" {
 
-int owc_abi_version(void) { return 6; }
+int owc_abi_version(void) { return 7; }
 
 int owc_tuning_set(const char* name, int value) {
   if (!name) return OWC_ERR_ARG;
@@ -132,6 +132,20 @@ int owc_patchify_u8(owc_ctx* ctx, const uint8_t* images, void* pixel_values, int
                     int W, const float* mean_host, const float* std_host, void* stream) {
   if (!ctx || !images || !pixel_values || !mean_host || !std_host) return OWC_ERR_ARG;
   RET(ctx, "owc_patchify_u8", owc_launch_patchify(images, pixel_values, ld, n, H, W, mean_host, std_host, ST(stream)));
+}
+
+int owc_quantize_rows_fp8(owc_ctx* ctx, const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int rows,
+                          int cols, void* stream) {
+  if (!ctx || !x || !q || !scale) return OWC_ERR_ARG;
+  RET(ctx, "owc_quantize_rows_fp8", owc_launch_quant_rows_fp8(x, ldx, q, ldq, scale, rows, cols, ST(stream)));
+}
+
+int owc_gemm_fp8(owc_ctx* ctx, const void* A, int64_t lda, const float* a_scale, const void* W, int64_t ldw,
+                 const float* w_scale, const void* bias, const void* R, int64_t ldr, void* C, int64_t ldc, int M, int N,
+                 int K, int epilogue, void* stream) {
+  if (!ctx || !A || !W || !C || !a_scale || !w_scale) return OWC_ERR_ARG;
+  RET(ctx, "owc_gemm_fp8",
+      owc_launch_gemm_fp8(A, lda, a_scale, W, ldw, w_scale, bias, R, ldr, C, ldc, M, N, K, epilogue, ST(stream)));
 }
 
 int owc_decode_update(owc_ctx* ctx, int32_t* next_tok, uint8_t* done, int32_t* out_tokens,

@@ -1,0 +1,176 @@
+// Fused GEMM epilogues shared by the bf16 and the fp8 kernels (gemm_bf16.hip, gemm_fp8.hip): the accumulator layout is
+// the dtype-independent 16x16 C/D map of gfx950 with SWAPPED operands (D^T = W . A^T): per 16x16 tile a lane owns row
+// fr = lane & 15 and the 4 consecutive columns 4 * (lane >> 4) .. +3.
+#pragma once
+#include "owc_common.h"
+
+namespace {
+
+// v_rcp_f32 (1 ulp) instead of an IEEE division: the result is rounded to bf16 right after
+__device__ __forceinline__ float act_quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float act_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+// ---- epilogue ----
+// After the MFMAs a lane owns, per 16x16 tile, 4 consecutive columns of one row (8 bytes of bf16).  The
+// store tail is instruction-issue bound, so adjacent tile pairs are first exchanged across 16-lane rows
+// with v_permlane16_swap (odd rows of the first <-> even rows of the second): every lane then owns 8
+// consecutive columns and bias / residual / output move as 16-byte accesses (half the instructions).
+// Loads are issued unconditionally from clamped addresses so they batch; only stores are predicated.
+__device__ __forceinline__ void swap16(float& x, float& y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+
+// `ctile` != NULL: instead of going to memory, the finished bf16 values are parked in a block-wide LDS image of the output
+// tile (row pitch `cpitch` bytes, 16-byte chunks XOR-swizzled by row & 7, block-local origin (lrow0, lcol0)) and
+// store_ctile() writes them out as whole rows.  Why: a lane group of the MFMA layout only covers 64 contiguous bytes of
+// a row, and half-line writes measurably slow the whole kernel (ablation: full-line pattern +2..8 %).
+template <int EPI, int MT, bool FULL = false>
+__device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mrow0, int ncol0, int fr, int fq,
+                                              const bf16_t* __restrict__ bias, const bf16_t* R, long ldr,
+                                              void* Cv, long ldc, int M, int N, const owc_gemm_aux& aux,
+                                              char* ctile = nullptr, int cpitch = 0, int lrow0 = 0, int lcol0 = 0) {
+  if constexpr (EPI == OWC_EPI_F32) {
+    float* C = (float*)Cv;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mrow0 + mt * 16 + fr;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = ncol0 + nt * 16 + fq * 4;
+        f32x4 v = acc[nt][mt];
+        if (bias != nullptr && n < N) {
+          const bf16x4 b = *(const bf16x4*)(bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bf2f(b[e]);
+        }
+        if (FULL || (m < M && n < N)) *(f32x4*)(C + (long)m * ldc + n) = v;
+      }
+    }
+  } else if constexpr (EPI == OWC_EPI_SWIGLU) {
+    bf16_t* C = (bf16_t*)Cv;
+    const int odd = fq & 1;
+    const int f = (ncol0 >> 1) + odd * 16 + (fq >> 1) * 8;  // first of this lane's 8 output features
+    const int nout = N >> 1;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mrow0 + mt * 16 + fr;
+      float o0[4], o1[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o0[e] = rbf(rbf(act_silu(rbf(acc[0][mt][e]))) * rbf(acc[1][mt][e]));
+        o1[e] = rbf(rbf(act_silu(rbf(acc[2][mt][e]))) * rbf(acc[3][mt][e]));
+        swap16(o0[e], o1[e]);
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = f2bf(o0[e]);
+        o[4 + e] = f2bf(o1[e]);
+      }
+      if (ctile) {
+        const int lr = lrow0 + mt * 16 + fr, lc = (lcol0 >> 1) + odd * 16 + (fq >> 1) * 8;
+        *(bf16x8*)(ctile + lr * cpitch + (((lc >> 3) ^ (lr & 7)) << 4)) = o;
+      } else if (FULL || (m < M && f < nout)) {
+        *(bf16x8*)(C + (long)m * ldc + f) = o;
+      }
+    }
+  } else {
+    bf16_t* C = (bf16_t*)Cv;
+    const int odd = fq & 1;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int n = ncol0 + (2 * p + odd) * 16 + (fq >> 1) * 8;  // first of this lane's 8 columns
+      const int nc = min(n, N - 8);
+      float bv[8];
+      if (bias != nullptr) {
+        const bf16x8 b = *(const bf16x8*)(bias + nc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = bf2f(b[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+      }
+      // all residual rows of this column block are read before the first store (R may alias C)
+      bf16x8 rr[MT];
+      if constexpr (EPI == OWC_EPI_RESIDUAL) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          rr[mt] = *(const bf16x8*)(R + (long)min(mrow0 + mt * 16 + fr, M - 1) * ldr + nc);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = mrow0 + mt * 16 + fr;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[2 * p][mt][e];
+          v[4 + e] = acc[2 * p + 1][mt][e];
+          swap16(v[e], v[4 + e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + bv[e]);
+        if constexpr (EPI == OWC_EPI_VROPE) {
+          // apply_rotary_pos_emb_vision (HF:225-236) on pair-interleaved columns: (2j, 2j+1) hold the
+          // original (j, j + head_dim/2); angle j uses the row's h position for j < head_dim/4, else w.
+          if (n < aux.rope_cols) {
+            const int quarter = aux.head_dim >> 2;
+            const int j0 = (n % aux.head_dim) >> 1;  // multiple of 4, never straddles `quarter`
+            const int2 hw = *(const int2*)(aux.pos_hw + 2 * (long)min(m, M - 1));
+            const int ti = (j0 < quarter) ? hw.x * quarter + j0 : hw.y * quarter + (j0 - quarter);
+            const f32x4 c4 = *(const f32x4*)(aux.cos_t + ti);
+            const f32x4 s4 = *(const f32x4*)(aux.sin_t + ti);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x1 = v[2 * e], x2 = v[2 * e + 1];
+              v[2 * e] = x1 * c4[e] - x2 * s4[e];
+              v[2 * e + 1] = x2 * c4[e] + x1 * s4[e];
+            }
+          }
+        }
+        if constexpr (EPI == OWC_EPI_QUICK_GELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = act_quick_gelu(v[e]);
+        } else if constexpr (EPI == OWC_EPI_GELU_ERF) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = act_gelu_erf(v[e]);
+        } else if constexpr (EPI == OWC_EPI_RESIDUAL) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bf2f(rr[mt][e]);
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+        if (ctile) {
+          const int lr = lrow0 + mt * 16 + fr, lc = lcol0 + (2 * p + odd) * 16 + (fq >> 1) * 8;
+          *(bf16x8*)(ctile + lr * cpitch + (((lc >> 3) ^ (lr & 7)) << 4)) = o;
+        } else if (FULL || (m < M && n < N)) {
+          *(bf16x8*)(C + (long)m * ldc + n) = o;
+        }
+      }
+    }
+  }
+}
+
+// Second half of the LDS-staged epilogue: the block's output tile (rows x cols bf16, pitch = cols * 2 bytes) leaves LDS as
+// whole rows - a wave-instruction covers 64 lanes x 16 B = 1 KiB of consecutive row segments.
+template <int WAVES>
+__device__ __forceinline__ void store_ctile(const char* ctile, int rows, int cols, bf16_t* C, long ldc, int m0, int n0,
+                                            int M, int Ncols, int w, int l) {
+  const int lpr = cols >> 3;            // lanes per row (16-byte chunks)
+  const int rpi = 64 / lpr;             // rows per wave-instruction
+  const int rows_per_wave = rows / WAVES;
+  const int c = l % lpr;
+  const int r_in = l / lpr;
+  const int n = n0 + c * 8;
+#pragma unroll 4
+  for (int it = 0; it < rows_per_wave / rpi; ++it) {
+    const int r = w * rows_per_wave + it * rpi + r_in;
+    const bf16x8 v = *(const bf16x8*)(ctile + r * (cols * 2) + ((c ^ (r & 7)) << 4));
+    if (m0 + r < M && n < Ncols) *(bf16x8*)(C + (long)(m0 + r) * ldc + n) = v;
+  }
+}
+
+}  // namespace

@@ -1,0 +1,270 @@
+// fp8 (OCP e4m3fn) path of the decoder projections (BASELINE.json config #5: Qwen2-VL-72B fp8 MFMA decode; no reference
+// counterpart - the reference's only reduced-precision loader is bitsandbytes, src/models/_base.py:116-121).
+//
+//   quant_rows_fp8_kernel : q[r][c] = rne_e4m3(x[r][c] / s[r]),  s[r] = max|x[r]| / 448  (per token / per output channel)
+//   gemm_fp8_nt_256_kernel: C[M,N] = epilogue((A8[M,K] . W8[N,K]^T) * sa[m] * sw[n] + bias)   (bf16 out)
+//
+// The GEMM is the 256x256 bf16 kernel (gemm_bf16.hip) with one change of arithmetic: a K-tile is 128 fp8 elements, i.e. the
+// same 128-byte rows, the same LDS image, swizzle and LDS-DMA schedule, but each lane's operand is 32 consecutive K bytes
+// (two swizzled 16-byte chunks) and the product is ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16x16 tile with unit block
+// scales (e8m0 0x7f): 4x the K of the bf16 instruction in 2x its cycles = twice the bf16 rate per byte staged.
+// Operand map checked with exact integer data (tools/probes/probe_fp8_mfma.hip): lane l holds row l & 15,
+// k = 32 * (l >> 4) + j, j = 0..31; C/D is the dtype-independent 16x16 map.
+#include "gemm_epilogue.h"
+#include "owc_internal.h"
+
+namespace {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BT = 256, BKB = 128;                 // tile edge, K-tile in BYTES (= fp8 elements)
+constexpr int OP_BYTES = BT * BKB;                 // 32 KiB per operand per stage
+constexpr int STAGE_BYTES = 2 * OP_BYTES;
+constexpr int GROUP_M2 = 4;
+constexpr int LDS_BYTES = 2 * STAGE_BYTES + 8192;  // + the dump area of the branch-free tail
+
+// ---- row quantiser: one wave per row, the row cached in registers (bf16x8 chunks) ----
+template <int NC>
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ X, long ldx,
+                                                             uint8_t* __restrict__ Q, long ldq,
+                                                             float* __restrict__ S, int rows, int cols) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= rows) return;
+  const bf16_t* x = X + (long)row * ldx;
+  const int nch = cols >> 3;
+  bf16x8 c[NC];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int ch = i * 64 + l;
+    if (ch < nch) {
+      c[i] = *(const bf16x8*)(x + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(bf2f(c[i][e])));
+    }
+  }
+  amax = wave_max(amax);
+  const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
+  if (l == 0) S[row] = scale;
+  uint8_t* q = Q + (long)row * ldq;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int ch = i * 64 + l;
+    if (ch < nch) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(bf2f(c[i][e]) / scale, -448.0f), 448.0f);
+      int lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+      *(int2*)(q + ch * 8) = make_int2(lo, hi);
+    }
+  }
+}
+
+// ---- GEMM ----
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_fp8_nt_256_kernel(
+    const uint8_t* __restrict__ A, long lda, const float* __restrict__ SA, const uint8_t* __restrict__ W, long ldw,
+    const float* __restrict__ SW, const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv, long ldc,
+    int M, int N, int K, int tiles_m, int tiles_n, owc_gemm_aux aux) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int nblk = tiles_m * tiles_n;
+  const int nk = K / BKB;
+
+  // tile id -> (m0, n0): the blocks of one XCD (id & 7) walk a contiguous, GROUP_M-major range of tiles
+  int m0, n0;
+  {
+    const int bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int width = GROUP_M2 * tiles_n;
+    const int group = lid / width;
+    const int first_m = group * GROUP_M2;
+    const int gsize = min(tiles_m - first_m, GROUP_M2);
+    m0 = (first_m + (lid % width) % gsize) * BT;
+    n0 = ((lid % width) / gsize) * BT;
+  }
+  // DMA sources: wave w stages rows [32w, 32w+32) of both operand tiles (4 pieces of 8 rows x 128 B)
+  const char* abase = (const char*)(A + (long)m0 * lda);
+  const char* wbase = (const char*)(W + (long)n0 * ldw);
+  unsigned aoff[4], woff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 32 * w + 8 * j + (l >> 3);
+    const int c = (l & 7) ^ ((row >> 1) & 7);
+    aoff[j] = (unsigned)((long)min(row, M - 1 - m0) * lda + c * 16);
+    woff[j] = (unsigned)((long)min(row, N - 1 - n0) * ldw + c * 16);
+  }
+  auto stage = [&](int buf, int kt) {
+    char* la = lds + buf * STAGE_BYTES + w * 4096;
+    const long kb = (long)kt * BKB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      glds16(abase + kb + aoff[j], la + j * 1024);
+      glds16(wbase + kb + woff[j], la + OP_BYTES + j * 1024);
+    }
+  };
+  // One A piece + one W piece of stage kt into LDS at `la` (+ OP_BYTES for W).  The hot loop has no branch: the two
+  // K-tiles past the end re-fetch the last stage into a spare 8 KiB dump area behind the two stage buffers.
+  auto stage_piece = [&](char* la, char* lw, int kt, int j) {
+    const long kb = (long)kt * BKB;
+    glds16(abase + kb + aoff[j], la + j * 1024);
+    glds16(wbase + kb + woff[j], lw + j * 1024);
+  };
+
+  const int wr = w >> 2, wc = w & 3;
+  const int fr = l & 15, fq = l >> 4;
+  const int swz = (fr >> 1) & 7;
+  const int rowA = (wr * 128 + fr) * 128;
+  const int rowW = OP_BYTES + (wc * 64 + fr) * 128;
+  const int chlo = ((2 * fq) ^ swz) << 4, chhi = ((2 * fq + 1) ^ swz) << 4;  // the lane's 32 K bytes = two 16-B chunks
+
+  f32x4 acc[4][8];  // [nt][mt]
+  i32x8 xa[2], ya[2], wk[4];  // A fragments of two m tiles (double-buffered), W fragments of the K-tile
+
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  auto rd = [&](i32x8& dst, const char* p) {
+    const i32x4 lo = *(const i32x4*)(p + chlo), hi = *(const i32x4*)(p + chhi);
+    dst = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto read_a = [&](i32x8 (&dst)[2], const char* sbase, int quarter) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) rd(dst[t], sbase + rowA + (quarter * 2 + t) * 2048);
+  };
+  auto mfma = [&](const i32x8& wf, const i32x8& af, f32x4& c) {
+    c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, af, c, 0, 0, 0, 0x7f, 0, 0x7f);
+  };
+  // 8 MFMAs: m tiles (2q, 2q+1) x the 4 n tiles
+  auto phase = [&](const i32x8 (&af)[2], int q) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) mfma(wk[n], af[m], acc[n][q * 2 + m]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  stage(0, 0);
+  if (nk > 1) {
+    stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  read_a(xa, lds, 0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) rd(wk[t], lds + rowW + t * 2048);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* cur = lds + (kt & 1) * STAGE_BYTES;
+    const char* nxt = lds + ((kt + 1) & 1) * STAGE_BYTES;
+    read_a(ya, cur, 1);
+    phase(xa, 0);
+    read_a(xa, cur, 2);
+    phase(ya, 1);
+    read_a(ya, cur, 3);
+    phase(xa, 2);
+    // all LDS reads of stage kt by this wave are complete and its DMA pieces of stage kt+1 have landed: the barrier publishes
+    // stage kt+1 and frees stage kt's buffer, into which the DMA of stage kt+2 goes during the last phase
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const bool issue = kt + 2 < nk;
+    char* dsta = issue ? lds + (kt & 1) * STAGE_BYTES + w * 4096 : lds + 2 * STAGE_BYTES;
+    char* dstw = issue ? dsta + OP_BYTES : dsta + 4096;
+    const int kq = issue ? kt + 2 : nk - 1;
+    read_a(xa, nxt, 0);  // (after the last K-tile this reads stale LDS that nothing uses: no branch in the hot loop)
+    // phase 3: m tiles 6, 7; after its last use each W fragment is refilled from stage kt+1, DMA pieces in between
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      __builtin_amdgcn_s_setprio(1);
+      mfma(wk[n], ya[0], acc[n][6]);
+      mfma(wk[n], ya[1], acc[n][7]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      rd(wk[n], nxt + rowW + n * 2048);
+      stage_piece(dsta, dstw, kq, n);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // dequantise: acc * sa[m] * sw[n], then the shared bf16 epilogue (bias / activation / residual / SwiGLU, LDS-staged rows)
+  {
+    f32x4 swv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) swv[nt] = *(const f32x4*)(SW + min(n0 + wc * 64 + nt * 16 + fq * 4, N - 4));
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const float sa = SA[min(m0 + wr * 128 + mt * 16 + fr, M - 1)];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[nt][mt][e] = acc[nt][mt][e] * sa * swv[nt][e];
+    }
+  }
+  constexpr int CCOLS = EPI == OWC_EPI_SWIGLU ? BT / 2 : BT;
+  gemm_epilogue<EPI, 8>(acc, m0 + wr * 128, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux, lds, CCOLS * 2, wr * 128,
+                        wc * 64);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  store_ctile<8>(lds, BT, CCOLS, (bf16_t*)Cv, ldc, m0, EPI == OWC_EPI_SWIGLU ? (n0 >> 1) : n0, M,
+                 EPI == OWC_EPI_SWIGLU ? (N >> 1) : N, w, l);
+}
+
+template <int EPI>
+int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw, const float* sw, const void* bias,
+               const void* R, long ldr, void* C, long ldc, int M, int N, int K, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_fp8_nt_256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS_BYTES) != hipSuccess)
+      return OWC_ERR_HIP;
+    attr_set = true;
+  }
+  const int tiles_m = (M + BT - 1) / BT, tiles_n = (N + BT - 1) / BT;
+  const owc_gemm_aux aux = {nullptr, nullptr, nullptr, 0, 8};
+  hipLaunchKernelGGL(gemm_fp8_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), LDS_BYTES, s,
+                     (const uint8_t*)A, lda, sa, (const uint8_t*)W, ldw, sw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C,
+                     ldc, M, N, K, tiles_m, tiles_n, aux);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+}  // namespace
+
+int owc_launch_quant_rows_fp8(const void* X, long ldx, void* Q, long ldq, float* S, int rows, int cols, hipStream_t st) {
+  if (rows <= 0 || cols <= 0 || (cols & 7) || (ldx & 7) || (ldq & 7) || cols > 16 * 512 * 4) return OWC_ERR_SHAPE;
+#define OWC_Q(C_)                                                                                                  \
+  hipLaunchKernelGGL((quant_rows_fp8_kernel<C_>), dim3((rows + 3) / 4), dim3(256), 0, st, (const bf16_t*)X, ldx,     \
+                     (uint8_t*)Q, ldq, S, rows, cols)
+  if (cols <= 2048) OWC_Q(4); else if (cols <= 8192) OWC_Q(16); else OWC_Q(64);
+#undef OWC_Q
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_gemm_fp8(const void* A, long lda, const float* sa, const void* W, long ldw, const float* sw,
+                        const void* bias, const void* R, long ldr, void* C, long ldc, int M, int N, int K, int epi,
+                        hipStream_t s) {
+  if (M <= 0 || N <= 0 || K <= 0) return OWC_ERR_SHAPE;
+  if ((K % BKB) || (lda & 15) || (ldw & 15) || (N & 7) || (ldc & 7)) return OWC_ERR_SHAPE;  // whole 128-byte K-tiles, 16-B rows
+  if (epi == OWC_EPI_SWIGLU && (N & 31)) return OWC_ERR_SHAPE;
+  if (epi == OWC_EPI_RESIDUAL && (R == nullptr || (ldr & 7))) return OWC_ERR_ARG;
+  if (!sa || !sw) return OWC_ERR_ARG;
+  switch (epi) {
+    case OWC_EPI_NONE: return launch_fp8<OWC_EPI_NONE>(A, lda, sa, W, ldw, sw, bias, R, ldr, C, ldc, M, N, K, s);
+    case OWC_EPI_RESIDUAL: return launch_fp8<OWC_EPI_RESIDUAL>(A, lda, sa, W, ldw, sw, bias, R, ldr, C, ldc, M, N, K, s);
+    case OWC_EPI_SWIGLU: return launch_fp8<OWC_EPI_SWIGLU>(A, lda, sa, W, ldw, sw, bias, R, ldr, C, ldc, M, N, K, s);
+    default: return OWC_ERR_ARG;  // the decoder needs no other epilogue on this path
+  }
+}

@@ -43,6 +43,33 @@ def gemm_bf16(a, w, bias=None, *, epilogue=EPI_NONE, residual=None, out=None):
     return out
 
 
+def quantize_rows_fp8(x, out=None, scale=None):
+    """bf16 [rows, cols] -> (uint8 e4m3fn codes [rows, cols], float32 scales [rows]): q = rne(x / s), s = max|x| / 448."""
+    assert x.dtype == BF16 and x.dim() == 2 and x.stride(1) == 1
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
+    if scale is None:
+        scale = torch.empty(rows, dtype=F32, device=x.device)
+    _call("owc_quantize_rows_fp8", _dev(x), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), scale.data_ptr(), rows, cols)
+    return out, scale
+
+
+def gemm_fp8(a8, a_scale, w8, w_scale, bias=None, *, epilogue=EPI_NONE, residual=None, out=None):
+    """``out[M,N] bf16 = epilogue((a8 @ w8.T) * a_scale[:, None] * w_scale[None, :] + bias)`` on the scaled fp8 MFMA."""
+    assert a8.dtype == torch.uint8 and w8.dtype == torch.uint8 and a8.stride(1) == 1 and w8.stride(1) == 1
+    assert a_scale.dtype == F32 and w_scale.dtype == F32 and a8.shape[1] == w8.shape[1]
+    m, k = a8.shape
+    n = w8.shape[0]
+    n_out = n // 2 if epilogue == EPI_SWIGLU else n
+    if out is None:
+        out = torch.empty((m, n_out), dtype=BF16, device=a8.device)
+    _call("owc_gemm_fp8", _dev(a8), a8.data_ptr(), a8.stride(0), a_scale.data_ptr(), w8.data_ptr(), w8.stride(0), w_scale.data_ptr(),
+          ptr(bias), ptr(residual), residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0), m, n, k,
+          epilogue)
+    return out
+
+
 def gemm_f32(a, w, bias=None, *, epilogue=EPI_NONE, residual=None, out=None):
     assert a.dtype == F32 and w.dtype == F32 and a.stride(1) == 1 and w.stride(1) == 1
     m, k = a.shape

@@ -1,0 +1,84 @@
+"""numpy restatement of the fp8 (OCP e4m3fn) decoder arithmetic (TEST INFRASTRUCTURE ONLY).
+
+No reference counterpart: the reference's only reduced-precision path is bitsandbytes int8 / nf4
+(`src/models/_base.py:116-121`); BASELINE.json config #5 asks for an fp8 MFMA decoder instead, so parity is
+REDEFINED here as: (1) the quantiser and the fp8 GEMM are bit-defined by this file and the
+HIP kernels must reproduce it (bytes and scales exactly; products are exact in fp32, sums to accumulation order),
+(2) the fp8 model is compared with the bf16 model through a stated logit tolerance and top-1 agreement rate.
+
+Format: OCP FP8 E4M3 "fn" (1-4-3, bias 7, no infinities, max 448, 0x7f/0xff = NaN) - what gfx950's v_cvt_pk_fp8_f32 and
+the f8f6f4 MFMA use (not MI300's fnuz).  Scheme: per-row symmetric scales, s = max|x| / 448 (1 for an all-zero row),
+q = rne_e4m3(x / s); activations per token (dynamic), weights per output channel (static).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .np_ops import bf16_round, maybe_bf16
+
+E4M3_MAX = np.float32(448.0)
+
+
+def _decode_table() -> np.ndarray:
+    t = np.zeros(256, np.float32)
+    for c in range(256):
+        s, e, m = c >> 7, (c >> 3) & 15, c & 7
+        if e == 15 and m == 7:
+            v = np.nan
+        elif e == 0:
+            v = m * 2.0 ** -9
+        else:
+            v = (1 + m / 8.0) * 2.0 ** (e - 7)
+        t[c] = -v if s else v
+    return t
+
+
+E4M3_DECODE = _decode_table()
+_POS = E4M3_DECODE[:127].astype(np.float64)  # codes 0..126 ascending (0 .. 448)
+
+
+def e4m3_encode(x: np.ndarray) -> np.ndarray:
+    """float32 -> e4m3fn codes, round to nearest even, saturating at +-448."""
+    x = np.asarray(x, np.float32)
+    a = np.minimum(np.abs(x).astype(np.float64), 448.0)
+    hi = np.searchsorted(_POS, a, side="left").clip(0, 126)
+    lo = (hi - 1).clip(0, 126)
+    dlo, dhi = a - _POS[lo], _POS[hi] - a
+    pick_hi = (dhi < dlo) | ((dhi == dlo) & ((hi & 1) == 0))   # tie -> even code (mantissa LSB 0)
+    code = np.where(pick_hi, hi, lo).astype(np.uint8)
+    return np.where(np.signbit(x), code | 0x80, code).astype(np.uint8)
+
+
+def e4m3_decode(q: np.ndarray) -> np.ndarray:
+    return E4M3_DECODE[np.asarray(q, np.uint8)]
+
+
+def quantize_rows(x: np.ndarray):
+    """[rows, cols] float32 (bf16-representable in the decoder) -> (codes uint8, scale float32[rows])."""
+    x = np.asarray(x, np.float32)
+    amax = np.abs(x).max(axis=-1)
+    scale = np.where(amax > 0, amax / E4M3_MAX, np.float32(1.0)).astype(np.float32)
+    return e4m3_encode((x / scale[..., None]).astype(np.float32)), scale
+
+
+def linear_fp8(x: np.ndarray, wq: np.ndarray, ws: np.ndarray, bias=None, *, bf16=True, xq=None, xs=None) -> np.ndarray:
+    """y = bf16(((q(x) . wq^T) * sx[m] * sw[n]) + bias): x [T, K] -> [T, N]; wq uint8 [N, K], ws float32 [N]."""
+    if xq is None:
+        xq, xs = quantize_rows(x)
+    acc = e4m3_decode(xq).astype(np.float64) @ e4m3_decode(wq).astype(np.float64).T   # exact products, exact sum
+    y = acc.astype(np.float32) * xs[:, None].astype(np.float32) * ws[None, :].astype(np.float32)
+    if bias is not None:
+        y = y + np.asarray(bias, np.float32)
+    return maybe_bf16(y.astype(np.float32), bf16)
+
+
+def quantize_decoder(w: dict, prefix: str, n_layers: int) -> dict:
+    """Per-output-channel e4m3 weights for the decoder projections of a HF state dict (q/k/v/o/gate/up/down);
+    returns name -> (codes, scales).  Embedding, norms and lm_head stay bf16."""
+    out = {}
+    for i in range(n_layers):
+        for n in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"):
+            k = f"{prefix}layers.{i}.{n}.weight"
+            out[k] = quantize_rows(bf16_round(w[k]))
+    return out

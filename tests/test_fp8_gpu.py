@@ -1,0 +1,84 @@
+"""fp8 (OCP e4m3fn) decoder path on the GPU, through the C ABI, against oracle/fp8_np.py.
+
+Parity bars (stated; the reference has no fp8 path):
+* quantiser: codes and scales bit-identical to the oracle;
+* fp8 GEMM on identical quantised operands: products are exact in fp32, only the summation order differs ->
+  bf16 outputs within 1 bf16 ulp of the oracle's exactly-summed result, >= 95 % bit-identical;
+* model level (tests/test_fp8_model_gpu.py): logits vs the fp8 oracle within 3 %, vs the bf16 model within a stated bound.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fp8_np as F
+from oracle import np_ops
+from tests.util import assert_bf16_close, bf16_randn, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 8), (5, 256), (131, 3584), (64, 8192), (9, 29568)])
+def test_quantize_rows_exact(gpu, rows, cols):
+    from lmms_owc_amd import ops
+
+    x = bf16_randn((rows, cols), rows * 7 + cols, 3.0, gpu)
+    x[0, : min(cols, 16)] = 0.0
+    if rows > 2:
+        x[2] = 0.0  # all-zero row -> scale 1, codes 0
+        x[1, 3] = 1000.0  # an outlier sets that row's scale
+    q, s = ops.quantize_rows_fp8(x)
+    wq, ws = F.quantize_rows(to_np(x))
+    assert np.array_equal(to_np(s), ws)
+    got = q.cpu().numpy()
+    same = got == wq
+    # +0 and -0 are the same number (0x00 / 0x80)
+    assert np.all(same | (((got & 0x7F) == 0) & ((wq & 0x7F) == 0)))
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(256, 256, 128, "none"), (300, 520, 384, "bias"), (1024, 1536, 3584, "none"),
+                                       (129, 264, 256, "res"), (512, 1024, 512, "swiglu"), (40, 64, 8192, "bias")])
+def test_gemm_fp8_matches_oracle(gpu, m, n, k, epi):
+    from lmms_owc_amd import _lib, ops
+    from lmms_owc_amd.engine.qwen2vl import interleave_gate_up
+
+    x = bf16_randn((m, k), m + n, 1.0, gpu)
+    w = bf16_randn((n, k), k + 1, 0.05, gpu)
+    xq, xs = ops.quantize_rows_fp8(x)
+    wq, ws = ops.quantize_rows_fp8(w)
+    nxq, nxs, nwq, nws = xq.cpu().numpy(), to_np(xs), wq.cpu().numpy(), to_np(ws)
+    bias = bf16_randn((n,), 5, 0.5, gpu) if epi == "bias" else None
+    if epi == "swiglu":
+        f = n // 2
+        # rows [0, f) = gate, [f, 2f) = up; the kernel wants them interleaved per 16 (codes and scales alike)
+        gq = interleave_gate_up(wq[:f].view(torch.int8), wq[f:].view(torch.int8)).view(torch.uint8)
+        gs = interleave_gate_up(ws[:f, None], ws[f:, None])[:, 0].contiguous()
+        out = to_np(ops.gemm_fp8(xq, xs, gq, gs, epilogue=_lib.EPI_SWIGLU))
+        y = F.linear_fp8(None, nwq, nws, xq=nxq, xs=nxs)
+        g, u = y[:, :f], y[:, f:]
+        want = np_ops.bf16_round(np_ops.bf16_round(g / (1.0 + np.exp(-g))) * u)
+        assert np.abs(out - want).max() <= 2.0 ** -6 * np.abs(want).max()
+        return
+    if epi == "res":
+        r = bf16_randn((m, n), 9, 1.0, gpu)
+        out = to_np(ops.gemm_fp8(xq, xs, wq, ws, epilogue=_lib.EPI_RESIDUAL, residual=r))
+        want = np_ops.bf16_round(F.linear_fp8(None, nwq, nws, xq=nxq, xs=nxs) + to_np(r))
+        assert np.abs(out - want).max() <= 2.0 ** -7 * np.abs(want).max()
+        return
+    out = to_np(ops.gemm_fp8(xq, xs, wq, ws, bias))
+    want = F.linear_fp8(None, nwq, nws, None if bias is None else to_np(bias), xq=nxq, xs=nxs)
+    # helper unit: 2^-8 relative, so 2.0 = one true bf16 ulp (a rounding-boundary flip under a different summation order)
+    assert_bf16_close(out, want, ulps=2.0, min_exact=0.95, atol=2.0 ** -9 * np.abs(want).max())
+
+
+def test_fp8_quantisation_error_is_small(gpu):
+    """The redefined-parity yardstick at op level: fp8 linear vs the bf16 linear on the same operands."""
+    from lmms_owc_amd import ops
+
+    x = bf16_randn((512, 4096), 1, 1.0, gpu)
+    w = bf16_randn((1024, 4096), 2, 0.02, gpu)
+    y16 = to_np(ops.gemm_bf16(x, w))
+    xq, xs = ops.quantize_rows_fp8(x)
+    wq, ws = ops.quantize_rows_fp8(w)
+    y8 = to_np(ops.gemm_fp8(xq, xs, wq, ws))
+    rel = np.linalg.norm(y8 - y16) / np.linalg.norm(y16)
+    assert rel < 0.06, rel   # e4m3 (3 mantissa bits) on both operands: ~2^-4 per element / sqrt statistics

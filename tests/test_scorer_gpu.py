@@ -43,7 +43,7 @@ def test_embed_matches_oracle_ragged(gpu):
         np.testing.assert_allclose(to_np(sc.embed(ids, mask)), B.sentence_embed(w, c, ids, mask), atol=2e-5)
 
 
-@pytest.mark.parametrize("N,C,k", [(1, 3, 1), (100, 37, 5), (513, 397, 5), (64, 1000, 16)])
+@pytest.mark.parametrize("N,C,k", [(1, 3, 1), (100, 37, 5), (513, 397, 5), (64, 1000, 16), (300, 10450, 5)])  # last: config #5's ~10k-class set
 def test_cosine_topk(gpu, N, C, k):
     from lmms_owc_amd.engine.scorer import SentenceScorer
 
