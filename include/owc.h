@@ -60,9 +60,10 @@ int owc_tuning_set(const char* name, int value);
 int owc_abi_version(void); /* bumped whenever a signature in this header changes */
 
 /* ---- measurement hooks (bench.py roofline leg) ------------------------------------------------ */
-/* When enabled, every owc_gemm_bf16-family launch (also inside the model drivers) is bracketed by a
+/* When enabled, every owc_gemm_bf16 / owc_gemm_fp8 launch (also inside the model drivers) is bracketed by a
  * HIP-event pair on its own stream.  owc_gemm_profile_read (call after synchronising) returns the summed
- * kernel time, the summed algorithmic FLOPs (2*M*N*K per launch) and the launch count, then resets. */
+ * kernel time, the summed algorithmic FLOPs (2*M*N*K per launch) and the launch count, then resets.
+ * Every output is an ARRAY OF TWO: [0] the bf16 GEMMs, [1] the fp8 GEMMs. */
 int owc_gemm_profile_enable(owc_ctx* ctx, int on);
 int owc_gemm_profile_read(owc_ctx* ctx, double* total_ms, double* total_flops, int64_t* launches);
 
@@ -216,7 +217,13 @@ int owc_clip_patchify_u8(owc_ctx* ctx, const uint8_t* images, void* patches, int
 typedef struct owc_llm_layer {
   const void *ln1_w, *qkv_w, *qkv_b, *o_w, *ln2_w, *gateup_w, *down_w;
   /* qkv_w = cat(q_proj, k_proj, v_proj) rows; gateup_w = gate/up rows interleaved per 16 */
+  /* owc_llm_weights.weight_dtype == OWC_WEIGHTS_FP8: the four projection weights above are e4m3fn codes [N, K] (same row
+   * order) from owc_quantize_rows_fp8 and these are their per-row scales; NULL / unused for bf16 weights */
+  const float *qkv_s, *o_s, *gateup_s, *down_s;
 } owc_llm_layer;
+
+#define OWC_WEIGHTS_BF16 0
+#define OWC_WEIGHTS_FP8 1
 
 typedef struct owc_llm_weights {
   int32_t n_layers, d_model, n_q_heads, n_kv_heads, head_dim, d_ff, vocab;
@@ -228,6 +235,8 @@ typedef struct owc_llm_weights {
   const void* lm_head_w;         /* [vocab, d_model] (== embed when tied) */
   const float *rope_cos, *rope_sin; /* [rope_positions][head_dim/2], bf16-rounded values */
   int32_t rope_positions;
+  int32_t weight_dtype;          /* OWC_WEIGHTS_BF16 | OWC_WEIGHTS_FP8 (decoder projections only: embedding, norms, biases and
+                                    lm_head stay bf16; activations are quantised per token in front of every fp8 projection) */
 } owc_llm_weights;
 
 typedef struct owc_kv_cache {

@@ -20,7 +20,7 @@ _lock = threading.Lock()
 _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = range(6)
 
@@ -59,7 +59,8 @@ class ClipWeights(C.Structure):
 
 
 class LlmLayer(C.Structure):
-    _fields_ = [(n, vp) for n in ("ln1_w", "qkv_w", "qkv_b", "o_w", "ln2_w", "gateup_w", "down_w")]
+    _fields_ = [(n, vp) for n in ("ln1_w", "qkv_w", "qkv_b", "o_w", "ln2_w", "gateup_w", "down_w",
+                                  "qkv_s", "o_s", "gateup_s", "down_s")]
 
 
 class LlmWeights(C.Structure):
@@ -68,8 +69,11 @@ class LlmWeights(C.Structure):
         ("n_kv_heads", C.c_int32), ("head_dim", C.c_int32), ("d_ff", C.c_int32), ("vocab", C.c_int32),
         ("mrope_sec0", C.c_int32), ("mrope_sec1", C.c_int32), ("rms_eps", f32),
         ("embed", vp), ("layers", C.POINTER(LlmLayer)), ("final_norm_w", vp), ("lm_head_w", vp),
-        ("rope_cos", vp), ("rope_sin", vp), ("rope_positions", C.c_int32),
+        ("rope_cos", vp), ("rope_sin", vp), ("rope_positions", C.c_int32), ("weight_dtype", C.c_int32),
     ]
+
+
+WEIGHTS_BF16, WEIGHTS_FP8 = 0, 1
 
 
 class KvCache(C.Structure):

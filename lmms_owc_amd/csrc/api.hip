@@ -15,7 +15,7 @@
 
 extern "C" {
 
-int owc_abi_version(void) { return 7; }
+int owc_abi_version(void) { return 8; }
 
 int owc_tuning_set(const char* name, int value) {
   if (!name) return OWC_ERR_ARG;
@@ -164,9 +164,14 @@ int owc_gemm_profile_enable(owc_ctx* ctx, int on) {
 
 int owc_gemm_profile_read(owc_ctx* ctx, double* total_ms, double* total_flops, int64_t* launches) {
   if (!ctx || !total_ms || !total_flops || !launches) return OWC_ERR_ARG;
-  long n = 0;
-  int rc = owc_gemm_profile_collect(total_ms, total_flops, &n);
-  *launches = n;
+  double ms[2], fl[2];
+  long n[2] = {0, 0};
+  int rc = owc_gemm_profile_collect(ms, fl, n);
+  for (int k = 0; k < 2; ++k) {
+    total_ms[k] = ms[k];
+    total_flops[k] = fl[k];
+    launches[k] = n[k];
+  }
   RET(ctx, "owc_gemm_profile_read", rc);
 }
 

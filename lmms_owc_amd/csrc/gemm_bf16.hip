@@ -25,6 +25,9 @@
 #include "gemm_epilogue.h"
 #include <vector>
 
+int owc_gemm_profile_begin(double flops, int kind, hipStream_t s);
+void owc_gemm_profile_end(int handle, hipStream_t s);
+
 namespace {
 
 // ---- optional live profiling of THIS kernel (bench.py roofline leg): one HIP-event pair per launch on
@@ -33,6 +36,7 @@ struct GemmProfile {
   bool on = false;
   std::vector<hipEvent_t> ev;  // start/stop pairs
   std::vector<double> flops;
+  std::vector<int> kind;  // 0 = bf16 GEMM, 1 = fp8 GEMM
   size_t used = 0;
 };
 GemmProfile g_prof;
@@ -358,20 +362,7 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
       return OWC_ERR_HIP;
     attr_set = true;
   }
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (g_prof.on) {
-    if (g_prof.used + 2 > g_prof.ev.size()) {
-      hipEvent_t a, b;
-      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return OWC_ERR_HIP;
-      g_prof.ev.push_back(a);
-      g_prof.ev.push_back(b);
-    }
-    e0 = g_prof.ev[g_prof.used];
-    e1 = g_prof.ev[g_prof.used + 1];
-    g_prof.used += 2;
-    g_prof.flops.push_back(2.0 * (double)M * (double)N * (double)K);
-    (void)hipEventRecord(e0, s);
-  }
+  const int prof = owc_gemm_profile_begin(2.0 * (double)M * (double)N * (double)K, 0, s);
   if (big)
     hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), 2 * STAGE_BYTES, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
@@ -380,7 +371,7 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
     hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
                        (const bf16_t*)R, ldr, C, ldc, M, N, K, zeros, tiles_m, tiles_n, aux);
-  if (e1) (void)hipEventRecord(e1, s);
+  owc_gemm_profile_end(prof, s);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 
@@ -427,24 +418,54 @@ void owc_gemm_profile_set(int on) {
   g_prof.on = on != 0;
   g_prof.used = 0;
   g_prof.flops.clear();
+  g_prof.kind.clear();
+}
+
+// Brackets one GEMM launch (bf16 or fp8) with an event pair when profiling is on; returns a handle for _end (-1: off).
+int owc_gemm_profile_begin(double flops, int kind, hipStream_t s) {
+  if (!g_prof.on) return -1;
+  if (g_prof.used + 2 > g_prof.ev.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+    g_prof.ev.push_back(a);
+    g_prof.ev.push_back(b);
+  }
+  const int idx = (int)g_prof.used;
+  g_prof.used += 2;
+  g_prof.flops.push_back(flops);
+  g_prof.kind.push_back(kind);
+  (void)hipEventRecord(g_prof.ev[idx], s);
+  return idx;
+}
+
+void owc_gemm_profile_end(int handle, hipStream_t s) {
+  if (handle >= 0) (void)hipEventRecord(g_prof.ev[handle + 1], s);
 }
 
 // Sums the recorded launches (the caller has synchronised the stream): total kernel milliseconds,
 // total algorithmic FLOPs (2*M*N*K per launch) and the launch count; then resets the recording.
 int owc_gemm_profile_collect(double* total_ms, double* total_flops, long* launches) {
-  double ms = 0.0, fl = 0.0;
+  // [0..2] bf16 totals, [3..5] fp8 totals (ms, flops, launches as doubles in total_ms[] when the caller passes 6 slots)
+  double ms[2] = {0.0, 0.0}, fl[2] = {0.0, 0.0};
+  long cnt[2] = {0, 0};
   const size_t n = g_prof.used / 2;
   for (size_t i = 0; i < n; ++i) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return OWC_ERR_HIP;
-    ms += t;
-    fl += g_prof.flops[i];
+    const int k = g_prof.kind[i] ? 1 : 0;
+    ms[k] += t;
+    fl[k] += g_prof.flops[i];
+    ++cnt[k];
   }
-  *total_ms = ms;
-  *total_flops = fl;
-  *launches = (long)n;
+  total_ms[0] = ms[0];
+  total_flops[0] = fl[0];
+  launches[0] = cnt[0];
+  total_ms[1] = ms[1];
+  total_flops[1] = fl[1];
+  launches[1] = cnt[1];
   g_prof.used = 0;
   g_prof.flops.clear();
+  g_prof.kind.clear();
   return OWC_OK;
 }
 

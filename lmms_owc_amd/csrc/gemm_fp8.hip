@@ -12,6 +12,7 @@
 // k = 32 * (l >> 4) + j, j = 0..31; C/D is the dtype-independent 16x16 map.
 #include "gemm_epilogue.h"
 #include "owc_internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -21,7 +22,7 @@ constexpr int BT = 256, BKB = 128;                 // tile edge, K-tile in BYTES
 constexpr int OP_BYTES = BT * BKB;                 // 32 KiB per operand per stage
 constexpr int STAGE_BYTES = 2 * OP_BYTES;
 constexpr int GROUP_M2 = 4;
-constexpr int LDS_BYTES = 2 * STAGE_BYTES + 8192;  // + the dump area of the branch-free tail
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;
 
 // ---- row quantiser: one wave per row, the row cached in registers (bf16x8 chunks) ----
 template <int NC>
@@ -51,6 +52,49 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int ch = i * 64 + l;
+    if (ch < nch) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(bf2f(c[i][e]) / scale, -448.0f), 448.0f);
+      int lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+      *(int2*)(q + ch * 8) = make_int2(lo, hi);
+    }
+  }
+}
+
+// wide rows (cols > 4096): one 256-thread block per row, up to 16 chunks of 8 per thread, amax through LDS
+__global__ __launch_bounds__(256) void quant_rows_fp8_wide_kernel(const bf16_t* __restrict__ X, long ldx,
+                                                                  uint8_t* __restrict__ Q, long ldq,
+                                                                  float* __restrict__ S, int rows, int cols) {
+  __shared__ float red[4];
+  const int t = threadIdx.x, row = blockIdx.x;
+  const bf16_t* x = X + (long)row * ldx;
+  const int nch = cols >> 3;
+  bf16x8 c[16];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int ch = i * 256 + t;
+    if (ch < nch) {
+      c[i] = *(const bf16x8*)(x + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(bf2f(c[i][e])));
+    }
+  }
+  amax = wave_max(amax);
+  if ((t & 63) == 0) red[t >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
+  if (t == 0) S[row] = scale;
+  uint8_t* q = Q + (long)row * ldq;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int ch = i * 256 + t;
     if (ch < nch) {
       float v[8];
 #pragma unroll
@@ -112,12 +156,11 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256_kernel(
       glds16(wbase + kb + woff[j], la + OP_BYTES + j * 1024);
     }
   };
-  // One A piece + one W piece of stage kt into LDS at `la` (+ OP_BYTES for W).  The hot loop has no branch: the two
-  // K-tiles past the end re-fetch the last stage into a spare 8 KiB dump area behind the two stage buffers.
-  auto stage_piece = [&](char* la, char* lw, int kt, int j) {
+  auto stage_piece = [&](int buf, int kt, int j) {
+    char* la = lds + buf * STAGE_BYTES + w * 4096;
     const long kb = (long)kt * BKB;
     glds16(abase + kb + aoff[j], la + j * 1024);
-    glds16(wbase + kb + woff[j], lw + j * 1024);
+    glds16(wbase + kb + woff[j], la + OP_BYTES + j * 1024);
   };
 
   const int wr = w >> 2, wc = w & 3;
@@ -169,7 +212,10 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256_kernel(
 #pragma unroll
   for (int t = 0; t < 4; ++t) rd(wk[t], lds + rowW + t * 2048);
 
-  for (int kt = 0; kt < nk; ++kt) {
+  // One K-tile; ISSUE is a compile-time flag (a run-time "if (issue)" around the DMA splits the body into basic blocks and the
+  // compiler then sinks every MFMA behind the last of them - measured 4x slower), so the last two K-tiles are peeled.
+  auto ktile = [&](int kt, auto issue_tag) {
+    constexpr bool ISSUE = decltype(issue_tag)::value;
     const char* cur = lds + (kt & 1) * STAGE_BYTES;
     const char* nxt = lds + ((kt + 1) & 1) * STAGE_BYTES;
     read_a(ya, cur, 1);
@@ -181,11 +227,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256_kernel(
     // all LDS reads of stage kt by this wave are complete and its DMA pieces of stage kt+1 have landed: the barrier publishes
     // stage kt+1 and frees stage kt's buffer, into which the DMA of stage kt+2 goes during the last phase
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    const bool issue = kt + 2 < nk;
-    char* dsta = issue ? lds + (kt & 1) * STAGE_BYTES + w * 4096 : lds + 2 * STAGE_BYTES;
-    char* dstw = issue ? dsta + OP_BYTES : dsta + 4096;
-    const int kq = issue ? kt + 2 : nk - 1;
-    read_a(xa, nxt, 0);  // (after the last K-tile this reads stale LDS that nothing uses: no branch in the hot loop)
+    read_a(xa, nxt, 0);  // (after the last K-tile this reads stale LDS that nothing uses)
     // phase 3: m tiles 6, 7; after its last use each W fragment is refilled from stage kt+1, DMA pieces in between
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -196,10 +238,13 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256_kernel(
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       rd(wk[n], nxt + rowW + n * 2048);
-      stage_piece(dsta, dstw, kq, n);
+      if constexpr (ISSUE) stage_piece(kt & 1, kt + 2, n);
       __builtin_amdgcn_sched_barrier(0);
     }
-  }
+  };
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) ktile(kt, std::true_type{});
+  for (; kt < nk; ++kt) ktile(kt, std::false_type{});
 
   // dequantise: acc * sa[m] * sw[n], then the shared bf16 epilogue (bias / activation / residual / SwiGLU, LDS-staged rows)
   {
@@ -235,20 +280,26 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
   }
   const int tiles_m = (M + BT - 1) / BT, tiles_n = (N + BT - 1) / BT;
   const owc_gemm_aux aux = {nullptr, nullptr, nullptr, 0, 8};
+  const int prof = owc_gemm_profile_begin(2.0 * (double)M * (double)N * (double)K, 1, s);
   hipLaunchKernelGGL(gemm_fp8_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), LDS_BYTES, s,
                      (const uint8_t*)A, lda, sa, (const uint8_t*)W, ldw, sw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C,
                      ldc, M, N, K, tiles_m, tiles_n, aux);
+  owc_gemm_profile_end(prof, s);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 
 }  // namespace
 
 int owc_launch_quant_rows_fp8(const void* X, long ldx, void* Q, long ldq, float* S, int rows, int cols, hipStream_t st) {
-  if (rows <= 0 || cols <= 0 || (cols & 7) || (ldx & 7) || (ldq & 7) || cols > 16 * 512 * 4) return OWC_ERR_SHAPE;
+  if (rows <= 0 || cols <= 0 || (cols & 7) || (ldx & 7) || (ldq & 7) || cols > 16 * 256 * 8) return OWC_ERR_SHAPE;
 #define OWC_Q(C_)                                                                                                  \
   hipLaunchKernelGGL((quant_rows_fp8_kernel<C_>), dim3((rows + 3) / 4), dim3(256), 0, st, (const bf16_t*)X, ldx,     \
                      (uint8_t*)Q, ldq, S, rows, cols)
-  if (cols <= 2048) OWC_Q(4); else if (cols <= 8192) OWC_Q(16); else OWC_Q(64);
+  if (cols <= 2048) OWC_Q(4);
+  else if (cols <= 4096) OWC_Q(8);
+  else
+    hipLaunchKernelGGL(quant_rows_fp8_wide_kernel, dim3(rows), dim3(256), 0, st, (const bf16_t*)X, ldx, (uint8_t*)Q, ldq, S,
+                       rows, cols);
 #undef OWC_Q
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }

@@ -62,7 +62,9 @@ int owc_launch_gemm_f32(const float* A, long lda, const float* W, long ldw, cons
                         const float* R, long ldr, float* C, long ldc, int M, int N, int K, int epi,
                         const void* zeros, hipStream_t s);
 void owc_gemm_profile_set(int on);
-int owc_gemm_profile_collect(double* total_ms, double* total_flops, long* launches);
+int owc_gemm_profile_collect(double* total_ms, double* total_flops, long* launches);  // arrays of 2: [bf16, fp8]
+int owc_gemm_profile_begin(double flops, int kind, hipStream_t s);
+void owc_gemm_profile_end(int handle, hipStream_t s);
 void owc_gemm_set_big_min_m(int m);
 void owc_gemm_set_dbg(int v);
 int owc_launch_gemm_bf16_aux(const void* A, long lda, const void* W, long ldw, const void* bias,

@@ -97,11 +97,16 @@ size_t owc_llm_workspace_bytes(const owc_llm_weights* w, int T, int n_seq) {
   b += owc_align256(t * (size_t)w->d_ff * 2);                         // mlp
   b += owc_align256((size_t)n_seq * d * 2);                           // last-token hidden
   b += owc_align256((size_t)n_seq * (size_t)w->vocab * 2);            // logits
+  if (w->weight_dtype == OWC_WEIGHTS_FP8) {
+    size_t widest = d > (size_t)w->d_ff ? d : (size_t)w->d_ff;
+    if ((size_t)w->n_q_heads * w->head_dim > widest) widest = (size_t)w->n_q_heads * w->head_dim;
+    b += owc_align256(t * widest) + owc_align256(t * 4);            // per-token e4m3 codes + scales
+  }
   return b + 1024;
 }
 
 static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* cache, void* x,
-                      void* h, void* qkv, void* attn, void* mlp, const int32_t* pos3,
+                      void* h, void* qkv, void* attn, void* mlp, void* q8, float* qs, const int32_t* pos3,
                       int64_t pos_stride, const int32_t* tok_slot, const int32_t* tok_idx,
                       const int32_t* q_start, const int32_t* o_start, const int32_t* k_start,
                       const int32_t* k_len, const int32_t* q_len, int n_seq, int T, int max_q_len,
@@ -111,14 +116,22 @@ static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache
   const int G = Hq / Hkv;
   const float scale = 1.0f / sqrtf((float)hd);
   const size_t layer_elems = (size_t)cache->n_slots * Hkv * cache->s_max * hd;
+  const bool fp8 = w->weight_dtype == OWC_WEIGHTS_FP8;
+  // one decoder projection: bf16 weights -> owc_gemm_bf16; fp8 weights -> per-token quantisation of the input rows, then the
+  // scaled-fp8-MFMA GEMM with the same fused epilogue
+  auto linear = [&](const void* in, long ld_in, const void* wt, const float* ws, const void* bias, const void* res, void* out,
+                    long ld_out, int N, int K, int epi) -> int {
+    if (!fp8) return owc_launch_gemm_bf16(in, ld_in, wt, K, bias, res, ld_out, out, ld_out, T, N, K, epi, ctx->zeros, st);
+    OWC_TRY(owc_launch_quant_rows_fp8(in, ld_in, q8, K, qs, T, K, st));
+    return owc_launch_gemm_fp8(q8, K, qs, wt, K, ws, bias, res, ld_out, out, ld_out, T, N, K, epi, st);
+  };
   for (int i = 0; i < w->n_layers; ++i) {
     const owc_llm_layer& L = w->layers[i];
     bf16_t* kc = (bf16_t*)cache->k + (size_t)i * layer_elems;
     bf16_t* vc = (bf16_t*)cache->v + (size_t)i * layer_elems;
     // self-attention block (HF:601-614)
     OWC_TRY(owc_launch_rmsnorm(x, d, L.ln1_w, h, d, T, d, w->rms_eps, nullptr, st));
-    OWC_TRY(owc_launch_gemm_bf16(h, d, L.qkv_w, d, L.qkv_b, nullptr, 0, qkv, NQKV, T, NQKV, d,
-                                 OWC_EPI_NONE, ctx->zeros, st));
+    OWC_TRY(linear(h, d, L.qkv_w, L.qkv_s, L.qkv_b, nullptr, qkv, NQKV, NQKV, d, OWC_EPI_NONE));
     OWC_TRY(owc_launch_mrope_kv(qkv, NQKV, pos3, pos_stride, w->rope_cos, w->rope_sin, kc, vc, tok_slot,
                                 tok_idx, T, Hq, Hkv, cache->s_max, w->mrope_sec0, w->mrope_sec1, bcast_first, bcast_n, st));
     if (!decode) {
@@ -131,14 +144,11 @@ static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache
                                    (long)cache->s_max * hd, attn, hd, (long)G * hd, q_start, o_start,
                                    k_start, k_len, q_len, n_seq, Hkv, 1, hd, G, 0, scale, st));
     }
-    OWC_TRY(owc_launch_gemm_bf16(attn, (long)Hq * hd, L.o_w, (long)Hq * hd, nullptr, x, d, x, d, T, d,
-                                 Hq * hd, OWC_EPI_RESIDUAL, ctx->zeros, st));
+    OWC_TRY(linear(attn, (long)Hq * hd, L.o_w, L.o_s, nullptr, x, x, d, d, Hq * hd, OWC_EPI_RESIDUAL));
     // MLP block (HF:617-620, :464-466)
     OWC_TRY(owc_launch_rmsnorm(x, d, L.ln2_w, h, d, T, d, w->rms_eps, nullptr, st));
-    OWC_TRY(owc_launch_gemm_bf16(h, d, L.gateup_w, d, nullptr, nullptr, 0, mlp, F, T, 2 * F, d,
-                                 OWC_EPI_SWIGLU, ctx->zeros, st));
-    OWC_TRY(owc_launch_gemm_bf16(mlp, F, L.down_w, F, nullptr, x, d, x, d, T, d, F, OWC_EPI_RESIDUAL,
-                                 ctx->zeros, st));
+    OWC_TRY(linear(h, d, L.gateup_w, L.gateup_s, nullptr, nullptr, mlp, F, 2 * F, d, OWC_EPI_SWIGLU));
+    OWC_TRY(linear(mlp, F, L.down_w, L.down_s, nullptr, x, x, d, d, F, OWC_EPI_RESIDUAL));
   }
   return OWC_OK;
 }
@@ -155,6 +165,8 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
     return OWC_ERR_ARG;
   if (n_out <= 0 || n_out > n_seq) OWC_FAIL(ctx, OWC_ERR_ARG, "owc_llm_prefill: 0 < n_out <= n_seq");
   if (w->head_dim != 128) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_llm_prefill: head_dim must be 128");
+  if (w->weight_dtype == OWC_WEIGHTS_FP8 && ((w->d_model % 128) || (w->d_ff % 128)))
+    OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_llm_prefill: fp8 weights need d_model and d_ff to be multiples of 128");
   if (ws_bytes < owc_llm_workspace_bytes(w, T, n_seq)) OWC_FAIL(ctx, OWC_ERR_WORKSPACE, "owc_llm_prefill: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int d = w->d_model;
@@ -167,9 +179,17 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
   void* last = cv.take((size_t)n_seq * d * 2);
   void* logits = cv.take((size_t)n_seq * w->vocab * 2);
   if (logits_out) logits = logits_out;
+  void* q8 = nullptr;
+  float* qs = nullptr;
+  if (w->weight_dtype == OWC_WEIGHTS_FP8) {
+    size_t widest = (size_t)(d > w->d_ff ? d : w->d_ff);
+    if ((size_t)w->n_q_heads * w->head_dim > widest) widest = (size_t)w->n_q_heads * w->head_dim;
+    q8 = cv.take((size_t)T * widest);
+    qs = (float*)cv.take((size_t)T * 4);
+  }
 
   OWC_TRY(owc_launch_embed(ids, img_index, w->embed, img_embeds, x, T, d, st));
-  OWC_TRY(llm_layers(ctx, w, cache, x, h, qkv, attn, mlp, pos3, T, tok_slot, tok_idx, seq_start, nullptr,
+  OWC_TRY(llm_layers(ctx, w, cache, x, h, qkv, attn, mlp, q8, qs, pos3, T, tok_slot, tok_idx, seq_start, nullptr,
                      k_start, seq_len, q_len, n_seq, T, max_len, false, bcast_first_slot, bcast_n_slots, st));
   // final norm on the last token of every prompt only, then lm_head + greedy argmax
   OWC_TRY(owc_launch_rmsnorm(x, d, w->final_norm_w, last, d, n_out, d, w->rms_eps, last_index, st));
@@ -201,10 +221,18 @@ int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cac
   void* last = cv.take((size_t)B * d * 2);
   void* logits = cv.take((size_t)B * w->vocab * 2);
   if (logits_out) logits = logits_out;
+  void* q8 = nullptr;
+  float* qs = nullptr;
+  if (w->weight_dtype == OWC_WEIGHTS_FP8) {
+    size_t widest = (size_t)(d > w->d_ff ? d : w->d_ff);
+    if ((size_t)w->n_q_heads * w->head_dim > widest) widest = (size_t)w->n_q_heads * w->head_dim;
+    q8 = cv.take((size_t)B * widest);
+    qs = (float*)cv.take((size_t)B * 4);
+  }
 
   OWC_TRY(owc_launch_embed(tok_io, nullptr, w->embed, nullptr, x, B, d, st));
   // the three mrope streams of a generated token are identical: pos_stride 0 re-reads `pos`
-  OWC_TRY(llm_layers(ctx, w, cache, x, h, qkv, attn, mlp, pos, 0, slot, write_idx, q_start, o_start,
+  OWC_TRY(llm_layers(ctx, w, cache, x, h, qkv, attn, mlp, q8, qs, pos, 0, slot, write_idx, q_start, o_start,
                      k_start, k_len, q_len, B, B, w->n_q_heads / w->n_kv_heads, true, 0, 0, st));
   OWC_TRY(owc_launch_rmsnorm(x, d, w->final_norm_w, last, d, B, d, w->rms_eps, nullptr, st));
   OWC_TRY(owc_launch_gemm_bf16(last, d, w->lm_head_w, d, nullptr, nullptr, 0, logits, w->vocab, B,

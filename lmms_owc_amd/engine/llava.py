@@ -47,6 +47,7 @@ class LlavaDims:
     image_token_id: int = 32000
     max_positions: int = 4096
     merge: int = 1
+    decoder_dtype: str = "bf16"        # "fp8": see Qwen2VLDims.decoder_dtype
     # LLaVA-NeXT anyres (None -> LLaVA-1.5: one 336x336 view)
     grid_pinpoints: tuple | None = None
 

@@ -47,6 +47,7 @@ class Qwen2VLDims:
     image_token_id: int = 151655
     max_positions: int = 4096      # rope table length (prompt + generated positions)
     max_grid: int = 256            # vision rope table length (patches per side)
+    decoder_dtype: str = "bf16"    # "fp8": decoder projections as e4m3fn weights + per-token e4m3fn activations (config #5)
 
 
 DIMS = {
@@ -167,6 +168,9 @@ class Qwen2VLWeights:
         """Decoder weights -> owc_llm_weights.  `T`: HF prefix of the text model; Llama-family decoders
         (LLaVA) have no q/k/v biases (qkv_b stays NULL)."""
         d = self.dims
+        fp8 = getattr(d, "decoder_dtype", "bf16") == "fp8"
+        if getattr(d, "decoder_dtype", "bf16") not in ("bf16", "fp8"):
+            raise ValueError("decoder_dtype must be 'bf16' or 'fp8'")
         ll = (_lib.LlmLayer * d.n_layers)()
         for i in range(d.n_layers):
             p = f"{T}layers.{i}."
@@ -174,14 +178,18 @@ class Qwen2VLWeights:
                                get(p + "self_attn.v_proj.weight")], 0).contiguous()
             gu = interleave_gate_up(get(p + "mlp.gate_proj.weight"), get(p + "mlp.up_proj.weight"))
             ll[i].ln1_w = self._k(get(p + "input_layernorm.weight"))
+            o_w, down_w = get(p + "self_attn.o_proj.weight"), get(p + "mlp.down_proj.weight")
+            if fp8:  # per-output-channel e4m3fn codes + float scales; the bf16 tensors are dropped right away
+                (qkv_w, ll[i].qkv_s), (o_w, ll[i].o_s) = self._q8(qkv_w), self._q8(o_w)
+                (gu, ll[i].gateup_s), (down_w, ll[i].down_s) = self._q8(gu), self._q8(down_w)
             ll[i].qkv_w = self._k(qkv_w)
             if qkv_bias:
                 ll[i].qkv_b = self._k(torch.cat([get(p + "self_attn.q_proj.bias"), get(p + "self_attn.k_proj.bias"),
                                                  get(p + "self_attn.v_proj.bias")], 0).contiguous())
-            ll[i].o_w = self._k(get(p + "self_attn.o_proj.weight"))
+            ll[i].o_w = self._k(o_w)
             ll[i].ln2_w = self._k(get(p + "post_attention_layernorm.weight"))
             ll[i].gateup_w = self._k(gu)
-            ll[i].down_w = self._k(get(p + "mlp.down_proj.weight"))
+            ll[i].down_w = self._k(down_w)
         self._llm_layers = ll
         m = self.llm
         m.n_layers, m.d_model, m.n_q_heads, m.n_kv_heads = d.n_layers, d.d_model, d.n_q_heads, d.n_kv_heads
@@ -194,6 +202,12 @@ class Qwen2VLWeights:
         m.lm_head_w = m.embed if d.tie_embeddings else self._k(get("lm_head.weight"))
         lc, ls = ops.rope_table(d.max_positions, d.head_dim // 2, d.head_dim, d.rope_theta, True, self.device)
         m.rope_cos, m.rope_sin, m.rope_positions = self._k(lc), self._k(ls), d.max_positions
+        m.weight_dtype = _lib.WEIGHTS_FP8 if fp8 else _lib.WEIGHTS_BF16
+
+    def _q8(self, w_bf16: torch.Tensor):
+        """bf16 [N, K] -> (e4m3fn codes uint8 [N, K], pointer of the float32 row scales) via owc_quantize_rows_fp8."""
+        codes, scales = ops.quantize_rows_fp8(w_bf16)
+        return codes, self._k(scales)
 
     def nbytes(self) -> int:
         seen, total = set(), 0

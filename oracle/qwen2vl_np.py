@@ -193,9 +193,19 @@ class KVCache:
 
 
 def llm_forward(w: dict, cfg: Cfg, x: np.ndarray, pos3: np.ndarray, cache: KVCache, *, bf16=False,
-                taps: dict | None = None) -> np.ndarray:
-    """Qwen2VLTextModel layers + final norm (HF:762-846, :575-625) on embeddings x [S, d]; appends to cache."""
+                taps: dict | None = None, fp8: dict | None = None) -> np.ndarray:
+    """Qwen2VLTextModel layers + final norm (HF:762-846, :575-625) on embeddings x [S, d]; appends to cache.
+    `fp8` (name -> (e4m3 codes, row scales), oracle/fp8_np.quantize_decoder): the seven decoder projections run as
+    per-token-quantised fp8 linears instead (config #5; everything else stays in the model dtype)."""
     tc = cfg.text
+
+    def lin(name, inp, bias=None):
+        if fp8 is not None:
+            from . import fp8_np
+
+            return fp8_np.linear_fp8(inp, *fp8[name], bias, bf16=bf16)
+        return ops.linear(inp, w[name], bias, bf16=bf16)
+
     d, Hq, Hkv = tc.hidden_size, tc.num_attention_heads, tc.num_key_value_heads
     hd = d // Hq
     cos, sin = _mrope_cos_sin(pos3, tc, hd, bf16)
@@ -203,9 +213,9 @@ def llm_forward(w: dict, cfg: Cfg, x: np.ndarray, pos3: np.ndarray, cache: KVCac
         p = f"{T}layers.{i}."
         h = ops.rms_norm(x, w[p + "input_layernorm.weight"], tc.rms_norm_eps, bf16=bf16)
         # Qwen2 has q/k/v biases, Llama-family decoders (LLaVA) do not
-        q = ops.linear(h, w[p + "self_attn.q_proj.weight"], w.get(p + "self_attn.q_proj.bias"), bf16=bf16)
-        k = ops.linear(h, w[p + "self_attn.k_proj.weight"], w.get(p + "self_attn.k_proj.bias"), bf16=bf16)
-        v = ops.linear(h, w[p + "self_attn.v_proj.weight"], w.get(p + "self_attn.v_proj.bias"), bf16=bf16)
+        q = lin(p + "self_attn.q_proj.weight", h, w.get(p + "self_attn.q_proj.bias"))
+        k = lin(p + "self_attn.k_proj.weight", h, w.get(p + "self_attn.k_proj.bias"))
+        v = lin(p + "self_attn.v_proj.weight", h, w.get(p + "self_attn.v_proj.bias"))
         S = x.shape[0]
         q = q.reshape(S, Hq, hd).transpose(1, 0, 2)
         k = k.reshape(S, Hkv, hd).transpose(1, 0, 2)
@@ -217,13 +227,13 @@ def llm_forward(w: dict, cfg: Cfg, x: np.ndarray, pos3: np.ndarray, cache: KVCac
         rep = Hq // Hkv
         a = _attn(q, np.repeat(kk, rep, 0), np.repeat(vv, rep, 0), hd ** -0.5, True, bf16)
         a = a.transpose(1, 0, 2).reshape(S, Hq * hd)
-        x = maybe_bf16(x + ops.linear(a, w[p + "self_attn.o_proj.weight"], bf16=bf16), bf16)
+        x = maybe_bf16(x + lin(p + "self_attn.o_proj.weight", a), bf16)
         if taps is not None and i == 0:
             taps["layer0_post_attn"] = x.copy()
         h = ops.rms_norm(x, w[p + "post_attention_layernorm.weight"], tc.rms_norm_eps, bf16=bf16)
-        g = ops.silu(ops.linear(h, w[p + "mlp.gate_proj.weight"], bf16=bf16), bf16=bf16)
-        u = ops.linear(h, w[p + "mlp.up_proj.weight"], bf16=bf16)
-        m = ops.linear(maybe_bf16(g * u, bf16), w[p + "mlp.down_proj.weight"], bf16=bf16)
+        g = ops.silu(lin(p + "mlp.gate_proj.weight", h), bf16=bf16)
+        u = lin(p + "mlp.up_proj.weight", h)
+        m = lin(p + "mlp.down_proj.weight", maybe_bf16(g * u, bf16))
         x = maybe_bf16(x + m, bf16)
     return ops.rms_norm(x, w[T + "norm.weight"], tc.rms_norm_eps, bf16=bf16)
 
@@ -239,7 +249,7 @@ def greedy_argmax(logits: np.ndarray) -> np.ndarray:
 
 
 def generate(w: dict, cfg: Cfg, input_ids: np.ndarray, pixel_values: np.ndarray | None, grid_thw, max_new_tokens: int,
-             *, bf16=False, eos_token_id: int | None = None, pad_token_id: int = 0, return_logits=False):
+             *, bf16=False, eos_token_id: int | None = None, pad_token_id: int = 0, return_logits=False, fp8: dict | None = None):
     """Greedy generation for ONE prompt (reference batch size is 1, src/models/_base.py:103-104):
     HF:1144-1205 (embed + image scatter + rope index) then the GenerationMixin greedy loop."""
     tc = cfg.text
@@ -253,7 +263,7 @@ def generate(w: dict, cfg: Cfg, input_ids: np.ndarray, pixel_values: np.ndarray 
         pos3 = np.tile(np.arange(len(ids))[None], (3, 1))
         delta = 0
     cache = KVCache(tc.num_hidden_layers)
-    h = llm_forward(w, cfg, x, pos3, cache, bf16=bf16)
+    h = llm_forward(w, cfg, x, pos3, cache, bf16=bf16, fp8=fp8)
     logits = lm_head(w, cfg, h[-1:], bf16=bf16)
     all_logits = [logits[0].copy()]
     out, done = [], False
@@ -269,7 +279,7 @@ def generate(w: dict, cfg: Cfg, input_ids: np.ndarray, pixel_values: np.ndarray 
             continue
         x = maybe_bf16(w[T + "embed_tokens.weight"][np.array([tok])], bf16)
         p = np.full((3, 1), cur_len + delta, np.int64)  # HF:1130-1137: arange(past, past+1) + rope_deltas
-        h = llm_forward(w, cfg, x, p, cache, bf16=bf16)
+        h = llm_forward(w, cfg, x, p, cache, bf16=bf16, fp8=fp8)
         logits = lm_head(w, cfg, h[-1:], bf16=bf16)
         all_logits.append(logits[0].copy())
         cur_len += 1

@@ -77,8 +77,9 @@ def main() -> None:
         out = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
-    _lib.check(lib.owc_gemm_profile_read(ctx, C.byref(ms), C.byref(fl), C.byref(n)), 0)
+    ms2, fl2, n2 = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int64 * 2)()
+    _lib.check(lib.owc_gemm_profile_read(ctx, ms2, fl2, n2), 0)
+    ms, fl, n = C.c_double(ms2[0]), C.c_double(fl2[0]), C.c_int64(n2[0])
     lib.owc_gemm_profile_enable(ctx, 0)
     assert out.shape == (B, T)
     ips = B * args.steps / dt
