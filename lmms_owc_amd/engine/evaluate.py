@@ -72,7 +72,8 @@ def evaluate(lm, task_dict: dict, limit: int | float | None = None, log_samples:
         lim = None if limit is None else (int(n_docs * limit) if isinstance(limit, float) and limit < 1.0 else int(limit))
         task.build_all_requests(limit=lim, rank=rank, world_size=world)
         reqs = task.instances
-        resps = lm.generate_until(reqs) if reqs else []
+        # requests of a task share one type (generate_until | generate_until_multi_round): dispatch like _engine.py:243-262
+        resps = getattr(lm, task.OUTPUT_TYPE)(reqs) if reqs else []
         for r, x in zip(reqs, resps, strict=True):
             r.resps.append(x)
         if dist is not None:

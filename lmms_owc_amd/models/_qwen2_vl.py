@@ -45,12 +45,17 @@ class ByteTokenizer:
         return [self.decode(r) for r in rows]
 
     def chat_ids(self, question: str, n_image_tokens: list[int]) -> list[int]:
+        return self.chat_ids_turns([("user", question, n_image_tokens)])
+
+    def chat_ids_turns(self, turns: list[tuple]) -> list[int]:
+        """ChatML ids of a conversation: turns = [(role, text, n_image_tokens per image)], generation prompt appended."""
         ids = [self.im_start] + self.encode("system\n" + SYSTEM_PROMPT) + [self.im_end] + self.encode("\n")
-        ids += [self.im_start] + self.encode("user\n")
-        for n in n_image_tokens:
-            ids += [self.vision_start] + [self.image_pad] * n + [self.vision_end]
-        ids += self.encode(question) + [self.im_end] + self.encode("\n") + [self.im_start] + self.encode("assistant\n")
-        return ids
+        for role, text, n_image_tokens in turns:
+            ids += [self.im_start] + self.encode(role + "\n")
+            for n in n_image_tokens:
+                ids += [self.vision_start] + [self.image_pad] * n + [self.vision_end]
+            ids += self.encode(text) + [self.im_end] + self.encode("\n")
+        return ids + [self.im_start] + self.encode("assistant\n")
 
 
 class Qwen2VL(Model):
@@ -99,8 +104,89 @@ class Qwen2VL(Model):
     def loglikelihood(self, requests: list) -> list[tuple[float, bool]]:
         raise NotImplementedError("Loglikelihood is not implemented for Qwen2_VL")  # as the reference (:141)
 
-    def generate_until_multi_round(self, requests: list) -> list[str]:
-        raise NotImplementedError("multi-round generation is outside the accelerated path (SURVEY.md §8f)")
+    def generate_until_multi_round(self, requests: list) -> list[tuple]:
+        """Multi-round dialogue (the `*_llamav_o1` tasks; reference :350-616): every round re-asks the task's
+        `doc_to_text(doc, round_idx=, previous_round_results=, last_round_info=)`, appends the user turn to the running
+        conversation (the image travels in round 0 only), generates greedily and cuts the answer at the `until` terms;
+        the result per request is the tuple of per-round answers.  Batched over documents; the image embeddings of
+        round 0 are kept on the GPU and reused by the later rounds (the reference re-encodes the image every round)."""
+        res: list[tuple] = []
+
+        def _collate(x):
+            return -len(self._tokenizer.encode(x[0])), x[0]
+
+        reordered = utils.Collator([reg.args for reg in requests], _collate, grouping=True)
+        for chunk in reordered.get_batched(n=self.batch_size, batch_fn=None):
+            contexts, all_gen_kwargs, doc_to_visual, doc_to_text, doc_ids, tasks, splits = zip(*chunk, strict=True)
+            task, split = tasks[0], splits[0]
+            gen_kwargs = dict(all_gen_kwargs[0])
+            tok = self._tokenizer
+            until = gen_kwargs.pop("until", [tok.decode([tok.eos_token_id])])
+            until = [until] if isinstance(until, str) else until
+            if not isinstance(until, list):
+                raise ValueError(f"Expected `gen_kwargs['until']` to be of type Union[str,list] but got {type(until)}")
+            max_new = int(gen_kwargs.get("max_new_tokens", 128))
+            if gen_kwargs.get("temperature", 0) not in (0, 0.0) or gen_kwargs.get("num_beams", 1) != 1:
+                raise NotImplementedError("the HIP decoder implements greedy decoding (temperature 0, 1 beam)")
+            docs = [self.task_dict[task][split][did] for did in doc_ids]
+            visuals_per_doc = [doc_to_visual[0](d) for d in docs]
+            prepared = list(self._pool.map(lambda v: imageproc.prepare_image(v, self._min_pixels, self._max_pixels),
+                                           [v for vs in visuals_per_doc for v in vs]))
+            it = iter(prepared)
+            arrs_per_doc = [[next(it) for _ in vs] for vs in visuals_per_doc]
+            grids_per_doc = [[(1, a.shape[1] // 14, a.shape[2] // 14) for a in arrs] for arrs in arrs_per_doc]
+            emb = None
+            if prepared:  # round 0's images, embedded once
+                emb = self._model.encode_images(self._pixel_values(prepared), [g for gs in grids_per_doc for g in gs])
+            turns = [[] for _ in docs]           # running conversations: (role, text, n_image_tokens)
+            round_results: list[list[str]] = []  # [round][doc]
+            round_idx, texts = 0, [c.replace("<image>", "") for c in contexts]
+            while True:
+                if round_idx:
+                    outs = [doc_to_text[0](d, round_idx=round_idx, previous_round_results=[r[i] for r in round_results],
+                                           last_round_info=None) for i, d in enumerate(docs)]
+                    if outs[0][2]:  # terminal signal (the reference looks at the first document of the batch, :462)
+                        break
+                    texts = [o[1].replace("<image>", "") for o in outs]
+                prompts = []
+                for i, text in enumerate(texts):
+                    n_tok = [g[1] * g[2] // 4 for g in grids_per_doc[i]] if round_idx == 0 else []
+                    turns[i].append(("user", text, n_tok))
+                    prompts.append(self._conversation_ids(turns[i]))
+                pad = tok.pad_token_id if tok.pad_token_id is not None else 0
+                out = self._model.generate(prompts, emb, grids_per_doc, max_new, eos_token_id=tok.eos_token_id,
+                                           pad_token_id=pad).cpu().numpy()
+                rows = []
+                for r in out:
+                    stop = np.flatnonzero(r == tok.eos_token_id)
+                    rows.append(r[: stop[0]] if len(stop) else r)
+                answers = tok.batch_decode(rows, skip_special_tokens=True, clean_up_tokenization_spaces=False)
+                for i, ans in enumerate(answers):
+                    for term in until:
+                        if len(term) > 0:
+                            ans = ans.split(term)[0]
+                    answers[i] = ans
+                    turns[i].append(("assistant", ans, []))
+                round_results.append(answers)
+                round_idx += 1
+            res.extend(zip(*round_results, strict=True))
+            self.cache_hook.add_partial("generate_until_multi_round", (contexts[0], gen_kwargs), round_results)
+        return reordered.get_original(res)
+
+    def _conversation_ids(self, turns: list[tuple]) -> np.ndarray:
+        tok = self._tokenizer
+        if isinstance(tok, ByteTokenizer):
+            return np.asarray(tok.chat_ids_turns(turns), dtype=np.int32)
+        messages = [{"role": "system", "content": SYSTEM_PROMPT}]
+        n_all = []
+        for role, text, n_image_tokens in turns:
+            messages.append({"role": role, "content": [{"type": "image"} for _ in n_image_tokens] + [{"type": "text", "text": text}]})
+            n_all += list(n_image_tokens)
+        ids = tok.encode(tok.apply_chat_template(messages, tokenize=False, add_generation_prompt=True))
+        out, it = [], iter(n_all)
+        for t in ids:
+            out.extend([t] * next(it) if t == self._dims.image_token_id else [t])
+        return np.asarray(out, dtype=np.int32)
 
     # ------------------------------------------------------------------ prompt building
     def _prompt_ids(self, context: str, n_image_tokens: list[int]) -> np.ndarray:

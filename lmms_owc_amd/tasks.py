@@ -6,7 +6,11 @@
 * `process_results`, generate_until branch (src/data/tasks/_manager.py:938-942, :1030-1090): strip the
   response, call `fn(references=[gold], predictions=[pred], **kw)` and fall back to storing `[gold, [pred]]`
   for passthrough metrics;
-* the `take_first` filter (src/data/filters/_selection.py:36-52).
+* the `take_first` filter (src/data/filters/_selection.py:36-52);
+* `output_type: generate_until_multi_round` (the `*_llamav_o1` configs): request tuple
+  `(context, gen_kwargs, doc_to_visual, doc_to_text, doc_id, task, split)` (_manager.py:903-915) where
+  `doc_to_text(doc, round_idx=, previous_round_results=, last_round_info=)` follows
+  `_caltech101_utils.doc_to_text_multi_round` (:29-72); `process_results` scores the LAST round (_manager.py:1033-1036).
 
 Task definitions are small YAML files (prompt, generation kwargs, metric list) mirroring
 src/data/tasks/_classification/*/base.yaml + assets/_default_template_yaml; documents come from a JSONL
@@ -61,11 +65,18 @@ class ClassificationTask:
 
     def __init__(self, name: str, docs: list[dict], prompt: str = "What type of object is in this photo?",
                  pre_prompt: str = "", post_prompt: str = "", generation_kwargs: dict | None = None,
-                 metric_list: list[dict] | None = None, split: str = "test") -> None:
+                 metric_list: list[dict] | None = None, split: str = "test", output_type: str = "generate_until",
+                 prompts: list[str] | None = None) -> None:
+        if output_type not in ("generate_until", "generate_until_multi_round"):
+            raise ValueError(f"unsupported output_type {output_type!r} (generate_until, generate_until_multi_round)")
+        self.OUTPUT_TYPE = output_type
         self.task_name = name
         self.split = split
         self.docs = docs
         self.prompt, self.pre_prompt, self.post_prompt = prompt, pre_prompt, post_prompt
+        self.prompts = prompts
+        if output_type == "generate_until_multi_round" and (not isinstance(prompts, list) or len(prompts) < 2):
+            raise ValueError("`multi_round` expects at least two questions")
         self.generation_kwargs = dict(generation_kwargs or {"max_new_tokens": 64, "do_sample": False})
         self.metric_list = metric_list or DEFAULT_METRICS
         self._metric_fn, self._metric_kwargs, self._agg, self._higher = {}, {}, {}, {}
@@ -86,7 +97,21 @@ class ClassificationTask:
         return {self.split: self.docs}
 
     def doc_to_text(self, doc: dict) -> str:
+        if self.OUTPUT_TYPE == "generate_until_multi_round":
+            return self.doc_to_text_multi_round(doc)
         return f"{self.pre_prompt}{self.prompt}{self.post_prompt}"
+
+    def doc_to_text_multi_round(self, doc: dict, round_idx: int | None = None, previous_round_results: list | None = None,
+                                last_round_info: dict | None = None):
+        """Round protocol of the reference: without a round index the first question; otherwise
+        `(visual, text, should_terminate, previous_round_results, last_round_info)` - the image only travels in round 0
+        (later rounds return visual None and rely on the message history in `last_round_info`)."""
+        previous_round_results = [] if previous_round_results is None else previous_round_results
+        if round_idx is None:
+            return f"{self.pre_prompt}{self.prompts[0]}{self.post_prompt}"
+        if round_idx < len(self.prompts):
+            return None, f"{self.pre_prompt}{self.prompts[round_idx]}{self.post_prompt}", False, previous_round_results, last_round_info
+        return None, None, True, previous_round_results, last_round_info
 
     @staticmethod
     def doc_to_target(doc: dict) -> str:
@@ -106,8 +131,12 @@ class ClassificationTask:
         self.instances = []
         it = utils.create_iterator(enumerate(self.docs), rank, world_size, limit)
         for doc_id, doc in it:
-            args = (self.doc_to_text(doc), dict(self.generation_kwargs), self.doc_to_visual, doc_id, self.task_name, self.split)
-            self.instances.append(TaskInstance("generate_until", args, idx=0, doc=doc, task_name=self.task_name, doc_id=doc_id))
+            if self.OUTPUT_TYPE == "generate_until_multi_round":
+                args = (self.doc_to_text(doc), dict(self.generation_kwargs), self.doc_to_visual, self.doc_to_text_multi_round, doc_id,
+                        self.task_name, self.split)
+            else:
+                args = (self.doc_to_text(doc), dict(self.generation_kwargs), self.doc_to_visual, doc_id, self.task_name, self.split)
+            self.instances.append(TaskInstance(self.OUTPUT_TYPE, args, idx=0, doc=doc, task_name=self.task_name, doc_id=doc_id))
 
     def apply_filters(self) -> None:
         for inst in self.instances:  # default ensemble ("none", [take_first])
@@ -116,7 +145,10 @@ class ClassificationTask:
     def process_results(self, doc: dict, results: list) -> dict:
         if isinstance(results, list) and results and isinstance(results[0], list):
             results = results[0]
-        result = [r.strip() for r in results]
+        if self.OUTPUT_TYPE == "generate_until_multi_round":  # one tuple of per-round answers per response: score the last
+            result = [r[-1].strip() for r in results]
+        else:
+            result = [r.strip() for r in results]
         gold = [self.doc_to_target(doc)]
         out = {}
         for metric, fn in self._metric_fn.items():
@@ -139,7 +171,7 @@ class ClassificationTask:
 def load_task(name: str, *, data_root: str | Path = "data", include_path: str | Path | None = None) -> ClassificationTask:
     """`name` is a YAML task config (task_configs/ or --include_path) or `synthetic:<n>:<H>x<W>[:<classes>]`."""
     if name.startswith("synthetic"):
-        return synthetic_task(name)
+        return synthetic_task(name)  # "synthetic-mr:..." = the multi-round (llamav_o1-style) variant
     for base in ([Path(include_path)] if include_path else []) + [CONFIG_DIR]:
         f = base / f"{name}.yaml"
         if f.exists():
@@ -149,10 +181,13 @@ def load_task(name: str, *, data_root: str | Path = "data", include_path: str | 
         raise KeyError(f"unknown task '{name}' (no {name}.yaml under {CONFIG_DIR} or --include_path)")
     msk = (cfg.get("model_specific_kwargs") or {}).get("default", {})
     docs = load_docs(Path(cfg.get("dataset_path", Path(data_root) / name)), cfg.get("test_split", "test"))
-    return ClassificationTask(cfg.get("task", name), docs, prompt=msk.get("prompt", "What type of object is in this photo?"),
+    output_type = cfg.get("output_type", "generate_until")
+    # default question of the reference's doc_to_text when a config has no `prompt` key (_caltech101_utils.py:23)
+    return ClassificationTask(cfg.get("task", name), docs, prompt=msk.get("prompt", "What's in the image?"),
                               pre_prompt=msk.get("pre_prompt", ""), post_prompt=msk.get("post_prompt", ""),
                               generation_kwargs=cfg.get("generation_kwargs"), metric_list=cfg.get("metric_list"),
-                              split=cfg.get("test_split", "test"))
+                              split=cfg.get("test_split", "test"), output_type=output_type,
+                              prompts=msk.get("prompts") if output_type == "generate_until_multi_round" else None)
 
 
 def load_docs(path: Path, split: str) -> list[dict]:
@@ -186,4 +221,9 @@ def synthetic_task(spec: str) -> ClassificationTask:
     for i in range(n):
         arr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         docs.append({"visual": Image.fromarray(arr, "RGB"), "target": names[i % c]})
+    if parts[0] == "synthetic-mr":
+        return ClassificationTask("synthetic", docs, generation_kwargs={"max_new_tokens": 6, "do_sample": False},
+                                  output_type="generate_until_multi_round",
+                                  prompts=["What type of object in this photo? Generate a summary of the picture.",
+                                           "Generate a detailed caption for the image.", "Generate the final answer based on reasoning steps."])
     return ClassificationTask("synthetic", docs, generation_kwargs={"max_new_tokens": 8, "do_sample": False})

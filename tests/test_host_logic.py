@@ -337,3 +337,35 @@ def test_imagenet1k_task_config_loads_from_manifest(tmp_path):
     t.build_all_requests(limit=None, rank=1, world_size=2)
     assert t.task_name == "imagenet1k" and len(t.docs) == 3 and [i.doc_id for i in t.instances] == [1]
     assert t.instances[0].args[0] == "What type of object is in this photo?" and t.instances[0].args[1]["max_new_tokens"] == 64
+
+
+def test_multi_round_task_protocol(tmp_path):
+    """`*_llamav_o1` configs: output_type generate_until_multi_round, 7-tuple requests, the round protocol of the reference's
+    doc_to_text_multi_round (_caltech101_utils.py:29-72) and last-round scoring (_manager.py:1033-1036)."""
+    import yaml
+
+    from lmms_owc_amd import tasks
+
+    cfg = yaml.safe_load((ROOT / "lmms_owc_amd" / "task_configs" / "caltech101_llamav_o1.yaml").read_text())
+    assert cfg["output_type"] == "generate_until_multi_round" and len(cfg["model_specific_kwargs"]["default"]["prompts"]) == 4
+    assert cfg["generation_kwargs"] == {"max_new_tokens": 256, "do_sample": False}
+    t = tasks.load_task("synthetic-mr:3:56x56:2")
+    t.build_all_requests(limit=None, rank=0, world_size=1)
+    inst = t.instances[0]
+    assert inst.request_type == "generate_until_multi_round" and len(inst.args) == 7
+    ctx, gen_kwargs, doc_to_visual, doc_to_text, doc_id, task_name, split = inst.args
+    assert ctx == t.prompts[0] and callable(doc_to_text) and doc_id == 0
+    v, text, stop, prev, info = doc_to_text(t.docs[0], round_idx=1, previous_round_results=["a"], last_round_info={"k": 1})
+    assert v is None and text == t.prompts[1] and stop is False and prev == ["a"] and info == {"k": 1}
+    assert doc_to_text(t.docs[0], round_idx=len(t.prompts))[2] is True
+    out = t.process_results(t.docs[0], [("summary", "caption", " class 0 ")])
+    assert out["exact_match"] == 1.0   # the last round, stripped, against target "class 0"
+    with pytest.raises(ValueError):
+        tasks.ClassificationTask("x", [], output_type="generate_until_multi_round", prompts=["only one"])
+    # every mirrored config parses and names a known output type / metric set
+    names = sorted(p.stem for p in (ROOT / "lmms_owc_amd" / "task_configs").glob("*.yaml"))
+    assert len(names) >= 97 and "food101_fine_grained" in names and "ucf101_zero_shot_cot" in names
+    for n in names:
+        c = yaml.safe_load((ROOT / "lmms_owc_amd" / "task_configs" / f"{n}.yaml").read_text())
+        assert c["task"] == n and c["output_type"] in ("generate_until", "generate_until_multi_round")
+        assert [m["metric"] for m in c["metric_list"]] == ["exact_match", "semantic_similarity", "textual_inclusion"]

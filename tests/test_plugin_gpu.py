@@ -268,3 +268,41 @@ def test_eval_ranking_cli_matches_reference(gpu, tmp_path, capsys):
                                                                     "--log-level", "WARNING"]))
     assert res["toytask"]["scores"] == gold["default"]["scores"]
     assert capsys.readouterr().out == gold["default"]["stdout"]
+
+
+def test_multi_round_generation(gpu, scorer):
+    """generate_until_multi_round (the `*_llamav_o1` tasks): a tuple of per-round answers per document, independent of the
+    batch size, every round generated from the running conversation (checked against a hand-built conversation fed to the
+    engine directly), and the evaluate loop scores the last round."""
+    import torch
+
+    from lmms_owc_amd import ops
+    from lmms_owc_amd.engine.evaluate import simple_evaluate
+    from lmms_owc_amd.models import get_model, imageproc
+    from lmms_owc_amd.pipelines import text
+    from lmms_owc_amd.tasks import load_task
+
+    text.set_sentence_bert(scorer, HashTokenizer())   # (an earlier test installs its own tokenizer)
+    task = load_task("synthetic-mr:5:56x84:3")
+    task.build_all_requests(limit=None, rank=0, world_size=1)
+    outs = []
+    for bs in (1, 3):
+        lm = get_model("custom-model", model_type="qwen2-vl", model_name_or_path="synthetic:tiny", batch_size=bs)
+        lm.task_dict[task.task_name] = task.dataset
+        outs.append(lm.generate_until_multi_round(task.instances))
+    assert outs[0] == outs[1] and len(outs[0]) == 5 and all(isinstance(o, tuple) and len(o) == 3 for o in outs[0])
+    # round 2 of document 1, rebuilt by hand: system + (user: image + q0) + (assistant: a0) + (user: q1) + (assistant: a1) + (user: q2)
+    tok, eng = lm.tokenizer, lm.model
+    img = imageproc.prepare_image(task.docs[1]["visual"], lm._min_pixels, lm._max_pixels)
+    grid = (1, img.shape[1] // 14, img.shape[2] // 14)
+    emb = eng.encode_images(ops.patchify_u8(torch.from_numpy(img[None]).to(gpu), imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD), [grid])
+    a0, a1, a2 = outs[0][1]
+    ids = tok.chat_ids_turns([("user", task.prompts[0], [grid[1] * grid[2] // 4]), ("assistant", a0, []), ("user", task.prompts[1], []),
+                              ("assistant", a1, []), ("user", task.prompts[2], [])])
+    toks = eng.generate([np.asarray(ids, np.int32)], emb, [[grid]], 6, eos_token_id=tok.eos_token_id, pad_token_id=0).cpu().numpy()[0]
+    stop = np.flatnonzero(toks == tok.eos_token_id)
+    assert tok.decode(toks[: stop[0]] if len(stop) else toks) == a2
+    res = simple_evaluate(model="custom-model", model_args="model_type=qwen2-vl,model_name_or_path=synthetic:tiny", tasks=["synthetic-mr:4:56x56:2"],
+                          batch_size=2, limit=4)
+    smp = res["samples"]["synthetic"]
+    assert len(smp) == 4 and len(smp[0]["filtered_resps"][0]) == 3 and "semantic_similarity,none" in res["results"]["synthetic"]
