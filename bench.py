@@ -161,6 +161,8 @@ def main() -> None:
                     help="fp8 = e4m3fn decoder projections (BASELINE config #5; never the default: the headline is bf16)")
     ap.add_argument("--scorer-labels", type=int, default=65536)
     ap.add_argument("--scorer-classes", type=int, default=397)
+    ap.add_argument("--vit-chunk", type=int, default=None, help="vision-tower tokens per launch group (engine default if unset)")
+    ap.add_argument("--prefill-chunk", type=int, default=None, help="packed prefill rows per launch group (engine default if unset)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=2)
     args = ap.parse_args()
@@ -198,7 +200,8 @@ def main() -> None:
 
         dims = dataclasses.replace(dims, decoder_dtype=args.decoder_dtype)
     weights = Qwen2VLWeights.random(dims, device, seed=1234)
-    engine = Qwen2VLEngine(weights)
+    ekw = {k: v for k, v in (('vit_chunk_tokens', args.vit_chunk), ('prefill_chunk_tokens', args.prefill_chunk)) if v}
+    engine = Qwen2VLEngine(weights, **ekw)
     B, T = args.batch, args.new_tokens
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     pix = torch.randn((B * 1024, 1176), generator=gen, device=device, dtype=torch.bfloat16)

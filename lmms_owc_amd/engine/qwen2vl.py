@@ -252,7 +252,7 @@ def _param_shape(d: Qwen2VLDims, name: str) -> tuple:
 class Qwen2VLEngine:
     """Batched open-world classification forward: pixel_values + prompt ids -> greedy token ids."""
 
-    def __init__(self, weights: Qwen2VLWeights, *, vit_chunk_tokens: int = 65536, prefill_chunk_tokens: int = 32768,
+    def __init__(self, weights: Qwen2VLWeights, *, vit_chunk_tokens: int = 131072, prefill_chunk_tokens: int = 65536,
                  share_prefix: bool = True, min_shared_prefix: int = 4):
         self.share_prefix = share_prefix            # prefill the prompts' common leading text tokens once per chunk
         self.min_shared_prefix = min_shared_prefix
