@@ -133,6 +133,11 @@ int owc_attention_bf16(owc_ctx* ctx, const void* Q, int64_t q_ts, int64_t q_hs, 
 int owc_quantize_rows_fp8(owc_ctx* ctx, const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int rows,
                           int cols, void* stream);
 
+/* RMSNorm (owc_rmsnorm_bf16 arithmetic) fused with owc_quantize_rows_fp8 of its output: bit-identical to running the two, without
+ * the bf16 round trip through memory.  Used in front of the qkv and gate/up projections of the fp8 decoder. */
+int owc_rmsnorm_quant_fp8(owc_ctx* ctx, const void* x, int64_t ldx, const void* weight, void* q, int64_t ldq, float* scale,
+                          int rows, int d, float eps, void* stream);
+
 /* C[M,N] bf16 = epilogue((A8[M,K] . W8[N,K]^T) * a_scale[m] * w_scale[n] + bias) on v_mfma_scale_f32_16x16x128_f8f6f4.
  * K % 128 == 0, lda / ldw in bytes and % 16 == 0; epilogue in {OWC_EPI_NONE, OWC_EPI_RESIDUAL, OWC_EPI_SWIGLU}
  * (SWIGLU: W rows and w_scale interleaved gate/up per 16 like owc_gemm_bf16). */

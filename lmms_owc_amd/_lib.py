@@ -20,7 +20,7 @@ _lock = threading.Lock()
 _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = range(6)
 
@@ -112,6 +112,7 @@ SIGNATURES: dict[str, tuple] = {
     "owc_attention_bf16": (i32, [vp, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, vp,
                                  i32, i32, i32, i32, i32, i32, f32, vp]),
     "owc_quantize_rows_fp8": (i32, [vp, vp, i64, vp, i64, vp, i32, i32, vp]),
+    "owc_rmsnorm_quant_fp8": (i32, [vp, vp, i64, vp, vp, i64, vp, i32, i32, f32, vp]),
     "owc_gemm_fp8": (i32, [vp, vp, i64, vp, vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "owc_embed_tokens": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "owc_argmax_bf16": (i32, [vp, vp, i64, i32, i32, vp, vp]),

@@ -15,7 +15,7 @@
 
 extern "C" {
 
-int owc_abi_version(void) { return 8; }
+int owc_abi_version(void) { return 9; }
 
 int owc_tuning_set(const char* name, int value) {
   if (!name) return OWC_ERR_ARG;
@@ -138,6 +138,12 @@ int owc_quantize_rows_fp8(owc_ctx* ctx, const void* x, int64_t ldx, void* q, int
                           int cols, void* stream) {
   if (!ctx || !x || !q || !scale) return OWC_ERR_ARG;
   RET(ctx, "owc_quantize_rows_fp8", owc_launch_quant_rows_fp8(x, ldx, q, ldq, scale, rows, cols, ST(stream)));
+}
+
+int owc_rmsnorm_quant_fp8(owc_ctx* ctx, const void* x, int64_t ldx, const void* weight, void* q, int64_t ldq, float* scale,
+                          int rows, int d, float eps, void* stream) {
+  if (!ctx || !x || !weight || !q || !scale) return OWC_ERR_ARG;
+  RET(ctx, "owc_rmsnorm_quant_fp8", owc_launch_rmsnorm_quant_fp8(x, ldx, weight, q, ldq, scale, rows, d, eps, ST(stream)));
 }
 
 int owc_gemm_fp8(owc_ctx* ctx, const void* A, int64_t lda, const float* a_scale, const void* W, int64_t ldw,

@@ -12,12 +12,15 @@ namespace {
 // ------------------------------------------------------------------------------------------
 constexpr int NORM_MAXC = 16;  // chunks of 8 per lane -> rows up to 8192
 
-template <bool RMS, int NORM_C>  // NORM_C = chunks per lane this instantiation covers (d <= 512 * NORM_C)
+// QUANT (fp8 decoder, RMS only): the normalised bf16 row never goes to memory; it is quantised per token exactly as
+// owc_quantize_rows_fp8 would quantise it (s = max|y| / 448, q = rne_e4m3(y / s)) and Y / ldy address the e4m3 codes.
+template <bool RMS, int NORM_C, bool QUANT = false>  // NORM_C = chunks per lane this instantiation covers (d <= 512 * NORM_C)
 __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ X, long ldx,
                                                    const bf16_t* __restrict__ Wt,
                                                    const bf16_t* __restrict__ Bs,
                                                    bf16_t* __restrict__ Y, long ldy, int rows, int d,
-                                                   float eps, const int* __restrict__ row_index) {
+                                                   float eps, const int* __restrict__ row_index,
+                                                   float* __restrict__ qscale = nullptr) {
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + w;
   if (row >= rows) return;
@@ -61,6 +64,41 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ X,
     }
     var = wave_sum(var) * inv_d;
     rstd = rsqrtf(var + eps);
+  }
+  if constexpr (QUANT) {
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NORM_C; ++i) {
+      const int ch = i * 64 + l;
+      if (ch < nch) {
+        const bf16x8 wv = *(const bf16x8*)(Wt + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          c[i][e] = f2bf(bf2f(wv[e]) * rbf(bf2f(c[i][e]) * rstd));  // the bf16 value the un-fused kernel would store
+          amax = fmaxf(amax, fabsf(bf2f(c[i][e])));
+        }
+      }
+    }
+    amax = wave_max(amax);
+    const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (l == 0) qscale[row] = scale;
+    uint8_t* q = (uint8_t*)Y + (long)row * ldy;
+#pragma unroll
+    for (int i = 0; i < NORM_C; ++i) {
+      const int ch = i * 64 + l;
+      if (ch < nch) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(bf2f(c[i][e]) / scale, -448.0f), 448.0f);
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+        *(int2*)(q + ch * 8) = make_int2(lo, hi);
+      }
+    }
+    return;
   }
   bf16_t* y = Y + (long)row * ldy;
 #pragma unroll
@@ -420,6 +458,18 @@ int owc_launch_rmsnorm(const void* X, long ldx, const void* W, void* Y, long ldy
                      (const bf16_t*)W, (const bf16_t*)nullptr, (bf16_t*)Y, ldy, rows, d, eps, row_index)
   if (d <= 1536) OWC_RMS(3); else if (d <= 4096) OWC_RMS(8); else OWC_RMS(16);
 #undef OWC_RMS
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+// RMSNorm fused with the per-token e4m3fn quantisation of its output (fp8 decoder): Q [rows, d] codes, S [rows] scales.
+int owc_launch_rmsnorm_quant_fp8(const void* X, long ldx, const void* W, void* Q, long ldq, float* S, int rows, int d,
+                                 float eps, hipStream_t st) {
+  if ((d & 7) || d > NORM_MAXC * 512 || (ldx & 7) || (ldq & 7) || rows <= 0) return OWC_ERR_SHAPE;
+#define OWC_RMSQ(C_)                                                                                               \
+  hipLaunchKernelGGL((norm_kernel<true, C_, true>), dim3((rows + 3) / 4), dim3(256), 0, st, (const bf16_t*)X, ldx,   \
+                     (const bf16_t*)W, (const bf16_t*)nullptr, (bf16_t*)Q, ldq, rows, d, eps, (const int*)nullptr, S)
+  if (d <= 1536) OWC_RMSQ(3); else if (d <= 4096) OWC_RMSQ(8); else OWC_RMSQ(16);
+#undef OWC_RMSQ
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 

@@ -76,6 +76,8 @@ int owc_launch_clip_patchify(const uint8_t* img, void* out, long ldo, int kpad, 
 int owc_launch_clip_embed(const void* pe, const void* pos_cls, void* x, int n_img, int tokens, int E,
                           hipStream_t st);
 int owc_launch_seq_iota(int* start, int* len, int n, int L, hipStream_t st);
+int owc_launch_rmsnorm_quant_fp8(const void* X, long ldx, const void* W, void* Q, long ldq, float* S, int rows, int d,
+                                 float eps, hipStream_t st);
 int owc_launch_quant_rows_fp8(const void* X, long ldx, void* Q, long ldq, float* S, int rows, int cols, hipStream_t st);
 int owc_launch_gemm_fp8(const void* A, long lda, const float* sa, const void* W, long ldw, const float* sw,
                         const void* bias, const void* R, long ldr, void* C, long ldc, int M, int N, int K, int epi,

@@ -119,19 +119,24 @@ static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache
   const bool fp8 = w->weight_dtype == OWC_WEIGHTS_FP8;
   // one decoder projection: bf16 weights -> owc_gemm_bf16; fp8 weights -> per-token quantisation of the input rows, then the
   // scaled-fp8-MFMA GEMM with the same fused epilogue
+  // (`in` == NULL: the rows are already in q8 / qs, put there by the fused RMSNorm + quantise kernel)
   auto linear = [&](const void* in, long ld_in, const void* wt, const float* ws, const void* bias, const void* res, void* out,
                     long ld_out, int N, int K, int epi) -> int {
     if (!fp8) return owc_launch_gemm_bf16(in, ld_in, wt, K, bias, res, ld_out, out, ld_out, T, N, K, epi, ctx->zeros, st);
-    OWC_TRY(owc_launch_quant_rows_fp8(in, ld_in, q8, K, qs, T, K, st));
+    if (in) OWC_TRY(owc_launch_quant_rows_fp8(in, ld_in, q8, K, qs, T, K, st));
     return owc_launch_gemm_fp8(q8, K, qs, wt, K, ws, bias, res, ld_out, out, ld_out, T, N, K, epi, st);
+  };
+  auto norm = [&](const void* gamma) -> int {  // h = rmsnorm(x) (bf16), or straight to e4m3 codes for the fp8 projections
+    if (fp8) return owc_launch_rmsnorm_quant_fp8(x, d, gamma, q8, d, qs, T, d, w->rms_eps, st);
+    return owc_launch_rmsnorm(x, d, gamma, h, d, T, d, w->rms_eps, nullptr, st);
   };
   for (int i = 0; i < w->n_layers; ++i) {
     const owc_llm_layer& L = w->layers[i];
     bf16_t* kc = (bf16_t*)cache->k + (size_t)i * layer_elems;
     bf16_t* vc = (bf16_t*)cache->v + (size_t)i * layer_elems;
     // self-attention block (HF:601-614)
-    OWC_TRY(owc_launch_rmsnorm(x, d, L.ln1_w, h, d, T, d, w->rms_eps, nullptr, st));
-    OWC_TRY(linear(h, d, L.qkv_w, L.qkv_s, L.qkv_b, nullptr, qkv, NQKV, NQKV, d, OWC_EPI_NONE));
+    OWC_TRY(norm(L.ln1_w));
+    OWC_TRY(linear(fp8 ? nullptr : h, d, L.qkv_w, L.qkv_s, L.qkv_b, nullptr, qkv, NQKV, NQKV, d, OWC_EPI_NONE));
     OWC_TRY(owc_launch_mrope_kv(qkv, NQKV, pos3, pos_stride, w->rope_cos, w->rope_sin, kc, vc, tok_slot,
                                 tok_idx, T, Hq, Hkv, cache->s_max, w->mrope_sec0, w->mrope_sec1, bcast_first, bcast_n, st));
     if (!decode) {
@@ -146,8 +151,8 @@ static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache
     }
     OWC_TRY(linear(attn, (long)Hq * hd, L.o_w, L.o_s, nullptr, x, x, d, d, Hq * hd, OWC_EPI_RESIDUAL));
     // MLP block (HF:617-620, :464-466)
-    OWC_TRY(owc_launch_rmsnorm(x, d, L.ln2_w, h, d, T, d, w->rms_eps, nullptr, st));
-    OWC_TRY(linear(h, d, L.gateup_w, L.gateup_s, nullptr, nullptr, mlp, F, 2 * F, d, OWC_EPI_SWIGLU));
+    OWC_TRY(norm(L.ln2_w));
+    OWC_TRY(linear(fp8 ? nullptr : h, d, L.gateup_w, L.gateup_s, nullptr, nullptr, mlp, F, 2 * F, d, OWC_EPI_SWIGLU));
     OWC_TRY(linear(mlp, F, L.down_w, L.down_s, nullptr, x, x, d, d, F, OWC_EPI_RESIDUAL));
   }
   return OWC_OK;

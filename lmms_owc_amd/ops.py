@@ -55,6 +55,16 @@ def quantize_rows_fp8(x, out=None, scale=None):
     return out, scale
 
 
+def rmsnorm_quant_fp8(x, w, eps):
+    """rmsnorm(x) quantised per token to e4m3fn without materialising the bf16 rows: (codes uint8 [rows, d], scales f32 [rows])."""
+    assert x.dtype == BF16 and w.dtype == BF16 and x.dim() == 2 and x.stride(1) == 1
+    rows, d = x.shape
+    q = torch.empty((rows, d), dtype=torch.uint8, device=x.device)
+    s = torch.empty(rows, dtype=F32, device=x.device)
+    _call("owc_rmsnorm_quant_fp8", _dev(x), x.data_ptr(), x.stride(0), w.data_ptr(), q.data_ptr(), q.stride(0), s.data_ptr(), rows, d, float(eps))
+    return q, s
+
+
 def gemm_fp8(a8, a_scale, w8, w_scale, bias=None, *, epilogue=EPI_NONE, residual=None, out=None):
     """``out[M,N] bf16 = epilogue((a8 @ w8.T) * a_scale[:, None] * w_scale[None, :] + bias)`` on the scaled fp8 MFMA."""
     assert a8.dtype == torch.uint8 and w8.dtype == torch.uint8 and a8.stride(1) == 1 and w8.stride(1) == 1

@@ -82,3 +82,15 @@ def test_fp8_quantisation_error_is_small(gpu):
     y8 = to_np(ops.gemm_fp8(xq, xs, wq, ws))
     rel = np.linalg.norm(y8 - y16) / np.linalg.norm(y16)
     assert rel < 0.06, rel   # e4m3 (3 mantissa bits) on both operands: ~2^-4 per element / sqrt statistics
+
+
+@pytest.mark.parametrize("rows,d", [(7, 256), (300, 1536), (65, 3584), (33, 8192)])
+def test_rmsnorm_quant_is_the_two_kernels_fused(gpu, rows, d):
+    """The fused RMSNorm + quantise kernel of the fp8 decoder is bit-identical to owc_rmsnorm_bf16 followed by owc_quantize_rows_fp8."""
+    from lmms_owc_amd import ops
+
+    x = bf16_randn((rows, d), rows + d, 2.0, gpu)
+    w = (1.0 + 0.1 * bf16_randn((d,), 3, 1.0, gpu).float()).to(torch.bfloat16)
+    q1, s1 = ops.quantize_rows_fp8(ops.rmsnorm(x, w, 1e-6))
+    q2, s2 = ops.rmsnorm_quant_fp8(x, w, 1e-6)
+    assert torch.equal(s1, s2) and torch.equal(q1, q2)

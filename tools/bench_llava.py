@@ -43,6 +43,7 @@ def main() -> None:
     ap.add_argument("--new-tokens", type=int, default=16)
     ap.add_argument("--image-size", default="480x640", help="HxW of the synthetic source images (anyres tiling depends on it)")
     ap.add_argument("--text-tokens", type=int, default=48)
+    ap.add_argument("--decoder-dtype", default="bf16", choices=["bf16", "fp8"])
     args = ap.parse_args()
     from lmms_owc_amd import _lib
     from lmms_owc_amd.engine import anyres
@@ -52,6 +53,10 @@ def main() -> None:
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
     d = DIMS[args.model]
+    if args.decoder_dtype != "bf16":
+        import dataclasses
+
+        d = dataclasses.replace(d, decoder_dtype=args.decoder_dtype)
     eng = LlavaEngine(LlavaWeights.random(d, device, seed=1234))
     h, w = (int(x) for x in args.image_size.split("x"))
     nv = anyres.num_views((h, w), d.grid_pinpoints, d.image_size) if d.grid_pinpoints else 1
@@ -79,7 +84,8 @@ def main() -> None:
     dt = time.perf_counter() - t0
     ms2, fl2, n2 = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int64 * 2)()
     _lib.check(lib.owc_gemm_profile_read(ctx, ms2, fl2, n2), 0)
-    ms, fl, n = C.c_double(ms2[0]), C.c_double(fl2[0]), C.c_int64(n2[0])
+    ms, fl, n = C.c_double(ms2[0] + ms2[1]), C.c_double(fl2[0] + fl2[1]), C.c_int64(n2[0] + n2[1])
+    fp8_tf = fl2[1] / (ms2[1] * 1e-3) / 1e12 if ms2[1] > 0 else None
     lib.owc_gemm_profile_enable(ctx, 0)
     assert out.shape == (B, T)
     ips = B * args.steps / dt
@@ -93,7 +99,7 @@ def main() -> None:
                       "roofline": {"bound": "mfma", "achieved": fl.value / (ms.value * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                                    "frac": fl.value / (ms.value * 1e-3) / PEAK, "share_of_step_time": ms.value * 1e-3 / dt,
                                    "launches": int(n.value)},
-                      "weights_gb": eng.w.nbytes() / 1e9}), flush=True)
+                      "decoder_dtype": args.decoder_dtype, "fp8_gemm_tflops": fp8_tf, "weights_gb": eng.w.nbytes() / 1e9}), flush=True)
 
 
 if __name__ == "__main__":
