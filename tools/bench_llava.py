@@ -90,7 +90,7 @@ def main() -> None:
     assert out.shape == (B, T)
     ips = B * args.steps / dt
     f = flops(d, nv, S, T)
-    print(json.dumps({"metric": f"images/s {args.model} open-world classify (1 GPU)", "value": ips, "unit": "images/s", "dtype": "bf16",
+    print(json.dumps({"metric": f"images/s {args.model} open-world classify (1 GPU)", "value": ips, "unit": "images/s", "dtype": "bf16" if args.decoder_dtype == "bf16" else "fp8-e4m3 decoder projections, bf16 elsewhere",
                       "data": "synthetic", "ms_per_step": dt / args.steps * 1e3,
                       "config": {"workload": f"{args.model}: {B} synthetic {h}x{w} images per step, {nv} CLIP view(s) of {d.image_size}px each, "
                                              f"prompt S={S} ({len(rows[0])} image tokens), {T} forced greedy tokens, random weights",
