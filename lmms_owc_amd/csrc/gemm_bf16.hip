@@ -254,13 +254,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
   // 16 MFMAs: rows half mh of the wave tile, all 4 n tiles, one 32-deep k-step
   auto phase = [&](const bf16x8 (&af)[4], const bf16x8 (&wf)[4], int mh) {
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int m = 0; m < 4; ++m)
         acc[n][mh * 4 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], af[m], acc[n][mh * 4 + m], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -270,18 +268,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
+  #pragma unroll
       for (int m = 0; m < 4; ++m)
         acc[n][mh * 4 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], af[m], acc[n][mh * 4 + m], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
       if (issue) stage_piece(buf, kt2, n);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 
   setup(blockIdx.x);
+  // static priority for the second-dispatched half (the arbitration loser of every SIMD pair), no per-phase flips: +1 % on the
+  // decoder shapes against per-phase s_setprio around the MFMA groups (interleaved A/B of two builds on one device)
+  if (w >= 4) __builtin_amdgcn_s_setprio(1);
   stage(0, 0);
   if (nk > 1) {
     stage(1, 1);
