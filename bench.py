@@ -309,7 +309,12 @@ def main() -> None:
             "roofline": {"bound": "mfma", "kernel": "gemm_fp8_nt_256_kernel (decoder projections)" if fp8_run else "gemm_bf16_nt_kernel (all epilogues)",
                          "achieved": gemm_tflops, "peak": PEAK_FP8_TFLOPS if fp8_run else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": gemm_tflops / (PEAK_FP8_TFLOPS if fp8_run else PEAK_BF16_TFLOPS),
-                         "traffic": None, "launches": int(n_launch.value), "kernel_ms_total": ms.value,
+                         "traffic": None,
+                         "traffic_note": "not collectable inside this process (PMC passes serialise ~24k launches); separate rocprofv3 --pmc pass on the "
+                                         "largest GEMM of the step (7b gate/up, M 18304 N 37888 K 3584), profiles/r01_pmc_gemm_summary.json: FETCH_SIZE x2 "
+                                         "(gfx950 correction) = 7.6 GB per launch against 1.1 GB algorithmic (A + W + C once): the panels of a 4x8-tile XCD "
+                                         "patch do not fit the 4 MB L2 across patches, 78 % L2 hit = compulsory floor (DESIGN.md section 4 notes)",
+                         "launches": int(n_launch.value), "kernel_ms_total": ms.value,
                          "share_of_step_time": ms.value * 1e-3 / (time_or(dt)), "method":
                              "HIP events around every launch of the timed region on the launch stream; achieved = sum(2MNK) / sum(t)"},
         }

@@ -38,7 +38,20 @@ def main():
         ops.attention(q, (Hq + 2 * Hkv) * 128, 128, kc, 128, smax * 128, vc, 128, smax * 128, o2, Hq * 128, 128, st2, kst2, ln2,
                       n_seq=nb, n_heads=Hq, kv_group=Hq // Hkv, head_dim=128, max_q_len=S, causal=True, scale=128 ** -0.5)
 
-    for name, fn, flops in (("vit hd80 64x1024", vit, 4.0 * n * H * L * L * hd), ("prefill hd128 114x286 causal", prefill, 2.0 * nb * Hq * S * S * 128)):
+    # LLaVA-NeXT-34B prefill: 24 prompts x 2388, 56 q heads / 8 kv heads x 128
+    nb3, S3, Hq3, Hkv3 = 24, 2388, 56, 8
+    q3 = torch.randn(nb3 * S3, (Hq3 + 2 * Hkv3) * 128, device=dev).to(torch.bfloat16)
+    kc3 = torch.randn(nb3, Hkv3, S3 + 16, 128, device=dev).to(torch.bfloat16)
+    vc3 = torch.randn(nb3, Hkv3, S3 + 16, 128, device=dev).to(torch.bfloat16)
+    o3 = torch.empty(nb3 * S3, Hq3 * 128, device=dev, dtype=torch.bfloat16)
+    st3, kst3, ln3 = i32(np.arange(nb3) * S3, dev), i32(np.arange(nb3) * Hkv3 * (S3 + 16), dev), i32(np.full(nb3, S3), dev)
+
+    def prefill_long():
+        ops.attention(q3, (Hq3 + 2 * Hkv3) * 128, 128, kc3, 128, (S3 + 16) * 128, vc3, 128, (S3 + 16) * 128, o3, Hq3 * 128, 128, st3, kst3,
+                      ln3, n_seq=nb3, n_heads=Hq3, kv_group=Hq3 // Hkv3, head_dim=128, max_q_len=S3, causal=True, scale=128 ** -0.5)
+
+    for name, fn, flops in (("vit hd80 64x1024", vit, 4.0 * n * H * L * L * hd), ("prefill hd128 114x286 causal", prefill, 2.0 * nb * Hq * S * S * 128),
+                            ("prefill hd128 24x2388 causal (llava-34b)", prefill_long, 2.0 * nb3 * Hq3 * S3 * S3 * 128)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -49,7 +62,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
-        print(f"{name:32s} {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s", flush=True)
+        print(f"{name:42s} {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":
