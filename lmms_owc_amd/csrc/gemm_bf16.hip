@@ -42,6 +42,7 @@ struct GemmProfile {
 GemmProfile g_prof;
 int g_gemm_dbg = 0;       // timing-experiment knob (OWC_GEMM_DBG / owc_tuning_set "gemm_dbg"), results are garbage unless 0 or 512:
                           // 1 no DMA, 2 DMA re-reads K-tiles 0/1 (all L2 hits), 4 no epilogue, 512 direct (un-staged) epilogue stores
+int g_skinny_max_m = 64;   // M at and below which the weight-streaming skinny kernel runs (0 disables: A-B knob "gemm_skinny_max_m")
 int g_big_min_tiles = 192;  // fewer 256x256 tiles than this -> use the 128x128 kernel
 int g_big_min_m = 1024;  // M at and above which the 256x128 3-stage kernel is used (OWC_GEMM_BIG_MIN_M)
 
@@ -343,6 +344,132 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
 }
 
 
+
+// ------------------------------------------------------------------------------------------------
+// Skinny-M variant (M <= 64: greedy decode at the reference's own batch sizes, 1 ... a few dozen sequences).  There the
+// GEMM is a weight STREAM: every byte of W is read once per step, the arithmetic is nothing, and the tiled kernels above
+// leave most CUs idle (the o / down projections of the 7B decoder are 28 tiles wide).  Here ONE WAVE owns 16 rows of W
+// (32 for SwiGLU: the gate and the up rows of the same 16 features) over the whole K: W fragments go global -> registers
+// (16 B per lane, no LDS, no barrier) through a ring of DEPTH 128-wide super-steps kept in flight, the activations (a few
+// KB, L1 / L2 resident) are fetched per super-step.  Every output element is ONE MFMA accumulation chain over K in
+// ascending order with the same operand roles as the tiled kernels, so the result is bit-identical to theirs: which kernel
+// ran never shows in the output (batch invariance across decode batch sizes and against the prefill).
+// Requires K % 128 == 0, N % 16 == 0 (32 for SwiGLU).
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int MT, int DEPTH>
+__global__ __launch_bounds__(64) void gemm_bf16_skinny_kernel(
+    const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw, const bf16_t* __restrict__ bias,
+    const bf16_t* R, long ldr, bf16_t* C, long ldc, int M, int N, int K) {
+  constexpr int NT = EPI == OWC_EPI_SWIGLU ? 2 : 1;
+  const int l = threadIdx.x;
+  const int fr = l & 15, fq = l >> 4;
+  const int n0 = blockIdx.x * (16 * NT);
+  const int nss = K >> 7;  // 128-wide super-steps
+
+  const bf16_t* wrow[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) wrow[nt] = W + (long)(n0 + nt * 16 + fr) * ldw + fq * 8;
+  const bf16_t* arow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) arow[mt] = A + (long)min(mt * 16 + fr, M - 1) * lda + fq * 8;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // rings only ever indexed with compile-time constants (the ring loop below is fully unrolled).  A super-step is 4 * MT * NT
+  // MFMAs, far shorter than an L2 hit, so the activations ride the same ring as the weights.
+  bf16x8 ring[DEPTH][NT][4];
+  bf16x8 xring[DEPTH][MT][4];
+  auto load_w = [&](int i, int ss) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) ring[i][nt][ks] = *(const bf16x8*)(wrow[nt] + ss * 128 + ks * 32);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) xring[i][mt][ks] = *(const bf16x8*)(arow[mt] + ss * 128 + ks * 32);
+  };
+  auto compute = [&](int i, int ss) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[i][nt][ks], xring[i][mt][ks], acc[mt][nt], 0, 0, 0);
+  };
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i)
+    if (i < nss) load_w(i, i);
+  for (int base = 0; base < nss; base += DEPTH) {
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) {
+      const int ss = base + i;
+      if (ss < nss) {
+        compute(i, ss);
+        if (ss + DEPTH < nss) load_w(i, ss + DEPTH);
+      }
+    }
+  }
+  // lane holds row m = 16 mt + fr, columns n0 + 16 nt + 4 fq .. +3
+  if constexpr (EPI == OWC_EPI_SWIGLU) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mt * 16 + fr;
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf(rbf(act_silu(rbf(acc[mt][0][e]))) * rbf(acc[mt][1][e]));
+      if (m < M) *(bf16x4*)(C + (long)m * ldc + (n0 >> 1) + fq * 4) = o;
+    }
+  } else {
+    const int n = n0 + fq * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) {
+      const bf16x4 b = *(const bf16x4*)(bias + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = bf2f(b[e]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mt * 16 + fr;
+      bf16x4 o;
+      if constexpr (EPI == OWC_EPI_RESIDUAL) {
+        const bf16x4 r = *(const bf16x4*)(R + (long)min(m, M - 1) * ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(rbf(acc[mt][0][e] + bv[e]) + bf2f(r[e]));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[mt][0][e] + bv[e]);
+      }
+      if (m < M) *(bf16x4*)(C + (long)m * ldc + n) = o;
+    }
+  }
+}
+
+template <int EPI>
+bool launch_skinny(const void* A, long lda, const void* W, long ldw, const void* bias, const void* R, long ldr, void* C,
+                   long ldc, int M, int N, int K, hipStream_t s) {
+  if constexpr (EPI == OWC_EPI_NONE || EPI == OWC_EPI_RESIDUAL || EPI == OWC_EPI_SWIGLU) {  // what a decoder step needs
+    constexpr int ROWS = EPI == OWC_EPI_SWIGLU ? 32 : 16;
+    if (M > 64 || (K & 127) || (N % ROWS) || g_skinny_max_m < M) return false;
+    const dim3 grid(N / ROWS), block(64);
+#define OWC_SK(MT_, D_)                                                                                               \
+  hipLaunchKernelGGL((gemm_bf16_skinny_kernel<EPI, MT_, D_>), grid, block, 0, s, (const bf16_t*)A, lda, (const bf16_t*)W, \
+                     ldw, (const bf16_t*)bias, (const bf16_t*)R, ldr, (bf16_t*)C, ldc, M, N, K)
+    constexpr int NT_ = EPI == OWC_EPI_SWIGLU ? 2 : 1;
+    // super-steps in flight per wave: 16 VGPRs each per (n tile + m tile), about 192 VGPRs of ring in all
+    if (M <= 16) OWC_SK(1, 12 / (NT_ + 1)); else if (M <= 32) OWC_SK(2, 12 / (NT_ + 2)); else if (M <= 48) OWC_SK(3, 12 / (NT_ + 3));
+    else OWC_SK(4, 2);
+#undef OWC_SK
+    return true;
+  }
+  return false;
+}
+
 template <int EPI>
 int launch(const void* A, long lda, const void* W, long ldw, const void* bias, const void* R,
            long ldr, void* C, long ldc, int M, int N, int K, const void* zeros, hipStream_t s,
@@ -362,6 +489,10 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
     attr_set = true;
   }
   const int prof = owc_gemm_profile_begin(2.0 * (double)M * (double)N * (double)K, 0, s);
+  if (launch_skinny<EPI>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, s)) {
+    owc_gemm_profile_end(prof, s);
+    return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+  }
   if (big)
     hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), 2 * STAGE_BYTES, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
@@ -470,3 +601,4 @@ int owc_gemm_profile_collect(double* total_ms, double* total_flops, long* launch
 
 void owc_gemm_set_big_min_m(int m) { g_big_min_m = m; }
 void owc_gemm_set_dbg(int v) { g_gemm_dbg = v; }
+void owc_gemm_set_skinny_max_m(int v) { g_skinny_max_m = v; }

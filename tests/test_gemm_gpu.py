@@ -129,3 +129,49 @@ def test_gemm_epilogues_large_kernel(gpu, epi):
             atol = 2.0**-7 * float(np.abs(y).max())
     torch.cuda.synchronize()
     assert_bf16_close(to_np(out), want, ulps=4.0, min_exact=0.80, atol=atol)
+
+
+@pytest.mark.parametrize("m", [1, 7, 16, 17, 33, 64])
+@pytest.mark.parametrize("epi", ["bias", "residual", "swiglu"])
+def test_gemm_skinny_kernel(gpu, m, epi):
+    """M <= 64 with K % 128 == 0, N % 16 == 0 runs the weight-streaming kernel (decode at small batch): same oracle, and the
+    result is BIT-IDENTICAL to the tiled kernel's (one ascending MFMA accumulation chain per output in both) and independent
+    of M (batch invariance)."""
+    from lmms_owc_amd import _lib, ops
+
+    n, k = 1216, 3584
+    a = bf16_randn((m, k), 40 + m, device=gpu)
+    b = bf16_randn((n,), 6, device=gpu)
+    lib = _lib.load()
+    if epi == "swiglu":
+        f = n // 2
+        wg = bf16_randn((f, k), 8, 0.03, device=gpu)
+        wu = bf16_randn((f, k), 9, 0.03, device=gpu)
+        w = torch.stack([wg.view(f // 16, 16, k), wu.view(f // 16, 16, k)], dim=1).reshape(n, k).contiguous()
+        run = lambda x: ops.gemm_bf16(x, w, None, epilogue=_lib.EPI_SWIGLU)  # noqa: E731
+        g = np_ops.linear(to_np(a), to_np(wg), bf16=True)
+        u = np_ops.linear(to_np(a), to_np(wu), bf16=True)
+        want = np_ops.bf16_round(np_ops.silu(g, bf16=True) * u)
+        atol = 2.0 ** -7 * float(np.abs(want).max())   # a product of two rounded factors: one ulp of the largest output
+    else:
+        w = bf16_randn((n, k), 5, 0.03, device=gpu)
+        y = _oracle(a, w, b)
+        if epi == "residual":
+            r = bf16_randn((m, n), 7, device=gpu)
+            run = lambda x: ops.gemm_bf16(x, w, b, epilogue=_lib.EPI_RESIDUAL, residual=r[: x.shape[0]])  # noqa: E731
+            want = np_ops.bf16_round(to_np(r) + y)
+            atol = 2.0 ** -7 * float(np.abs(y).max())
+        else:
+            run = lambda x: ops.gemm_bf16(x, w, b)  # noqa: E731
+            want, atol = y, 1e-4
+    out = to_np(run(a))
+    assert_bf16_close(out, want, ulps=4.0, min_exact=0.80, atol=atol)
+    # the tiled kernel on the same operands (skinny kernel switched off)
+    lib.owc_tuning_set(b"gemm_skinny_max_m", 0)
+    try:
+        tiled = to_np(run(a))
+    finally:
+        lib.owc_tuning_set(b"gemm_skinny_max_m", 64)
+    assert np.array_equal(out, tiled)
+    # row 0 alone gives the same bits as row 0 inside the batch
+    assert np.array_equal(to_np(run(a[:1]))[0], out[0])

@@ -1,0 +1,29 @@
+"""Per-token decode latency of the 7B decoder at small batch sizes (the reference's default is batch size 1)."""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from lmms_owc_amd.engine.qwen2vl import DIMS, Qwen2VLEngine, Qwen2VLWeights  # noqa: E402
+
+dev = torch.device("cuda:0")
+d = DIMS[sys.argv[1] if len(sys.argv) > 1 else "qwen2-vl-7b"]
+eng = Qwen2VLEngine(Qwen2VLWeights.random(d, dev, seed=1))
+r = np.random.default_rng(0)
+for B in ([int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (1, 4, 16, 64, 256)):
+    prompts = [r.integers(1000, 30000, 286).astype(np.int32) for _ in range(B)]
+    ts = {}
+    for T in (2, 34):
+        eng.generate(prompts, None, [[] for _ in prompts], T)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eng.generate(prompts, None, [[] for _ in prompts], T)
+        torch.cuda.synchronize()
+        ts[T] = (time.perf_counter() - t0) / 3
+    per_tok = (ts[34] - ts[2]) / 32
+    wbytes = eng.w.nbytes() - 2 * d.vocab * d.d_model * (0 if d.tie_embeddings else 1)
+    print(f"B={B:4d}  {per_tok * 1e3:7.3f} ms/token-step  ({B / per_tok:9.1f} tok/s)  weight stream {wbytes / per_tok / 1e12:5.2f} TB/s", flush=True)
