@@ -19,7 +19,10 @@ int owc_abi_version(void) { return 9; }
 
 int owc_tuning_set(const char* name, int value) {
   if (!name) return OWC_ERR_ARG;
-  if (!strcmp(name, "gemm_skinny_max_m")) owc_gemm_set_skinny_max_m(value);
+  if (!strcmp(name, "gemm_skinny_max_m")) {
+    owc_gemm_set_skinny_max_m(value);
+    owc_gemm_fp8_set_skinny_max_m(value);
+  }
   else if (!strcmp(name, "gemm_big_min_m")) owc_gemm_set_big_min_m(value);
   else if (!strcmp(name, "gemm_dbg")) owc_gemm_set_dbg(value);
   else if (!strcmp(name, "attn_dbg")) owc_attn_set_dbg(value);

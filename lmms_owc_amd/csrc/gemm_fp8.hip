@@ -22,6 +22,7 @@ constexpr int BT = 256, BKB = 128;                 // tile edge, K-tile in BYTES
 constexpr int OP_BYTES = BT * BKB;                 // 32 KiB per operand per stage
 constexpr int STAGE_BYTES = 2 * OP_BYTES;
 constexpr int GROUP_M2 = 4;
+int g_fp8_skinny_max_m = 64;  // follows the "gemm_skinny_max_m" knob
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;
 
 // ---- row quantiser: one wave per row, the row cached in registers (bf16x8 chunks) ----
@@ -168,7 +169,10 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256_kernel(
   const int swz = (fr >> 1) & 7;
   const int rowA = (wr * 128 + fr) * 128;
   const int rowW = OP_BYTES + (wc * 64 + fr) * 128;
-  const int chlo = ((2 * fq) ^ swz) << 4, chhi = ((2 * fq + 1) ^ swz) << 4;  // the lane's 32 K bytes = two 16-B chunks
+  // the lane's 32 operand bytes = 16-B chunks fq and 4 + fq of the 128-byte K-tile row (any fixed pairing of bytes with operand
+  // slots works as long as A and W use the same one; this one makes a wave-instruction of the skinny kernel below read 64
+  // contiguous bytes per row, and both kernels must agree to stay bit-identical)
+  const int chlo = (fq ^ swz) << 4, chhi = ((4 + fq) ^ swz) << 4;
 
   f32x4 acc[4][8];  // [nt][mt]
   i32x8 xa[2], ya[2], wk[4];  // A fragments of two m tiles (double-buffered), W fragments of the K-tile
@@ -268,6 +272,116 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256_kernel(
                  EPI == OWC_EPI_SWIGLU ? (N >> 1) : N, w, l);
 }
 
+
+// ---- skinny-M variant (M <= 64, decode at small batch): the fp8 twin of gemm_bf16_skinny_kernel.  One wave owns 16 rows of W8
+// (32 for SwiGLU) over the whole K; a super-step is 128 fp8 elements = 32 bytes per lane and ONE scaled MFMA per (m tile, n
+// tile); weights and activation codes ride a fully unrolled register ring.  One ascending accumulation chain per output, same
+// operand roles as the tiled kernel: bit-identical to it.
+template <int EPI, int MT, int DEPTH>
+__global__ __launch_bounds__(64) void gemm_fp8_skinny_kernel(
+    const uint8_t* __restrict__ A, long lda, const float* __restrict__ SA, const uint8_t* __restrict__ W, long ldw,
+    const float* __restrict__ SW, const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, bf16_t* C, long ldc, int M,
+    int N, int K) {
+  constexpr int NT = EPI == OWC_EPI_SWIGLU ? 2 : 1;
+  const int l = threadIdx.x;
+  const int fr = l & 15, fq = l >> 4;
+  const int n0 = blockIdx.x * (16 * NT);
+  const int nss = K >> 7;
+  const uint8_t* wrow[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) wrow[nt] = W + (long)(n0 + nt * 16 + fr) * ldw + fq * 16;
+  const uint8_t* arow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) arow[mt] = A + (long)min(mt * 16 + fr, M - 1) * lda + fq * 16;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  i32x8 ring[DEPTH][NT], xring[DEPTH][MT];
+  auto ld32 = [&](const uint8_t* p) -> i32x8 {
+    const i32x4 lo = *(const i32x4*)p, hi = *(const i32x4*)(p + 64);  // chunks fq and 4 + fq, as in the tiled kernel
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto load = [&](int i, int ss) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) ring[i][nt] = ld32(wrow[nt] + ss * 128);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xring[i][mt] = ld32(arow[mt] + ss * 128);
+  };
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i)
+    if (i < nss) load(i, i);
+  for (int base = 0; base < nss; base += DEPTH) {
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) {
+      const int ss = base + i;
+      if (ss < nss) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ring[i][nt], xring[i][mt], acc[mt][nt], 0, 0, 0, 0x7f, 0, 0x7f);
+        if (ss + DEPTH < nss) load(i, ss + DEPTH);
+      }
+    }
+  }
+  // dequantise + epilogue: lane holds row m = 16 mt + fr, columns n0 + 16 nt + 4 fq .. +3
+  f32x4 swv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) swv[nt] = *(const f32x4*)(SW + n0 + nt * 16 + fq * 4);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mt * 16 + fr;
+    const float sa = SA[min(m, M - 1)];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[mt][nt][e] = acc[mt][nt][e] * sa * swv[nt][e];
+    bf16x4 o;
+    if constexpr (EPI == OWC_EPI_SWIGLU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf(rbf(act_silu(rbf(acc[mt][0][e]))) * rbf(acc[mt][1][e]));
+      if (m < M) *(bf16x4*)(C + (long)m * ldc + (n0 >> 1) + fq * 4) = o;
+    } else {
+      const int n = n0 + fq * 4;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias != nullptr) {
+        const bf16x4 b = *(const bf16x4*)(bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = bf2f(b[e]);
+      }
+      if constexpr (EPI == OWC_EPI_RESIDUAL) {
+        const bf16x4 r = *(const bf16x4*)(R + (long)min(m, M - 1) * ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(rbf(acc[mt][0][e] + bv[e]) + bf2f(r[e]));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[mt][0][e] + bv[e]);
+      }
+      if (m < M) *(bf16x4*)(C + (long)m * ldc + n) = o;
+    }
+  }
+}
+
+template <int EPI>
+bool launch_fp8_skinny(const void* A, long lda, const float* sa, const void* W, long ldw, const float* sw, const void* bias,
+                       const void* R, long ldr, void* C, long ldc, int M, int N, int K, hipStream_t s) {
+  constexpr int ROWS = EPI == OWC_EPI_SWIGLU ? 32 : 16;
+  if (M > 64 || (N % ROWS) || g_fp8_skinny_max_m < M) return false;
+  const dim3 grid(N / ROWS), block(64);
+#define OWC_SK8(MT_, D_)                                                                                               \
+  hipLaunchKernelGGL((gemm_fp8_skinny_kernel<EPI, MT_, D_>), grid, block, 0, s, (const uint8_t*)A, lda, sa,              \
+                     (const uint8_t*)W, ldw, sw, (const bf16_t*)bias, (const bf16_t*)R, ldr, (bf16_t*)C, ldc, M, N, K)
+  constexpr int NT_ = EPI == OWC_EPI_SWIGLU ? 2 : 1;
+  // 8 VGPRs per (n tile + m tile) per super-step in flight, about 192 VGPRs of ring
+  if (M <= 16) OWC_SK8(1, 24 / (NT_ + 1)); else if (M <= 32) OWC_SK8(2, 24 / (NT_ + 2)); else if (M <= 48) OWC_SK8(3, 24 / (NT_ + 3));
+  else OWC_SK8(4, 24 / (NT_ + 4));
+#undef OWC_SK8
+  return true;
+}
+
 template <int EPI>
 int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw, const float* sw, const void* bias,
                const void* R, long ldr, void* C, long ldc, int M, int N, int K, hipStream_t s) {
@@ -281,6 +395,10 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
   const int tiles_m = (M + BT - 1) / BT, tiles_n = (N + BT - 1) / BT;
   const owc_gemm_aux aux = {nullptr, nullptr, nullptr, 0, 8};
   const int prof = owc_gemm_profile_begin(2.0 * (double)M * (double)N * (double)K, 1, s);
+  if (launch_fp8_skinny<EPI>(A, lda, sa, W, ldw, sw, bias, R, ldr, C, ldc, M, N, K, s)) {
+    owc_gemm_profile_end(prof, s);
+    return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+  }
   hipLaunchKernelGGL(gemm_fp8_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), LDS_BYTES, s,
                      (const uint8_t*)A, lda, sa, (const uint8_t*)W, ldw, sw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C,
                      ldc, M, N, K, tiles_m, tiles_n, aux);
@@ -289,6 +407,8 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
 }
 
 }  // namespace
+
+void owc_gemm_fp8_set_skinny_max_m(int v) { g_fp8_skinny_max_m = v; }
 
 int owc_launch_quant_rows_fp8(const void* X, long ldx, void* Q, long ldq, float* S, int rows, int cols, hipStream_t st) {
   if (rows <= 0 || cols <= 0 || (cols & 7) || (ldx & 7) || (ldq & 7) || cols > 16 * 256 * 8) return OWC_ERR_SHAPE;

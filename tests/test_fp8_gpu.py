@@ -94,3 +94,38 @@ def test_rmsnorm_quant_is_the_two_kernels_fused(gpu, rows, d):
     q1, s1 = ops.quantize_rows_fp8(ops.rmsnorm(x, w, 1e-6))
     q2, s2 = ops.rmsnorm_quant_fp8(x, w, 1e-6)
     assert torch.equal(s1, s2) and torch.equal(q1, q2)
+
+
+@pytest.mark.parametrize("m", [1, 16, 33, 64])
+@pytest.mark.parametrize("epi", ["bias", "res", "swiglu"])
+def test_gemm_fp8_skinny_kernel(gpu, m, epi):
+    """M <= 64 runs the weight-streaming fp8 kernel (decode at small batch): oracle parity, BIT-IDENTICAL to the tiled fp8 kernel,
+    and row 0 alone equals row 0 inside the batch."""
+    from lmms_owc_amd import _lib, ops
+    from lmms_owc_amd.engine.qwen2vl import interleave_gate_up
+
+    n, k = 1216, 3584
+    lib = _lib.load()
+    x = bf16_randn((m, k), 70 + m, 1.0, gpu)
+    w = bf16_randn((n, k), 71, 0.03, gpu)
+    xq, xs = ops.quantize_rows_fp8(x)
+    wq, ws = ops.quantize_rows_fp8(w)
+    bias = bf16_randn((n,), 5, 0.5, gpu) if epi == "bias" else None
+    r = bf16_randn((m, n), 9, 1.0, gpu) if epi == "res" else None
+    if epi == "swiglu":
+        f = n // 2
+        wq = interleave_gate_up(wq[:f].view(torch.int8), wq[f:].view(torch.int8)).view(torch.uint8)
+        ws = interleave_gate_up(ws[:f, None], ws[f:, None])[:, 0].contiguous()
+    kw = dict(epilogue={"bias": _lib.EPI_NONE, "res": _lib.EPI_RESIDUAL, "swiglu": _lib.EPI_SWIGLU}[epi])
+    run = lambda q, s_, rr: ops.gemm_fp8(q, s_, wq, ws, bias, residual=rr, **kw)  # noqa: E731
+    out = run(xq, xs, r)
+    lib.owc_tuning_set(b"gemm_skinny_max_m", 0)
+    try:
+        tiled = run(xq, xs, r)
+    finally:
+        lib.owc_tuning_set(b"gemm_skinny_max_m", 64)
+    assert torch.equal(out, tiled)
+    assert torch.equal(run(xq[:1], xs[:1], None if r is None else r[:1])[0], out[0])
+    if epi == "bias":
+        want = F.linear_fp8(None, wq.cpu().numpy(), to_np(ws), to_np(bias), xq=xq.cpu().numpy(), xs=to_np(xs))
+        assert_bf16_close(to_np(out), want, ulps=2.0, min_exact=0.95, atol=2.0 ** -9 * np.abs(want).max())

@@ -11,6 +11,10 @@ from lmms_owc_amd.engine.qwen2vl import DIMS, Qwen2VLEngine, Qwen2VLWeights  # n
 
 dev = torch.device("cuda:0")
 d = DIMS[sys.argv[1] if len(sys.argv) > 1 else "qwen2-vl-7b"]
+if len(sys.argv) > 3:  # decoder dtype: bf16 | fp8
+    import dataclasses
+
+    d = dataclasses.replace(d, decoder_dtype=sys.argv[3])
 eng = Qwen2VLEngine(Qwen2VLWeights.random(d, dev, seed=1))
 r = np.random.default_rng(0)
 for B in ([int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (1, 4, 16, 64, 256)):
