@@ -277,12 +277,15 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
  *   pos: int32[B] rope position of the fed token (same for the 3 mrope streams);
  *   slot/write_idx/k_start/k_len/q_start/o_start/q_len: int32[B] cache addressing
  *     (k_len = write_idx + 1; q_start[b] = b * (Hq + 2 Hkv); o_start[b] = b * Hq; q_len[b] = Hq / Hkv);
- *   done: uint8[B]; out_tokens[b * out_stride + step] receives the emitted token. */
+ *   done: uint8[B]; out_tokens[b * out_stride + step] receives the emitted token.
+ *   step_state (optional, int32[1] on the device): when non-NULL the output column is read from step_state[0] (`step` is
+ *     ignored) and, after the step, pos[b], write_idx[b], k_len[b] and step_state[0] are incremented IN PLACE, so that
+ *     consecutive decode steps are byte-identical launch sequences: capture one in a hipGraph and replay it. */
 int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* cache,
-                        int32_t* tok_io, const int32_t* pos, const int32_t* slot,
-                        const int32_t* write_idx, const int32_t* k_start, const int32_t* k_len,
+                        int32_t* tok_io, int32_t* pos, const int32_t* slot,
+                        int32_t* write_idx, const int32_t* k_start, int32_t* k_len,
                         const int32_t* q_start, const int32_t* o_start, const int32_t* q_len,
-                        uint8_t* done, int32_t* out_tokens, int out_stride, int step, int B,
+                        uint8_t* done, int32_t* out_tokens, int out_stride, int step, int32_t* step_state, int B,
                         int eos_id0, int eos_id1, int pad_id, void* logits_out, void* workspace,
                         size_t ws_bytes, void* stream);
 

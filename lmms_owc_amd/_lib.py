@@ -20,7 +20,7 @@ _lock = threading.Lock()
 _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = range(6)
 
@@ -126,7 +126,7 @@ SIGNATURES: dict[str, tuple] = {
     "owc_llm_prefill": (i32, [vp, C.POINTER(LlmWeights), C.POINTER(KvCache), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                               i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "owc_llm_decode_step": (i32, [vp, C.POINTER(LlmWeights), C.POINTER(KvCache), vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                                  vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
+                                  vp, vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "owc_decode_update": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "owc_bert_workspace_bytes": (sz, [C.POINTER(BertWeights), i32, i32]),
     "owc_bert_embed": (i32, [vp, C.POINTER(BertWeights), vp, vp, i32, i32, vp, vp, sz, vp]),

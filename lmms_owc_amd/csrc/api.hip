@@ -15,7 +15,7 @@
 
 extern "C" {
 
-int owc_abi_version(void) { return 9; }
+int owc_abi_version(void) { return 10; }
 
 int owc_tuning_set(const char* name, int value) {
   if (!name) return OWC_ERR_ARG;
@@ -163,7 +163,7 @@ int owc_decode_update(owc_ctx* ctx, int32_t* next_tok, uint8_t* done, int32_t* o
                       void* stream) {
   if (!ctx || !next_tok || !done || !out_tokens) return OWC_ERR_ARG;
   RET(ctx, "owc_decode_update",
-      owc_launch_decode_update(next_tok, done, out_tokens, out_stride, step, B, eos_id0, eos_id1, pad_id, ST(stream)));
+      owc_launch_decode_update(next_tok, done, out_tokens, out_stride, step, nullptr, B, eos_id0, eos_id1, pad_id, ST(stream)));
 }
 
 int owc_gemm_profile_enable(owc_ctx* ctx, int on) {

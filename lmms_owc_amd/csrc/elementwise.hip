@@ -310,15 +310,29 @@ __global__ __launch_bounds__(256) void argmax_kernel(const bf16_t* __restrict__ 
 
 // Decode bookkeeping (HF GenerationMixin greedy loop): finished sequences emit pad, EOS marks done.
 __global__ void decode_update_kernel(int* __restrict__ next_tok, uint8_t* __restrict__ done,
-                                     int* __restrict__ out_tokens, int out_stride, int step, int B,
-                                     int eos0, int eos1, int pad) {
+                                     int* __restrict__ out_tokens, int out_stride, int step,
+                                     const int* __restrict__ step_state, int B, int eos0, int eos1, int pad) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  if (step_state) step = step_state[0];  // graph-replayed decode: the column lives on the device
   int t = next_tok[b];
   if (done[b]) t = pad;
   out_tokens[(long)b * out_stride + step] = t;
   if (t == eos0 || t == eos1) done[b] = 1;
   next_tok[b] = t;
+}
+
+// Graph-replayed decode: advance the per-sequence rope position / cache write index / key count and the output column on
+// the device, so the next step is the same launch sequence with the same arguments.
+__global__ void decode_advance_kernel(int* __restrict__ pos, int* __restrict__ widx, int* __restrict__ klen,
+                                      int* __restrict__ step_state, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) {
+    pos[b] += 1;
+    widx[b] += 1;
+    klen[b] += 1;
+  }
+  if (b == 0) step_state[0] += 1;
 }
 
 // uint8 CHW image -> normalised, patchified pixel_values row (HF Qwen2VLImageProcessor._preprocess,
@@ -519,9 +533,14 @@ int owc_launch_argmax(const void* logits, long ld, int rows, int V, int* out, hi
 }
 
 int owc_launch_decode_update(int* next_tok, uint8_t* done, int* out_tokens, int out_stride, int step,
-                             int B, int eos0, int eos1, int pad, hipStream_t st) {
+                             const int* step_state, int B, int eos0, int eos1, int pad, hipStream_t st) {
   hipLaunchKernelGGL(decode_update_kernel, dim3((B + 255) / 256), dim3(256), 0, st, next_tok, done,
-                     out_tokens, out_stride, step, B, eos0, eos1, pad);
+                     out_tokens, out_stride, step, step_state, B, eos0, eos1, pad);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_decode_advance(int* pos, int* widx, int* klen, int* step_state, int B, hipStream_t st) {
+  hipLaunchKernelGGL(decode_advance_kernel, dim3((B + 255) / 256), dim3(256), 0, st, pos, widx, klen, step_state, B);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 

@@ -205,10 +205,10 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
 }
 
 int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* cache,
-                        int32_t* tok_io, const int32_t* pos, const int32_t* slot,
-                        const int32_t* write_idx, const int32_t* k_start, const int32_t* k_len,
+                        int32_t* tok_io, int32_t* pos, const int32_t* slot,
+                        int32_t* write_idx, const int32_t* k_start, int32_t* k_len,
                         const int32_t* q_start, const int32_t* o_start, const int32_t* q_len,
-                        uint8_t* done, int32_t* out_tokens, int out_stride, int step, int B,
+                        uint8_t* done, int32_t* out_tokens, int out_stride, int step, int32_t* step_state, int B,
                         int eos_id0, int eos_id1, int pad_id, void* logits_out, void* workspace,
                         size_t ws_bytes, void* stream) {
   if (!ctx || !w || !cache || !tok_io || !pos || !slot || !write_idx || !k_start || !k_len ||
@@ -243,8 +243,9 @@ int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cac
   OWC_TRY(owc_launch_gemm_bf16(last, d, w->lm_head_w, d, nullptr, nullptr, 0, logits, w->vocab, B,
                                w->vocab, d, OWC_EPI_NONE, ctx->zeros, st));
   OWC_TRY(owc_launch_argmax(logits, w->vocab, B, w->vocab, tok_io, st));
-  OWC_TRY(owc_launch_decode_update(tok_io, done, out_tokens, out_stride, step, B, eos_id0, eos_id1,
+  OWC_TRY(owc_launch_decode_update(tok_io, done, out_tokens, out_stride, step, step_state, B, eos_id0, eos_id1,
                                    pad_id, st));
+  if (step_state) OWC_TRY(owc_launch_decode_advance(pos, write_idx, k_len, step_state, B, st));
   return OWC_OK;
 }
 

@@ -129,3 +129,22 @@ def test_shared_prefix_is_bit_identical(setup, gpu):
     shared2 = Qwen2VLEngine(eng.w, vit_chunk_tokens=64, prefill_chunk_tokens=40, share_prefix=True, min_shared_prefix=2)
     c = shared2.generate(prompts, emb, grids, 6)
     assert torch.equal(a, c)
+
+
+def test_graph_replayed_decode_equals_eager(setup, gpu):
+    """owc_llm_decode_step with a device-side step state is a fixed launch sequence: steps 2.. replayed from ONE captured hipGraph
+    give exactly the eager loop's tokens (also with EOS stopping and pads)."""
+    from lmms_owc_amd.engine.qwen2vl import Qwen2VLEngine
+
+    cfg, w, eng, g = setup
+    eager = Qwen2VLEngine(eng.w, graph_decode=False)
+    graph = Qwen2VLEngine(eng.w, graph_decode=True)
+    r = np.random.default_rng(11)
+    prompts = [r.integers(1, 400, 9 + 2 * i) for i in range(5)]
+    a = eager.generate(prompts, None, [[] for _ in prompts], 12)
+    b = graph.generate(prompts, None, [[] for _ in prompts], 12)
+    assert torch.equal(a, b)
+    eos = int(a[0, 3])  # a token sequence 0 emits at step 3: from there on it must be padded in both
+    a2 = eager.generate(prompts, None, [[] for _ in prompts], 12, eos_token_id=eos, pad_token_id=0, stop_check_every=2)
+    b2 = graph.generate(prompts, None, [[] for _ in prompts], 12, eos_token_id=eos, pad_token_id=0, stop_check_every=2)
+    assert torch.equal(a2, b2) and int((a2[0, 4:] != 0).sum()) == 0
