@@ -402,19 +402,23 @@ __global__ __launch_bounds__(64) void gemm_bf16_skinny_kernel(
         for (int nt = 0; nt < NT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[i][nt][ks], xring[i][mt][ks], acc[mt][nt], 0, 0, 0);
   };
+  // Branch-free steady state (with conditionals around the loads the compiler falls back to vmcnt(0) after every refill and
+  // the ring degenerates to depth 1): loads past the end re-read the last super-step (an L2 hit nobody consumes), whole
+  // rounds run unconditionally, the last partial round only computes.
 #pragma unroll
-  for (int i = 0; i < DEPTH; ++i)
-    if (i < nss) load_w(i, i);
-  for (int base = 0; base < nss; base += DEPTH) {
+  for (int i = 0; i < DEPTH; ++i) load_w(i, min(i, nss - 1));
+  int ss = 0;
+  for (; ss + DEPTH <= nss; ss += DEPTH) {
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i) {
-      const int ss = base + i;
-      if (ss < nss) {
-        compute(i, ss);
-        if (ss + DEPTH < nss) load_w(i, ss + DEPTH);
-      }
+      compute(i, ss + i);
+      load_w(i, min(ss + i + DEPTH, nss - 1));
     }
   }
+  const int rem = nss - ss;
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i)
+    if (i < rem) compute(i, ss + i);
   // lane holds row m = 16 mt + fr, columns n0 + 16 nt + 4 fq .. +3
   if constexpr (EPI == OWC_EPI_SWIGLU) {
 #pragma unroll

@@ -310,23 +310,29 @@ __global__ __launch_bounds__(64) void gemm_fp8_skinny_kernel(
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) xring[i][mt] = ld32(arow[mt] + ss * 128);
   };
+  auto compute = [&](int i) {
 #pragma unroll
-  for (int i = 0; i < DEPTH; ++i)
-    if (i < nss) load(i, i);
-  for (int base = 0; base < nss; base += DEPTH) {
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ring[i][nt], xring[i][mt], acc[mt][nt], 0, 0, 0, 0x7f, 0, 0x7f);
+  };
+  // Branch-free steady state (see gemm_bf16_skinny_kernel): loads past the end re-read the last super-step, whole rounds run
+  // unconditionally, the last partial round only computes.
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i) load(i, min(i, nss - 1));
+  int ss = 0;
+  for (; ss + DEPTH <= nss; ss += DEPTH) {
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i) {
-      const int ss = base + i;
-      if (ss < nss) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ring[i][nt], xring[i][mt], acc[mt][nt], 0, 0, 0, 0x7f, 0, 0x7f);
-        if (ss + DEPTH < nss) load(i, ss + DEPTH);
-      }
+      compute(i);
+      load(i, min(ss + i + DEPTH, nss - 1));
     }
   }
+  const int rem = nss - ss;
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i)
+    if (i < rem) compute(i);
   // dequantise + epilogue: lane holds row m = 16 mt + fr, columns n0 + 16 nt + 4 fq .. +3
   f32x4 swv[NT];
 #pragma unroll
