@@ -68,7 +68,10 @@ class LLaVA(Model):
     def __init__(self, model_name_or_path: str = "llava-hf/llava-1.5-7b-hf", attn_implementation: str | None = None,
                  chat_template: str | None = None, use_cache: bool = True, batch_size: int = 1, device_map: str = "auto",
                  dtype: str | torch.dtype = "bfloat16", load_in_8bit: bool = False, load_in_4bit: bool = False,
-                 **kwargs) -> None:
+                 decoder_dtype: str = "bf16", **kwargs) -> None:
+        if decoder_dtype not in ("bf16", "fp8"):  # the one kwarg beyond the reference's: fp8 decoder projections
+            raise ValueError("decoder_dtype must be 'bf16' or 'fp8'")
+        self._decoder_dtype = decoder_dtype
         self._model_name_or_path = model_name_or_path
         self._attn_implementation = attn_implementation  # accepted; attention is always the fused HIP kernel
         self._chat_template = chat_template
@@ -81,7 +84,8 @@ class LLaVA(Model):
         name = self._model_name_or_path
         if name.startswith("synthetic:"):
             tok = LlavaByteTokenizer()
-            dims = LlavaDims(**{**DIMS[name.split(":", 1)[1]].__dict__, "image_token_id": tok.image_token_id})
+            dims = LlavaDims(**{**DIMS[name.split(":", 1)[1]].__dict__, "image_token_id": tok.image_token_id,
+                                "decoder_dtype": self._decoder_dtype})
             weights = LlavaWeights.random(dims, self._device, seed=1234)
             self._tokenizer = tok
         else:
@@ -91,6 +95,7 @@ class LLaVA(Model):
 
                 path = Path(snapshot_download(name))
             dims = dims_from_hf_config(json.loads((path / "config.json").read_text()))
+            dims = LlavaDims(**{**dims.__dict__, "decoder_dtype": self._decoder_dtype})
             weights = LlavaWeights.from_state_dict(dims, LlavaCheckpoint(path), self._device)
             from transformers import AutoTokenizer
 

@@ -63,7 +63,12 @@ class Qwen2VL(Model):
                  use_flash_attention_2: bool | None = False, max_pixels: int = 1024 * 28 * 28,
                  min_pixels: int = 4 * 28 * 28, batch_size: int = 1, device_map: str = "auto",
                  dtype: str | torch.dtype = "bfloat16", load_in_8bit: bool = False, load_in_4bit: bool = False,
-                 **kwargs) -> None:
+                 decoder_dtype: str = "bf16", **kwargs) -> None:
+        # `decoder_dtype` is the one kwarg the reference does not have: "fp8" runs the decoder projections on the e4m3fn path
+        # (`--model_args decoder_dtype=fp8`).  The reference's bitsandbytes switches stay rejected.
+        if decoder_dtype not in ("bf16", "fp8"):
+            raise ValueError("decoder_dtype must be 'bf16' or 'fp8'")
+        self._decoder_dtype = decoder_dtype
         self._model_name_or_path = model_name_or_path
         self._use_cache = use_cache                    # the HIP decoder always uses its KV cache
         self._use_flash_attention_2 = use_flash_attention_2  # accepted; attention is always the fused HIP kernel
@@ -79,7 +84,7 @@ class Qwen2VL(Model):
             key = name.split(":", 1)[1]
             dims = DIMS[key]
             tok = ByteTokenizer()
-            dims = Qwen2VLDims(**{**dims.__dict__, "image_token_id": tok.image_pad})
+            dims = Qwen2VLDims(**{**dims.__dict__, "image_token_id": tok.image_pad, "decoder_dtype": self._decoder_dtype})
             weights = Qwen2VLWeights.random(dims, self._device, seed=1234)
             self._tokenizer = tok
         else:
@@ -89,6 +94,7 @@ class Qwen2VL(Model):
 
                 path = Path(snapshot_download(name))
             dims = dims_from_hf_config(json.loads((path / "config.json").read_text()))
+            dims = Qwen2VLDims(**{**dims.__dict__, "decoder_dtype": self._decoder_dtype})
             weights = Qwen2VLWeights.from_state_dict(dims, LazyCheckpoint(path), self._device)
             from transformers import AutoTokenizer
 

@@ -306,3 +306,22 @@ def test_multi_round_generation(gpu, scorer):
                           batch_size=2, limit=4)
     smp = res["samples"]["synthetic"]
     assert len(smp) == 4 and len(smp[0]["filtered_resps"][0]) == 3 and "semantic_similarity,none" in res["results"]["synthetic"]
+
+
+@pytest.mark.parametrize("model_type,name", [("qwen2-vl", "tiny"), ("llava", "tiny-next")])
+def test_fp8_decoder_through_the_plugin(gpu, model_type, name):
+    """`--model_args decoder_dtype=fp8`: the plug-ins build the e4m3fn decoder; answers are batch-invariant and mostly agree with bf16."""
+    from lmms_owc_amd.models import get_model
+    from lmms_owc_amd.tasks import load_task
+
+    task = load_task("synthetic:6:70x120:3")
+    task.build_all_requests(limit=None, rank=0, world_size=1)
+    outs = {}
+    for key, kw in {"fp8_1": dict(decoder_dtype="fp8", batch_size=1), "fp8_4": dict(decoder_dtype="fp8", batch_size=4), "bf16": dict(batch_size=4)}.items():
+        lm = get_model("custom-model", model_type=model_type, model_name_or_path=f"synthetic:{name}", **kw)
+        lm.task_dict[task.task_name] = task.dataset
+        outs[key] = lm.generate_until(task.instances)
+    assert outs["fp8_1"] == outs["fp8_4"] and len(outs["fp8_4"]) == 6
+    assert lm.model.w.llm.weight_dtype == 0
+    with pytest.raises(ValueError):
+        get_model("custom-model", model_type=model_type, model_name_or_path=f"synthetic:{name}", decoder_dtype="int4")
