@@ -43,6 +43,7 @@ GemmProfile g_prof;
 int g_gemm_dbg = 0;       // timing-experiment knob (OWC_GEMM_DBG / owc_tuning_set "gemm_dbg"), results are garbage unless 0 or 512:
                           // 1 no DMA, 2 DMA re-reads K-tiles 0/1 (all L2 hits), 4 no epilogue, 512 direct (un-staged) epilogue stores
 int g_skinny_max_m = 64;   // M at and below which the weight-streaming skinny kernel runs (0 disables: A-B knob "gemm_skinny_max_m")
+int g_mid_max_tiles = 256;  // fewer 128x128 tiles than this -> 64x64 tiles (0 disables: A-B knob "gemm_mid_max_tiles")
 int g_big_min_tiles = 192;  // fewer 256x256 tiles than this -> use the 128x128 kernel
 int g_big_min_m = 1024;  // M at and above which the 256x128 3-stage kernel is used (OWC_GEMM_BIG_MIN_M)
 
@@ -151,6 +152,88 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
   gemm_epilogue<EPI, 4>(acc, m0 + wm * 64, n0 + wn * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 64x64x64 variant for the in-between shapes (M above the skinny kernel's 64 rows but too few 128x128 tiles to occupy the 256
+// CUs: decode at batch 65-512, the prefill of a single prompt).  4 waves, wave w owns rows [16w, 16w+16) x all 64 columns (one m
+// tile x four n tiles, so the shared epilogue applies with MT = 1); 32 KiB of LDS per block, five blocks per CU.  Same ascending
+// K accumulation chain as every other kernel here (bit-identical results), K tails from the zero page.
+// ------------------------------------------------------------------------------------------------
+constexpr int B64 = 64;
+constexpr int TILE64_BYTES = B64 * BK * 2;  // 8 KiB per operand tile
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
+    const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
+    const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv,
+    long ldc, int M, int N, int K, const void* __restrict__ zeros, int tiles_m, int tiles_n, owc_gemm_aux aux) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // [buf][A|W][64 rows][128 B]
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int nblk = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int width = GROUP_M * tiles_n;
+  const int group = lid / width;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(tiles_m - first_m, GROUP_M);
+  const int m0 = (first_m + (lid % width) % gsize) * B64, n0 = ((lid % width) / gsize) * B64;
+
+  // staging: wave w moves rows [16w, 16w+16) of both tiles, 2 pieces of 8 rows
+  const char* asrc[2];
+  const char* wsrc[2];
+  int kchunk[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 16 * w + 8 * j + (l >> 3);
+    const int c = (l & 7) ^ ((row >> 1) & 7);
+    kchunk[j] = c * 8;
+    asrc[j] = (const char*)(A + (long)min(m0 + row, M - 1) * lda + c * 8);
+    wsrc[j] = (const char*)(W + (long)min(n0 + row, N - 1) * ldw + c * 8);
+  }
+  const int nk = (K + BK - 1) / BK;
+  auto stage = [&](int buf, int kt) {
+    char* la = lds + buf * (2 * TILE64_BYTES) + w * 2048;
+    char* lw = la + TILE64_BYTES;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = (k0 + kchunk[j]) < K;
+      glds16(ok ? (const void*)(asrc[j] + (long)k0 * 2) : zeros, la + j * 1024);
+      glds16(ok ? (const void*)(wsrc[j] + (long)k0 * 2) : zeros, lw + j * 1024);
+    }
+  };
+  const int fr = l & 15, fq = l >> 4;
+  const int swz = (fr >> 1) & 7;
+  const int offA0 = (w * 16 + fr) * 128 + (((0 + fq) ^ swz) << 4), offA1 = (w * 16 + fr) * 128 + (((4 + fq) ^ swz) << 4);
+  const int offW0 = fr * 128 + (((0 + fq) ^ swz) << 4), offW1 = fr * 128 + (((4 + fq) ^ swz) << 4);
+
+  f32x4 acc[4][1];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* la = lds + cur * (2 * TILE64_BYTES);
+    const char* lw = la + TILE64_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 fa = *(const bf16x8*)(la + (ks ? offA1 : offA0));
+      bf16x8 fw[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fw[t] = *(const bf16x8*)(lw + (ks ? offW1 : offW0) + t * 16 * 128);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa, acc[nt][0], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  gemm_epilogue<EPI, 1>(acc, m0 + w * 16, n0, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Large-M variant: 256x256x64 block tile, 512 threads = 8 waves (2 along M x 4 along N), 128x64 per wave
@@ -501,7 +584,12 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
     hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), 2 * STAGE_BYTES, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
                        (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, g_gemm_dbg, aux);
-  else
+  else if (g_mid_max_tiles > 0 && tiles_m * tiles_n < g_mid_max_tiles) {  // too few 128x128 tiles for 256 CUs: 64x64 tiles
+    const int tm64 = (M + B64 - 1) / B64, tn64 = (N + B64 - 1) / B64;
+    hipLaunchKernelGGL(gemm_bf16_nt_64_kernel<EPI>, dim3(tm64 * tn64), dim3(256), 4 * TILE64_BYTES, s,
+                       (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
+                       (const bf16_t*)R, ldr, C, ldc, M, N, K, zeros, tm64, tn64, aux);
+  } else
     hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
                        (const bf16_t*)R, ldr, C, ldc, M, N, K, zeros, tiles_m, tiles_n, aux);
@@ -605,4 +693,5 @@ int owc_gemm_profile_collect(double* total_ms, double* total_flops, long* launch
 
 void owc_gemm_set_big_min_m(int m) { g_big_min_m = m; }
 void owc_gemm_set_dbg(int v) { g_gemm_dbg = v; }
+void owc_gemm_set_mid_max_tiles(int v) { g_mid_max_tiles = v; }
 void owc_gemm_set_skinny_max_m(int v) { g_skinny_max_m = v; }

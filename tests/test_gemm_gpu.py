@@ -175,3 +175,25 @@ def test_gemm_skinny_kernel(gpu, m, epi):
     assert np.array_equal(out, tiled)
     # row 0 alone gives the same bits as row 0 inside the batch
     assert np.array_equal(to_np(run(a[:1]))[0], out[0])
+
+
+@pytest.mark.parametrize("m,n,k", [(286, 3584, 3584), (128, 1216, 1176), (500, 264, 640)])
+def test_gemm_mid_kernel_bit_identical_to_128_tiles(gpu, m, n, k):
+    """Shapes with few 128x128 tiles run 64x64 tiles; every kernel accumulates one ascending K chain per output, so the bits
+    are the same whichever tile size computed them."""
+    from lmms_owc_amd import _lib, ops
+
+    a = bf16_randn((m, k), 60 + m, device=gpu)
+    w = bf16_randn((n, k), 61, 0.05, device=gpu)
+    b = bf16_randn((n,), 62, device=gpu)
+    r = bf16_randn((m, n), 63, device=gpu)
+    lib = _lib.load()
+    outs = []
+    for knob in (256, 0):
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", knob)
+        outs.append((ops.gemm_bf16(a, w, b), ops.gemm_bf16(a, w, b, epilogue=_lib.EPI_RESIDUAL, residual=r),
+                     ops.gemm_bf16(a, w, b, epilogue=_lib.EPI_QUICK_GELU)))
+    lib.owc_tuning_set(b"gemm_mid_max_tiles", 256)
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    assert_bf16_close(to_np(outs[0][0]), _oracle(a, w, b), atol=1e-4)
