@@ -19,7 +19,10 @@ int owc_abi_version(void) { return 10; }
 
 int owc_tuning_set(const char* name, int value) {
   if (!name) return OWC_ERR_ARG;
-  if (!strcmp(name, "gemm_mid_max_tiles")) owc_gemm_set_mid_max_tiles(value);
+  if (!strcmp(name, "gemm_mid_max_tiles")) {
+    owc_gemm_set_mid_max_tiles(value);
+    owc_gemm_fp8_set_mid_max_tiles(value);
+  }
   else if (!strcmp(name, "gemm_skinny_max_m")) {
     owc_gemm_set_skinny_max_m(value);
     owc_gemm_fp8_set_skinny_max_m(value);

@@ -23,6 +23,7 @@ constexpr int OP_BYTES = BT * BKB;                 // 32 KiB per operand per sta
 constexpr int STAGE_BYTES = 2 * OP_BYTES;
 constexpr int GROUP_M2 = 4;
 int g_fp8_skinny_max_m = 64;  // follows the "gemm_skinny_max_m" knob
+int g_fp8_mid_max_tiles = 128;  // fewer 256x256 tiles than this -> 64x64 tiles (follows "gemm_mid_max_tiles": 0 disables)
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;
 
 // ---- row quantiser: one wave per row, the row cached in registers (bf16x8 chunks) ----
@@ -273,6 +274,87 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256_kernel(
 }
 
 
+// ---- 64x64x128 variant for the in-between shapes (M above the skinny kernel's 64 rows, too few 256x256 tiles for the 256 CUs:
+// fp8 decode at batch 65 .. ~1000, single-prompt prefill).  The fp8 twin of gemm_bf16_nt_64_kernel: 4 waves, wave w owns rows
+// [16w, 16w+16) x 64 columns, one scaled MFMA per n tile per K-tile, 32 KiB LDS, same ascending chain (bit-identical).
+constexpr int B64 = 64;
+constexpr int TILE64_BYTES = B64 * BKB;  // 8 KiB per operand tile
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_fp8_nt_64_kernel(
+    const uint8_t* __restrict__ A, long lda, const float* __restrict__ SA, const uint8_t* __restrict__ W, long ldw,
+    const float* __restrict__ SW, const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv, long ldc,
+    int M, int N, int K, int tiles_m, int tiles_n, owc_gemm_aux aux) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // [buf][A|W][64 rows][128 B]
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int nblk = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int width = 8 * tiles_n;
+  const int group = lid / width;
+  const int first_m = group * 8;
+  const int gsize = min(tiles_m - first_m, 8);
+  const int m0 = (first_m + (lid % width) % gsize) * B64, n0 = ((lid % width) / gsize) * B64;
+  const char* asrc[2];
+  const char* wsrc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 16 * w + 8 * j + (l >> 3);
+    const int c = (l & 7) ^ ((row >> 1) & 7);
+    asrc[j] = (const char*)(A + (long)min(m0 + row, M - 1) * lda + c * 16);
+    wsrc[j] = (const char*)(W + (long)min(n0 + row, N - 1) * ldw + c * 16);
+  }
+  const int nk = K / BKB;
+  auto stage = [&](int buf, int kt) {
+    char* la = lds + buf * (2 * TILE64_BYTES) + w * 2048;
+    const long kb = (long)kt * BKB;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      glds16(asrc[j] + kb, la + j * 1024);
+      glds16(wsrc[j] + kb, la + TILE64_BYTES + j * 1024);
+    }
+  };
+  const int fr = l & 15, fq = l >> 4;
+  const int swz = (fr >> 1) & 7;
+  const int chlo = (fq ^ swz) << 4, chhi = ((4 + fq) ^ swz) << 4;  // the operand byte pairing of the tiled kernel
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  auto rd = [&](const char* p) -> i32x8 {
+    const i32x4 lo = *(const i32x4*)(p + chlo), hi = *(const i32x4*)(p + chhi);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  f32x4 acc[4][1];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* la = lds + cur * (2 * TILE64_BYTES);
+    const i32x8 fa = rd(la + (w * 16 + fr) * 128);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const i32x8 fw = rd(la + TILE64_BYTES + (nt * 16 + fr) * 128);
+      acc[nt][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw, fa, acc[nt][0], 0, 0, 0, 0x7f, 0, 0x7f);
+    }
+    __syncthreads();
+  }
+  {
+    const float sa = SA[min(m0 + w * 16 + fr, M - 1)];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const f32x4 swv = *(const f32x4*)(SW + min(n0 + nt * 16 + fq * 4, N - 4));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[nt][0][e] = acc[nt][0][e] * sa * swv[e];
+    }
+  }
+  gemm_epilogue<EPI, 1>(acc, m0 + w * 16, n0, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
+}
+
 // ---- skinny-M variant (M <= 64, decode at small batch): the fp8 twin of gemm_bf16_skinny_kernel.  One wave owns 16 rows of W8
 // (32 for SwiGLU) over the whole K; a super-step is 128 fp8 elements = 32 bytes per lane and ONE scaled MFMA per (m tile, n
 // tile); weights and activation codes ride a fully unrolled register ring.  One ascending accumulation chain per output, same
@@ -405,6 +487,13 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
     owc_gemm_profile_end(prof, s);
     return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
   }
+  if (g_fp8_mid_max_tiles > 0 && tiles_m * tiles_n < g_fp8_mid_max_tiles) {  // too few 256x256 tiles for the 256 CUs
+    const int tm64 = (M + B64 - 1) / B64, tn64 = (N + B64 - 1) / B64;
+    hipLaunchKernelGGL(gemm_fp8_nt_64_kernel<EPI>, dim3(tm64 * tn64), dim3(256), 4 * TILE64_BYTES, s, (const uint8_t*)A, lda, sa,
+                       (const uint8_t*)W, ldw, sw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C, ldc, M, N, K, tm64, tn64, aux);
+    owc_gemm_profile_end(prof, s);
+    return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+  }
   hipLaunchKernelGGL(gemm_fp8_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), LDS_BYTES, s,
                      (const uint8_t*)A, lda, sa, (const uint8_t*)W, ldw, sw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C,
                      ldc, M, N, K, tiles_m, tiles_n, aux);
@@ -415,6 +504,7 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
 }  // namespace
 
 void owc_gemm_fp8_set_skinny_max_m(int v) { g_fp8_skinny_max_m = v; }
+void owc_gemm_fp8_set_mid_max_tiles(int v) { g_fp8_mid_max_tiles = v ? 128 : 0; }
 
 int owc_launch_quant_rows_fp8(const void* X, long ldx, void* Q, long ldq, float* S, int rows, int cols, hipStream_t st) {
   if (rows <= 0 || cols <= 0 || (cols & 7) || (ldx & 7) || (ldq & 7) || cols > 16 * 256 * 8) return OWC_ERR_SHAPE;

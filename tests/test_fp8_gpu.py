@@ -129,3 +129,24 @@ def test_gemm_fp8_skinny_kernel(gpu, m, epi):
     if epi == "bias":
         want = F.linear_fp8(None, wq.cpu().numpy(), to_np(ws), to_np(bias), xq=xq.cpu().numpy(), xs=to_np(xs))
         assert_bf16_close(to_np(out), want, ulps=2.0, min_exact=0.95, atol=2.0 ** -9 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(300, 520, 384, "bias"), (1000, 1536, 1024, "res"), (2048, 4096, 512, "bias"), (512, 1024, 512, "swiglu")])
+def test_gemm_fp8_tile_sizes_bit_identical(gpu, m, n, k, epi):
+    """64x64 tiles (few-tile shapes) and 256x256 tiles give the same bits: one ascending chain of scaled MFMAs per output."""
+    from lmms_owc_amd import _lib, ops
+
+    lib = _lib.load()
+    x = bf16_randn((m, k), 80 + m, 1.0, gpu)
+    w = bf16_randn((n, k), 81, 0.05, gpu)
+    xq, xs = ops.quantize_rows_fp8(x)
+    wq, ws = ops.quantize_rows_fp8(w)
+    bias = bf16_randn((n,), 5, 0.5, gpu) if epi == "bias" else None
+    r = bf16_randn((m, n), 9, 1.0, gpu) if epi == "res" else None
+    e = {"bias": _lib.EPI_NONE, "res": _lib.EPI_RESIDUAL, "swiglu": _lib.EPI_SWIGLU}[epi]
+    outs = []
+    for knob in (1, 0):
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 256 if knob else 0)
+        outs.append(ops.gemm_fp8(xq, xs, wq, ws, bias, epilogue=e, residual=r))
+    lib.owc_tuning_set(b"gemm_mid_max_tiles", 256)
+    assert torch.equal(outs[0], outs[1])
