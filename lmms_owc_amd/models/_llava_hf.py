@@ -19,7 +19,6 @@ import numpy as np
 import torch
 
 from .. import utils
-from ..engine import anyres
 from ..engine.llava import DIMS, NEXT_PINPOINTS, LlavaDims, LlavaEngine, LlavaWeights
 from . import imageproc
 from ._api import register_model

@@ -13,7 +13,6 @@ Weights: dict name -> float32 ndarray with HF state-dict names (`model.visual...
 
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass, field
 
 import numpy as np

@@ -1,7 +1,6 @@
 """Scorer parity on the GPU: fp32 HIP BERT encoder + cosine kernels vs the oracle and the golden
 vectors the REFERENCE's encode_sentence_bert / semantic_similarity produced (tests/golden/scorer.npz).
 Tolerance: 1e-4 on cosine (BASELINE.json north_star), we assert 2e-5."""
-import json
 from pathlib import Path
 
 import numpy as np
