@@ -19,7 +19,7 @@
 
 namespace {
 
-int g_attn_dbg = 0;  // timing experiments (OWC_ATTN_DBG): 1 = no K/V DMA in the loop, 2 = no exp
+int g_attn_dbg = 0;  // timing experiment (owc_tuning_set "attn_dbg"): 1 = no K/V DMA in the loop
 
 constexpr int QB = 128;  // query rows per block
 constexpr int KB = 64;   // keys per tile
@@ -95,45 +95,55 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
   const bf16_t* Kb = K + (long)hk * k_hs;
   const bf16_t* Vb = V + (long)hk * v_hs;
 
-  // per-piece DMA source offsets (bytes from the sequence's first K/V row), hoisted out of the tile loop
+  // per-piece DMA source offsets (bytes from the sequence's first K/V row), hoisted out of the tile loop.
+  // piece p = w + 4i: K pieces first, then V pieces (whether piece i is a V piece is a compile-time fact when NP % 4 == 0)
   constexpr int NPW = (2 * C::NP + 3) / 4;  // pieces per wave
+  constexpr bool STATIC_KV = (C::NP % 4) == 0;
+  const char* Kseq = (const char*)(Kb + ks0 * k_ts);
+  const char* Vseq = (const char*)(Vb + ks0 * v_ts);
+  auto piece_isv = [&](int i) { return STATIC_KV ? (4 * i >= C::NP) : (w + 4 * i >= C::NP); };
+  auto piece_key = [&](int i) {  // tile row this lane's chunk of piece i belongs to
+    const int pp = w + 4 * i - (piece_isv(i) ? C::NP : 0);
+    return (pp * 64 + l) / C::CPR;
+  };
   unsigned poff[NPW];
-  int pkey[NPW];
 #pragma unroll
   for (int i = 0; i < NPW; ++i) {
-    const int p = w + 4 * i;
-    const bool isv = p >= C::NP;
-    const int pp = isv ? p - C::NP : p;
+    const int pp = w + 4 * i - (piece_isv(i) ? C::NP : 0);
     const int ci = pp * 64 + l;
     const int key = ci / C::CPR;
     const int pos = ci - key * C::CPR;
     const int c = C::SWZ ? (pos ^ ((key & 7) << 1)) : pos;
-    pkey[i] = key;
-    poff[i] = (unsigned)((long)key * (isv ? v_ts : k_ts) * 2 + c * 16);
+    poff[i] = (unsigned)((long)key * (piece_isv(i) ? v_ts : k_ts) * 2 + c * 16);
   }
-  const char* Kseq = (const char*)(Kb + ks0 * k_ts);
-  const char* Vseq = (const char*)(Vb + ks0 * v_ts);
 
+  // a full tile costs no vector ALU work beyond a pointer bump: uniform base (sequence + tile) + the hoisted 32-bit lane
+  // offset; only the ragged last tile clamps rows per lane (kept a separate branch so the selects stay out of the common path)
   auto stage = [&](int buf, int t) {
     char* base = lds + buf * (2 * C::TILE);
-    const bool full = (t * KB + KB) <= L;  // wave-uniform: no row clamping needed
+    if ((t * KB + KB) <= L) {
+      // the tile bases are pinned in SGPRs (opaque to the loop-strength-reduction pass, which otherwise keeps one 64-bit
+      // VGPR pointer per piece): the DMA then uses the scalar-base + 32-bit lane-offset form
+      const char* kt0 = Kseq + (long)t * KB * k_ts * 2;
+      const char* vt0 = Vseq + (long)t * KB * v_ts * 2;
+      asm volatile("" : "+s"(kt0), "+s"(vt0));
 #pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-      const int p = w + 4 * i;  // wave-uniform piece id
-      if (p < 2 * C::NP) {
-        const bool isv = p >= C::NP;
-        const int pp = isv ? p - C::NP : p;
-        const long ts2 = (isv ? v_ts : k_ts) * 2;
-        const char* sq = isv ? Vseq : Kseq;
-        const char* src;
-        if (full) {
-          src = sq + (long)t * KB * ts2 + poff[i];
-        } else {
-          const int key = pkey[i];
-          src = sq + (long)min(t * KB + key, L - 1) * ts2 + (poff[i] - (unsigned)((long)key * ts2));
+      for (int i = 0; i < NPW; ++i)
+        if (w + 4 * i < 2 * C::NP) {
+          const bool isv = piece_isv(i);
+          glds16((isv ? vt0 : kt0) + poff[i], base + (isv ? C::TILE - C::NP * 1024 : 0) + (w + 4 * i) * 1024);
         }
-        glds16(src, base + (isv ? C::TILE : 0) + pp * 1024);
-      }
+    } else {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < NPW; ++i)
+        if (w + 4 * i < 2 * C::NP) {
+          const bool isv = piece_isv(i);
+          const long ts2 = (isv ? v_ts : k_ts) * 2;
+          const int key = piece_key(i);
+          const char* src = (isv ? Vseq : Kseq) + (long)min(t * KB + key, L - 1) * ts2 + (poff[i] - (unsigned)((long)key * ts2));
+          glds16(src, base + (isv ? C::TILE - C::NP * 1024 : 0) + (w + 4 * i) * 1024);
+        }
     }
   };
 
@@ -176,9 +186,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
         if (C::CPR % 4 == 0 || ks < C::KS - 1) {
           kf = *(const bf16x8*)(krow + ((c ^ kswz) << 4));
         } else {
+          // head_dim 80: chunks 10, 11 of the last k-step do not exist; the Q fragment is zero there, so any
+          // finite K data (the row's last real chunk) contributes exactly 0
           const int cc = min(c, C::CPR - 1);
           kf = *(const bf16x8*)(krow + ((cc ^ kswz) << 4));
-          if (c >= C::CPR) kf = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
         }
         s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
         s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
@@ -186,38 +197,50 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     }
 
     // ---- online softmax (lane = query column; keys 16kt + 4g + r) ----
+    // ragged / causal masking is needed on the last tiles only: keep it a real (wave-uniform) branch -- written
+    // as selects it costs ~70 VALU per tile on every tile, and the loop is VALU-bound
     const bool edge = (t * KB + KB > L) || (CAUSAL && (t * KB + KB - 1 > qb * QB + w * 32 + coff));
+    if (edge) {
+      asm volatile("" ::: "memory");  // keeps the compiler from if-converting the block into selects
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = t * KB + kt * 16 + g * 4 + r;
+            if (key >= L || (CAUSAL && key > qrow[qt] + coff)) s[kt][qt][r] = -1e30f;
+          }
+    }
     bf16x8 pf[2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      // raw scores; the softmax scale (and log2 e) is folded into the exp2 argument by one fma per element
+      // raw scores; the softmax scale (and log2 e) is folded into the exp2 argument by one (packed) fma per pair
       float mx = -1e30f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (edge) {
-            const int key = t * KB + kt * 16 + g * 4 + r;
-            if (key >= L || (CAUSAL && key > qrow[qt] + coff)) s[kt][qt][r] = -1e30f;
-          }
-          mx = fmaxf(mx, s[kt][qt][r]);
-        }
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mnew = fmaxf(mrun[qt], mx);
       const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * scale_log2e);
       const float neg = -mnew * scale_log2e;
       mrun[qt] = mnew;
-      float sum = 0.f;
+      const f32x2 sc2 = (f32x2){scale_log2e, scale_log2e}, ng2 = (f32x2){neg, neg};
+      f32x2 sum2 = (f32x2){0.f, 0.f};
       float x[4][4];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = (dbg & 2) ? s[kt][qt][r] : __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], scale_log2e, neg));
-          x[kt][r] = p;
-          sum += p;
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 a = (f32x2){s[kt][qt][r], s[kt][qt][r + 1]} * sc2 + ng2;  // v_pk_fma_f32
+          const f32x2 p = (f32x2){__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+          x[kt][r] = p[0];
+          x[kt][r + 1] = p[1];
+          sum2 += p;  // v_pk_add_f32
         }
+      const float sum = sum2[0] + sum2[1];
       lrun[qt] = lrun[qt] * alpha + sum;
       // the running max rarely moves after the first tiles: skip the O rescale when no lane needs it
       if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {

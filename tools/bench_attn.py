@@ -50,6 +50,19 @@ def main():
         ops.attention(q3, (Hq3 + 2 * Hkv3) * 128, 128, kc3, 128, (S3 + 16) * 128, vc3, 128, (S3 + 16) * 128, o3, Hq3 * 128, 128, st3, kst3,
                       ln3, n_seq=nb3, n_heads=Hq3, kv_group=Hq3 // Hkv3, head_dim=128, max_q_len=S3, causal=True, scale=128 ** -0.5)
 
+    from lmms_owc_amd import _lib
+    vals = [0]
+    for a in sys.argv[1:]:
+        if a.startswith("--dbg="):
+            vals = [int(v, 0) for v in a[6:].split(",")]
+    for rep in range(2):
+      for v in vals:
+        _lib.load().owc_tuning_set(b"attn_dbg", v)
+        print(f"-- attn_dbg = {v:#x}")
+        bench_all(vit, prefill, prefill_long, n, H, L, hd, nb, Hq, S, nb3, Hq3, S3)
+
+
+def bench_all(vit, prefill, prefill_long, n, H, L, hd, nb, Hq, S, nb3, Hq3, S3):
     for name, fn, flops in (("vit hd80 64x1024", vit, 4.0 * n * H * L * L * hd), ("prefill hd128 114x286 causal", prefill, 2.0 * nb * Hq * S * S * 128),
                             ("prefill hd128 24x2388 causal (llava-34b)", prefill_long, 2.0 * nb3 * Hq3 * S3 * S3 * 128)):
         for _ in range(3):
