@@ -35,6 +35,17 @@ struct Cfg {
   static constexpr bool SWZ = (HD % 128) == 0;    // 256-B rows need the XOR swizzle
 };
 
+// max over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48), result in every lane: two register swaps
+// (v_permlane16_swap / v_permlane32_swap, VALU) instead of two ds_bpermute round trips through the LDS
+__device__ __forceinline__ float max_over_groups(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // {r0,r0,r2,r2}, {r1,r1,r3,r3}
+  const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const unsigned v = __float_as_uint(m);
+  const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // {lo,lo}, {hi,hi}
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     const bf16_t* __restrict__ Q, long q_ts, long q_hs, const bf16_t* __restrict__ K, long k_ts,
@@ -221,8 +232,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = max_over_groups(mx);
       const float mnew = fmaxf(mrun[qt], mx);
       const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * scale_log2e);
       const float neg = -mnew * scale_log2e;
