@@ -56,7 +56,8 @@ const char* owc_last_error(const owc_ctx* ctx);
 /* A-B / tuning knobs (process-wide; the same switches owc_init reads from the environment):
  * "gemm_big_min_m" (OWC_GEMM_BIG_MIN_M), "gemm_skinny_max_m" (0 disables the weight-streaming small-M kernel), "gemm_mid_max_tiles"
  * (0 disables the 64x64-tile kernel), "gemm_dbg"
- * (OWC_GEMM_DBG), "attn_dbg" (OWC_ATTN_DBG).
+ * (OWC_GEMM_DBG), "attn_dbg" (OWC_ATTN_DBG), "prefill_prune_last" (0: owc_llm_prefill runs the last layer's attention / o-proj /
+ * MLP on every row instead of the last-token rows only -- same logits bit for bit, tested).
  * Returns OWC_ERR_ARG for an unknown name.  Measurement aid only: no reference counterpart. */
 int owc_tuning_set(const char* name, int value);
 int owc_abi_version(void); /* bumped whenever a signature in this header changes */

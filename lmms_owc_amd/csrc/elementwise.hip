@@ -420,6 +420,26 @@ __global__ __launch_bounds__(256) void clip_embed_kernel(const bf16_t* __restric
   *(bf16x8*)(x + row * E + ch * 8) = p;
 }
 
+// Last-layer pruning of the prefill (qwen2vl.hip): out[j] = X[idx[j]] (16-byte chunks), and the index triple that maps the
+// last token of prompt j onto the decode-style attention launch (rows = the G q heads of a kv group).
+__global__ void gather_rows_kernel(const bf16_t* __restrict__ X, long ldx, const int* __restrict__ idx, bf16_t* __restrict__ Y,
+                                   long ldy, int n, int chunks) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)n * chunks) return;
+  const int j = (int)(i / chunks), c = (int)(i - (long)j * chunks);
+  *(bf16x8*)(Y + (long)j * ldy + c * 8) = *(const bf16x8*)(X + (long)idx[j] * ldx + c * 8);
+}
+
+__global__ void last_rows_prep_kernel(const int* __restrict__ last_index, int* __restrict__ q_start, int* __restrict__ o_start,
+                                      int* __restrict__ q_len, int n, int qkv_heads, int n_q_heads, int group) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) {
+    q_start[j] = last_index[j] * qkv_heads;
+    o_start[j] = j * n_q_heads;
+    q_len[j] = group;
+  }
+}
+
 __global__ void seq_iota_kernel(int* __restrict__ start, int* __restrict__ len, int n, int L) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
@@ -445,6 +465,21 @@ int owc_launch_clip_embed(const void* pe, const void* pos_cls, void* x, int n_im
   const long total = (long)n_img * tokens * (E >> 3);
   hipLaunchKernelGGL(clip_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                      (const bf16_t*)pe, (const bf16_t*)pos_cls, (bf16_t*)x, n_img, tokens, E);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_gather_rows(const void* X, long ldx, const int* idx, void* Y, long ldy, int n, int width, hipStream_t st) {
+  if (n <= 0 || (width & 7) || (ldx & 7) || (ldy & 7)) return OWC_ERR_SHAPE;
+  const long total = (long)n * (width / 8);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const bf16_t*)X, ldx, idx,
+                     (bf16_t*)Y, ldy, n, width / 8);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_last_rows_prep(const int* last_index, int* q_start, int* o_start, int* q_len, int n, int qkv_heads,
+                              int n_q_heads, int group, hipStream_t st) {
+  hipLaunchKernelGGL(last_rows_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, last_index, q_start, o_start, q_len, n,
+                     qkv_heads, n_q_heads, group);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 

@@ -76,11 +76,15 @@ int owc_launch_gemm_bf16_aux(const void* A, long lda, const void* W, long ldw, c
                              const void* R, long ldr, void* C, long ldc, int M, int N, int K, int epi,
                              const void* zeros, hipStream_t s, const owc_gemm_aux* aux);
 void owc_attn_set_dbg(int v);
+void owc_llm_set_prune_last(int v);
 int owc_launch_clip_patchify(const uint8_t* img, void* out, long ldo, int kpad, int n_img, int S,
                              const float* mean, const float* stdv, hipStream_t st);
 int owc_launch_clip_embed(const void* pe, const void* pos_cls, void* x, int n_img, int tokens, int E,
                           hipStream_t st);
 int owc_launch_seq_iota(int* start, int* len, int n, int L, hipStream_t st);
+int owc_launch_gather_rows(const void* X, long ldx, const int* idx, void* Y, long ldy, int n, int width, hipStream_t st);
+int owc_launch_last_rows_prep(const int* last_index, int* q_start, int* o_start, int* q_len, int n, int qkv_heads,
+                              int n_q_heads, int group, hipStream_t st);
 int owc_launch_rmsnorm_quant_fp8(const void* X, long ldx, const void* W, void* Q, long ldq, float* S, int rows, int d,
                                  float eps, hipStream_t st);
 int owc_launch_quant_rows_fp8(const void* X, long ldx, void* Q, long ldq, float* S, int rows, int cols, hipStream_t st);

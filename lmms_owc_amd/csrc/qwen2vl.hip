@@ -95,7 +95,8 @@ size_t owc_llm_workspace_bytes(const owc_llm_weights* w, int T, int n_seq) {
   b += owc_align256(t * qkv * 2);                                     // qkv
   b += owc_align256(t * (size_t)w->n_q_heads * w->head_dim * 2);      // attn
   b += owc_align256(t * (size_t)w->d_ff * 2);                         // mlp
-  b += owc_align256((size_t)n_seq * d * 2);                           // last-token hidden
+  b += owc_align256((size_t)n_seq * d * 2) * 2;                       // last-token residual rows, last-token hidden
+  b += owc_align256((size_t)n_seq * 4) * 3;                           // last-token attention index triple
   b += owc_align256((size_t)n_seq * (size_t)w->vocab * 2);            // logits
   if (w->weight_dtype == OWC_WEIGHTS_FP8) {
     size_t widest = d > (size_t)w->d_ff ? d : (size_t)w->d_ff;
@@ -105,41 +106,61 @@ size_t owc_llm_workspace_bytes(const owc_llm_weights* w, int T, int n_seq) {
   return b + 1024;
 }
 
+static int g_prune_last = 1;  // owc_tuning_set("prefill_prune_last", 0): full last layer (the A side of the bit-identity test)
+
+// `last_index` != NULL (prefill): only the last token of the first `n_out` sequences feeds the lm_head, so the LAST layer
+// computes K/V (and the KV-cache write) for every row but attention, o-proj and the MLP for those n_out rows only, into the
+// compact residual rows `xl` -- the same values the full computation leaves in x[last_index[j]] (every kernel accumulates a
+// row independently of its neighbours), minus 1/n_layers of the prefill's o-proj + MLP work.
 static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* cache, void* x,
                       void* h, void* qkv, void* attn, void* mlp, void* q8, float* qs, const int32_t* pos3,
                       int64_t pos_stride, const int32_t* tok_slot, const int32_t* tok_idx,
                       const int32_t* q_start, const int32_t* o_start, const int32_t* k_start,
                       const int32_t* k_len, const int32_t* q_len, int n_seq, int T, int max_q_len,
-                      bool decode, int bcast_first, int bcast_n, hipStream_t st) {
+                      bool decode, int bcast_first, int bcast_n, const int32_t* last_index, int n_out, void* xl,
+                      int32_t* idx3, hipStream_t st) {
   const int d = w->d_model, Hq = w->n_q_heads, Hkv = w->n_kv_heads, hd = w->head_dim, F = w->d_ff;
   const int NQKV = (Hq + 2 * Hkv) * hd;
   const int G = Hq / Hkv;
   const float scale = 1.0f / sqrtf((float)hd);
   const size_t layer_elems = (size_t)cache->n_slots * Hkv * cache->s_max * hd;
   const bool fp8 = w->weight_dtype == OWC_WEIGHTS_FP8;
-  // one decoder projection: bf16 weights -> owc_gemm_bf16; fp8 weights -> per-token quantisation of the input rows, then the
-  // scaled-fp8-MFMA GEMM with the same fused epilogue
+  // one decoder projection over M rows: bf16 weights -> owc_gemm_bf16; fp8 weights -> per-token quantisation of the input
+  // rows, then the scaled-fp8-MFMA GEMM with the same fused epilogue
   // (`in` == NULL: the rows are already in q8 / qs, put there by the fused RMSNorm + quantise kernel)
-  auto linear = [&](const void* in, long ld_in, const void* wt, const float* ws, const void* bias, const void* res, void* out,
-                    long ld_out, int N, int K, int epi) -> int {
-    if (!fp8) return owc_launch_gemm_bf16(in, ld_in, wt, K, bias, res, ld_out, out, ld_out, T, N, K, epi, ctx->zeros, st);
-    if (in) OWC_TRY(owc_launch_quant_rows_fp8(in, ld_in, q8, K, qs, T, K, st));
-    return owc_launch_gemm_fp8(q8, K, qs, wt, K, ws, bias, res, ld_out, out, ld_out, T, N, K, epi, st);
+  auto linear = [&](int M, const void* in, long ld_in, const void* wt, const float* ws, const void* bias, const void* res,
+                    void* out, long ld_out, int N, int K, int epi) -> int {
+    if (!fp8) return owc_launch_gemm_bf16(in, ld_in, wt, K, bias, res, ld_out, out, ld_out, M, N, K, epi, ctx->zeros, st);
+    if (in) OWC_TRY(owc_launch_quant_rows_fp8(in, ld_in, q8, K, qs, M, K, st));
+    return owc_launch_gemm_fp8(q8, K, qs, wt, K, ws, bias, res, ld_out, out, ld_out, M, N, K, epi, st);
   };
-  auto norm = [&](const void* gamma) -> int {  // h = rmsnorm(x) (bf16), or straight to e4m3 codes for the fp8 projections
-    if (fp8) return owc_launch_rmsnorm_quant_fp8(x, d, gamma, q8, d, qs, T, d, w->rms_eps, st);
-    return owc_launch_rmsnorm(x, d, gamma, h, d, T, d, w->rms_eps, nullptr, st);
+  auto norm = [&](int M, const void* xin, const void* gamma) -> int {  // h = rmsnorm(x) (bf16), or straight to e4m3 codes
+    if (fp8) return owc_launch_rmsnorm_quant_fp8(xin, d, gamma, q8, d, qs, M, d, w->rms_eps, st);
+    return owc_launch_rmsnorm(xin, d, gamma, h, d, M, d, w->rms_eps, nullptr, st);
   };
   for (int i = 0; i < w->n_layers; ++i) {
     const owc_llm_layer& L = w->layers[i];
     bf16_t* kc = (bf16_t*)cache->k + (size_t)i * layer_elems;
     bf16_t* vc = (bf16_t*)cache->v + (size_t)i * layer_elems;
+    const bool tail = last_index && g_prune_last && i == w->n_layers - 1;  // last prefill layer: only the n_out last-token rows go on
     // self-attention block (HF:601-614)
-    OWC_TRY(norm(L.ln1_w));
-    OWC_TRY(linear(fp8 ? nullptr : h, d, L.qkv_w, L.qkv_s, L.qkv_b, nullptr, qkv, NQKV, NQKV, d, OWC_EPI_NONE));
+    OWC_TRY(norm(T, x, L.ln1_w));
+    OWC_TRY(linear(T, fp8 ? nullptr : h, d, L.qkv_w, L.qkv_s, L.qkv_b, nullptr, qkv, NQKV, NQKV, d, OWC_EPI_NONE));
     OWC_TRY(owc_launch_mrope_kv(qkv, NQKV, pos3, pos_stride, w->rope_cos, w->rope_sin, kc, vc, tok_slot,
                                 tok_idx, T, Hq, Hkv, cache->s_max, w->mrope_sec0, w->mrope_sec1, bcast_first, bcast_n, st));
-    if (!decode) {
+    int M = T;
+    void* xr = x;
+    if (tail) {
+      // the last token sees every key of its sequence: the decode mapping below, one "sequence" per output
+      int32_t *qs_l = idx3, *os_l = idx3 + owc_align256((size_t)n_seq * 4) / 4, *ql_l = os_l + owc_align256((size_t)n_seq * 4) / 4;
+      OWC_TRY(owc_launch_last_rows_prep(last_index, qs_l, os_l, ql_l, n_out, Hq + 2 * Hkv, Hq, G, st));
+      OWC_TRY(owc_launch_attention(qkv, hd, (long)G * hd, kc, hd, (long)cache->s_max * hd, vc, hd,
+                                   (long)cache->s_max * hd, attn, hd, (long)G * hd, qs_l, os_l,
+                                   k_start, k_len, ql_l, n_out, Hkv, 1, hd, G, 0, scale, st));
+      OWC_TRY(owc_launch_gather_rows(x, d, last_index, xl, d, n_out, d, st));
+      M = n_out;
+      xr = xl;
+    } else if (!decode) {
       OWC_TRY(owc_launch_attention(qkv, NQKV, hd, kc, hd, (long)cache->s_max * hd, vc, hd,
                                    (long)cache->s_max * hd, attn, (long)Hq * hd, hd, q_start, nullptr,
                                    k_start, k_len, q_len, n_seq, Hq, G, hd, max_q_len, 1, scale, st));
@@ -149,11 +170,11 @@ static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache
                                    (long)cache->s_max * hd, attn, hd, (long)G * hd, q_start, o_start,
                                    k_start, k_len, q_len, n_seq, Hkv, 1, hd, G, 0, scale, st));
     }
-    OWC_TRY(linear(attn, (long)Hq * hd, L.o_w, L.o_s, nullptr, x, x, d, d, Hq * hd, OWC_EPI_RESIDUAL));
+    OWC_TRY(linear(M, attn, (long)Hq * hd, L.o_w, L.o_s, nullptr, xr, xr, d, d, Hq * hd, OWC_EPI_RESIDUAL));
     // MLP block (HF:617-620, :464-466)
-    OWC_TRY(norm(L.ln2_w));
-    OWC_TRY(linear(fp8 ? nullptr : h, d, L.gateup_w, L.gateup_s, nullptr, nullptr, mlp, F, 2 * F, d, OWC_EPI_SWIGLU));
-    OWC_TRY(linear(mlp, F, L.down_w, L.down_s, nullptr, x, x, d, d, F, OWC_EPI_RESIDUAL));
+    OWC_TRY(norm(M, xr, L.ln2_w));
+    OWC_TRY(linear(M, fp8 ? nullptr : h, d, L.gateup_w, L.gateup_s, nullptr, nullptr, mlp, F, 2 * F, d, OWC_EPI_SWIGLU));
+    OWC_TRY(linear(M, mlp, F, L.down_w, L.down_s, nullptr, xr, xr, d, d, F, OWC_EPI_RESIDUAL));
   }
   return OWC_OK;
 }
@@ -181,7 +202,11 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
   void* qkv = cv.take((size_t)T * (w->n_q_heads + 2 * w->n_kv_heads) * w->head_dim * 2);
   void* attn = cv.take((size_t)T * w->n_q_heads * w->head_dim * 2);
   void* mlp = cv.take((size_t)T * w->d_ff * 2);
+  void* xl = cv.take((size_t)n_seq * d * 2);
   void* last = cv.take((size_t)n_seq * d * 2);
+  int32_t* idx3 = (int32_t*)cv.take((size_t)n_seq * 4);
+  cv.take((size_t)n_seq * 4);
+  cv.take((size_t)n_seq * 4);
   void* logits = cv.take((size_t)n_seq * w->vocab * 2);
   if (logits_out) logits = logits_out;
   void* q8 = nullptr;
@@ -195,9 +220,11 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
 
   OWC_TRY(owc_launch_embed(ids, img_index, w->embed, img_embeds, x, T, d, st));
   OWC_TRY(llm_layers(ctx, w, cache, x, h, qkv, attn, mlp, q8, qs, pos3, T, tok_slot, tok_idx, seq_start, nullptr,
-                     k_start, seq_len, q_len, n_seq, T, max_len, false, bcast_first_slot, bcast_n_slots, st));
-  // final norm on the last token of every prompt only, then lm_head + greedy argmax
-  OWC_TRY(owc_launch_rmsnorm(x, d, w->final_norm_w, last, d, n_out, d, w->rms_eps, last_index, st));
+                     k_start, seq_len, q_len, n_seq, T, max_len, false, bcast_first_slot, bcast_n_slots, last_index, n_out, xl,
+                     idx3, st));
+  // final norm on the last token of every prompt only (the rows the last layer left in xl), then lm_head + greedy argmax
+  if (!g_prune_last) OWC_TRY(owc_launch_gather_rows(x, d, last_index, xl, d, n_out, d, st));
+  OWC_TRY(owc_launch_rmsnorm(xl, d, w->final_norm_w, last, d, n_out, d, w->rms_eps, nullptr, st));
   OWC_TRY(owc_launch_gemm_bf16(last, d, w->lm_head_w, d, nullptr, nullptr, 0, logits, w->vocab, n_out,
                                w->vocab, d, OWC_EPI_NONE, ctx->zeros, st));
   OWC_TRY(owc_launch_argmax(logits, w->vocab, n_out, w->vocab, next_tok, st));
@@ -238,7 +265,7 @@ int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cac
   OWC_TRY(owc_launch_embed(tok_io, nullptr, w->embed, nullptr, x, B, d, st));
   // the three mrope streams of a generated token are identical: pos_stride 0 re-reads `pos`
   OWC_TRY(llm_layers(ctx, w, cache, x, h, qkv, attn, mlp, q8, qs, pos, 0, slot, write_idx, q_start, o_start,
-                     k_start, k_len, q_len, B, B, w->n_q_heads / w->n_kv_heads, true, 0, 0, st));
+                     k_start, k_len, q_len, B, B, w->n_q_heads / w->n_kv_heads, true, 0, 0, nullptr, 0, nullptr, nullptr, st));
   OWC_TRY(owc_launch_rmsnorm(x, d, w->final_norm_w, last, d, B, d, w->rms_eps, nullptr, st));
   OWC_TRY(owc_launch_gemm_bf16(last, d, w->lm_head_w, d, nullptr, nullptr, 0, logits, w->vocab, B,
                                w->vocab, d, OWC_EPI_NONE, ctx->zeros, st));
@@ -250,3 +277,5 @@ int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cac
 }
 
 }  // extern "C"
+
+void owc_llm_set_prune_last(int v) { g_prune_last = v != 0; }

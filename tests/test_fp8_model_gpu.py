@@ -70,3 +70,22 @@ def test_fp8_vs_bf16_agreement(setup, gpu):
     # batching invariance holds for the fp8 decoder too (per-token scales do not see the batch)
     single = to_np(e8.generate([prompts[5]], None, [[]], 4))
     assert np.array_equal(single[0], to_np(t8)[5])
+
+
+def test_fp8_pruned_last_prefill_layer_is_bit_identical(setup, gpu):
+    """Per-token quantisation is row-local, so running the last prefill layer on the last-token rows only must not change a bit
+    of the fp8 decoder's logits or tokens either."""
+    from lmms_owc_amd import _lib
+
+    cfg, w, e8, _ = setup
+    r = np.random.default_rng(11)
+    prompts = [r.integers(1, 490, 9 + 3 * i).astype(np.int64) for i in range(5)]
+    lib = _lib.load()
+    try:
+        assert lib.owc_tuning_set(b"prefill_prune_last", 0) == 0
+        a, la = e8.generate(prompts, None, [[] for _ in prompts], 4, return_logits=True)
+        assert lib.owc_tuning_set(b"prefill_prune_last", 1) == 0
+        b, lb = e8.generate(prompts, None, [[] for _ in prompts], 4, return_logits=True)
+        assert torch.equal(la, lb) and torch.equal(a, b)
+    finally:
+        lib.owc_tuning_set(b"prefill_prune_last", 1)

@@ -131,6 +131,37 @@ def test_shared_prefix_is_bit_identical(setup, gpu):
     assert torch.equal(a, c)
 
 
+def test_pruned_last_prefill_layer_is_bit_identical(setup, gpu):
+    """owc_llm_prefill runs the last layer's attention / o-proj / MLP on the last-token rows only (K/V still for every row);
+    the first-step logits and all generated tokens must equal the full last layer bit for bit, with and without the
+    shared-prefix segment, for the bf16 decoder."""
+    from lmms_owc_amd import _lib
+    from lmms_owc_amd.engine.qwen2vl import Qwen2VLEngine
+
+    cfg, w, eng, g = setup
+    r = np.random.default_rng(5)
+    head = r.integers(1, 400, 6)
+    prompts, grids, pixs = [], [], []
+    for i, grid in enumerate([[(1, 4, 4)], [(1, 6, 4)], [(1, 4, 8)]]):
+        n_img = grid[0][1] * grid[0][2] // 4
+        prompts.append(np.concatenate([head, np.full(n_img, cfg.image_token_id), r.integers(1, 400, 2 + 2 * i)]))
+        grids.append(grid)
+        pixs.append(recipes.pixel_values(grid, 40 + i))
+    pix = torch.from_numpy(np.concatenate(pixs)).to(torch.bfloat16).to(gpu)
+    emb = eng.encode_images(pix, [gg for gs in grids for gg in gs])
+    lib = _lib.load()
+    try:
+        for share in (False, True):
+            e = Qwen2VLEngine(eng.w, vit_chunk_tokens=64, prefill_chunk_tokens=4096, share_prefix=share, min_shared_prefix=2)
+            assert lib.owc_tuning_set(b"prefill_prune_last", 0) == 0
+            a, la = e.generate(prompts, emb, grids, 5, return_logits=True)
+            assert lib.owc_tuning_set(b"prefill_prune_last", 1) == 0
+            b, lb = e.generate(prompts, emb, grids, 5, return_logits=True)
+            assert torch.equal(la, lb) and torch.equal(a, b)
+    finally:
+        lib.owc_tuning_set(b"prefill_prune_last", 1)
+
+
 def test_graph_replayed_decode_equals_eager(setup, gpu):
     """owc_llm_decode_step with a device-side step state is a fixed launch sequence: steps 2.. replayed from ONE captured hipGraph
     give exactly the eager loop's tokens (also with EOS stopping and pads)."""
