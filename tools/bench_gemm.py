@@ -95,9 +95,11 @@ def main():
         knob = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--knob=")), "gemm_dbg")
         return ab(dev, next((a for a in sys.argv[1:] if not a.startswith("--")), None), knob.encode())
     only = next((a for a in sys.argv[1:] if not a.startswith("--")), None)
+    m_over = next((int(a[4:]) for a in sys.argv[1:] if a.startswith("--m=")), 0)  # e.g. --m=131072: the vision launch group
     for name, m, n, k in SHAPES:
-        if only and name != only:
+        if only and not name.startswith(only):
             continue
+        m = m_over or m
         a = torch.randn(m, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
         out = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
