@@ -41,7 +41,8 @@ struct GemmProfile {
 };
 GemmProfile g_prof;
 int g_gemm_dbg = 0;       // timing-experiment knob (OWC_GEMM_DBG / owc_tuning_set "gemm_dbg"), results are garbage unless 0 or 512:
-                          // 1 no DMA, 2 DMA re-reads K-tiles 0/1 (all L2 hits), 4 no epilogue, 512 direct (un-staged) epilogue stores
+                          // 1 no DMA, 2 DMA re-reads K-tiles 0/1 (all L2 hits), 4 no epilogue, 512 direct (un-staged) epilogue stores,
+                          // 2048 no per-K-tile barrier, 4096 no DMA wait at the barrier
 int g_skinny_max_m = 64;   // M at and below which the weight-streaming skinny kernel runs (0 disables: A-B knob "gemm_skinny_max_m")
 int g_mid_max_tiles = 256;  // fewer 128x128 tiles than this -> 64x64 tiles (0 disables: A-B knob "gemm_mid_max_tiles")
 int g_big_min_tiles = 192;  // fewer 256x256 tiles than this -> use the 128x128 kernel
@@ -394,7 +395,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
     // every LDS read of stage kt by this wave has completed (lgkmcnt(0), issued >= one phase ago) and its DMA
     // pieces of stage kt+1 have landed (issued a whole K-tile ago); the barrier publishes stage kt+1 and proves
     // stage kt's buffer is no longer read by anyone.
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (dbg & 2048) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // timing experiment: no barrier
+    else if (dbg & 4096) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // timing experiment: no DMA wait
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (kt + 1 < nk) {
       read_a(xa, nxt, 0, ch0);  // next K-tile, phase 1
       read_w(wk0, nxt, ch0);
