@@ -178,6 +178,9 @@ def main() -> None:
     ap.add_argument("--vit-chunk", type=int, default=None, help="vision-tower tokens per launch group (engine default if unset)")
     ap.add_argument("--prefill-chunk", type=int, default=None, help="packed prefill rows per launch group (engine default if unset)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nominal-forward", action="store_true",
+                    help="run the model's nominal forward: full last prefill layer on every row and no shared-prefix segment "
+                         "(same tokens bit for bit; shows what the two dead-work eliminations are worth)")
     ap.add_argument("--cpu-images", type=int, default=2)
     args = ap.parse_args()
 
@@ -215,6 +218,9 @@ def main() -> None:
         dims = dataclasses.replace(dims, decoder_dtype=args.decoder_dtype)
     weights = Qwen2VLWeights.random(dims, device, seed=1234)
     ekw = {k: v for k, v in (('vit_chunk_tokens', args.vit_chunk), ('prefill_chunk_tokens', args.prefill_chunk)) if v}
+    if args.nominal_forward:
+        ekw['share_prefix'] = False
+        _lib.check(_lib.load().owc_tuning_set(b"prefill_prune_last", 0), 0)
     engine = Qwen2VLEngine(weights, **ekw)
     B, T = args.batch, args.new_tokens
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
@@ -307,7 +313,7 @@ def main() -> None:
         # executed FLOPs: what every utilisation figure below is priced on
         s_prompt = S_TEXT_BEFORE + S_IMG + S_TEXT_AFTER
         per_chunk = max(1, min(B, (engine.prefill_chunk_tokens - S_TEXT_BEFORE) // (s_prompt - S_TEXT_BEFORE))) if engine.share_prefix else 1
-        f_img = f_model - pruned_flops_per_image(dims, per_chunk)
+        f_img = f_model if args.nominal_forward else f_model - pruned_flops_per_image(dims, per_chunk)
         gemm_tflops = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         result = {
             "metric": "images/sec (whole node) Qwen2-VL-7B open-world classify; label-cosine/sec",
