@@ -327,7 +327,7 @@ def main() -> None:
             "images_per_s_from_host_uint8": pcie_images_per_s,  # PCIe-inclusive (H2D + GPU patchify + step), not `value`
             "label_cosine_per_sec": labels_per_s,
             "label_cosine_config": {"labels_per_gpu": n_lab, "tokens_per_label": L, "classes": args.scorer_classes, "top_k": 5,
-                                    "encoder": "MiniLM-L6 (BERT 6x384) fp32 on f32-input MFMA"},
+                                    "encoder": "MiniLM-L6 (BERT 6x384) fp32; linears as 3-piece bf16 splits on the bf16 MFMA (fp32-level error, tests/test_scorer_gpu.py)"},
             "model_flops_per_image": f_model,      # the model's nominal forward
             "executed_flops_per_image": f_img,     # minus the last prefill layer's dead rows (see pruned_flops_per_image)
             "mfma_frac_end_to_end": images_per_s / world * f_img / (PEAK_BF16_TFLOPS * 1e12),  # always against the bf16 peak

@@ -3,7 +3,7 @@
 // BertModel forward, mask-weighted mean pooling with clamp(min=1e-9), L2 normalisation) and of
 // semantic_similarity's paired torch.bmm (src/data/metrics/_group.py:537-544), plus the
 // all-classes cosine top-k the north star asks for.  The reference's CPU path is fp32, so every
-// GEMM here runs on the exact f32-input MFMA (gemm_f32.hip); the small kernels below are HBM/latency
+// GEMM here runs as three-piece bf16 splits on the bf16 MFMA (gemm_f32.hip; the exact f32-input MFMA kernel stays selectable); the small kernels below are HBM/latency
 // bound and use one wave per row.
 #include "../../include/owc.h"
 #include "owc_internal.h"
@@ -330,16 +330,16 @@ int owc_bert_embed(owc_ctx* ctx, const owc_bert_weights* w, const int32_t* ids, 
   const float scale = 1.0f / sqrtf(32.0f);
   for (int i = 0; i < w->n_layers; ++i) {
     const owc_bert_layer& Ly = w->layers[i];
-    OWC_TRY(owc_launch_gemm_f32(x, H, Ly.qkv_w, H, Ly.qkv_b, nullptr, 0, qkv, 3 * H, T, 3 * H, H,
+    OWC_TRY(owc_launch_gemm_f32_bert(x, H, Ly.qkv_w, H, Ly.qkv_b, nullptr, 0, qkv, 3 * H, T, 3 * H, H,
                                 OWC_EPI_NONE, ctx->zeros, st));
     hipLaunchKernelGGL(bert_attn_kernel<32>, dim3(n * NH), dim3(64), attn_lds, st, qkv, mask, cx, L, H, NH, scale);
     // x = LN(dense(ctx) + x)
-    OWC_TRY(owc_launch_gemm_f32(cx, H, Ly.o_w, H, Ly.o_b, x, H, x, H, T, H, H, OWC_EPI_RESIDUAL, ctx->zeros, st));
+    OWC_TRY(owc_launch_gemm_f32_bert(cx, H, Ly.o_w, H, Ly.o_b, x, H, x, H, T, H, H, OWC_EPI_RESIDUAL, ctx->zeros, st));
     hipLaunchKernelGGL(ln_f32_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, Ly.ln1_w, Ly.ln1_b, T, H, w->ln_eps);
     // x = LN(dense(gelu(dense(x))) + x)
-    OWC_TRY(owc_launch_gemm_f32(x, H, Ly.fc1_w, H, Ly.fc1_b, nullptr, 0, ff, I, T, I, H, OWC_EPI_GELU_ERF,
+    OWC_TRY(owc_launch_gemm_f32_bert(x, H, Ly.fc1_w, H, Ly.fc1_b, nullptr, 0, ff, I, T, I, H, OWC_EPI_GELU_ERF,
                                 ctx->zeros, st));
-    OWC_TRY(owc_launch_gemm_f32(ff, I, Ly.fc2_w, I, Ly.fc2_b, x, H, x, H, T, H, I, OWC_EPI_RESIDUAL, ctx->zeros, st));
+    OWC_TRY(owc_launch_gemm_f32_bert(ff, I, Ly.fc2_w, I, Ly.fc2_b, x, H, x, H, T, H, I, OWC_EPI_RESIDUAL, ctx->zeros, st));
     hipLaunchKernelGGL(ln_f32_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, Ly.ln2_w, Ly.ln2_b, T, H, w->ln_eps);
   }
   hipLaunchKernelGGL(pool_norm_kernel, dim3((n + 3) / 4), dim3(256), 0, st, x, mask, out, n, L, H);

@@ -62,6 +62,10 @@ int owc_launch_patchify(const uint8_t* img, void* out, long ldo, int n_img, int 
 int owc_launch_gemm_f32(const float* A, long lda, const float* W, long ldw, const float* bias,
                         const float* R, long ldr, float* C, long ldc, int M, int N, int K, int epi,
                         const void* zeros, hipStream_t s);
+int owc_launch_gemm_f32_bert(const float* A, long lda, const float* W, long ldw, const float* bias,
+                        const float* R, long ldr, float* C, long ldc, int M, int N, int K, int epi,
+                        const void* zeros, hipStream_t s);
+void owc_bert_set_x3(int v);
 void owc_gemm_profile_set(int on);
 int owc_gemm_profile_collect(double* total_ms, double* total_flops, long* launches);  // arrays of 2: [bf16, fp8]
 int owc_gemm_profile_begin(double flops, int kind, hipStream_t s);

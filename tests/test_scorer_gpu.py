@@ -31,6 +31,30 @@ def test_embed_matches_reference_golden(gpu, kind, n, L):
     np.testing.assert_allclose(cos, g[f"{kind}_semantic_similarity_none"], atol=2e-5)
 
 
+def test_bf16x3_linears_match_the_exact_f32_mfma(gpu):
+    """The encoder's linears run as three-piece bf16 splits of the fp32 operands (6 bf16 MFMAs per block, gemm_f32.hip); the
+    exact f32-input MFMA kernel stays selectable.  Both must sit within the golden tolerance, and within 2e-6 of each other."""
+    from lmms_owc_amd import _lib
+    from lmms_owc_amd.engine.scorer import BertWeights, SentenceScorer
+
+    g = np.load(GOLD / "scorer.npz")
+    c = recipes.bert_cfg("minilm")
+    sc = SentenceScorer(BertWeights(c, recipes.bert_weights(c, 1234), gpu))
+    ids, mask = recipes.label_tokens(8, 16, c["vocab_size"], seed=21)
+    lib = _lib.load()
+    try:
+        assert lib.owc_tuning_set(b"bert_bf16x3", 0) == 0
+        exact = to_np(sc.embed(ids, mask))
+        assert lib.owc_tuning_set(b"bert_bf16x3", 1) == 0
+        split = to_np(sc.embed(ids, mask))
+    finally:
+        lib.owc_tuning_set(b"bert_bf16x3", 1)
+    np.testing.assert_allclose(exact, g["minilm_ref_embeds"], atol=2e-5)
+    np.testing.assert_allclose(split, g["minilm_ref_embeds"], atol=2e-5)
+    np.testing.assert_allclose(split, exact, atol=2e-6)
+    assert not np.array_equal(split, exact)  # the knob really switches kernels
+
+
 def test_embed_matches_oracle_ragged(gpu):
     from lmms_owc_amd.engine.scorer import BertWeights, SentenceScorer
 
