@@ -246,22 +246,32 @@ __global__ __launch_bounds__(256) void gemm_f32x3_nt_kernel(
 #pragma unroll
     for (int t = 0; t < 4; ++t)
       split3(*(const f32x4*)(la + offA0 + t * 16 * 128), *(const f32x4*)(la + offA1 + t * 16 * 128), ah[t], am[t], al[t]);
+    bf16x8 wh[2], wmd[2], wl[2];
+    split3(w0[0], w1[0], wh[0], wmd[0], wl[0]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      bf16x8 wh, wmd, wl;
-      split3(w0[nt], w1[nt], wh, wmd, wl);
+      const int c_ = nt & 1, n_ = c_ ^ 1;
+      if (nt < 3) split3(w0[nt + 1], w1[nt + 1], wh[n_], wmd[n_], wl[n_]);  // rides under this n tile's MFMAs
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         f32x4 c = acc[nt][mt];
         // small terms first
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmd, am[mt], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[mt], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al[mt], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmd, ah[mt], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am[mt], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[mt], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmd[c_], am[mt], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[c_], ah[mt], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[c_], al[mt], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmd[c_], ah[mt], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[c_], am[mt], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[c_], ah[mt], c, 0, 0, 0);
         acc[nt][mt] = c;
       }
+      // one MFMA, then two of the next fragment's splitting instructions, ...
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
