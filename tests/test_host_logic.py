@@ -369,3 +369,26 @@ def test_multi_round_task_protocol(tmp_path):
         c = yaml.safe_load((ROOT / "lmms_owc_amd" / "task_configs" / f"{n}.yaml").read_text())
         assert c["task"] == n and c["output_type"] in ("generate_until", "generate_until_multi_round")
         assert [m["metric"] for m in c["metric_list"]] == ["exact_match", "semantic_similarity", "textual_inclusion"]
+
+
+def test_bench_flop_accounting():
+    """bench.py prices utilisation on executed FLOPs: the nominal forward minus the last prefill layer's dead
+    rows and the shared-prefix rows.  The subtraction must be the closed form of exactly those rows."""
+    import bench
+    from lmms_owc_amd.engine.qwen2vl import DIMS
+
+    d = DIMS["qwen2-vl-7b"]
+    S, P = bench.S_TEXT_BEFORE + bench.S_IMG + bench.S_TEXT_AFTER, bench.S_TEXT_BEFORE
+    assert S == 286
+    f_model = bench.flops_per_image(d, 16)
+    assert 5.4e12 < f_model < 5.5e12
+    H, KV, hd, dm, ff, L = d.n_q_heads, d.n_kv_heads, d.head_dim, d.d_model, d.d_ff, d.n_layers
+    row_tail = 2 * H * hd * dm + 6 * dm * ff                      # o-proj + MLP of one row
+    row_full = 2 * dm * (H + 2 * KV) * hd + row_tail              # + qkv
+    last_only = bench.pruned_flops_per_image(d, 1)                # one prompt per group: nothing shared
+    assert last_only == (S - 1) * row_tail + 2 * S * S * H * hd - 4 * S * H * hd
+    many = bench.pruned_flops_per_image(d, 240)
+    shared = many - last_only
+    want = P * (1 - 1 / 240) * ((L - 1) * row_full + 2 * dm * (H + 2 * KV) * hd)
+    assert abs(shared - want) <= 1e-6 * want
+    assert 0.05 < many / f_model < 0.06                           # 5.5 % of the nominal forward
