@@ -334,11 +334,13 @@ def main() -> None:
             "roofline": {"bound": "mfma", "kernel": "gemm_fp8_nt_256_kernel (decoder projections)" if fp8_run else "gemm_bf16_nt_kernel (all epilogues)",
                          "achieved": gemm_tflops, "peak": PEAK_FP8_TFLOPS if fp8_run else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": gemm_tflops / (PEAK_FP8_TFLOPS if fp8_run else PEAK_BF16_TFLOPS),
-                         "traffic": None,
-                         "traffic_note": "not collectable inside this process (PMC passes serialise ~24k launches); separate rocprofv3 --pmc pass on the "
-                                         "largest GEMM of the step (7b gate/up, M 18304 N 37888 K 3584), profiles/r01_pmc_gemm_summary.json: FETCH_SIZE x2 "
-                                         "(gfx950 correction) = 7.6 GB per launch against 1.1 GB algorithmic (A + W + C once): the panels of a 4x8-tile XCD "
-                                         "patch do not fit the 4 MB L2 across patches, 78 % L2 hit = compulsory floor (DESIGN.md section 4 notes)",
+                         "traffic": None if fp8_run or args.model != "7b" else 31287994880,
+                         "traffic_note": "bytes per launch of the step's largest launch class (7B gate/up, M 65536 = one prefill launch group, N 37888, "
+                                         "K 3584), from separate rocprofv3 --pmc passes on the final kernel (FETCH_SIZE x2 for the gfx950 correction + "
+                                         "WRITE_SIZE, profiles/r01_pmc_gemm_traffic_final.json) - PMC passes cannot run inside this process (they serialise "
+                                         "~24k launches).  Algorithmic bytes of that launch (A + W + C once) = 5.7 GB; measured 31.3 GB = C once (exact) + 26.3 GB "
+                                         "of operand fetches = 2MNK/256 x (1/4 + 1/8): every 4x8-tile XCD patch re-fetches its panels (L2 4 MB; 78 % L2 hit is the "
+                                         "floor of that patch shape, DESIGN.md section 4 notes)",
                          "launches": int(n_launch.value), "kernel_ms_total": ms.value,
                          "share_of_step_time": ms.value * 1e-3 / (time_or(dt)), "method":
                              "HIP events around every launch of the timed region on the launch stream; achieved = sum(2MNK) / sum(t)"},
