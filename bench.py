@@ -334,7 +334,7 @@ def main() -> None:
             "roofline": {"bound": "mfma", "kernel": "gemm_fp8_nt_256_kernel (decoder projections)" if fp8_run else "gemm_bf16_nt_kernel (all epilogues)",
                          "achieved": gemm_tflops, "peak": PEAK_FP8_TFLOPS if fp8_run else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": gemm_tflops / (PEAK_FP8_TFLOPS if fp8_run else PEAK_BF16_TFLOPS),
-                         "traffic": None if fp8_run or args.model != "7b" else 31287994880,
+                         "traffic": None if fp8_run or args.model != "7b" or B < 256 else 31287994880,  # only where a full 65536-row prefill group exists
                          "traffic_note": "bytes per launch of the step's largest launch class (7B gate/up, M 65536 = one prefill launch group, N 37888, "
                                          "K 3584), from separate rocprofv3 --pmc passes on the final kernel (FETCH_SIZE x2 for the gfx950 correction + "
                                          "WRITE_SIZE, profiles/r01_pmc_gemm_traffic_final.json) - PMC passes cannot run inside this process (they serialise "
