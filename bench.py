@@ -9,8 +9,10 @@ the label-cosine/s of the scorer leg, the MFMA roofline of the dominant kernel (
 around every launch of the timed region) and the reference's CPU HuggingFace path timed on the host cores.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
+  python bench.py --gpus 8 --steps 3 --warmup 1          # spawns its own 8 ranks (one process per GPU, RCCL)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
-         bench.py --gpus 8 --steps 3 --warmup 1
+         bench.py --gpus 8 --steps 3 --warmup 1          # or under a launcher that already set RANK / WORLD_SIZE
+  python bench.py --gpus 2 --dry-run                     # CPU check of the launcher + rendezvous (gloo), no HIP
 """
 
 from __future__ import annotations
@@ -163,6 +165,66 @@ def prompt_ids(image_token_id: int) -> np.ndarray:
                            r.integers(1000, 150000, S_TEXT_AFTER)]).astype(np.int32)
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: this (parent) process has not touched the GPU; it starts N children
+    of the same command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (one process per GPU, the analogue of the
+    reference's `accelerate launch --num_processes N`, scripts/schedule_batch.sh:109-112), waits for all of them and
+    returns the first non-zero exit code.  Rank 0 inherits stdout, so its ONE JSON line is this command's output; the other
+    ranks' stdout goes to stderr.  No exec: the children are ordinary subprocesses."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OWC_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        live = dict(enumerate(procs))
+        while live:   # poll ALL ranks: a rank that died must not leave the others waiting in a collective
+            for r, p in list(live.items()):
+                code = p.poll()
+                if code is None:
+                    continue
+                del live[r]
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"[bench] rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                    for q in live.values():
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return rc
+
+
+def dry_run(args, world: int, rank: int) -> None:
+    """Launcher / rendezvous check that stops before HIP init: gloo all_reduce over the ranks, rank 0 prints a stub line."""
+    seen = 1
+    if os.environ.get("OWC_BENCH_DRYRUN_FAIL_RANK") == str(rank):   # test hook: exit-code propagation of the launcher
+        raise SystemExit(7)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        assert seen == dist.get_world_size() == world
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": args.gpus, "world_size_seen": seen, "steps": args.steps,
+                          "warmup": args.warmup, "self_launched": bool(os.environ.get("OWC_BENCH_SELF_LAUNCHED"))}), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,13 +244,20 @@ def main() -> None:
                     help="run the model's nominal forward: full last prefill layer on every row and no shared-prefix segment "
                          "(same tokens bit for bit; shows what the two dead-work eliminations are worth)")
     ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--dry-run", action="store_true", help="launcher + rendezvous check on CPU (gloo); stops before HIP init")
+    ap.add_argument("--one-gpu-value", type=float, default=None,
+                    help="images/s of the 1-GPU run: adds scaling_efficiency = value / (N * this) to the line")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))   # nothing above this line has touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)

@@ -316,7 +316,8 @@ class Qwen2VLEngine:
     # -- decoder -----------------------------------------------------------------------
     def generate(self, prompts: list, img_embeds: torch.Tensor | None, grids_per_prompt: list, max_new_tokens: int,
                  *, eos_token_id: int = -1, pad_token_id: int = 0, stop_check_every: int = 8,
-                 return_logits: bool = False, img_rows: list | None = None):
+                 return_logits: bool = False, img_rows: list | None = None, forced_tokens=None,
+                 return_step_logits: bool = False):
         """Greedy generation for a batch of prompts.
 
         prompts[b]: 1-D int array of token ids holding image_token_id placeholders;
@@ -324,7 +325,11 @@ class Qwen2VLEngine:
         img_embeds: rows for all image tokens of all prompts, in prompt order;
         img_rows[b] (optional): explicit row of `img_embeds` for every image token of prompt b (engines whose
         feature buffer is not already in token order, e.g. LLaVA's CLS-skipping / anyres packing).
-        Returns int32 [B, max_new_tokens] (pad after EOS) and, optionally, the first-step logits.
+        forced_tokens (optional, int [B, max_new_tokens]): teacher forcing for parity tests - the token FED at step
+        j+1 is forced_tokens[b][j] instead of the engine's own argmax (which is still what the returned tokens hold),
+        so every step's logits are conditional on the reference's continuation; EOS handling must be off.
+        Returns int32 [B, max_new_tokens] (pad after EOS) and, optionally, the first-step logits [B, vocab]
+        (`return_logits`) or every step's logits [max_new_tokens, B, vocab] (`return_step_logits`).
         """
         d = self.d
         B = len(prompts)
@@ -366,7 +371,14 @@ class Qwen2VLEngine:
             raise ValueError("prompt + generation exceeds the rope table (raise Qwen2VLDims.max_positions)")
 
         next_tok = torch.empty(B, dtype=I32, device=self.device)
-        first_logits = torch.empty((B, d.vocab), dtype=BF16, device=self.device) if return_logits else None
+        step_logits = torch.empty((max_new_tokens, B, d.vocab), dtype=BF16, device=self.device) if return_step_logits else None
+        first_logits = step_logits[0] if return_step_logits else (
+            torch.empty((B, d.vocab), dtype=BF16, device=self.device) if return_logits else None)
+        forced = None
+        if forced_tokens is not None:
+            if eos_token_id >= 0:
+                raise ValueError("forced_tokens needs EOS handling off (eos_token_id = -1)")
+            forced = self._i32(np.asarray(forced_tokens).reshape(B, max_new_tokens).T)   # [T, B]: one contiguous row per step
 
         # ---- prefill in chunks of whole prompts (chunk size counted in packed ROWS: with a shared prefix every
         # prompt contributes len - P rows, so more prompts fit the same GEMM M)
@@ -387,6 +399,8 @@ class Qwen2VLEngine:
         rc = self._lib.owc_decode_update(self._ctx, next_tok.data_ptr(), done.data_ptr(), out_tokens.data_ptr(),
                                          max_new_tokens, 0, B, eos_token_id, eos1, pad_token_id, _lib.stream_ptr())
         _lib.check(rc, self.dev_index)
+        if forced is not None:
+            next_tok.copy_(forced[0])
         if max_new_tokens > 1:
             steps = np.arange(max_new_tokens - 1, dtype=np.int64)[:, None]
             pos_all = self._i32(max_pos[None, :] + 1 + steps)      # rope position of the token fed at step j+1
@@ -405,15 +419,18 @@ class Qwen2VLEngine:
                     self._ctx, C.byref(self.w.llm), C.byref(cache), next_tok.data_ptr(), pos_t.data_ptr(),
                     slot.data_ptr(), widx_t.data_ptr(), k_start.data_ptr(), klen_t.data_ptr(),
                     q_start.data_ptr(), o_start.data_ptr(), q_len.data_ptr(), done.data_ptr(), out_tokens.data_ptr(),
-                    max_new_tokens, j, _lib.ptr(state), B, eos_token_id, eos1, pad_token_id, None, ws.data_ptr(), ws.numel(),
+                    max_new_tokens, j, _lib.ptr(state), B, eos_token_id, eos1, pad_token_id,
+                    step_logits[j].data_ptr() if step_logits is not None else None, ws.data_ptr(), ws.numel(),
                     _lib.stream_ptr())
                 _lib.check(rc, self.dev_index)
+                if forced is not None:
+                    next_tok.copy_(forced[j])
 
             def all_done(j):
                 return eos_token_id >= 0 and stop_check_every and j % stop_check_every == 0 and bool(done.all().item())
 
             j = 1
-            if self.graph_decode and B <= self.graph_max_batch and max_new_tokens >= 4:
+            if self.graph_decode and B <= self.graph_max_batch and max_new_tokens >= 4 and forced is None and step_logits is None:
                 # Small batches are launch-bound (~250 tiny launches per step): steps 2.. replay ONE captured hipGraph.  The
                 # step keeps its own rope position / write index / key count / output column on the device
                 # (`step_state`), so every replay is the same launch sequence with the same arguments.
@@ -437,6 +454,8 @@ class Qwen2VLEngine:
                     if all_done(j):
                         out_tokens[:, j + 1:] = pad_token_id
                         break
+        if return_step_logits:
+            return out_tokens, step_logits
         return (out_tokens, first_logits) if return_logits else out_tokens
 
     def _common_prefix(self, prompts, b0: int, b1: int) -> int:

@@ -160,6 +160,8 @@ class LLaVA(Model):
         for chunk in reordered.get_batched(n=self.batch_size, batch_fn=None):
             contexts, all_gen_kwargs, doc_to_visual, doc_ids, tasks, splits = zip(*chunk, strict=True)
             task, split = tasks[0], splits[0]
+            for g in all_gen_kwargs:   # the reference (batch size 1) pops it from EVERY request's own dict, which is what the
+                g.pop("until", None)   # samples file later records under `arguments` (_engine.py:262-266, _tracker.py:318-322)
             gen_kwargs = dict(all_gen_kwargs[0])
             gen_kwargs.pop("until", None)  # read and never applied by the reference (:310-320)
             max_new = int(gen_kwargs.get("max_new_tokens", 1024))

@@ -19,6 +19,7 @@ manifest, a `datasets.load_from_disk` directory, or a seeded synthetic generator
 
 from __future__ import annotations
 
+import copy
 import json
 from dataclasses import dataclass, field
 from pathlib import Path
@@ -77,6 +78,10 @@ class ClassificationTask:
         if output_type == "generate_until_multi_round" and (not isinstance(prompts, list) or len(prompts) < 2):
             raise ValueError("`multi_round` expects at least two questions")
         self.generation_kwargs = dict(generation_kwargs or {"max_new_tokens": 64, "do_sample": False})
+        if "temperature" in self.generation_kwargs:
+            self.generation_kwargs["temperature"] = float(self.generation_kwargs["temperature"])
+        if "until" not in self.generation_kwargs:   # TaskConfig.__post_init__, src/data/tasks/_config.py:199-205
+            self.generation_kwargs["until"] = ["\n\n"]   # [fewshot_delimiter]
         self.metric_list = metric_list or DEFAULT_METRICS
         self._metric_fn, self._metric_kwargs, self._agg, self._higher = {}, {}, {}, {}
         for m in self.metric_list:
@@ -130,11 +135,12 @@ class ClassificationTask:
         self.instances = []
         it = utils.create_iterator(enumerate(self.docs), rank, world_size, limit)
         for doc_id, doc in it:
+            gk = copy.deepcopy(self.generation_kwargs)   # _manager.py:897, :906
             if self.OUTPUT_TYPE == "generate_until_multi_round":
-                args = (self.doc_to_text(doc), dict(self.generation_kwargs), self.doc_to_visual, self.doc_to_text_multi_round, doc_id,
+                args = (self.doc_to_text(doc), gk, self.doc_to_visual, self.doc_to_text_multi_round, doc_id,
                         self.task_name, self.split)
             else:
-                args = (self.doc_to_text(doc), dict(self.generation_kwargs), self.doc_to_visual, doc_id, self.task_name, self.split)
+                args = (self.doc_to_text(doc), gk, self.doc_to_visual, doc_id, self.task_name, self.split)
             self.instances.append(TaskInstance(self.OUTPUT_TYPE, args, idx=0, doc=doc, task_name=self.task_name, doc_id=doc_id))
 
     def apply_filters(self) -> None:

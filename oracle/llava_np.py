@@ -117,8 +117,9 @@ def pack_anyres(w: dict, cfg: LlavaCfg, feats: np.ndarray, image_size) -> np.nda
 
 def generate(w: dict, cfg: LlavaCfg, input_ids: np.ndarray, pixel_values: np.ndarray | None, max_new_tokens: int, *,
              bf16=False, eos_token_id: int | None = None, pad_token_id: int = 0, return_logits=False,
-             image_sizes=None, views_per_image=None):
+             image_sizes=None, views_per_image=None, forced_tokens=None):
     """Greedy generation for ONE prompt whose <image> placeholders are already expanded to one id per feature row.
+    `forced_tokens`: teacher forcing - the token fed after step j is forced_tokens[j]; `out` still holds the argmax.
     LLaVA-NeXT: pixel_values holds all views of all images, `views_per_image` / `image_sizes` (h, w) split them."""
     qcfg = Q.Cfg(text=cfg.text, image_token_id=cfg.image_token_id)
     ids = np.asarray(input_ids).astype(np.int64)
@@ -142,7 +143,8 @@ def generate(w: dict, cfg: LlavaCfg, input_ids: np.ndarray, pixel_values: np.nda
         out.append(tok)
         if (eos_token_id is not None and tok == eos_token_id) or step == max_new_tokens - 1:
             break
-        x = maybe_bf16(w[Q.T + "embed_tokens.weight"][np.array([tok])], bf16)
+        feed = tok if forced_tokens is None else int(forced_tokens[step])
+        x = maybe_bf16(w[Q.T + "embed_tokens.weight"][np.array([feed])], bf16)
         h = Q.llm_forward(w, qcfg, x, np.full((3, 1), cur, np.int64), cache, bf16=bf16)
         logits = Q.lm_head(w, qcfg, h[-1:], bf16=bf16)
         all_logits.append(logits[0].copy())

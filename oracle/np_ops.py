@@ -29,9 +29,9 @@ def maybe_bf16(x: np.ndarray, bf16: bool) -> np.ndarray:
 
 def linear(x, w, b=None, *, bf16=False):
     """torch.nn.functional.linear: x[M,K] @ w[N,K].T + b (fp32 accumulate, one rounding)."""
-    y = x.astype(np.float32) @ w.astype(np.float32).T
+    y = np.asarray(x, np.float32) @ np.asarray(w, np.float32).T   # asarray: no copy of an already-fp32 weight
     if b is not None:
-        y = y + b.astype(np.float32)
+        y = y + np.asarray(b, np.float32)
     return maybe_bf16(y, bf16)
 
 

@@ -248,9 +248,12 @@ def greedy_argmax(logits: np.ndarray) -> np.ndarray:
 
 
 def generate(w: dict, cfg: Cfg, input_ids: np.ndarray, pixel_values: np.ndarray | None, grid_thw, max_new_tokens: int,
-             *, bf16=False, eos_token_id: int | None = None, pad_token_id: int = 0, return_logits=False, fp8: dict | None = None):
+             *, bf16=False, eos_token_id: int | None = None, pad_token_id: int = 0, return_logits=False, fp8: dict | None = None,
+             forced_tokens=None):
     """Greedy generation for ONE prompt (reference batch size is 1, src/models/_base.py:103-104):
-    HF:1144-1205 (embed + image scatter + rope index) then the GenerationMixin greedy loop."""
+    HF:1144-1205 (embed + image scatter + rope index) then the GenerationMixin greedy loop.
+    `forced_tokens` (teacher forcing, parity tests): the token fed after step j is forced_tokens[j] instead of the
+    argmax, so step j+1's logits are conditional on a given continuation; `out` still holds the argmax."""
     tc = cfg.text
     ids = np.asarray(input_ids).astype(np.int64)
     x = maybe_bf16(w[T + "embed_tokens.weight"][ids], bf16)
@@ -276,7 +279,8 @@ def generate(w: dict, cfg: Cfg, input_ids: np.ndarray, pixel_values: np.ndarray 
             if done:
                 break
             continue
-        x = maybe_bf16(w[T + "embed_tokens.weight"][np.array([tok])], bf16)
+        feed = tok if forced_tokens is None else int(forced_tokens[step])
+        x = maybe_bf16(w[T + "embed_tokens.weight"][np.array([feed])], bf16)
         p = np.full((3, 1), cur_len + delta, np.int64)  # HF:1130-1137: arange(past, past+1) + rope_deltas
         h = llm_forward(w, cfg, x, p, cache, bf16=bf16, fp8=fp8)
         logits = lm_head(w, cfg, h[-1:], bf16=bf16)

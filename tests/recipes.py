@@ -64,7 +64,33 @@ def qwen2vl_shapes(cfg: Cfg) -> dict[str, tuple]:
     return s
 
 
+_BIG = 1 << 24   # elements; no golden fixture holds a tensor this large, so the chunked generator below changes none of them
+
+
+def _fill_big(name: str, shape: tuple, seed: int) -> np.ndarray:
+    """Projection weights of the 7B / 34B / 72B-width slices (up to 242 M elements): row blocks drawn from independent
+    float32 streams keyed by (seed, name, block) on a thread pool - same statistics as `_fill`, minutes faster."""
+    import concurrent.futures as cf
+    import os
+
+    rows, fan_in = shape[0], int(np.prod(shape[1:]))
+    out = np.empty((rows, fan_in), np.float32)
+    step = 512
+    scale = np.float32(1.0 / np.sqrt(fan_in))
+
+    def block(r0):
+        r = np.random.default_rng([seed, zlib.crc32(name.encode()), r0])
+        x = r.standard_normal((min(step, rows - r0), fan_in), dtype=np.float32)
+        out[r0:r0 + step] = bf16_round(x * scale)
+
+    with cf.ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as ex:
+        list(ex.map(block, range(0, rows, step)))
+    return out.reshape(shape)
+
+
 def _fill(name: str, shape: tuple, seed: int) -> np.ndarray:
+    if int(np.prod(shape)) > _BIG and not (name.endswith("bias") or "norm" in name or "embed" in name):
+        return _fill_big(name, shape, seed)
     r = _rng(seed, name)
     if name.endswith("bias"):
         x = 0.05 * r.standard_normal(shape)
@@ -243,3 +269,66 @@ def ranking_runs(root, n_docs: int = 30):
             rows.append({"doc_id": doc_id, "filtered_resps": [ans], "target": tgt})
         (d / f"2026_samples_toytask.jsonl").write_text("\n".join(json.dumps(x) for x in rows) + "\n")
     return targets
+
+
+# ---------------------------------------------------------------- toy task / text fixtures (tools/gen_golden_formats.py)
+class HashTokenizer:
+    """Stand-in for AutoTokenizer on free text (no tokenizer files offline): [CLS]=1, one id per whitespace word
+    (3 + crc32(lower-cased word) % (vocab - 3)), [SEP]=2, pad 0, pad-to-longest.  Used on BOTH sides: injected into the
+    reference (`_text.sentence_bert_processor`) by the golden generator and into the HIP scorer by the GPU tests."""
+
+    def __init__(self, vocab_size: int, max_len: int = 32):
+        self.vocab, self.max_len = vocab_size, max_len
+
+    def encode(self, s: str) -> list[int]:
+        words = s.lower().split()[: self.max_len - 2]
+        return [1] + [3 + zlib.crc32(w.encode()) % (self.vocab - 3) for w in words] + [2]
+
+    def __call__(self, text, padding=True, truncation=True, return_tensors="np"):
+        rows = [self.encode(s) for s in text]
+        L = max(len(r) for r in rows)
+        ids = np.array([r + [0] * (L - len(r)) for r in rows], dtype=np.int64)
+        mask = np.array([[1] * len(r) + [0] * (L - len(r)) for r in rows], dtype=np.int64)
+        if return_tensors == "pt":
+            import torch
+
+            class Enc(dict):
+                def to(self, *a, **k):
+                    return self
+
+            return Enc(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask))
+        return {"input_ids": ids, "attention_mask": mask}
+
+
+def toy_nlp(text: str):
+    """Rule-based stand-in for spaCy's parser: noun chunks = the pieces between ',', ' and ', ' with ', ' of ', ' in ';
+    entities = maximal runs of Capitalised words.  Returns (noun_chunks, ents) as raw strings (case kept)."""
+    import re
+
+    chunks = [c.strip(" .!?") for c in re.split(r",| and | with | of | in ", text)]
+    chunks = [c for c in chunks if c]
+    ents = [m.group(0) for m in re.finditer(r"\b[A-Z][a-z]+(?: [A-Z][a-z]+)*\b", text)]
+    return chunks, ents
+
+
+TOY_CLASSES = ["golden_retriever", "sea_lion", "tabby_cat", "airplane", "grand_piano"]
+
+
+def toy_docs(n: int = 11) -> list[dict]:
+    return [{"visual": f"img{i}.jpg", "target": TOY_CLASSES[i % len(TOY_CLASSES)]} for i in range(n)]
+
+
+def toy_answer(doc_id: int, target: str) -> str:
+    """Deterministic stand-in answer of the stand-in model: exact / embedded / decorated / wrong, by document."""
+    t = target.replace("_", " ")
+    return [t, f"A photo of a {t}", f"The {t.title()} and a red ball", "something else entirely", f" {t.upper()}, $5 ",
+            f"this photo shows the {t} in a garden", f"{t}."][doc_id % 7]
+
+
+def toy_concept_items() -> list:
+    """(ref, pred) pairs for concept_semantic_similarity: str / [str] refs, str / [.., str] preds, duplicates, prefix words
+    ('the', 'a', 'its'), skip words ('this photo', 'image', 'it'), capitalised entities, a one-concept prediction."""
+    return [("sea lion", "The sea lion and its ball"), (["tabby cat"], "a Tabby Cat in this photo, it sleeps"),
+            ("airplane", ["ignored first round", "an image of the airplane with two wings"]), ("sea lion", "The sea lion and its ball"),
+            ("grand piano", "piano"), ("golden retriever", "A dog, the Golden Retriever of Scotland and a stick"),
+            (["airplane"], ["Boeing"]), ("tabby cat", "what type of object, some cat")]

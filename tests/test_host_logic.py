@@ -392,3 +392,22 @@ def test_bench_flop_accounting():
     want = P * (1 - 1 / 240) * ((L - 1) * row_full + 2 * dm * (H + 2 * KV) * hd)
     assert abs(shared - want) <= 1e-6 * want
     assert 0.05 < many / f_model < 0.06                           # 5.5 % of the nominal forward
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it spawns its 2 ranks itself (RANK / WORLD_SIZE / MASTER_* set,
+    parent never touches the GPU, no exec), rank 0 prints the one JSON line; a failing rank's exit code is propagated and
+    the surviving rank is stopped instead of hanging in the rendezvous.  `--dry-run` stops before HIP init (gloo)."""
+    import os
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run", "--steps", "5"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["world_size_seen"] == 2 and line["self_launched"] and line["steps"] == 5
+    bad = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                         env={**env, "OWC_BENCH_DRYRUN_FAIL_RANK": "1"}, timeout=300)
+    assert bad.returncode == 7 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]

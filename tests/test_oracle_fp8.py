@@ -36,3 +36,17 @@ def test_quantize_rows_algebra():
     assert (err <= np.abs(x) * 2.0 ** -4 + s[:, None] * 2.0 ** -10).all()   # half an ulp of a 3-bit mantissa (+ subnormal step)
     y = F.linear_fp8(x, *F.quantize_rows((r.standard_normal((5, 64)) * 0.1).astype(np.float32)), bf16=False)
     assert y.shape == (7, 5) and np.isfinite(y).all()
+
+
+def test_fast_encoder_equals_the_table_search_definition():
+    """e4m3_encode (bit arithmetic, threaded for big inputs) == e4m3_encode_search (nearest table entry, ties to even)."""
+    r = np.random.default_rng(5)
+    finite = F.E4M3_DECODE[~np.isnan(F.E4M3_DECODE)]
+    pos = np.sort(np.unique(np.abs(finite)))
+    mids = ((pos[:-1] + pos[1:]) / 2).astype(np.float32)
+    x = np.concatenate([r.standard_normal(300000).astype(np.float32) * r.choice([1e-3, 0.02, 1.0, 100.0, 1000.0], 300000).astype(np.float32),
+                        finite, mids, -mids, np.nextafter(mids, np.float32(0)), np.nextafter(mids, np.float32(1e9)),
+                        np.array([0.0, -0.0, 1e-30, 2.0 ** -10, 2.0 ** -9, 2.0 ** -6, 447.99, 448.0, 449.0, 1e9, -5000.0], np.float32)])
+    assert np.array_equal(F.e4m3_encode(x), F.e4m3_encode_search(x))
+    big = (r.standard_normal((1 << 22) + 12345).astype(np.float32) * 50)          # threaded path
+    assert np.array_equal(F.e4m3_encode(big), F.e4m3_encode_search(big))

@@ -154,6 +154,23 @@ def import_reference():
     col = getattr(ad, "Column", None)
     if col is not None and not hasattr(col, "unsqueeze"):  # datasets>=4 returns Column at _group.py:537
         col.unsqueeze = lambda s, d: torch.stack([torch.as_tensor(x) for x in s]).unsqueeze(d)
+    if col is not None and not getattr(ad.Dataset, "_owc_v3_getitem", False):
+        # datasets 3.1 (the reference's pin) returns the materialised column for `ds["name"]`: a stacked tensor under the
+        # torch format when the rows stack, else a list; datasets >= 4 returns a lazy Column, which torch.mean etc. reject
+        # (_group.py:318-330).  Restore the pinned behaviour.
+        orig = ad.Dataset.__getitem__
+
+        def getitem(self, key):
+            out = orig(self, key)
+            if isinstance(out, col):
+                rows = list(out)
+                if rows and all(isinstance(r, torch.Tensor) for r in rows) and len({tuple(r.shape) for r in rows}) == 1:
+                    return torch.stack(rows)
+                return rows
+            return out
+
+        ad.Dataset.__getitem__ = getitem
+        ad.Dataset._owc_v3_getitem = True
     import src.data.metrics as metrics  # noqa: F401
     import src.data.pipelines.text._text as text_mod
     import src.utils as utils
