@@ -73,17 +73,19 @@ def run_single(args: argparse.Namespace, date_id: str) -> dict | None:
     seeds = (seeds * 4)[:4] if len(seeds) == 1 else seeds
     limit = args.limit if args.limit is None or args.limit < 1.0 else int(args.limit)
     tracker = EngineTracker(output_path=args.output_path)
-    tracker.log_experiment_args(model_args=args.model_args)
+    tracker.log_experiment_args(model_source=args.model, model_args=args.model_args, system_instruction=args.system_instruction,
+                                chat_template=None, fewshot_as_multiturn=args.fewshot_as_multiturn)
     results = simple_evaluate(model=args.model, model_args=args.model_args, tasks=args.tasks.split(","),
                               batch_size=int(args.batch_size), limit=limit, gen_kwargs=args.gen_kwargs,
                               random_seed=seeds[0] or 0, numpy_random_seed=seeds[1] or 1234, torch_random_seed=seeds[2] or 1234,
-                              include_path=args.include_path, data_root=args.data_root, log_samples=args.log_samples or True)
+                              fewshot_random_seed=seeds[3] or 1234, include_path=args.include_path, data_root=args.data_root,
+                              log_samples=args.log_samples, use_cache=args.use_cache, datetime_str=date_id)
     if results is not None:
-        samples = results.pop("samples")
+        samples = results.pop("samples") if args.log_samples else None   # eval_model.py:217-233
         tracker.save_results_aggregated(results=results, samples=samples, datetime_str=date_id)
         if args.log_samples:
-            for task_name, task_samples in samples.items():
-                tracker.save_results_samples(task_name=task_name, samples=task_samples)
+            for task_name in results["configs"]:
+                tracker.save_results_samples(task_name=task_name, samples=samples[task_name])
         print(utils.make_table(results))
     return results
 

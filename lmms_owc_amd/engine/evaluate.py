@@ -2,18 +2,32 @@
 `evaluate` :32-389) that open-world classification exercises:
 
   seed -> build tasks + model -> per task: strided shard (rank r owns docs r, r+W, ...) -> requests ->
-  `model.generate_until(requests)` -> take_first filter -> per-doc `process_results` -> sample records
-  (incl. the three sha256 hashes, `_engine.py:262-279`) -> gather to rank 0 -> aggregation
+  `model.generate_until(requests)` -> [ONE fixed-width all_gather of the shard's answers] -> rank 0: take_first filter ->
+  per-doc `process_results` -> sample records (incl. the three sha256 hashes, `_engine.py:262-279`) -> aggregation
   (`calculate_aggregate_metric`, tasks/_base.py:742-774; stderr only for `mean`).
 
-Multi-GPU: one process per GPU, no data-path collective; a single `gather_object` per task moves the
-per-doc records (a few hundred bytes each) to rank 0 over RCCL/gloo.  Uneven shards need no padding here
-(the reference pads by repeating the last request, `_engine.py:176-191`, and then discards the extras).
+The results dict carries the reference's keys (`results` incl. `alias`, `group_subtasks`, `configs`, `versions`, `n-shot`,
+`higher_is_better`, `n-samples`, `config`, `git_hash`, `date`; pinned on the reference's own output in
+tests/golden/engine_formats.json).
+
+Multi-GPU: one process per GPU, no data-path collective.  The reference moves pickled per-doc dicts with two
+`gather_object` calls per task (`_engine.py:298-315`); here every rank contributes a FIXED-WIDTH int32 record per document,
+
+    { doc_id, n, payload[width] }      payload = generated token ids (models with `generate_until_tokens`: the ids go
+                                        device -> RCCL -> rank 0 and are detokenised there) or the UTF-8 bytes of the
+                                        JSON-encoded answer (any other `Model` plug-in, multi-round tuples included),
+
+all ranks pad their shard to the largest shard (sizes follow from the shard function; the record width is agreed by one
+8-byte all_reduce(MAX)) and ONE `all_gather_into_tensor` (RCCL over xGMI; gloo in the CPU tests) brings them together.  Rank 0 then builds the records for ALL
+documents in doc_id order, so an N-rank run writes byte-identical files to a 1-rank run (the reference's N-rank file holds
+the same lines in rank-major order).  Uneven shards need no padding requests (the reference re-runs the last request,
+`_engine.py:176-191`, and discards the extras).
 """
 
 from __future__ import annotations
 
 import json
+import math
 import random
 from collections import defaultdict
 
@@ -25,6 +39,9 @@ from ..metrics import mean_stderr
 from ..models import get_model
 from ..tasks import ClassificationTask, load_task
 
+_SERIALIZABLE = (str, int, float, bool, list, dict, type(None))
+DOC_HASH_OF_NONE = utils.hash_string(json.dumps(None, indent=2, ensure_ascii=False))
+
 
 def _dist():
     import torch.distributed as dist
@@ -34,9 +51,10 @@ def _dist():
 
 def simple_evaluate(model: str, model_args: str | dict = "", tasks: list[str] | None = None, batch_size: int = 1,
                     limit: int | float | None = None, gen_kwargs: str | dict | None = None, random_seed: int = 0,
-                    numpy_random_seed: int = 1234, torch_random_seed: int = 1234, include_path: str | None = None,
-                    data_root: str = "data", log_samples: bool = True, task_objects: dict | None = None,
-                    model_object=None) -> dict | None:
+                    numpy_random_seed: int = 1234, torch_random_seed: int = 1234, fewshot_random_seed: int = 1234,
+                    include_path: str | None = None, data_root: str = "data", log_samples: bool = True,
+                    task_objects: dict | None = None, model_object=None, bootstrap_iters: int = 100000,
+                    use_cache: str | None = None, datetime_str: str | None = None) -> dict | None:
     random.seed(random_seed)
     np.random.seed(numpy_random_seed)
     torch.manual_seed(torch_random_seed)
@@ -44,84 +62,176 @@ def simple_evaluate(model: str, model_args: str | dict = "", tasks: list[str] | 
     for name in tasks or []:
         t = load_task(name, data_root=data_root, include_path=include_path)
         task_dict[t.task_name] = t  # requests carry task.task_name (tasks/_manager.py:895-902)
-    if isinstance(model_args, str):
-        model_args = utils.parse_string_args(model_args)
-    lm = model_object if model_object is not None else get_model(model, batch_size=batch_size, **model_args)
+    if not task_dict:
+        raise ValueError("No tasks specified, or no tasks found. Please verify the task names.")
+    model_args_str = model_args if isinstance(model_args, str) else ",".join(f"{k}={v}" for k, v in model_args.items())
+    kwargs = utils.parse_string_args(model_args) if isinstance(model_args, str) else dict(model_args)
+    lm = model_object if model_object is not None else get_model(model, batch_size=batch_size, **kwargs)
     lm.eval()
     torch.set_grad_enabled(False)
+    gk = None
     if gen_kwargs:
         gk = utils.parse_string_args(gen_kwargs) if isinstance(gen_kwargs, str) else dict(gen_kwargs)
-        for t in task_dict.values():
+        for t in task_dict.values():   # cli settings win over the yaml's (_engine.py:540-541)
             t.generation_kwargs.update(gk)
     for t in task_dict.values():
         lm.task_dict[t.task_name] = t.dataset
-    results = evaluate(lm, task_dict, limit=limit, log_samples=log_samples)
-    if results is not None:
-        results["config"] = {"model": model if isinstance(model, str) else type(lm).__name__, "model_args": model_args,
-                             "batch_size": batch_size, "limit": limit, "gen_kwargs": gen_kwargs,
-                             "random_seed": random_seed, "numpy_seed": numpy_random_seed, "torch_seed": torch_random_seed}
+    results = evaluate(lm, task_dict, limit=limit, log_samples=log_samples, bootstrap_iters=bootstrap_iters)
+    torch.set_grad_enabled(True)
+    if results is None:
+        return None
+    results["config"] = {"model": model if isinstance(model, str) else type(lm).__name__, "model_args": model_args_str,
+                         "batch_size": batch_size, "batch_sizes": [], "use_cache": use_cache, "limit": limit,
+                         "bootstrap_iters": bootstrap_iters, "gen_kwargs": gk, "random_seed": random_seed,
+                         "numpy_seed": numpy_random_seed, "torch_seed": torch_random_seed, "fewshot_seed": fewshot_random_seed}
+    results["git_hash"] = utils.get_git_commit_hash()
+    results["date"] = datetime_str
     return results
 
 
-def evaluate(lm, task_dict: dict, limit: int | float | None = None, log_samples: bool = True) -> dict | None:
+# ---------------------------------------------------------------- the one exchange step
+def shard_sizes(n_docs: int, limit: int | None, world: int) -> list[int]:
+    """Documents each rank owns under `create_iterator` (islice(docs, rank, limit, world)): known to every rank."""
+    stop = n_docs if limit is None else min(n_docs, int(limit))
+    return [len(range(r, stop, world)) for r in range(world)]
+
+
+def _pack_bytes(resps: list) -> tuple[np.ndarray, np.ndarray]:
+    """JSON -> UTF-8 -> int32 words, one row per answer (the generic `Model` plug-in path)."""
+    blobs = [json.dumps(x, ensure_ascii=False).encode("utf-8") for x in resps]
+    width = max([1] + [(len(b) + 3) // 4 for b in blobs])
+    mat = np.zeros((len(blobs), width), np.int32)
+    for i, b in enumerate(blobs):
+        mat[i].view(np.uint8)[: len(b)] = np.frombuffer(b, np.uint8)
+    return mat, np.array([len(b) for b in blobs], np.int32)
+
+
+def _unpack_bytes(row: np.ndarray, n: int):
+    out = json.loads(np.ascontiguousarray(row).view(np.uint8)[:n].tobytes().decode("utf-8"))
+    return tuple(out) if isinstance(out, list) else out   # multi-round answers are tuples of per-round strings
+
+
+def gather_answers(lm, reqs: list, resps, sizes: list[int], rank: int, world: int, dist, token_mode: bool) -> dict | None:
+    """All ranks: contribute this shard's answers as fixed-width records; rank 0 returns {doc_id: answer}."""
+    if token_mode:
+        payload, n = resps                       # int32 [n_local, T] (torch, on lm.device, or numpy) and lengths
+        payload = torch.as_tensor(payload, dtype=torch.int32)
+        n = torch.as_tensor(n, dtype=torch.int32)
+    else:
+        mat, nb = _pack_bytes(list(resps))
+        payload, n = torch.from_numpy(mat), torch.from_numpy(nb)
+    # RCCL moves device memory (the token ids never visit the host before the gather); gloo (CPU tests) host memory
+    device = torch.device(lm.device) if dist is not None and dist.get_backend() == "nccl" else torch.device("cpu")
+    width = torch.tensor([payload.shape[1] if payload.ndim == 2 and payload.shape[0] else 0], dtype=torch.int64, device=device)
+    if dist is not None:
+        dist.all_reduce(width, op=dist.ReduceOp.MAX)   # the widest record of any rank (8 bytes; a rank may own no document)
+    W = max(int(width.item()), 1)
+    rows = max(sizes)
+    rec = torch.zeros((rows, 2 + W), dtype=torch.int32, device=device)
+    k = len(reqs)
+    if k:
+        rec[:k, 0] = torch.tensor([r.doc_id for r in reqs], dtype=torch.int32, device=device)
+        rec[:k, 1] = n.to(device)
+        rec[:k, 2:2 + payload.shape[1]] = payload.to(device)
+    if dist is not None:
+        allrec = torch.empty((world * rows, 2 + W), dtype=torch.int32, device=device)
+        dist.all_gather_into_tensor(allrec, rec)
+    else:
+        allrec = rec
+    if rank != 0:
+        return None
+    allrec = allrec.cpu().numpy().reshape(world, rows, 2 + W)
+    out = {}
+    for r in range(world):
+        part = allrec[r, : sizes[r]]
+        if token_mode:
+            texts = lm.decode_tokens([row[2:2 + int(row[1])] for row in part]) if len(part) else []
+            for row, text in zip(part, texts):
+                out[int(row[0])] = text
+        else:
+            for row in part:
+                out[int(row[0])] = _unpack_bytes(row[2:], int(row[1]))
+    return out
+
+
+def evaluate(lm, task_dict: dict, limit: int | float | None = None, log_samples: bool = True,
+             bootstrap_iters: int | None = 100000) -> dict | None:
     rank, world = lm.rank, lm.world_size
     dist = _dist()
-    results: dict = {"results": {}, "samples": {}, "n-samples": {}, "higher_is_better": {}}
+    results: dict = {k: {} for k in ("results", "group_subtasks", "configs", "versions", "n-shot", "higher_is_better", "n-samples")}
+    results["samples"] = {}
     for task_name, task in task_dict.items():
         n_docs = len(task.docs)
-        lim = None if limit is None else (int(n_docs * limit) if isinstance(limit, float) and limit < 1.0 else int(limit))
-        task.build_all_requests(limit=lim, rank=rank, world_size=world)
+        if limit is not None:   # `_engine.py:125-126` (ceil; the converted value is reused for later tasks, as there)
+            limit = int(math.ceil(n_docs * limit)) if limit < 1.0 else int(limit)
+        task.build_all_requests(limit=limit, rank=rank, world_size=world)
         reqs = task.instances
-        # requests of a task share one type (generate_until | generate_until_multi_round): dispatch like _engine.py:243-262
-        resps = getattr(lm, task.OUTPUT_TYPE)(reqs) if reqs else []
-        for r, x in zip(reqs, resps, strict=True):
-            r.resps.append(x)
-        if dist is not None:
-            dist.barrier()
+        sizes = shard_sizes(n_docs, limit, world)
+        assert len(reqs) == sizes[rank]
+        # requests of a task share one type (generate_until | generate_until_multi_round): dispatch like _engine.py:180-198
+        token_mode = world > 1 and task.OUTPUT_TYPE == "generate_until" and hasattr(lm, "generate_until_tokens")
+        if token_mode:
+            resps = lm.generate_until_tokens(reqs)
+        else:
+            resps = getattr(lm, task.OUTPUT_TYPE)(reqs) if reqs else []
+        if world > 1:
+            answers = gather_answers(lm, reqs, resps, sizes, rank, world, dist, token_mode)
+        else:
+            answers = {r.doc_id: x for r, x in zip(reqs, resps, strict=True)}
+        if rank != 0:
+            continue
+        # ---- rank 0: records for ALL documents, in doc_id order
+        if world > 1:
+            own_args = {r.doc_id: r.arguments for r in reqs}   # keeps what the model did to its own requests' gen_kwargs
+            task.build_all_requests(limit=limit, rank=0, world_size=1)
+            for r in task.instances:
+                if r.doc_id in own_args:
+                    r.arguments = own_args[r.doc_id]
+                else:   # another rank's request: its model popped `until` the same way (models/_qwen2_vl.py)
+                    r.args[1].pop("until", None)
+            reqs = task.instances
+        for r in reqs:
+            r.resps.append(answers[r.doc_id])
         task.apply_filters()
         samples, metric_items = [], defaultdict(list)
         for req in reqs:
             doc = req.doc
             metrics = task.process_results(doc, [req.filtered_resps["none"]])
-            target = task.doc_to_target(doc)
-            saved_doc = {k: v for k, v in doc.items() if isinstance(v, (str, int, float, bool, list, dict, type(None)))}
             if log_samples:
+                target = task.doc_to_target(doc)
                 example = {
-                    "doc_id": req.doc_id, "doc": saved_doc, "target": target,
-                    "arguments": [a for a in req.args if isinstance(a, (str, int, float, bool, list, dict, type(None)))],
+                    "doc_id": req.doc_id, "doc": {k: v for k, v in doc.items() if "image" not in k}, "target": target,
+                    "arguments": [a for a in req.args if isinstance(a, _SERIALIZABLE)],
                     "resps": [req.resps], "filtered_resps": [req.filtered_resps["none"]],
-                    "doc_hash": utils.hash_string(json.dumps(saved_doc, indent=2, default=str, ensure_ascii=False)),
+                    # the reference hashes `requests[0].doc`, which its TaskInstance never sets (tasks/_manager.py:881 `# doc=doc`):
+                    # every record carries sha256("null") (`_engine.py:267-274`); kept for file compatibility
+                    "doc_hash": DOC_HASH_OF_NONE,
                     "prompt_hash": utils.hash_string(req.args[0]), "target_hash": utils.hash_string(str(target)),
                 }
                 example.update(metrics)
                 samples.append(example)
             for m, v in metrics.items():
-                metric_items[m].append((req.doc_id, v))
-        # ---- the only exchange step: per-doc records to rank 0
-        if dist is not None:
-            gathered_s = [None] * world if rank == 0 else None
-            gathered_m = [None] * world if rank == 0 else None
-            dist.gather_object(samples, gathered_s, dst=0)
-            dist.gather_object(dict(metric_items), gathered_m, dst=0)
-            if rank == 0:
-                samples = [s for part in gathered_s for s in part]
-                merged = defaultdict(list)
-                for part in gathered_m:
-                    for m, v in part.items():
-                        merged[m].extend(v)
-                metric_items = merged
-        if rank != 0:
-            continue
-        samples.sort(key=lambda s: s["doc_id"])
-        agg, out = task.aggregation(), {}
-        for m, items in metric_items.items():
-            vals = [v for _, v in sorted(items, key=lambda t: t[0])]
+                metric_items[m].append(v)
+        agg, out = task.aggregation(), {"alias": task_name}
+        for m, vals in metric_items.items():
             out[f"{m},none"] = agg[m](vals)
-            out[f"{m}_stderr,none"] = mean_stderr(vals) if agg[m].__name__ == "mean" and len(vals) > 1 else "N/A"
+            # stderr only for `mean` (`metric in can_bootstrap` compares a function with names, so nothing is ever bootstrapped),
+            # only for more than one value and only with bootstrap_iters > 0 (tasks/_base.py:758-771, metrics/_api.py:235-257)
+            has_stderr = agg[m].__name__ == "mean" and len(vals) > 1 and (bootstrap_iters or 0) > 0
+            out[f"{m}_stderr,none"] = mean_stderr(vals) if has_stderr else "N/A"
         results["results"][task_name] = out
-        results["samples"][task_name] = samples
-        results["n-samples"][task_name] = {"original": n_docs, "effective": len(samples) if log_samples else None}
+        results["group_subtasks"][task_name] = []
+        results["configs"][task_name] = task.dump_config()
+        results["versions"][task_name] = "Yaml"
+        results["n-shot"][task_name] = 0
         results["higher_is_better"][task_name] = task.higher_is_better()
+        results["n-samples"][task_name] = {"original": n_docs, "effective": min(limit if limit else n_docs, n_docs)}
+        if log_samples:
+            results["samples"][task_name] = samples
     if dist is not None:
         dist.barrier()
-    return results if rank == 0 else None
+    if rank != 0:
+        return None
+    if not log_samples:
+        results.pop("samples")
+    return results

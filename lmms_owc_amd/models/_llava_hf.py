@@ -150,7 +150,25 @@ class LLaVA(Model):
 
     # ------------------------------------------------------------------ the hot loop
     def generate_until(self, requests: list) -> list[str]:
-        res: list[str] = []
+        answers = self.decode_tokens(self._generate_rows(requests))
+        for req, ans in zip(requests, answers):
+            self.cache_hook.add_partial("generate_until", (req.args[0], req.args[1]), ans)
+        return answers
+
+    def generate_until_tokens(self, requests: list) -> tuple[np.ndarray, np.ndarray]:
+        """Fixed-width token records for the engine's end-of-task RCCL gather (see Qwen2VL.generate_until_tokens)."""
+        rows = self._generate_rows(requests)
+        T = max([1] + [len(r) for r in rows])
+        mat = np.zeros((len(rows), T), np.int32)
+        for i, r in enumerate(rows):
+            mat[i, : len(r)] = r
+        return mat, np.array([len(r) for r in rows], np.int32)
+
+    def decode_tokens(self, rows: list) -> list[str]:
+        return self._tokenizer.batch_decode([np.asarray(r) for r in rows], skip_special_tokens=True)
+
+    def _generate_rows(self, requests: list) -> list[np.ndarray]:
+        res: list[np.ndarray] = []
         d, eng, tok = self._dims, self._model, self._tokenizer
 
         def _collate(x):
@@ -189,14 +207,9 @@ class LLaVA(Model):
 
             eos = tok.eos_token_id
             out = eng.generate_from_features(prompts, feats, rows_per_prompt, max_new, eos_token_id=eos, pad_token_id=eos).cpu().numpy()
-            outs = []
             for r in out:
                 stop = np.flatnonzero(r == eos)
-                outs.append(r[: stop[0]] if len(stop) else r)
-            answers = tok.batch_decode(outs, skip_special_tokens=True)
-            for ans, ctx in zip(answers, contexts):
-                res.append(ans)
-                self.cache_hook.add_partial("generate_until", (ctx, gen_kwargs), ans)
+                res.append(r[: stop[0]] if len(stop) else r)
         return reordered.get_original(res)
 
 

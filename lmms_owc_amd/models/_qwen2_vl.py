@@ -101,9 +101,15 @@ class Qwen2VL(Model):
             self._tokenizer = AutoTokenizer.from_pretrained(str(path))
             self.chat_template = getattr(self._tokenizer, "chat_template", None)
         self._dims = dims
+        import os
         from concurrent.futures import ThreadPoolExecutor
 
-        self._pool = ThreadPoolExecutor(max_workers=8)
+        # host preparation: `OWC_PREP_THREADS` PIL workers (JPEG round trip + bicubic resize release the GIL) behind ONE
+        # preparation thread that runs up to `_lookahead` chunks ahead of the GPU (`_generate_rows`)
+        self._prep_threads = int(os.environ.get("OWC_PREP_THREADS", min(16, os.cpu_count() or 8)))
+        self._pool = ThreadPoolExecutor(max_workers=self._prep_threads)
+        self._prep_thread = ThreadPoolExecutor(max_workers=1)
+        self._lookahead = 2
         self._model = Qwen2VLEngine(weights)
         self._processor = self._tokenizer
 
@@ -214,70 +220,129 @@ class Qwen2VL(Model):
 
     # ------------------------------------------------------------------ the hot loop
     def generate_until(self, requests: list) -> list[str]:
-        res: list[str] = []
+        """`list[TaskInstance] -> list[str]`, same length and order (reference :143-348), batched and double-buffered."""
+        answers = self.decode_tokens(self._generate_rows(requests))
+        for req, ans in zip(requests, answers):
+            self.cache_hook.add_partial("generate_until", (req.args[0], req.args[1]), ans)
+        return answers
+
+    def generate_until_tokens(self, requests: list) -> tuple[np.ndarray, np.ndarray]:
+        """The same generation as fixed-width token records for the engine's end-of-task RCCL gather:
+        int32 [n, T] (ids up to EOS, zero-padded) and int32 [n] lengths, in request order; `decode_tokens` turns them
+        into the strings `generate_until` would have returned (rank 0 does that for every rank's records)."""
+        rows = self._generate_rows(requests)
+        T = max([1] + [len(r) for r in rows] + [int(r.args[1].get("max_new_tokens", 128)) for r in requests])
+        mat = np.zeros((len(rows), T), np.int32)
+        for i, r in enumerate(rows):
+            mat[i, : len(r)] = r
+        return mat, np.array([len(r) for r in rows], np.int32)
+
+    def decode_tokens(self, rows: list) -> list[str]:
+        return self._tokenizer.batch_decode([np.asarray(r) for r in rows], skip_special_tokens=True,
+                                            clean_up_tokenization_spaces=False)
+
+    def _prepare_chunk(self, chunk) -> dict:
+        """HOST stage of one chunk (runs on the preparation thread while the GPU works on the previous chunk): image fetch,
+        JPEG round trip + two-stage bicubic resize (`imageproc.prepare_image`, fanned out over the worker pool: PIL releases
+        the GIL), prompt token ids, and the chunk's uint8 images stacked into PINNED host memory for an asynchronous H2D."""
+        contexts, all_gen_kwargs, doc_to_visual, doc_ids, tasks, splits = zip(*chunk, strict=True)
+        task, split = tasks[0], splits[0]
+        for g in all_gen_kwargs:   # the reference (batch size 1) pops it from EVERY request's own dict, which is what the
+            g.pop("until", None)   # samples file later records under `arguments` (_engine.py:262-266, _tracker.py:318-322)
+        gen_kwargs = dict(all_gen_kwargs[0])   # popped and unused in the reference's single-round mode (:211-219)
+        max_new = int(gen_kwargs.get("max_new_tokens", 128))
+        if gen_kwargs.get("temperature", 0) not in (0, 0.0) or gen_kwargs.get("num_beams", 1) != 1:
+            raise NotImplementedError("the HIP decoder implements greedy decoding (temperature 0, 1 beam)")
+        visuals_per_doc = [doc_to_visual[0](self.task_dict[task][split][did]) for did in doc_ids]
+        flat = [v for vs in visuals_per_doc for v in vs]
+        prepared = iter(list(self._pool.map(lambda v: imageproc.prepare_image(v, self._min_pixels, self._max_pixels), flat)))
+        images, grids_per_prompt, prompts = [], [], []
+        for ctx, visuals in zip(contexts, visuals_per_doc):
+            arrs = [next(prepared) for _ in visuals]
+            grids = [(1, a.shape[1] // 14, a.shape[2] // 14) for a in arrs]
+            images += arrs
+            grids_per_prompt.append(grids)
+            prompts.append(self._prompt_ids(ctx.replace("<image>", ""), [g[1] * g[2] // 4 for g in grids]))
+        # same-size runs share one patchify launch; each run is staged in pinned memory
+        groups, i = [], 0
+        while i < len(images):
+            j = i
+            while j < len(images) and images[j].shape == images[i].shape:
+                j += 1
+            buf = torch.empty((j - i, *images[i].shape), dtype=torch.uint8, pin_memory=True)
+            np.stack(images[i:j], out=buf.numpy())
+            groups.append(buf)
+            i = j
+        return {"prompts": prompts, "grids": grids_per_prompt, "groups": groups, "max_new": max_new, "n": len(chunk)}
+
+    def _generate_rows(self, requests: list) -> list[np.ndarray]:
+        """Token rows (cut at EOS) per request, in request order.  Chunks of `batch_size` requests flow through a two-stage
+        pipeline: a preparation thread readies chunk k+1 (and k+2) while this thread enqueues chunk k's H2D copy, patchify,
+        vision tower, prefill and decode; chunk k's ids come back through a pinned buffer + event one chunk later, so the
+        stream always holds the next chunk's work when the host waits."""
+        from collections import deque
 
         def _collate(x):
             return -len(self._tokenizer.encode(x[0])), x[0]
 
         reordered = utils.Collator([reg.args for reg in requests], _collate, grouping=True)
-        for chunk in reordered.get_batched(n=self.batch_size, batch_fn=None):
-            contexts, all_gen_kwargs, doc_to_visual, doc_ids, tasks, splits = zip(*chunk, strict=True)
-            task, split = tasks[0], splits[0]
-            for g in all_gen_kwargs:   # the reference (batch size 1) pops it from EVERY request's own dict, which is what the
-                g.pop("until", None)   # samples file later records under `arguments` (_engine.py:262-266, _tracker.py:318-322)
-            gen_kwargs = dict(all_gen_kwargs[0])
-            gen_kwargs.pop("until", None)  # popped and unused in the reference's single-round mode (:211-219)
-            max_new = int(gen_kwargs.get("max_new_tokens", 128))
-            if gen_kwargs.get("temperature", 0) not in (0, 0.0) or gen_kwargs.get("num_beams", 1) != 1:
-                raise NotImplementedError("the HIP decoder implements greedy decoding (temperature 0, 1 beam)")
+        chunks = list(reordered.get_batched(n=self.batch_size, batch_fn=None))
+        tok = self._tokenizer
+        pad = tok.pad_token_id if tok.pad_token_id is not None else 0
+        rows: list[np.ndarray] = []
+        ahead, inflight = deque(), deque()
+        nxt = 0
 
-            images, grids_per_prompt, prompts = [], [], []
-            # JPEG round trip + bicubic resize are host work (PIL releases the GIL): a small thread pool keeps one
-            # rank's preparation rate above the GPU's image rate
-            visuals_per_doc = [doc_to_visual[0](self.task_dict[task][split][did]) for did in doc_ids]
-            flat = [v for vs in visuals_per_doc for v in vs]
-            prepared = iter(list(self._pool.map(
-                lambda v: imageproc.prepare_image(v, self._min_pixels, self._max_pixels), flat)))
-            for ctx, visuals in zip(contexts, visuals_per_doc):
-                arrs = [next(prepared) for _ in visuals]
-                grids = [(1, a.shape[1] // 14, a.shape[2] // 14) for a in arrs]
-                images += arrs
-                grids_per_prompt.append(grids)
-                n_tok = [g[1] * g[2] // 4 for g in grids]
-                prompts.append(self._prompt_ids(ctx.replace("<image>", ""), n_tok))
-
-            emb = None
-            if images:
-                pix = self._pixel_values(images)
-                emb = self._model.encode_images(pix, [g for gs in grids_per_prompt for g in gs])
-            tok = self._tokenizer
-            pad = tok.pad_token_id if tok.pad_token_id is not None else 0
-            out = self._model.generate(prompts, emb, grids_per_prompt, max_new, eos_token_id=tok.eos_token_id,
-                                       pad_token_id=pad).cpu().numpy()
-            rows = []
-            for r in out:
+        def finish(item) -> None:
+            host, ev = item
+            ev.synchronize()
+            for r in host.numpy():
                 stop = np.flatnonzero(r == tok.eos_token_id)
-                rows.append(r[: stop[0]] if len(stop) else r)
-            answers = tok.batch_decode(rows, skip_special_tokens=True, clean_up_tokenization_spaces=False)
-            for ans, ctx in zip(answers, contexts):
-                res.append(ans)
-                self.cache_hook.add_partial("generate_until", (ctx, gen_kwargs), ans)
-        return reordered.get_original(res)
+                rows.append(r[: stop[0]].copy() if len(stop) else r.copy())
 
-    def _pixel_values(self, images: list[np.ndarray]) -> torch.Tensor:
-        """uint8 CHW arrays (sides % 28 == 0) -> packed pixel_values rows on the GPU; same-size images share a launch."""
-        rows = sum((a.shape[1] // 14) * (a.shape[2] // 14) for a in images)
+        for k in range(len(chunks)):
+            while nxt < len(chunks) and len(ahead) < self._lookahead:
+                ahead.append(self._prep_thread.submit(self._prepare_chunk, chunks[nxt]))
+                nxt += 1
+            prep = ahead.popleft().result()
+            emb = None
+            if prep["groups"]:
+                emb = self._model.encode_images(self._pixel_values(prep["groups"]), [g for gs in prep["grids"] for g in gs])
+            out = self._model.generate(prep["prompts"], emb, prep["grids"], prep["max_new"], eos_token_id=tok.eos_token_id,
+                                       pad_token_id=pad)
+            host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+            host.copy_(out, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            inflight.append((host, ev))
+            if len(inflight) > 1:
+                finish(inflight.popleft())
+        while inflight:
+            finish(inflight.popleft())
+        return reordered.get_original(rows)
+
+    def _pixel_values(self, images: list) -> torch.Tensor:
+        """uint8 images (sides % 28 == 0) -> packed pixel_values rows on the GPU.  `images`: CHW numpy arrays (same-size
+        neighbours share a launch) or already-stacked [n, 3, H, W] uint8 tensors in pinned memory (asynchronous H2D)."""
+        groups = []
+        if images and isinstance(images[0], torch.Tensor):
+            groups = list(images)
+        else:
+            i = 0
+            while i < len(images):
+                j = i
+                while j < len(images) and images[j].shape == images[i].shape:
+                    j += 1
+                groups.append(torch.from_numpy(np.stack(images[i:j])))
+                i = j
+        rows = sum(g.shape[0] * (g.shape[2] // 14) * (g.shape[3] // 14) for g in groups)
         pix = torch.empty((rows, 1176), dtype=torch.bfloat16, device=self._device)
-        r0, i = 0, 0
-        while i < len(images):
-            j = i
-            while j < len(images) and images[j].shape == images[i].shape:
-                j += 1
-            batch = torch.from_numpy(np.stack(images[i:j])).to(self._device, non_blocking=True)
-            n = (j - i) * (images[i].shape[1] // 14) * (images[i].shape[2] // 14)
-            ops.patchify_u8(batch, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD, out=pix[r0:r0 + n])
+        r0 = 0
+        for g in groups:
+            n = g.shape[0] * (g.shape[2] // 14) * (g.shape[3] // 14)
+            ops.patchify_u8(g.to(self._device, non_blocking=True), imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD,
+                            out=pix[r0:r0 + n])
             r0 += n
-            i = j
         return pix
 
 

@@ -97,42 +97,75 @@ def embed_texts_unique(texts: list[str]) -> torch.Tensor:
     return z.index_select(0, idx).contiguous()
 
 
-# ---- concept extraction hook (reference: concept_extraction_spacy, _text.py:18-140) -----------------------
+# ---- concept extraction (reference: concept_extraction_spacy, _text.py:18-140) ----------------------------
+# Two plug points: `set_concept_nlp(fn)` replaces ONLY the parser (spaCy `en_core_web_lg` in the reference: noun chunks +
+# named entities per text) and keeps the reference's own post-processing below; `set_concept_extractor(fn)` replaces the
+# whole step.  The CPU NLP model itself is outside the accelerated path.
 concept_extractor = None  # callable(list[str], skip_words: list[str]) -> list[list[str]]
+concept_nlp = None        # callable(list[str]) -> list[(noun_chunk_texts: list[str], entity_texts: list[str])]
+
+_PREFIX_TERMS = ("a", "an", "the", "his", "her", "its", "their")   # articles + possessive pronouns (_text.py:61-67)
 
 
 def set_concept_extractor(fn) -> None:
-    """Plug the noun-chunk extractor used by `concept_semantic_similarity` (spaCy en_core_web_lg in the
-    reference; the CPU NLP pipeline itself is outside the accelerated path)."""
     global concept_extractor
     concept_extractor = fn
 
 
+def set_concept_nlp(fn) -> None:
+    global concept_nlp
+    concept_nlp = fn
+
+
+def _strip_prefix(concept: str) -> str:
+    for term in _PREFIX_TERMS:
+        if concept.startswith(term + " "):
+            return concept[len(term) + 1:]
+    return concept
+
+
+def postprocess_concepts(noun_chunks: list[str], ents: list[str], skip_words: list[str], remove_prefix_words: bool = True) -> list[str]:
+    """What `concept_extraction_spacy` does with spaCy's spans (_text.py:56-92), quirks included: everything is lower-cased;
+    a leading article / possessive is dropped; noun chunks in `skip_words` are skipped but duplicates among noun chunks are
+    KEPT; noun chunks are only recorded when `remove_prefix_words` is set (the append sits inside that branch); entities
+    are added when not already present."""
+    concepts: list[str] = []
+    for text in noun_chunks:
+        concept = text.lower()
+        if remove_prefix_words:
+            concept = _strip_prefix(concept)
+            if concept in skip_words:
+                continue
+            concepts.append(concept)
+    for text in ents:
+        concept = text.lower()
+        if remove_prefix_words:
+            concept = _strip_prefix(concept)
+            if concept in skip_words:
+                continue
+        if concept not in concepts:
+            concepts.append(concept)
+    return concepts
+
+
+def _spacy_nlp():
+    try:
+        import spacy
+
+        nlp = spacy.load("en_core_web_lg")
+    except Exception as e:  # spaCy / the model are not installed offline
+        raise RuntimeError("concept_semantic_similarity needs a parser: install spaCy + en_core_web_lg, or call "
+                           "lmms_owc_amd.pipelines.text.set_concept_nlp(fn) / set_concept_extractor(fn)") from e
+    return lambda texts: [([c.text for c in doc.noun_chunks], [e.text for e in doc.ents]) for doc in nlp.pipe(texts, batch_size=len(texts))]
+
+
 def extract_concepts(texts: list[str], skip_words: list[str]) -> list[list[str]]:
-    global concept_extractor
-    if concept_extractor is None:
-        try:
-            import spacy
-
-            nlp = spacy.load("en_core_web_lg")
-        except Exception as e:  # spaCy / the model are not installed offline
-            raise RuntimeError("concept_semantic_similarity needs a concept extractor: install spaCy + en_core_web_lg "
-                               "or call lmms_owc_amd.pipelines.text.set_concept_extractor(fn)") from e
-
-        def _spacy(batch, skip):
-            out = []
-            for doc in nlp.pipe(batch):
-                chunks = []
-                for ch in doc.noun_chunks:
-                    words = [t.text for t in ch if t.text.lower() not in skip]  # remove_prefix_words / skip words
-                    text = " ".join(words).strip()
-                    if text and text.lower() not in skip and text not in chunks:
-                        chunks.append(text)
-                out.append(chunks)
-            return out
-
-        concept_extractor = _spacy
-    return concept_extractor(texts, skip_words)
+    global concept_nlp
+    if concept_extractor is not None:
+        return concept_extractor(texts, skip_words)
+    if concept_nlp is None:
+        concept_nlp = _spacy_nlp()
+    return [postprocess_concepts(chunks, ents, skip_words, True) for chunks, ents in concept_nlp(list(texts))]
 
 
 def encode_sentence_bert(batch: dict, rank: int | None = None, **kwargs) -> dict:

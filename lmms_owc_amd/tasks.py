@@ -71,6 +71,7 @@ class ClassificationTask:
             raise ValueError(f"unsupported output_type {output_type!r} (generate_until, generate_until_multi_round)")
         self.OUTPUT_TYPE = output_type
         self.task_name = name
+        self.dataset_path = f"data/{name}"   # informational (results file); load_task overwrites it with the real path
         self.split = split
         self.docs = docs
         self.prompt, self.pre_prompt, self.post_prompt = prompt, pre_prompt, post_prompt
@@ -169,6 +170,21 @@ class ClassificationTask:
     def aggregation(self) -> dict:
         return dict(self._agg)
 
+    def dump_config(self) -> dict:
+        """`configs[task]` of the results file: the keys `TaskConfig.to_dict` writes for a classification task
+        (src/data/tasks/_config.py; key set and order pinned in tests/golden/engine_formats.json)."""
+        msk = {"pre_prompt": self.pre_prompt, "prompt": self.prompt, "post_prompt": self.post_prompt}
+        if self.prompts is not None:
+            msk["prompts"] = list(self.prompts)
+        return {
+            "task": self.task_name, "dataset_path": self.dataset_path, "dataset_kwargs": {}, "test_split": self.split,
+            "full_docs": False, "process_results_use_image": False, "doc_to_visual": repr(self.doc_to_visual),
+            "doc_to_text": repr(self.doc_to_text), "doc_to_target": repr(self.doc_to_target), "description": "",
+            "target_delimiter": " ", "fewshot_delimiter": "\n\n", "num_fewshot": 0, "metric_list": copy.deepcopy(self.metric_list),
+            "output_type": self.OUTPUT_TYPE, "generation_kwargs": copy.deepcopy(self.generation_kwargs), "repeats": 1,
+            "should_decontaminate": False, "metadata": [{"version": 0.0}], "model_specific_kwargs": {"default": dict(msk), **msk},
+        }
+
     def higher_is_better(self) -> dict:
         return dict(self._higher)
 
@@ -187,12 +203,15 @@ def load_task(name: str, *, data_root: str | Path = "data", include_path: str | 
     msk = (cfg.get("model_specific_kwargs") or {}).get("default", {})
     docs = load_docs(Path(cfg.get("dataset_path", Path(data_root) / name)), cfg.get("test_split", "test"))
     output_type = cfg.get("output_type", "generate_until")
+    dataset_path = str(cfg.get("dataset_path", Path(data_root) / name))
     # default question of the reference's doc_to_text when a config has no `prompt` key (_caltech101_utils.py:23)
-    return ClassificationTask(cfg.get("task", name), docs, prompt=msk.get("prompt", "What's in the image?"),
+    task = ClassificationTask(cfg.get("task", name), docs, prompt=msk.get("prompt", "What's in the image?"),
                               pre_prompt=msk.get("pre_prompt", ""), post_prompt=msk.get("post_prompt", ""),
                               generation_kwargs=cfg.get("generation_kwargs"), metric_list=cfg.get("metric_list"),
                               split=cfg.get("test_split", "test"), output_type=output_type,
                               prompts=msk.get("prompts") if output_type == "generate_until_multi_round" else None)
+    task.dataset_path = dataset_path
+    return task
 
 
 def load_docs(path: Path, split: str) -> list[dict]:

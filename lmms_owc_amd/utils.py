@@ -19,6 +19,34 @@ def hash_string(string: str) -> str:
     return hashlib.sha256(string.encode("utf-8")).hexdigest()
 
 
+def get_git_commit_hash() -> str | None:
+    """`git describe --always` of the checkout this package lives in, or None (_core_utils.py:87-108)."""
+    import os
+    import shutil
+    import subprocess
+
+    git = shutil.which("git")
+    if not git:
+        return None
+    try:
+        res = subprocess.run([git, "describe", "--always"], capture_output=True, text=True, check=True,
+                             cwd=os.path.dirname(os.path.abspath(__file__)))
+    except (subprocess.CalledProcessError, OSError):
+        return None
+    return res.stdout.strip()
+
+
+def convert_non_serializable(obj):
+    """`json.dumps(default=...)` of the reference's writers (_data_utils.py:89-102)."""
+    import numpy as np
+
+    if isinstance(obj, (np.int64, np.int32)):
+        return int(obj)
+    if isinstance(obj, set):
+        return list(obj)
+    return str(obj)
+
+
 def _string_arg_to_type(arg: str):
     low = arg.lower()
     if low == "true":
@@ -114,9 +142,9 @@ def make_table(results: dict) -> str:
     lines = ["| Task | Metric | Value | Stderr |", "|---|---|---:|---:|"]
     for task, metrics in results.get("results", {}).items():
         for k, v in metrics.items():
-            if k.endswith("_stderr") or k == "alias" or k.startswith(" "):
-                continue
             metric = k.split(",")[0]
+            if metric.endswith("_stderr") or k == "alias" or k.startswith(" "):
+                continue
             se = metrics.get(f"{metric}_stderr,{k.split(',')[1]}" if "," in k else f"{metric}_stderr", "N/A")
             val = f"{v:.4f}" if isinstance(v, (int, float)) else str(v)
             se = f"{se:.4f}" if isinstance(se, (int, float)) else str(se)

@@ -1,33 +1,55 @@
-"""Worker of test_evaluate_two_ranks_equals_one: runs the evaluate loop under gloo with a stub model
-(no GPU, CPU string metrics only) and lets rank 0 write the gathered result."""
-import json
+"""Worker of the world-size-2 tests in tests/test_host_logic.py: runs simple_evaluate + the tracker under gloo with a stub
+model (no GPU, CPU string metrics only); rank 0 writes the result files.  OWC_TEST_TOKENS=1 gives the stub the token-record
+interface (`generate_until_tokens` / `decode_tokens`) so the engine's token gather path is exercised as well."""
 import os
 import sys
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
+import numpy as np  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from lmms_owc_amd.engine.evaluate import evaluate  # noqa: E402
+from lmms_owc_amd.engine.evaluate import simple_evaluate  # noqa: E402
+from lmms_owc_amd.engine.tracker import EngineTracker  # noqa: E402
 from lmms_owc_amd.tasks import ClassificationTask  # noqa: E402
 
 
 class StubModel:
-    """Deterministic stand-in for a Model plug-in: answer depends only on the document."""
+    """Deterministic stand-in for a Model plug-in: the answer depends only on the document."""
+
+    device = "cpu"
 
     def __init__(self):
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world_size = dist.get_world_size() if dist.is_initialized() else 1
         self.task_dict = {}
 
+    def eval(self):
+        return self
+
     def generate_until(self, requests):
         out = []
         for r in requests:
             ctx, gk, d2v, doc_id, task, split = r.args
+            gk.pop("until", None)
             doc = self.task_dict[task][split][doc_id]
-            out.append(f" {doc['target'].replace('_', ' ')} " if doc_id % 3 else "something else")
+            out.append(f" {doc['target'].replace('_', ' ')} é" if doc_id % 3 else "something else, entirely longer than the others")
         return out
+
+
+class TokenStubModel(StubModel):
+    """Same answers through fixed-width token records (ids = UTF-8 bytes + 3), like the HIP model wrappers."""
+
+    def generate_until_tokens(self, requests):
+        rows = [[b + 3 for b in s.encode("utf-8")] for s in StubModel.generate_until(self, requests)]
+        mat = np.zeros((len(rows), 64), np.int32)
+        for i, r in enumerate(rows):
+            mat[i, : len(r)] = r
+        return mat, np.array([len(r) for r in rows], np.int32)
+
+    def decode_tokens(self, rows):
+        return [bytes(int(t) - 3 for t in r).decode("utf-8") for r in rows]
 
 
 def main():
@@ -39,12 +61,20 @@ def main():
                {"metric": "textual_inclusion", "aggregation": "mean"}]
     task = ClassificationTask("toy", docs, metric_list=metrics)
     task.doc_to_visual = lambda doc: []
-    lm = StubModel()
-    lm.task_dict["toy"] = task.dataset
-    res = evaluate(lm, {"toy": task}, limit=int(os.environ.get("OWC_TEST_LIMIT", "9")))
+    lm = TokenStubModel() if os.environ.get("OWC_TEST_TOKENS") == "1" else StubModel()
+    out_dir = Path(sys.argv[1])
+    tracker = EngineTracker(output_path=str(out_dir))
+    tracker.log_experiment_args(model_source="stub", model_args="")
+    date = "2026-01-02T03:04:05"
+    res = simple_evaluate(model="stub", task_objects={"toy": task}, limit=int(os.environ.get("OWC_TEST_LIMIT", "9")), model_object=lm,
+                          datetime_str=date)
+    assert (res is None) == (lm.rank != 0)
     if res is not None:
-        Path(sys.argv[1]).write_text(json.dumps({"results": {k: (v if isinstance(v, str) else float(v)) for k, v in res["results"]["toy"].items()},
-                                                 "samples": res["samples"]["toy"]}, default=float))
+        samples = res.pop("samples")
+        tracker.general["start_time"] = 0.0   # the three time fields are the only run-dependent bytes of the results file
+        tracker.save_results_aggregated(results=res, samples=samples, datetime_str=date)
+        for name in res["configs"]:
+            tracker.save_results_samples(task_name=name, samples=samples[name])
     if world > 1:
         dist.destroy_process_group()
 

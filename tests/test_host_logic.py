@@ -114,40 +114,45 @@ def test_smart_resize_and_prompt_ids():
     assert h * w >= 4 * 784
 
 
-def test_evaluate_two_ranks_equals_one(tmp_path):
-    """world_size-2 gloo run of the evaluate loop: the strided shards' union == the single-process output."""
+def _run_ranks(tmp_path, tag: str, world: int, port: int, extra_env: dict) -> dict:
+    """Files written by rank 0 of a `world`-rank gloo run of tests/dist_worker.py: {name: text}."""
+    import os
+
     worker = ROOT / "tests" / "dist_worker.py"
-    outs = []
-    for world in (1, 2):
-        out = tmp_path / f"w{world}.json"
-        procs = []
-        for rank in range(world):
-            env = {**__import__("os").environ, "RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
-                   "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(29611 + world)}
-            procs.append(subprocess.Popen([sys.executable, str(worker), str(out)], env=env, cwd=str(ROOT)))
-        for p in procs:
-            assert p.wait(timeout=300) == 0
-        outs.append(json.loads(out.read_text()))
+    out = tmp_path / f"{tag}{world}"
+    procs = []
+    for rank in range(world):
+        env = {**os.environ, "RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1",
+               "MASTER_PORT": str(port), **extra_env}
+        procs.append(subprocess.Popen([sys.executable, str(worker), str(out)], env=env, cwd=str(ROOT)))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    files = {p.name: p.read_text() for p in sorted(out.rglob("*")) if p.is_file()}
+    # end_time / total_evaluation_time_seconds are wall-clock and the config dump holds function reprs with addresses (as
+    # the reference's does): the only bytes allowed to differ between runs
+    mask = lambda t: re.sub(r" at 0x[0-9a-f]+", "", re.sub(r'"(end_time|total_evaluation_time_seconds)": [^\n]*', r'"\1": 0', t))  # noqa: E731
+    return {n: mask(t) for n, t in files.items()}
+
+
+@pytest.mark.parametrize("tokens", ["0", "1"])
+def test_evaluate_two_ranks_byte_identical_to_one(tmp_path, tokens):
+    """world_size-2 gloo run (uneven shards 5 / 4): ONE fixed-width all_gather of the answers, rank 0 builds every record;
+    the results JSON and the samples JSONL are BYTE-identical to the single-process run's - through the UTF-8 byte records
+    of a plain `Model` plug-in (tokens=0) and through the token records of the HIP wrappers' interface (tokens=1)."""
+    outs = [_run_ranks(tmp_path, f"t{tokens}w", world, 29611 + world + 10 * int(tokens), {"OWC_TEST_TOKENS": tokens}) for world in (1, 2)]
+    assert sorted(outs[0]) == sorted(outs[1]) and len(outs[0]) == 2
     assert outs[0] == outs[1]
-    assert [s["doc_id"] for s in outs[0]["samples"]] == list(range(9))
+    samples = [json.loads(ln) for ln in next(t for n, t in outs[0].items() if "_samples_" in n).splitlines()]
+    assert [s["doc_id"] for s in samples] == list(range(9))
+    assert samples[1]["filtered_resps"] == [" class 1 é"] and samples[0]["resps"] == [["something else, entirely longer than the others"]]
 
 
 def test_evaluate_rank_with_empty_shard(tmp_path):
     """limit=1 on two ranks: rank 1 owns no document (the reference pads by re-running a request; here the shard is
-    simply empty) and the gathered result equals the single-rank one."""
-    worker = ROOT / "tests" / "dist_worker.py"
-    outs = []
-    for world in (1, 2):
-        out = tmp_path / f"e{world}.json"
-        procs = []
-        for rank in range(world):
-            env = {**__import__("os").environ, "RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
-                   "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(29631 + world), "OWC_TEST_LIMIT": "1"}
-            procs.append(subprocess.Popen([sys.executable, str(worker), str(out)], env=env, cwd=str(ROOT)))
-        for p in procs:
-            assert p.wait(timeout=300) == 0
-        outs.append(json.loads(out.read_text()))
-    assert outs[0] == outs[1] and len(outs[0]["samples"]) == 1
+    simply empty and contributes zero-filled records); files byte-identical to the single-rank run."""
+    outs = [_run_ranks(tmp_path, "e", world, 29631 + world, {"OWC_TEST_LIMIT": "1"}) for world in (1, 2)]
+    assert outs[0] == outs[1]
+    assert len(next(t for n, t in outs[0].items() if "_samples_" in n).splitlines()) == 1
 
 
 def test_image_preprocessing_matches_hf_golden():

@@ -65,7 +65,7 @@ def test_evaluate_then_offline_metrics(gpu, scorer, tmp_path, capsys):
     assert [s["doc_id"] for s in samples] == [0, 1, 2, 3, 4]
     out_dir = tmp_path / "logs" / "schedule" / "synthetic" / "tiny-model"
     tr = EngineTracker(output_path=str(out_dir))
-    tr.log_experiment_args(model_args="")
+    tr.log_experiment_args(model_source="custom-model", model_args="")
     tr.save_results_aggregated({k: v for k, v in res.items() if k != "samples"}, res["samples"], "2026-01-01T00:00:00")
     f = tr.save_results_samples("synthetic", samples)
     rec = json.loads(f.read_text().splitlines()[0])
@@ -128,6 +128,43 @@ def test_concept_semantic_similarity(gpu, scorer):
     mn = info.group_fn(info.builder_fn(items), reduce="min")
     assert mn <= info.group_fn(info.builder_fn(items), reduce="mean") <= mx <= 1.0 + 1e-5
     assert abs(mx - np.mean([max(r[1]) for r in rows])) < 1e-6
+
+
+# ---------------------------------------------------------------- drop-in formats vs the reference's own output, HIP scorer
+@pytest.fixture()
+def ref_pipeline(gpu):
+    """What tools/gen_golden_formats.py injected into the reference, on the HIP scorer: tiny seeded BERT, HashTokenizer,
+    rule-based parser.  Restores the module state afterwards (other tests use the MiniLM-shaped `scorer` fixture)."""
+    from lmms_owc_amd.engine.scorer import BertWeights, SentenceScorer
+    from lmms_owc_amd.pipelines import text
+    from tests import format_fixtures as F
+    from tests import recipes
+
+    saved = (text.sentence_bert_model, text.sentence_bert_processor, text.concept_extractor, text.concept_nlp)
+    c = recipes.bert_cfg("tiny")
+    F.install_text_pipeline(SentenceScorer(BertWeights(c, recipes.bert_weights(c, 1234), gpu)))
+    yield F
+    text.sentence_bert_model, text.sentence_bert_processor, text.concept_extractor, text.concept_nlp = saved
+
+
+def test_engine_files_match_reference_tracker_gpu(ref_pipeline, tmp_path):
+    """simple_evaluate + EngineTracker with the HIP scorer behind the group metrics: samples JSONL byte-identical to the
+    file the REFERENCE's engine + tracker wrote for the same task and answers, results JSON equal key by key with the
+    scorer's values within 2e-5 (tests/golden/engine_formats.json)."""
+    _, files = ref_pipeline.run_engine(tmp_path / "out")
+    ref_pipeline.check_engine_files(files, tol=2e-5)
+
+
+def test_eval_metrics_cli_matches_reference_gpu(ref_pipeline, tmp_path, capsys):
+    """G9: eval_metrics.py on the reference's samples file -> same rewritten columns / formatting / printed table as the
+    reference's eval_metrics.main produced (tests/golden/eval_metrics.json), sentence metrics on the HIP scorer."""
+    ref_pipeline.check_eval_metrics(tmp_path, capsys, tol=2e-5)
+
+
+def test_concept_semantic_similarity_matches_reference_gpu(ref_pipeline):
+    """The reference's concept_semantic_similarity with the injected parser: same concept lists, similarities and the four
+    reductions within 2e-5 (tests/golden/concept_similarity.json)."""
+    ref_pipeline.check_concept_similarity(tol=2e-5)
 
 
 def test_real_checkpoint_loading_path(gpu, tmp_path):

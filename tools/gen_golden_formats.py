@@ -174,7 +174,7 @@ def run_engine(tmp: Path) -> dict:
     tracker = E.EngineTracker(output_path=str(out_dir))
     tm = TaskManager(include_path=str(tmp / "tasks"), include_defaults=False, model_name="stand-in")
     date = "2026-01-02T03:04:05"
-    res = E.simple_evaluate(model_name="stand-in", model_args="", tasks=["toytask"], batch_size=1, limit=7, bootstrap_iters=0,
+    res = E.simple_evaluate(model_name="stand-in", model_args="", tasks=["toytask"], batch_size=1, limit=7, bootstrap_iters=100000,
                             log_samples=True, engine_tracker=tracker, task_manager=tm, datetime_str=date,
                             cli_args=Namespace(process_with_media=False, output_path=str(out_dir)))
     samples = res.pop("samples")
