@@ -65,13 +65,15 @@ def pruned_flops_per_image(d, prompts_per_chunk: int) -> float:
     return float(last_layer + shared_rows * per_row)
 
 
-def cpu_baseline_lmm(model_key: str, new_tokens: int, n_images: int) -> dict:
-    """The reference's CPU path: HF Qwen2VLForConditionalGeneration, batch 1, greedy (src/models/_qwen2_vl.py:308-329)."""
+def cpu_baseline_lmm(dims, device, seed: int, new_tokens: int, pix_dev, hip_tokens, n_images: int) -> dict:
+    """The reference's CPU path: HF Qwen2VLForConditionalGeneration.generate, batch 1, greedy (src/models/_qwen2_vl.py:308-329),
+    on the SAME seeded weights (`random_param`, regenerated per HF parameter name and copied to the host) and the SAME
+    pixel_values / prompt ids as the HIP run's first `n_images` images; its tokens are compared with the HIP tokens."""
     from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
 
-    from lmms_owc_amd.engine.qwen2vl import DIMS
+    from lmms_owc_amd.engine.qwen2vl import hf_param_names, random_param
 
-    d = DIMS[model_key]
+    d = dims
     threads = min(os.cpu_count() or 1, 128)
     torch.set_num_threads(threads)
     cfg = Qwen2VLConfig(
@@ -86,11 +88,7 @@ def cpu_baseline_lmm(model_key: str, new_tokens: int, n_images: int) -> dict:
     cfg._attn_implementation = "sdpa"
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.bfloat16)
-    try:
-        import transformers.initialization as tinit  # noqa: F401
-        ctx = getattr(__import__("transformers.modeling_utils", fromlist=["no_init_weights"]), "no_init_weights", None)
-    except Exception:  # pragma: no cover
-        ctx = None
+    ctx = getattr(__import__("transformers.modeling_utils", fromlist=["no_init_weights"]), "no_init_weights", None)
     try:
         if ctx is not None:
             with ctx():
@@ -100,31 +98,40 @@ def cpu_baseline_lmm(model_key: str, new_tokens: int, n_images: int) -> dict:
     finally:
         torch.set_default_dtype(prev)
     model = model.to(torch.bfloat16).eval()
-    g = torch.Generator().manual_seed(1234)
+    sd = model.state_dict()
     with torch.no_grad():
-        for p in model.parameters():
-            p.uniform_(-0.02, 0.02, generator=g)
+        for name in hf_param_names(d):
+            sd[name].copy_(random_param(d, name, device, seed).reshape(sd[name].shape).cpu())
+        if d.tie_embeddings and "lm_head.weight" in sd:
+            sd["lm_head.weight"].copy_(sd["model.language_model.embed_tokens.weight"])
     ids = prompt_ids(d.image_token_id)
     inp = torch.from_numpy(ids.astype(np.int64))[None]
     mm = (inp == d.image_token_id).int()
     grid = torch.tensor([[1, 32, 32]])
-    times = []
+    times, same_first, same_all = [], 0, 0
     with torch.no_grad():
         for i in range(n_images):
-            pix = torch.randn(1024, 1176, generator=g).to(torch.bfloat16)
+            pix = pix_dev[i * 1024:(i + 1) * 1024].cpu()
             t0 = time.perf_counter()
-            model.generate(input_ids=inp, attention_mask=torch.ones_like(inp), pixel_values=pix, image_grid_thw=grid,
-                           mm_token_type_ids=mm, do_sample=False, num_beams=1, max_new_tokens=new_tokens,
-                           min_new_tokens=new_tokens, use_cache=True, pad_token_id=0)
+            gen = model.generate(input_ids=inp, attention_mask=torch.ones_like(inp), pixel_values=pix, image_grid_thw=grid,
+                                 mm_token_type_ids=mm, do_sample=False, num_beams=1, max_new_tokens=new_tokens,
+                                 min_new_tokens=new_tokens, use_cache=True, pad_token_id=0)
             times.append(time.perf_counter() - t0)
+            new = gen[0, inp.shape[1]:].tolist()
+            hip = [int(t) for t in hip_tokens[i].tolist()]
+            same_first += int(new[0] == hip[0])
+            same_all += int(new == hip)
     del model
     best = float(np.mean(times[1:])) if len(times) > 1 else float(times[0])
     import transformers
 
     return {"value": 1.0 / best, "unit": "images/s", "cores": threads, "kind": "reference",
-            "sample": f"{n_images} image(s) 448x448, batch 1, bf16, transformers {transformers.__version__} "
-                      f"Qwen2VLForConditionalGeneration.generate on CPU (greedy, {new_tokens} new tokens, random weights); "
-                      f"mean of images after the first; per-image s = {[round(t, 2) for t in times]}"}
+            "sample": f"{n_images} image(s) 448x448 = the HIP run's first images (same pixel_values, prompt ids and seeded weights), batch 1, "
+                      f"bf16, transformers {transformers.__version__} Qwen2VLForConditionalGeneration.generate on CPU (greedy, {new_tokens} "
+                      f"new tokens); mean of images after the first; per-image s = {[round(t, 2) for t in times]}",
+            "tokens_vs_hip": {"images": n_images, "first_token_equal": same_first, "all_tokens_equal": same_all,
+                              "note": "random weights give near-flat logits over a 152k vocabulary: a near-tie may flip under a different "
+                                      "fp32 summation order (parity is asserted by the teacher-forced tests, not here)"}}
 
 
 def cpu_baseline_scorer(n_labels: int, L: int) -> dict:
@@ -240,6 +247,7 @@ def main() -> None:
     ap.add_argument("--vit-chunk", type=int, default=None, help="vision-tower tokens per launch group (engine default if unset)")
     ap.add_argument("--prefill-chunk", type=int, default=None, help="packed prefill rows per launch group (engine default if unset)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pil-leg", action="store_true", help="skip the PIL -> generate_until -> strings leg")
     ap.add_argument("--nominal-forward", action="store_true",
                     help="run the model's nominal forward: full last prefill layer on every row and no shared-prefix segment "
                          "(same tokens bit for bit; shows what the two dead-work eliminations are worth)")
@@ -311,6 +319,13 @@ def main() -> None:
         torch.cuda.synchronize()
 
     lib, ctx = _lib.load(), _lib.ctx(local)
+    NK = len(_lib.PROF_KINDS)
+
+    def read_profile() -> dict:
+        ms, wk, n = (C.c_double * NK)(), (C.c_double * NK)(), (C.c_int64 * NK)()
+        _lib.check(lib.owc_profile_read(ctx, NK, ms, wk, n), local)
+        return {k: {"ms": ms[i], "work": wk[i], "launches": int(n[i])} for i, k in enumerate(_lib.PROF_KINDS)}
+
     for _ in range(args.warmup):
         step()
     sync()
@@ -319,19 +334,25 @@ def main() -> None:
     for _ in range(args.steps):
         out = step()
     sync()
-    dt = time.perf_counter() - t0
-    ms2, fl2, n2 = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int64 * 2)()
-    if rank == 0:
-        _lib.check(lib.owc_gemm_profile_read(ctx, ms2, fl2, n2), local)
-    fp8_run = args.decoder_dtype == "fp8"
-    ms, fl, n_launch = (C.c_double(ms2[1 if fp8_run else 0]), C.c_double(fl2[1 if fp8_run else 0]), C.c_int64(n2[1 if fp8_run else 0]))
+    dt_local = time.perf_counter() - t0
+    prof = read_profile() if rank == 0 else None
     lib.owc_gemm_profile_enable(ctx, 0)
+    fp8_run = args.decoder_dtype == "fp8"
     assert out.shape == (B, T)
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    tall = torch.tensor([dt_local], device=device, dtype=torch.float64)
+    per_rank_dt = [dt_local]
     if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        gathered = torch.empty(world, device=device, dtype=torch.float64)
+        dist.all_gather_into_tensor(gathered, tall)
+        per_rank_dt = gathered.tolist()
+    dt = max(per_rank_dt)                       # max over ranks
     images_per_s = world * B * args.steps / dt
+
+    # ---- outside the timed region: image 0's tokens inside the B-image batch == the same image run alone (batch invariance
+    # across the chunked vision / prefill launch groups and the batch-size dependent decode kernels)
+    emb0 = engine.encode_images(pix[:1024], flat_grids[:1])
+    alone = engine.generate(prompts[:1], emb0, grids[:1], T, eos_token_id=-1, pad_token_id=0).cpu()
+    invariant = bool(torch.equal(alone[0], out[0]))
 
     # ---- PCIe-inclusive leg (never `value`): the same step fed from host uint8 images (what the boundary hands over in a
     # real run): pinned H2D copy + GPU rescale/normalise/patchify + the step above
@@ -350,7 +371,19 @@ def main() -> None:
     if dist is not None:
         dist.all_reduce(pcie_dt, op=dist.ReduceOp.MAX)
     pcie_images_per_s = world * B / float(pcie_dt.item())
-    del host_u8, dev_u8, pix_h, emb_h
+    del dev_u8, pix_h, emb_h
+
+    # ---- real-boundary leg (never `value`): PIL images -> Qwen2VL.generate_until -> strings, i.e. the reference's plug-in
+    # contract end to end (JPEG round trip + bicubic resize + tokenise on the host worker pool, double-buffered against the GPU)
+    pil = None
+    if not args.no_pil_leg:
+        pil = pil_leg(engine, dims, host_u8, B, T, device, sync)
+        if dist is not None:
+            t = torch.tensor([pil["seconds"]], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            pil["seconds"] = float(t.item())
+        pil["images_per_s"] = world * pil["images"] / pil["seconds"]
+    del host_u8
 
     # ---- scorer leg: label-cosine/s (embed predictions + cosine top-5 against resident class embeddings)
     n_lab, L = args.scorer_labels, 16
@@ -368,14 +401,18 @@ def main() -> None:
 
     score()
     sync()
+    lib.owc_gemm_profile_enable(ctx, 1 if rank == 0 else 0)
     s0 = time.perf_counter()
     for _ in range(args.steps):
         tv, ti, paired = score()
     sync()
     sdt = torch.tensor([time.perf_counter() - s0], device=device, dtype=torch.float64)
+    sprof = read_profile() if rank == 0 else None
+    lib.owc_gemm_profile_enable(ctx, 0)
     if dist is not None:
         dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
     labels_per_s = world * n_lab * args.steps / float(sdt.item())
+    label_tokens = int(lens.sum().item())
 
     if rank == 0:
         f_model = flops_per_image(dims, T)
@@ -383,9 +420,12 @@ def main() -> None:
         s_prompt = S_TEXT_BEFORE + S_IMG + S_TEXT_AFTER
         per_chunk = max(1, min(B, (engine.prefill_chunk_tokens - S_TEXT_BEFORE) // (s_prompt - S_TEXT_BEFORE))) if engine.share_prefix else 1
         f_img = f_model if args.nominal_forward else f_model - pruned_flops_per_image(dims, per_chunk)
-        gemm_tflops = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        g = prof["gemm_fp8" if fp8_run else "gemm_bf16"]
+        gemm_tflops = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        peak = PEAK_FP8_TFLOPS if fp8_run else PEAK_BF16_TFLOPS
+        traffic = None if fp8_run else load_traffic(args, engine, B)
         result = {
-            "metric": "images/sec (whole node) Qwen2-VL-7B open-world classify; label-cosine/sec",
+            "metric": f"images/sec (whole node) Qwen2-VL-{args.model.upper()} open-world classify; label-cosine/sec",
             "value": images_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if not fp8_run else "fp8-e4m3 decoder projections (per-token / per-channel scales), bf16 elsewhere", "data": "synthetic",
@@ -393,33 +433,36 @@ def main() -> None:
                                    f"(1024 patches -> 256 image tokens), prompt S=286, {T} forced greedy tokens, seeded random "
                                    "weights of the real architecture; images strided across ranks, no data-path collective",
                        "images_per_gpu_per_step": B, "prompt_tokens": 286, "new_tokens": T, "parallelism": f"dp{world}"},
+            "per_rank_images_per_s": [B * args.steps / t for t in per_rank_dt],
+            "rccl_world_size": dist.get_world_size() if dist is not None else 1,
+            "batch_invariance_check": "ok: image 0's tokens inside the batch == the same image run alone" if invariant else
+                                      "MISMATCH: image 0's tokens differ between the batch and a single-image run",
             "images_per_s_from_host_uint8": pcie_images_per_s,  # PCIe-inclusive (H2D + GPU patchify + step), not `value`
+            "images_per_s_from_pil": pil,                       # the plug-in boundary end to end, not `value`
             "label_cosine_per_sec": labels_per_s,
-            "label_cosine_config": {"labels_per_gpu": n_lab, "tokens_per_label": L, "classes": args.scorer_classes, "top_k": 5,
+            "label_cosine_config": {"labels_per_gpu": n_lab, "tokens_per_label": f"uniform 2..{L} (mean {label_tokens / n_lab:.2f}), padded rows are not computed",
+                                    "classes": args.scorer_classes, "top_k": 5,
                                     "encoder": "MiniLM-L6 (BERT 6x384) fp32; linears as 3-piece bf16 splits on the bf16 MFMA (fp32-level error, tests/test_scorer_gpu.py)"},
             "model_flops_per_image": f_model,      # the model's nominal forward
             "executed_flops_per_image": f_img,     # minus the last prefill layer's dead rows (see pruned_flops_per_image)
             "mfma_frac_end_to_end": images_per_s / world * f_img / (PEAK_BF16_TFLOPS * 1e12),  # always against the bf16 peak
             "roofline": {"bound": "mfma", "kernel": "gemm_fp8_nt_256_kernel (decoder projections)" if fp8_run else "gemm_bf16_nt_kernel (all epilogues)",
-                         "achieved": gemm_tflops, "peak": PEAK_FP8_TFLOPS if fp8_run else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": gemm_tflops / (PEAK_FP8_TFLOPS if fp8_run else PEAK_BF16_TFLOPS),
-                         "traffic": None if fp8_run or args.model != "7b" or B < 256 else 31287994880,  # only where a full 65536-row prefill group exists
-                         "traffic_note": "bytes per launch of the step's largest launch class (7B gate/up, M 65536 = one prefill launch group, N 37888, "
-                                         "K 3584), from separate rocprofv3 --pmc passes on the final kernel (FETCH_SIZE x2 for the gfx950 correction + "
-                                         "WRITE_SIZE, profiles/r01_pmc_gemm_traffic_final.json) - PMC passes cannot run inside this process (they serialise "
-                                         "~24k launches).  Algorithmic bytes of that launch (A + W + C once) = 5.7 GB; measured 31.3 GB = C once (exact) + 26.3 GB "
-                                         "of operand fetches = 2MNK/256 x (1/4 + 1/8): every 4x8-tile XCD patch re-fetches its panels (L2 4 MB; 78 % L2 hit is the "
-                                         "floor of that patch shape, DESIGN.md section 4 notes)",
-                         "launches": int(n_launch.value), "kernel_ms_total": ms.value,
-                         "share_of_step_time": ms.value * 1e-3 / (time_or(dt)), "method":
-                             "HIP events around every launch of the timed region on the launch stream; achieved = sum(2MNK) / sum(t)"},
+                         "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tflops / peak,
+                         "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_source": traffic,
+                         "launches": g["launches"], "kernel_ms_total": g["ms"], "share_of_step_time": g["ms"] * 1e-3 / time_or(dt),
+                         "method": "HIP events around every launch of the timed region on the launch stream; achieved = sum(2MNK) / sum(t)"},
+            "roofline_attention": attention_rooflines(prof, dims, B, T, args.steps, dt),
+            "roofline_label_cosine": scorer_rooflines(sprof, n_lab, args.scorer_classes, 5, args.steps, float(sdt.item())),
         }
+        if args.one_gpu_value:
+            result["scaling_efficiency"] = images_per_s / (world * args.one_gpu_value)
         if fp8_run:
-            result["bf16_gemm_in_same_run"] = {"tflops": fl2[0] / (ms2[0] * 1e-3) / 1e12 if ms2[0] > 0 else 0.0, "kernel_ms_total": ms2[0],
-                                               "launches": int(n2[0])}
+            b16 = prof["gemm_bf16"]
+            result["bf16_gemm_in_same_run"] = {"tflops": b16["work"] / (b16["ms"] * 1e-3) / 1e12 if b16["ms"] > 0 else 0.0,
+                                               "kernel_ms_total": b16["ms"], "launches": b16["launches"]}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"] = cpu_baseline_lmm(key, T, args.cpu_images)
+                result["cpu_baseline"] = cpu_baseline_lmm(dims, device, 1234, T, pix, out, args.cpu_images)
                 result["cpu_baseline_label_cosine"] = cpu_baseline_scorer(4096, L)
             except Exception as e:  # the baseline must never sink the measurement
                 result["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "reference",
@@ -428,6 +471,98 @@ def main() -> None:
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if not invariant:
+        raise SystemExit("batch invariance check failed (the JSON line above carries the measurement)")
+
+
+def pil_leg(engine, dims, host_u8, B: int, T: int, device, sync) -> dict:
+    """PIL images -> `Qwen2VL.generate_until` -> strings on the engine of the main leg (same weights): 2 chunks of B / 2 images so
+    that the second chunk's host preparation overlaps the first chunk's GPU work."""
+    from PIL import Image
+
+    from lmms_owc_amd.models._qwen2_vl import ByteTokenizer, Qwen2VL
+    from lmms_owc_amd.tasks import ClassificationTask
+
+    n = B if B >= 2 else 2
+    bs = max(1, n // 2)
+    arr = host_u8[:n].permute(0, 2, 3, 1).contiguous().numpy()           # HWC uint8 (uniform noise: the slowest JPEG case)
+    docs = [{"visual": Image.fromarray(arr[i % len(arr)], "RGB"), "target": f"class_{i % 10}"} for i in range(n)]
+    task = ClassificationTask("bench", docs, generation_kwargs={"max_new_tokens": T, "do_sample": False})
+    lm = Qwen2VL.from_engine(engine, ByteTokenizer(), batch_size=bs, eos_token_id=-1)
+    lm.task_dict["bench"] = task.dataset
+    task.build_all_requests(limit=None, rank=0, world_size=1)
+    lm.generate_until(task.instances[: min(8, n)])                      # warm the worker pool / pinned allocator
+    sync()
+    t0 = time.perf_counter()
+    answers = lm.generate_until(task.instances)
+    sync()
+    dtp = time.perf_counter() - t0
+    assert len(answers) == n and all(isinstance(a, str) for a in answers)
+    return {"seconds": dtp, "images": n, "batch_size": bs, "prep_threads": lm._prep_threads, "host_cores": os.cpu_count(),
+            "what": "PIL 448x448 (uniform-noise pixels) -> JPEG round trip + smart_resize/bicubic + tokenise on the host pool -> pinned "
+                    "H2D -> patchify -> vision tower -> prefill -> 16 greedy tokens -> detokenised strings; chunk k+1 is prepared while "
+                    "chunk k runs on the GPU"}
+
+
+def load_traffic(args, engine, B: int) -> dict | None:
+    """roofline.traffic = HBM bytes per launch of the step's largest launch class, READ FROM the committed rocprofv3 PMC summary
+    (profiles/*_pmc_gemm_traffic*.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction on FETCH_SIZE) - never a
+    literal.  Only when this run contains that launch class: 7B, one full 65536-row prefill group, no tuning knob, bf16."""
+    if args.model != "7b" or B < 256 or engine.prefill_chunk_tokens != 65536 or args.nominal_forward:
+        return None
+    if any(k.startswith("OWC_GEMM_") for k in os.environ):
+        return None
+    cands = sorted((ROOT / "profiles").glob("r*_pmc_gemm_traffic*.json"))
+    if not cands:
+        return None
+    f = cands[-1]
+    try:
+        d = json.loads(f.read_text())
+        return {"bytes_per_launch": d["bytes_per_launch"], "algorithmic_bytes_per_launch": d.get("algorithmic_bytes_per_launch"),
+                "kernel": d.get("kernel"), "shape": d.get("shape"), "file": str(f.relative_to(ROOT)), "raw_counters": d.get("raw_csv")}
+    except (KeyError, ValueError):
+        return None
+
+
+def attention_rooflines(prof: dict, d, B: int, T: int, steps: int, dt: float) -> dict:
+    """Roofline objects of the two attention launch classes of the timed region (HIP events inside the library; the launcher
+    cannot see the device-side lengths, so the algorithmic FLOPs are priced here from the workload's shapes)."""
+    S = S_TEXT_BEFORE + S_IMG + S_TEXT_AFTER
+    vis = steps * B * d.v_depth * 4.0 * 1024 * 1024 * d.v_embed                      # QK^T + PV, non-causal, per image per layer
+    pre = steps * B * d.n_layers * 2.0 * S * S * d.n_q_heads * d.head_dim            # causal: half of 4 S^2 H hd
+    dec = steps * B * d.n_layers * sum(4.0 * (S + i) * d.n_q_heads * d.head_dim for i in range(T - 1))
+    out = {}
+    for name, kind, flops, kernel in (("vision", "attn_noncausal", vis, "attn_fwd_kernel<80,false>"),
+                                      ("decoder", "attn_causal", pre + dec, "attn_fwd_kernel<128,true> (prefill + decode steps)")):
+        p = prof[kind]
+        tf = flops / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
+        out[name] = {"bound": "mfma", "kernel": kernel, "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tf / PEAK_BF16_TFLOPS, "traffic": None, "launches": p["launches"], "kernel_ms_total": p["ms"],
+                     "share_of_step_time": p["ms"] * 1e-3 / time_or(dt)}
+    return out
+
+
+def scorer_rooflines(sprof: dict, n_lab: int, n_cls: int, k: int, steps: int, sdt: float) -> dict:
+    """Metric 2: the sentence encoder's linears (fp32 operands as 3 bf16 pieces, 6 piece-products per fp32 product on the bf16
+    MFMA: effective peak 2.5 PF / 6) and the cosine top-k kernel (HBM bytes 4 D (N + C) + 8 k N)."""
+    D = 384
+    gm, ck = sprof["scorer_gemm"], sprof["cosine_topk"]
+    eff_peak = PEAK_BF16_TFLOPS / 6.0
+    g_tf = gm["work"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
+    ck_bytes = steps * (4.0 * D * (n_lab + n_cls) + 8.0 * k * n_lab)
+    ck_gbs = ck_bytes / (ck["ms"] * 1e-3) / 1e9 if ck["ms"] > 0 else 0.0
+    ck_tf = ck["work"] / (ck["ms"] * 1e-3) / 1e12 if ck["ms"] > 0 else 0.0
+    return {
+        "embed_gemm": {"bound": "mfma", "kernel": "gemm_f32x3_nt_kernel (BERT linears, rows = real tokens only)", "achieved": g_tf,
+                       "peak": eff_peak, "unit": "TFLOP/s", "frac": g_tf / eff_peak, "traffic": None, "launches": gm["launches"],
+                       "kernel_ms_total": gm["ms"], "share_of_leg_time": gm["ms"] * 1e-3 / time_or(sdt),
+                       "peak_note": "fp32-equivalent FLOPs: each product costs six bf16 MFMA piece-products (2.5 PF / 6)"},
+        "cosine_topk": {"bound": "hbm", "kernel": "cosine_topk_kernel", "achieved": ck_gbs, "peak": 8000.0, "unit": "GB/s",
+                        "frac": ck_gbs / 8000.0, "traffic": None, "launches": ck["launches"], "kernel_ms_total": ck["ms"],
+                        "share_of_leg_time": ck["ms"] * 1e-3 / time_or(sdt), "mfma_f32_tflops": ck_tf,
+                        "note": "algorithmic bytes 4 D (N + C) + 8 k N; with C = 397 classes the kernel is bound by its f32-input MFMA "
+                                "work (2 N C D at the 157 TF f32 matrix rate), not by HBM"},
+    }
 
 
 def time_or(x: float) -> float:

@@ -50,6 +50,8 @@ enum owc_epilogue {
 };
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
+/* One context per PROCESS: the design is one process per GPU, and kernel attributes, tuning knobs and
+ * the profile recording are process-wide.  A second owc_init on a different device returns OWC_STATUS_ERR_ARG. */
 int owc_init(int device, owc_ctx** out);
 int owc_destroy(owc_ctx* ctx);
 const char* owc_last_error(const owc_ctx* ctx);
@@ -70,6 +72,19 @@ int owc_abi_version(void); /* bumped whenever a signature in this header changes
  * Every output is an ARRAY OF TWO: [0] the bf16 GEMMs, [1] the fp8 GEMMs. */
 int owc_gemm_profile_enable(owc_ctx* ctx, int on);
 int owc_gemm_profile_read(owc_ctx* ctx, double* total_ms, double* total_flops, int64_t* launches);
+/* The same recording, every launch class: arrays of n_kinds (<= OWC_PROF_KINDS) entries indexed by OWC_PROF_*.  `total_work` is
+ * 2*M*N*K for the GEMM classes and 2*N*C*D for the cosine top-k; the attention launcher only sees device-side sequence
+ * lengths, so its entry is 0 and the caller prices the launches from the shapes it passed (bench.py). */
+enum owc_prof_kind {
+  OWC_PROF_GEMM_BF16 = 0,     /* owc_gemm_bf16 and every bf16 Linear of the model drivers */
+  OWC_PROF_GEMM_FP8 = 1,      /* owc_gemm_fp8 (fp8 decoder projections) */
+  OWC_PROF_ATTN_NONCAUSAL = 2, /* owc_attention_bf16, causal = 0 (vision tower / CLIP) */
+  OWC_PROF_ATTN_CAUSAL = 3,   /* owc_attention_bf16, causal = 1 (decoder prefill and decode steps) */
+  OWC_PROF_SCORER_GEMM = 4,   /* the sentence encoder's linears (owc_bert_embed) */
+  OWC_PROF_COSINE_TOPK = 5,   /* cosine_topk_kernel */
+  OWC_PROF_KINDS = 6
+};
+int owc_profile_read(owc_ctx* ctx, int n_kinds, double* total_ms, double* total_work, int64_t* launches);
 
 /* ---- op level (each is one kernel launch; used by the model drivers below and by tests) ------ */
 
@@ -186,10 +201,12 @@ size_t owc_vit_workspace_bytes(const owc_vit_weights* w, int T);
 
 /* Qwen2VisionTransformerPretrainedModel.forward (HF:700-731): pixel_values[T, patch_k] ->
  * merged image embeddings out[T / merge_unit, out_dim].  seq_start/seq_len (int32[n_img]) are the
- * cu_seqlens of HF:711; pos_hw as in owc_vision_rope. */
+ * cu_seqlens of HF:711; pos_hw as in owc_vision_rope.  max_pos_hw = the largest patch coordinate + 1 in pos_hw (the host
+ * builds pos_hw from the grids, so it knows): OWC_STATUS_ERR_SHAPE when it exceeds w->rope_positions - the rotary table
+ * is indexed by these coordinates (smart_resize admits aspect ratios up to 200, i.e. grids far from square). */
 int owc_vit_forward(owc_ctx* ctx, const owc_vit_weights* w, const void* pixel_values, int64_t ld_pix,
                     const int32_t* pos_hw, const int32_t* seq_start, const int32_t* seq_len,
-                    int n_img, int T, int max_len, void* out, void* workspace, size_t ws_bytes,
+                    int n_img, int T, int max_len, int max_pos_hw, void* out, void* workspace, size_t ws_bytes,
                     void* stream);
 
 /* ---- model level: LLaVA image branch (CLIP ViT + projector) -------------------------------- */

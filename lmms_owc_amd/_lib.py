@@ -20,7 +20,7 @@ _lock = threading.Lock()
 _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = range(6)
 
@@ -118,7 +118,7 @@ SIGNATURES: dict[str, tuple] = {
     "owc_argmax_bf16": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "owc_patchify_u8": (i32, [vp, vp, vp, i64, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp]),
     "owc_vit_workspace_bytes": (sz, [C.POINTER(VitWeights), i32]),
-    "owc_vit_forward": (i32, [vp, C.POINTER(VitWeights), vp, i64, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]),
+    "owc_vit_forward": (i32, [vp, C.POINTER(VitWeights), vp, i64, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "owc_clip_workspace_bytes": (sz, [C.POINTER(ClipWeights), i32]),
     "owc_clip_forward": (i32, [vp, C.POINTER(ClipWeights), vp, i64, i32, vp, vp, sz, vp]),
     "owc_clip_patchify_u8": (i32, [vp, vp, vp, i64, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp]),
@@ -134,7 +134,10 @@ SIGNATURES: dict[str, tuple] = {
     "owc_paired_dot": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "owc_gemm_profile_enable": (i32, [vp, i32]),
     "owc_gemm_profile_read": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "owc_profile_read": (i32, [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
+
+PROF_KINDS = ("gemm_bf16", "gemm_fp8", "attn_noncausal", "attn_causal", "scorer_gemm", "cosine_topk")   # enum owc_prof_kind
 
 
 def lib_path() -> Path:
@@ -163,9 +166,13 @@ def load() -> C.CDLL:
 
 
 def ctx(device: int = 0) -> C.c_void_p:
-    """Per-device library context (needs a GPU)."""
+    """The process's library context (needs a GPU).  One process per GPU: a second device in the same process is refused
+    (kernel attributes, tuning knobs and the profile recording are process-wide in the library)."""
     lib = load()
     with _lock:
+        if _ctx and device not in _ctx:
+            raise OwcError(f"this process already drives cuda:{next(iter(_ctx))}; libowc_hip is one context per process "
+                           f"(one process per GPU) - cuda:{device} needs its own process")
         if device not in _ctx:
             h = C.c_void_p()
             rc = lib.owc_init(device, C.byref(h))

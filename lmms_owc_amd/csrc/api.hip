@@ -3,6 +3,7 @@
 #include "../../include/owc.h"
 #include "owc_internal.h"
 #include <string.h>
+#include <cstdio>
 #include <cstdlib>
 
 #define ST(s) ((hipStream_t)(s))
@@ -15,7 +16,7 @@
 
 extern "C" {
 
-int owc_abi_version(void) { return 10; }
+int owc_abi_version(void) { return 11; }
 
 int owc_tuning_set(const char* name, int value) {
   if (!name) return OWC_ERR_ARG;
@@ -36,9 +37,22 @@ int owc_tuning_set(const char* name, int value) {
   return OWC_OK;
 }
 
+static int g_ctx_device = -1;  // one context per process (one process per GPU): kernel attributes, knobs and the profile recording
+                               // are process-wide, so a second device in the same process is refused instead of half-working
+
+static void debug_knob_from_env(const char* env, void (*set)(int)) {
+  const char* e = getenv(env);
+  if (!e) return;
+  const int v = atoi(e);
+  set(v);
+  if (v != 0)  // these knobs switch parts of a kernel OFF for timing experiments: results are garbage
+    fprintf(stderr, "[libowc_hip] WARNING: %s=%d is a TIMING-ONLY debug knob - outputs of this process are NOT valid results\n", env, v);
+}
+
 int owc_init(int device, owc_ctx** out) {
   if (out == nullptr) return OWC_ERR_ARG;
   *out = nullptr;
+  if (g_ctx_device >= 0 && g_ctx_device != device) return OWC_ERR_ARG;
   if (hipSetDevice(device) != hipSuccess) return OWC_ERR_HIP;
   owc_ctx* ctx = new owc_ctx();
   ctx->device = device;
@@ -47,14 +61,16 @@ int owc_init(int device, owc_ctx** out) {
     return OWC_ERR_HIP;
   }
   if (const char* e = getenv("OWC_GEMM_BIG_MIN_M")) owc_gemm_set_big_min_m(atoi(e));  // tuning / A-B knob
-  if (const char* e = getenv("OWC_GEMM_DBG")) owc_gemm_set_dbg(atoi(e));                // timing-only experiments
-  if (const char* e = getenv("OWC_ATTN_DBG")) owc_attn_set_dbg(atoi(e));
+  debug_knob_from_env("OWC_GEMM_DBG", owc_gemm_set_dbg);  // timing-only experiments (loud on stderr when set)
+  debug_knob_from_env("OWC_ATTN_DBG", owc_attn_set_dbg);
+  g_ctx_device = device;
   *out = ctx;
   return OWC_OK;
 }
 
 int owc_destroy(owc_ctx* ctx) {
   if (ctx == nullptr) return OWC_ERR_ARG;
+  g_ctx_device = -1;
   if (ctx->zeros) (void)hipFree(ctx->zeros);
   delete ctx;
   return OWC_OK;
@@ -189,6 +205,14 @@ int owc_gemm_profile_read(owc_ctx* ctx, double* total_ms, double* total_flops, i
     launches[k] = n[k];
   }
   RET(ctx, "owc_gemm_profile_read", rc);
+}
+
+int owc_profile_read(owc_ctx* ctx, int n_kinds, double* total_ms, double* total_work, int64_t* launches) {
+  if (!ctx || !total_ms || !total_work || !launches || n_kinds <= 0 || n_kinds > OWC_PROF_KINDS) return OWC_ERR_ARG;
+  long n[OWC_PROF_KINDS];
+  const int rc = owc_profile_collect(n_kinds, total_ms, total_work, n);
+  for (int k = 0; k < n_kinds; ++k) launches[k] = n[k];
+  RET(ctx, "owc_profile_read", rc);
 }
 
 }  // extern "C"

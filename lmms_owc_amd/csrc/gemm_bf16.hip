@@ -36,7 +36,7 @@ struct GemmProfile {
   bool on = false;
   std::vector<hipEvent_t> ev;  // start/stop pairs
   std::vector<double> flops;
-  std::vector<int> kind;  // 0 = bf16 GEMM, 1 = fp8 GEMM
+  std::vector<int> kind;  // OWC_PROF_* launch class (include/owc.h)
   size_t used = 0;
 };
 GemmProfile g_prof;
@@ -667,31 +667,32 @@ void owc_gemm_profile_end(int handle, hipStream_t s) {
   if (handle >= 0) (void)hipEventRecord(g_prof.ev[handle + 1], s);
 }
 
-// Sums the recorded launches (the caller has synchronised the stream): total kernel milliseconds,
-// total algorithmic FLOPs (2*M*N*K per launch) and the launch count; then resets the recording.
-int owc_gemm_profile_collect(double* total_ms, double* total_flops, long* launches) {
-  // [0..2] bf16 totals, [3..5] fp8 totals (ms, flops, launches as doubles in total_ms[] when the caller passes 6 slots)
-  double ms[2] = {0.0, 0.0}, fl[2] = {0.0, 0.0};
-  long cnt[2] = {0, 0};
+// Sums the recorded launches per launch class (the caller has synchronised the stream): kernel milliseconds, algorithmic work
+// (FLOPs as given to _begin) and launch count for classes [0, n_kinds); then resets the recording.
+int owc_profile_collect(int n_kinds, double* total_ms, double* total_work, long* launches) {
+  for (int k = 0; k < n_kinds; ++k) {
+    total_ms[k] = 0.0;
+    total_work[k] = 0.0;
+    launches[k] = 0;
+  }
   const size_t n = g_prof.used / 2;
   for (size_t i = 0; i < n; ++i) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return OWC_ERR_HIP;
-    const int k = g_prof.kind[i] ? 1 : 0;
-    ms[k] += t;
-    fl[k] += g_prof.flops[i];
-    ++cnt[k];
+    const int k = g_prof.kind[i];
+    if (k < 0 || k >= n_kinds) continue;
+    total_ms[k] += t;
+    total_work[k] += g_prof.flops[i];
+    ++launches[k];
   }
-  total_ms[0] = ms[0];
-  total_flops[0] = fl[0];
-  launches[0] = cnt[0];
-  total_ms[1] = ms[1];
-  total_flops[1] = fl[1];
-  launches[1] = cnt[1];
   g_prof.used = 0;
   g_prof.flops.clear();
   g_prof.kind.clear();
   return OWC_OK;
+}
+
+int owc_gemm_profile_collect(double* total_ms, double* total_flops, long* launches) {  // classes 0 (bf16 GEMM), 1 (fp8 GEMM)
+  return owc_profile_collect(2, total_ms, total_flops, launches);
 }
 
 void owc_gemm_set_big_min_m(int m) { g_big_min_m = m; }

@@ -10,6 +10,7 @@
 // fragment read supplies 4 consecutive k of one row; lane group g reads chunk 4s+g, and the 4 floats
 // feed 4 successive 16x16x4 MFMAs — a fixed permutation of k applied identically to both operands.
 #include "owc_common.h"
+#include "owc_internal.h"
 
 namespace {
 
@@ -310,12 +311,14 @@ int launch(const float* A, long lda, const float* W, long ldw, const float* bias
       return OWC_ERR_HIP;
     attr_set = true;
   }
+  const int prof = owc_gemm_profile_begin(2.0 * (double)M * (double)N * (double)K, OWC_PROF_SCORER_GEMM, s);
   if (x3)
     hipLaunchKernelGGL(gemm_f32x3_nt_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, s, A,
                        lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, tiles_m, tiles_n);
   else
     hipLaunchKernelGGL(gemm_f32_nt_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, s, A,
                        lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, zeros, tiles_m, tiles_n);
+  owc_gemm_profile_end(prof, s);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 

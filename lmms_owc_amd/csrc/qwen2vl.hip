@@ -55,11 +55,13 @@ size_t owc_vit_workspace_bytes(const owc_vit_weights* w, int T) {
 
 int owc_vit_forward(owc_ctx* ctx, const owc_vit_weights* w, const void* pixel_values, int64_t ld_pix,
                     const int32_t* pos_hw, const int32_t* seq_start, const int32_t* seq_len,
-                    int n_img, int T, int max_len, void* out, void* workspace, size_t ws_bytes,
+                    int n_img, int T, int max_len, int max_pos_hw, void* out, void* workspace, size_t ws_bytes,
                     void* stream) {
   if (!ctx || !w || !pixel_values || !pos_hw || !seq_start || !seq_len || !out || !workspace)
     return OWC_ERR_ARG;
   if (T <= 0 || n_img <= 0 || (T % w->merge_unit) != 0) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_vit_forward: bad T");
+  if (max_pos_hw <= 0 || max_pos_hw > w->rope_positions)
+    OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_vit_forward: a grid side exceeds the vision rotary table (rope_positions)");
   if (ws_bytes < owc_vit_workspace_bytes(w, T)) OWC_FAIL(ctx, OWC_ERR_WORKSPACE, "owc_vit_forward: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int E = w->embed_dim, H = w->num_heads, hd = E / H, F = w->mlp_hidden;

@@ -46,7 +46,8 @@ class Qwen2VLDims:
     mrope_section: tuple = (16, 24, 24)
     image_token_id: int = 151655
     max_positions: int = 4096      # rope table length (prompt + generated positions)
-    max_grid: int = 256            # vision rope table length (patches per side)
+    max_grid: int = 1024           # vision rope table length (patches per side): covers max_pixels = 1024 * 28 * 28 at the
+                                   # processor's 200:1 aspect limit (sqrt(802816 * 200) / 14 = 905); checked per launch
     decoder_dtype: str = "bf16"    # "fp8": decoder projections as e4m3fn weights + per-token e4m3fn activations (config #5)
 
 
@@ -108,25 +109,7 @@ class Qwen2VLWeights:
     def random(cls, dims: Qwen2VLDims, device, seed: int = 1234) -> "Qwen2VLWeights":
         """Seeded N(0, 0.02)-style synthetic weights generated directly in HBM (benchmarks: no checkpoint offline)."""
         self = cls(dims, torch.device(device))
-        gen = torch.Generator(device=self.device)
-        counter = [0]
-
-        def get(name):
-            shape = _param_shape(dims, name)
-            counter[0] += 1
-            gen.manual_seed(seed * 100003 + counter[0])
-            if name.endswith("bias"):
-                t = torch.randn(shape, generator=gen, device=self.device, dtype=F32) * 0.02
-            elif "norm" in name or "ln_q" in name:
-                t = 1.0 + torch.randn(shape, generator=gen, device=self.device, dtype=F32) * 0.02
-            elif "embed_tokens" in name:
-                t = torch.randn(shape, generator=gen, device=self.device, dtype=BF16) * 0.05
-            else:
-                fan_in = int(np.prod(shape[1:]))
-                t = torch.randn(shape, generator=gen, device=self.device, dtype=BF16) * (1.0 / np.sqrt(fan_in))
-            return t.to(BF16).contiguous()
-
-        self._build(get)
+        self._build(lambda name: random_param(dims, name, self.device, seed))
         return self
 
     def _k(self, t: torch.Tensor) -> int:
@@ -218,6 +201,49 @@ class Qwen2VLWeights:
         return total
 
 
+def random_param(dims: Qwen2VLDims, name: str, device, seed: int = 1234) -> torch.Tensor:
+    """The synthetic value of HF parameter `name` (HF layout, bf16): a function of (seed, name) only, so the same tensor can be
+    regenerated anywhere - `Qwen2VLWeights.random` packs them for the HIP engine, bench.py's CPU baseline loads the very same
+    tensors into HF's Qwen2VLForConditionalGeneration."""
+    import zlib
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed((seed * 1000003 + zlib.crc32(name.encode())) & 0x7FFFFFFFFFFF)
+    shape = _param_shape(dims, name)
+    if name.endswith("bias"):
+        t = torch.randn(shape, generator=gen, device=device, dtype=F32) * 0.02
+    elif "norm" in name or "ln_q" in name:
+        t = 1.0 + torch.randn(shape, generator=gen, device=device, dtype=F32) * 0.02
+    elif "embed_tokens" in name:
+        t = torch.randn(shape, generator=gen, device=device, dtype=BF16) * 0.05
+    else:
+        fan_in = int(np.prod(shape[1:]))
+        t = torch.randn(shape, generator=gen, device=device, dtype=BF16) * (1.0 / np.sqrt(fan_in))
+    return t.to(BF16).contiguous()
+
+
+def hf_param_names(d: Qwen2VLDims) -> list[str]:
+    """Every HF parameter name of the architecture (transformers 5.x naming), i.e. the keys `random_param` is defined on."""
+    V, T = "model.visual.", "model.language_model."
+    names = [V + "patch_embed.proj.weight"]
+    for i in range(d.v_depth):
+        names += [f"{V}blocks.{i}.{n}" for n in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "attn.qkv.weight",
+                                                 "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "mlp.fc1.weight",
+                                                 "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")]
+    names += [V + n for n in ("merger.ln_q.weight", "merger.ln_q.bias", "merger.mlp.0.weight", "merger.mlp.0.bias",
+                              "merger.mlp.2.weight", "merger.mlp.2.bias")]
+    names.append(T + "embed_tokens.weight")
+    for i in range(d.n_layers):
+        names += [f"{T}layers.{i}.{n}" for n in ("self_attn.q_proj.weight", "self_attn.q_proj.bias", "self_attn.k_proj.weight",
+                                                 "self_attn.k_proj.bias", "self_attn.v_proj.weight", "self_attn.v_proj.bias",
+                                                 "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight",
+                                                 "mlp.down_proj.weight", "input_layernorm.weight", "post_attention_layernorm.weight")]
+    names.append(T + "norm.weight")
+    if not d.tie_embeddings:
+        names.append("lm_head.weight")
+    return names
+
+
 def _param_shape(d: Qwen2VLDims, name: str) -> tuple:
     E, F, hd = d.v_embed, d.v_mlp, d.head_dim
     E4 = E * d.merge ** 2
@@ -303,13 +329,17 @@ class Qwen2VLEngine:
 
     def _vit_chunk(self, pix, grid, lens, out) -> None:
         T = pix.shape[0]
+        max_side = max(max(h, w) for _, h, w in grid)
+        if max_side > self.d.max_grid:   # the rotary table is indexed by patch coordinates (smart_resize allows aspect 200:1)
+            raise ValueError(f"an image grid side of {max_side} patches exceeds the vision rotary table "
+                             f"(Qwen2VLDims.max_grid = {self.d.max_grid})")
         pos_hw = self._i32(positions.vision_pos_hw(grid, self.d.merge))
         starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
         seq_start, seq_len = self._i32(starts), self._i32(lens)
         nbytes = self._lib.owc_vit_workspace_bytes(C.byref(self.w.vit), T)
         ws = self._workspace(nbytes)
         rc = self._lib.owc_vit_forward(self._ctx, C.byref(self.w.vit), pix.data_ptr(), pix.stride(0), pos_hw.data_ptr(),
-                                       seq_start.data_ptr(), seq_len.data_ptr(), len(grid), T, max(lens), out.data_ptr(),
+                                       seq_start.data_ptr(), seq_len.data_ptr(), len(grid), T, max(lens), max_side, out.data_ptr(),
                                        ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, self.dev_index)
 

@@ -77,6 +77,44 @@ class Qwen2VL(Model):
         super().__init__(batch_size=batch_size, device_map=device_map, dtype=dtype, load_in_8bit=load_in_8bit,
                          load_in_4bit=load_in_4bit, distributed_types=["FSDP", "MULTI_GPU"], **kwargs)
 
+    @classmethod
+    def from_engine(cls, engine: Qwen2VLEngine, tokenizer, batch_size: int = 1, eos_token_id: int | None = None) -> "Qwen2VL":
+        """A plug-in around an engine that already holds its weights (bench.py's PIL leg, tests): no second weight set.
+        `eos_token_id=-1` disables EOS stopping (forced-length generation for benchmarks)."""
+        self = cls.__new__(cls)
+        self._model_name_or_path = "engine"
+        self._decoder_dtype = engine.d.decoder_dtype
+        self._max_pixels, self._min_pixels = 1024 * 28 * 28, 4 * 28 * 28
+        self._device = engine.device
+        self._rank, self._world_size = 0, 1
+        self.batch_size_per_gpu = int(batch_size)
+        from ._base import CacheHook
+
+        self.cache_hook = CacheHook(None)
+        self.chat_template = None
+        self.apply_chat_template = False
+        self.task_dict = {}
+        if eos_token_id is not None:
+            tokenizer.eos_token_id = eos_token_id
+        self._tokenizer = self._processor = tokenizer
+        if hasattr(tokenizer, "image_pad"):
+            tokenizer.image_pad = engine.d.image_token_id   # the engine scatters image rows at ITS placeholder id
+        self._dims = engine.d
+        self._model = engine
+        self._start_workers()
+        return self
+
+    def _start_workers(self) -> None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+
+        # host preparation: `OWC_PREP_THREADS` PIL workers (JPEG round trip + bicubic resize release the GIL) behind ONE
+        # preparation thread that runs up to `_lookahead` chunks ahead of the GPU (`_generate_rows`)
+        self._prep_threads = int(os.environ.get("OWC_PREP_THREADS", min(16, os.cpu_count() or 8)))
+        self._pool = ThreadPoolExecutor(max_workers=self._prep_threads)
+        self._prep_thread = ThreadPoolExecutor(max_workers=1)
+        self._lookahead = 2
+
     # ------------------------------------------------------------------ loading
     def load_model(self) -> None:
         name = self._model_name_or_path
@@ -101,15 +139,7 @@ class Qwen2VL(Model):
             self._tokenizer = AutoTokenizer.from_pretrained(str(path))
             self.chat_template = getattr(self._tokenizer, "chat_template", None)
         self._dims = dims
-        import os
-        from concurrent.futures import ThreadPoolExecutor
-
-        # host preparation: `OWC_PREP_THREADS` PIL workers (JPEG round trip + bicubic resize release the GIL) behind ONE
-        # preparation thread that runs up to `_lookahead` chunks ahead of the GPU (`_generate_rows`)
-        self._prep_threads = int(os.environ.get("OWC_PREP_THREADS", min(16, os.cpu_count() or 8)))
-        self._pool = ThreadPoolExecutor(max_workers=self._prep_threads)
-        self._prep_thread = ThreadPoolExecutor(max_workers=1)
-        self._lookahead = 2
+        self._start_workers()
         self._model = Qwen2VLEngine(weights)
         self._processor = self._tokenizer
 

@@ -133,3 +133,37 @@ def test_full_llava_15_7b_properties(gpu):
     for i in (0, n - 1):
         s = to_np(eng.generate_from_features([ids[i]], feats, [rows[i]], 6))
         assert np.array_equal(s[0], a[i]), i
+
+
+def test_full_7b_properties(gpu):
+    """BASELINE config #3 at its own dimensions - full Qwen2-VL-7B (3584 / 28 q / 4 kv heads / 18944, 28 layers, random weights),
+    with the bench's own chunking: 240 prompts span two prefill launch groups (65536 packed rows ~ 240 x 272 + the shared
+    prefix) and 136 images span two vision launch groups (131072 tokens = 128 images).  Properties: finite outputs,
+    determinism, and batch invariance - a sequence's tokens inside the chunked batch equal the same sequence run alone
+    (first / last of each launch group, i.e. across the group boundaries and the batch-size dependent decode kernels)."""
+    from lmms_owc_amd.engine.qwen2vl import DIMS, Qwen2VLEngine, Qwen2VLWeights
+
+    d = DIMS["qwen2-vl-7b"]
+    eng = Qwen2VLEngine(Qwen2VLWeights.random(d, gpu, seed=5))
+    g = torch.Generator(device=gpu).manual_seed(1)
+    n_img, n = 136, 240
+    pix = torch.randn((n_img * 1024, 1176), generator=g, device=gpu, dtype=torch.bfloat16)
+    emb_img = eng.encode_images(pix, [(1, 32, 32)] * n_img)          # two vision launch groups (128 + 8 images)
+    assert emb_img.shape == (n_img * 256, d.d_model) and bool(torch.isfinite(emb_img.float()).all())
+    # image 130 (second vision group) alone == inside the chunked launch
+    solo = eng.encode_images(pix[130 * 1024:131 * 1024], [(1, 32, 32)])
+    assert torch.equal(solo, emb_img[130 * 256:131 * 256])
+    r = np.random.default_rng(2)
+    head = r.integers(1000, 150000, 14)
+    ids = [np.concatenate([head, np.full(256, d.image_token_id), r.integers(1000, 150000, 16)]) for _ in range(n)]
+    pick = [i % n_img for i in range(n)]
+    rows = [256 * p + np.arange(256) for p in pick]
+    grids = [[(1, 32, 32)]] * n
+    assert eng._common_prefix(ids, 0, n) == 14
+    batch, logits = eng.generate(ids, emb_img, grids, 6, img_rows=rows, return_logits=True)
+    assert bool(torch.isfinite(logits.float()).all())
+    again = eng.generate(ids, emb_img, grids, 6, img_rows=rows)
+    assert torch.equal(batch, again)                                   # deterministic
+    for b in (0, 120, 238, 239):                                       # 238 / 239: the second prefill launch group
+        single = eng.generate([ids[b]], emb_img, [grids[b]], 6, img_rows=[rows[b]])
+        assert torch.equal(single[0], batch[b]), (b, single[0].tolist(), batch[b].tolist())

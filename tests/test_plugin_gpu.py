@@ -98,11 +98,14 @@ def test_eval_model_cli_end_to_end(gpu, scorer, tmp_path, capsys):
     eval_model.main(["--model", "custom-model", "--model_args", "model_type=qwen2-vl,model_name_or_path=synthetic:tiny",
                      "--tasks", "synthetic:5:56x56:2", "--batch_size", "3", "--limit", "4", "--log_samples",
                      "--output_path", str(out), "--verbosity", "DEBUG", "--gen_kwargs", "max_new_tokens=4"])
-    files = sorted(p.name for p in out.iterdir())
+    # `model_name_or_path=synthetic:tiny` contains "path=": like the reference's GeneralConfigTracker._get_model_name
+    # (_tracker.py:56-80) the run lands in the sub-directory of the sanitised name
+    sub = out / "synthetic__tiny"
+    files = sorted(p.name for p in sub.iterdir())
     assert any(f.endswith("_results.json") for f in files) and any("_samples_synthetic.jsonl" in f for f in files)
-    res = json.loads(next(out.glob("*_results.json")).read_text())
-    assert "synthetic" in res["results"] and "total_evaluation_time_seconds" in res
-    assert len(next(out.glob("*_samples_*.jsonl")).read_text().splitlines()) == 4
+    res = json.loads(next(sub.glob("*_results.json")).read_text())
+    assert "synthetic" in res["results"] and "total_evaluation_time_seconds" in res and res["model_name"] == "synthetic:tiny"
+    assert len(next(sub.glob("*_samples_*.jsonl")).read_text().splitlines()) == 4
     assert "| synthetic |" in capsys.readouterr().out
 
 
