@@ -388,12 +388,13 @@ def main() -> None:
     # ---- scorer leg: label-cosine/s (embed predictions + cosine top-5 against resident class embeddings)
     n_lab, L = args.scorer_labels, 16
     scorer = SentenceScorer(BertWeights.random(MINILM_L6, device, seed=7), max_batch=16384)
-    lg = torch.Generator(device=device).manual_seed(99 + rank)
-    lab_ids = torch.randint(1000, 30000, (n_lab, L), generator=lg, device=device, dtype=torch.int32)
-    lens = torch.randint(2, L + 1, (n_lab,), generator=lg, device=device)
-    lab_mask = (torch.arange(L, device=device)[None, :] < lens[:, None]).to(torch.int32)
+    # tokenised labels arrive on the HOST (a tokenizer's output): ids [n, 16], lengths uniform 2..16, right-padded
+    lr = np.random.default_rng(99 + rank)
+    lab_ids = lr.integers(1000, 30000, (n_lab, L)).astype(np.int32)
+    lens = lr.integers(2, L + 1, n_lab)
+    lab_mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int32)
     cls_z = scorer.embed(lab_ids[: args.scorer_classes], lab_mask[: args.scorer_classes])
-    label = torch.randint(0, args.scorer_classes, (n_lab,), generator=lg, device=device, dtype=torch.int32)
+    label = torch.from_numpy(lr.integers(0, args.scorer_classes, n_lab).astype(np.int32)).to(device)
 
     def score():
         z = scorer.embed(lab_ids, lab_mask)
@@ -412,7 +413,7 @@ def main() -> None:
     if dist is not None:
         dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
     labels_per_s = world * n_lab * args.steps / float(sdt.item())
-    label_tokens = int(lens.sum().item())
+    label_tokens = int(lens.sum())
 
     if rank == 0:
         f_model = flops_per_image(dims, T)

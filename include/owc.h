@@ -334,6 +334,16 @@ size_t owc_bert_workspace_bytes(const owc_bert_weights* w, int n, int L);
 int owc_bert_embed(owc_ctx* ctx, const owc_bert_weights* w, const int32_t* ids, const int32_t* mask,
                    int n, int L, float* out, void* workspace, size_t ws_bytes, void* stream);
 
+/* The same encoder over PACKED rows: only the tokens with attention_mask == 1 are rows (tok_ids / tok_pos: int32[T], tok_pos =
+ * the token's column in the padded matrix = its BERT position id; sequence s owns rows [seq_start[s], seq_start[s+1]),
+ * seq_start: int32[n + 1]; max_len = longest sequence).  Identical results to owc_bert_embed: in the reference
+ * (`padding=True`, _text.py:193-196) padded positions are masked out as keys and weigh 0 in the pooling, so their rows feed
+ * nothing; here they are simply not computed (labels of 2..16 tokens padded to 16 are ~45 % padding). */
+size_t owc_bert_packed_workspace_bytes(const owc_bert_weights* w, int T);
+int owc_bert_embed_packed(owc_ctx* ctx, const owc_bert_weights* w, const int32_t* tok_ids, const int32_t* tok_pos,
+                          const int32_t* seq_start, int n, int T, int max_len, float* out, void* workspace, size_t ws_bytes,
+                          void* stream);
+
 /* Cosine scorer: sim = preds[N,D] . classes[C,D]^T (rows already L2-normalised), never materialised:
  * top_val/top_idx[N][k] = k best classes per prediction (descending, lowest index on ties),
  * paired[N] = sim[i, label[i]] — the reference's torch.bmm pairing

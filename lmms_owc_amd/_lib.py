@@ -130,6 +130,8 @@ SIGNATURES: dict[str, tuple] = {
     "owc_decode_update": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "owc_bert_workspace_bytes": (sz, [C.POINTER(BertWeights), i32, i32]),
     "owc_bert_embed": (i32, [vp, C.POINTER(BertWeights), vp, vp, i32, i32, vp, vp, sz, vp]),
+    "owc_bert_packed_workspace_bytes": (sz, [C.POINTER(BertWeights), i32]),
+    "owc_bert_embed_packed": (i32, [vp, C.POINTER(BertWeights), vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]),
     "owc_cosine_topk": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "owc_paired_dot": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "owc_gemm_profile_enable": (i32, [vp, i32]),

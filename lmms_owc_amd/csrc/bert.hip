@@ -14,14 +14,14 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // out[t] = LayerNorm(word[ids[t]] + pos[t % L] + type[0])      (BERT: BertEmbeddings.forward)
 __global__ __launch_bounds__(256) void bert_embed_ln_kernel(
-    const int* __restrict__ ids, const float* __restrict__ word, const float* __restrict__ pos,
+    const int* __restrict__ ids, const int* __restrict__ tok_pos, const float* __restrict__ word, const float* __restrict__ pos,
     const float* __restrict__ type0, const float* __restrict__ g, const float* __restrict__ b,
     float* __restrict__ out, int T, int L, int H, float eps) {
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + w;
   if (t >= T) return;
   const float* we = word + (long)ids[t] * H;
-  const float* pe = pos + (long)(t % L) * H;
+  const float* pe = pos + (long)(tok_pos ? tok_pos[t] : t % L) * H;  // packed rows carry their own position id
   float v[16];
   float sum = 0.f;
   const int per = (H + 63) / 64;
@@ -163,6 +163,86 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(const float* __restrict_
     }
   }
   const float den = fmaxf(cnt, 1e-9f);
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    v[i] /= den;
+    sq += v[i] * v[i];
+  }
+  const float nrm = sqrtf(wave_sum(sq));
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = i * 64 + l;
+    if (i < per && c < H) out[(long)s * H + c] = v[i] / nrm;
+  }
+}
+
+// Packed (padding-free) variants: rows are the REAL tokens only, sequence s owns rows [seq_start[s], seq_start[s+1]).
+// Padded positions never reach the output in the reference either: they are masked out as keys (finfo.min) and get weight 0
+// in the pooling, so dropping their rows changes no result.
+template <int HD>
+__global__ __launch_bounds__(64) void bert_attn_packed_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_start,
+                                                              float* __restrict__ ctx, int H, int n_heads, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int s = blockIdx.x / n_heads, h = blockIdx.x % n_heads;
+  const long base = seq_start[s];
+  const int L = seq_start[s + 1] - (int)base;
+  float* ks = (float*)smem;           // [L][HD]
+  float* vs = ks + (size_t)L * HD;    // [L][HD]
+  for (int i = threadIdx.x; i < L * (HD / 4); i += blockDim.x) {
+    const int j = i / (HD / 4), c = i % (HD / 4);
+    const float* row = qkv + (base + j) * 3 * H + h * HD + c * 4;
+    *(f32x4*)(ks + j * HD + c * 4) = *(const f32x4*)(row + H);
+    *(f32x4*)(vs + j * HD + c * 4) = *(const f32x4*)(row + 2 * H);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L; i += blockDim.x) {
+    float q[HD], acc[HD];
+    const float* qr = qkv + (base + i) * 3 * H + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+      q[d] = qr[d];
+      acc[d] = 0.f;
+    }
+    float m = -INFINITY, lsum = 0.f;
+    for (int j = 0; j < L; ++j) {   // same key order and online-softmax arithmetic as bert_attn_kernel over the unmasked keys
+      float sc = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) sc += q[d] * ks[j * HD + d];
+      sc *= scale;
+      const float mn = fmaxf(m, sc);
+      const float a = expf(m - mn), p = expf(sc - mn);
+      lsum = lsum * a + p;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) acc[d] = acc[d] * a + p * vs[j * HD + d];
+      m = mn;
+    }
+    const float inv = 1.0f / lsum;
+    float* o = ctx + (base + i) * H + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = acc[d] * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void pool_norm_packed_kernel(const float* __restrict__ x, const int* __restrict__ seq_start,
+                                                               float* __restrict__ out, int n, int H) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int s = blockIdx.x * 4 + w;
+  if (s >= n) return;
+  float v[16];
+  const int per = (H + 63) / 64;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = 0.f;
+  const int t0 = seq_start[s], t1 = seq_start[s + 1];
+  for (int t = t0; t < t1; ++t) {
+    const float* row = x + (long)t * H;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = i * 64 + l;
+      if (i < per && c < H) v[i] += row[c];
+    }
+  }
+  const float den = fmaxf((float)(t1 - t0), 1e-9f);
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -325,7 +405,7 @@ int owc_bert_embed(owc_ctx* ctx, const owc_bert_weights* w, const int32_t* ids, 
       return OWC_ERR_HIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL(bert_embed_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, st, ids, w->word_emb, w->pos_emb,
+  hipLaunchKernelGGL(bert_embed_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, st, ids, (const int*)nullptr, w->word_emb, w->pos_emb,
                      w->type_emb, w->emb_ln_w, w->emb_ln_b, x, T, L, H, w->ln_eps);
   const float scale = 1.0f / sqrtf(32.0f);
   for (int i = 0; i < w->n_layers; ++i) {
@@ -344,6 +424,58 @@ int owc_bert_embed(owc_ctx* ctx, const owc_bert_weights* w, const int32_t* ids, 
   }
   hipLaunchKernelGGL(pool_norm_kernel, dim3((n + 3) / 4), dim3(256), 0, st, x, mask, out, n, L, H);
   if (hipGetLastError() != hipSuccess) OWC_FAIL(ctx, OWC_ERR_HIP, "owc_bert_embed: launch failure");
+  return OWC_OK;
+}
+
+size_t owc_bert_packed_workspace_bytes(const owc_bert_weights* w, int T) {
+  if (!w || T <= 0) return 0;
+  const size_t t = (size_t)T, H = (size_t)w->hidden;
+  return align256(t * H * 4) * 2 + align256(t * 3 * H * 4) + align256(t * (size_t)w->inter * 4) + 1024;
+}
+
+int owc_bert_embed_packed(owc_ctx* ctx, const owc_bert_weights* w, const int32_t* tok_ids, const int32_t* tok_pos,
+                          const int32_t* seq_start, int n, int T, int max_len, float* out, void* workspace, size_t ws_bytes,
+                          void* stream) {
+  if (!ctx || !w || !tok_ids || !tok_pos || !seq_start || !out || !workspace) return OWC_ERR_ARG;
+  const int H = w->hidden, NH = w->n_heads, I = w->inter;
+  if (n <= 0 || T <= 0 || max_len <= 0 || max_len > w->max_pos || H > 1024 || (H % NH) != 0 || H / NH != 32)
+    OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_bert_embed_packed: unsupported shape (head_dim must be 32, hidden <= 1024)");
+  if (ws_bytes < owc_bert_packed_workspace_bytes(w, T)) OWC_FAIL(ctx, OWC_ERR_WORKSPACE, "owc_bert_embed_packed: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  char* p = (char*)workspace;
+  float* x = (float*)p;
+  p += align256((size_t)T * H * 4);
+  float* cx = (float*)p;
+  p += align256((size_t)T * H * 4);
+  float* qkv = (float*)p;
+  p += align256((size_t)T * 3 * H * 4);
+  float* ff = (float*)p;
+  const size_t attn_lds = (size_t)max_len * 32 * 4 * 2;
+  if (attn_lds > 160 * 1024) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_bert_embed_packed: sequence too long for the LDS-resident attention");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)bert_attn_packed_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return OWC_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(bert_embed_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, st, tok_ids, tok_pos, w->word_emb, w->pos_emb,
+                     w->type_emb, w->emb_ln_w, w->emb_ln_b, x, T, 1, H, w->ln_eps);
+  const float scale = 1.0f / sqrtf(32.0f);
+  for (int i = 0; i < w->n_layers; ++i) {
+    const owc_bert_layer& Ly = w->layers[i];
+    OWC_TRY(owc_launch_gemm_f32_bert(x, H, Ly.qkv_w, H, Ly.qkv_b, nullptr, 0, qkv, 3 * H, T, 3 * H, H,
+                                OWC_EPI_NONE, ctx->zeros, st));
+    hipLaunchKernelGGL(bert_attn_packed_kernel<32>, dim3(n * NH), dim3(64), attn_lds, st, qkv, seq_start, cx, H, NH, scale);
+    OWC_TRY(owc_launch_gemm_f32_bert(cx, H, Ly.o_w, H, Ly.o_b, x, H, x, H, T, H, H, OWC_EPI_RESIDUAL, ctx->zeros, st));
+    hipLaunchKernelGGL(ln_f32_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, Ly.ln1_w, Ly.ln1_b, T, H, w->ln_eps);
+    OWC_TRY(owc_launch_gemm_f32_bert(x, H, Ly.fc1_w, H, Ly.fc1_b, nullptr, 0, ff, I, T, I, H, OWC_EPI_GELU_ERF,
+                                ctx->zeros, st));
+    OWC_TRY(owc_launch_gemm_f32_bert(ff, I, Ly.fc2_w, I, Ly.fc2_b, x, H, x, H, T, H, I, OWC_EPI_RESIDUAL, ctx->zeros, st));
+    hipLaunchKernelGGL(ln_f32_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, Ly.ln2_w, Ly.ln2_b, T, H, w->ln_eps);
+  }
+  hipLaunchKernelGGL(pool_norm_packed_kernel, dim3((n + 3) / 4), dim3(256), 0, st, x, seq_start, out, n, H);
+  if (hipGetLastError() != hipSuccess) OWC_FAIL(ctx, OWC_ERR_HIP, "owc_bert_embed_packed: launch failure");
   return OWC_OK;
 }
 

@@ -23,6 +23,7 @@
 //    tiles in GROUP_M-major order so A/W panels are reused out of that XCD's L2.
 #include "owc_common.h"
 #include "gemm_epilogue.h"
+#include <type_traits>
 #include <vector>
 
 int owc_gemm_profile_begin(double flops, int kind, hipStream_t s);
@@ -46,6 +47,7 @@ int g_gemm_dbg = 0;       // timing-experiment knob (OWC_GEMM_DBG / owc_tuning_s
 int g_skinny_max_m = 64;   // M at and below which the weight-streaming skinny kernel runs (0 disables: A-B knob "gemm_skinny_max_m")
 int g_mid_max_tiles = 256;  // fewer 128x128 tiles than this -> 64x64 tiles (0 disables: A-B knob "gemm_mid_max_tiles")
 int g_big_min_tiles = 192;  // fewer 256x256 tiles than this -> use the 128x128 kernel
+int g_pingpong = 1;       // 256x256 launches with K % 128 == 0 use the ping-pong kernel (A-B knob "gemm_pingpong", 0 = lock-step kernel)
 int g_big_min_m = 1024;  // M at and above which the 256x128 3-stage kernel is used (OWC_GEMM_BIG_MIN_M)
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -432,6 +434,222 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
 
 
 // ------------------------------------------------------------------------------------------------
+// Ping-pong variant of the 256x256x64 kernel (same tile, same LDS image, same epilogue, bit-identical results): the two
+// waves of every SIMD alternate ROLES instead of running in lock-step.  Waves 0-3 (wr = 0, one per SIMD) and waves 4-7
+// (wr = 1, their SIMD partners) run the same program shifted by one barrier interval: while one group issues the 16 MFMAs
+// of a C quadrant (64 rows x 32 columns x K = 64), the other group reads its next fragments from LDS and issues the
+// LDS-DMA of a later half-tile; at the next barrier they swap.  A K-tile is 4 phases (quadrants (0,0) (0,1) (1,1) (1,0) of
+// the wave's 128 x 64 tile), a phase is [load section] s_barrier [MFMA section] s_barrier.  Counters on the lock-step
+// kernel (profiles/): MFMA pipe busy 60 %, waves parked 32 % of their cycles - all eight waves reach their
+// LDS reads, their DMA waits and the per-K-tile barrier together, so a SIMD's matrix pipe idles whenever its two waves do.
+// Here a SIMD always has one wave in its MFMA section (MI355X_MICROARCH.md "Two waves per SIMD"; cdna_hip_programming.md
+// "The 256^2 8-phase template").
+//
+// Staging: an operand K-tile (256 rows x 128 B) is two half-tiles of 128 rows; wave w stages rows 16w..16w+15 of each
+// half (2 LDS-DMA instructions).  Schedule for K-tile u (phases p0..p3), buffers = u & 1:
+//   p0  read A(rows half 0 of the wave tile, u)  [8 ds_read_b128]   issue A half 1 of u+1
+//   p1  read W(cols half 1, u)                   [4]
+//   p2  read A(rows half 1, u)                   [8]                issue W half 0 of u+2      wait: W(u+1) landed
+//   p3  read W(cols half 0, u+1) -> other set    [4]                issue W half 1, A half 0 of u+2   wait: A(u+1) landed
+// Each wait is a counted vmcnt(6) (three half-tiles stay in flight) at the END of a load section; the data is read one
+// phase later (RAW: counted wait -> barrier -> read, for both groups); a region is restaged at the earliest one phase
+// after its last read, whose lgkmcnt(0) also sits before the barrier (WAR).  The tail (last two K-tiles) is peeled with
+// exact counts.  Requires K % 128 == 0 (an even number of K-tiles: the W fragment sets alternate between two register
+// blocks so that p3 can fetch the next tile's set while this tile's is still in use).
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
+    const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
+    const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv, long ldc, int M, int N, int K,
+    int tiles_m, int tiles_n, int dbg, owc_gemm_aux aux) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int nblk = tiles_m * tiles_n;
+  const int nk = K / BK;
+
+  // tile id -> (m0, n0): identical to gemm_bf16_nt_256_kernel
+  int m0, n0;
+  {
+    const int bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int width = GROUP_M2 * tiles_n;
+    const int group = lid / width;
+    const int first_m = group * GROUP_M2;
+    const int gsize = min(tiles_m - first_m, GROUP_M2);
+    m0 = (first_m + (lid % width) % gsize) * BT;
+    n0 = ((lid % width) / gsize) * BT;
+  }
+  const char* abase = (const char*)(A + (long)m0 * lda);
+  const char* wbase = (const char*)(W + (long)n0 * ldw);
+  // DMA sources of this wave: half h, piece j -> rows 128h + 16w + 8j .. +8 (lane: row + (l >> 3), chunk l & 7, swizzled)
+  unsigned aoff[2][2], woff[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = 128 * h + 16 * w + 8 * j + (l >> 3);
+      const int c = (l & 7) ^ ((row >> 1) & 7);
+      aoff[h][j] = (unsigned)((long)min(row, M - 1 - m0) * lda * 2 + c * 16);
+      woff[h][j] = (unsigned)((long)min(row, N - 1 - n0) * ldw * 2 + c * 16);
+    }
+  auto issue_a = [&](int kt, int h) {  // A half-tile h of K-tile kt -> buffer kt & 1
+    char* dst = lds + (kt & 1) * STAGE_BYTES + (128 * h + 16 * w) * 128;
+    const long kb = (long)kt * (BK * 2);
+    glds16(abase + kb + aoff[h][0], dst);
+    glds16(abase + kb + aoff[h][1], dst + 1024);
+  };
+  auto issue_w = [&](int kt, int h) {
+    char* dst = lds + (kt & 1) * STAGE_BYTES + OP_BYTES + (128 * h + 16 * w) * 128;
+    const long kb = (long)kt * (BK * 2);
+    glds16(wbase + kb + woff[h][0], dst);
+    glds16(wbase + kb + woff[h][1], dst + 1024);
+  };
+
+  const int wr = w >> 2, wc = w & 3;
+  const int fr = l & 15, fq = l >> 4;
+  const int swz = (fr >> 1) & 7;
+  const int rowA = (wr * 128 + fr) * 128;
+  const int rowW = OP_BYTES + (wc * 64 + fr) * 128;
+  const int ch0 = ((0 + fq) ^ swz) << 4, ch1 = ((4 + fq) ^ swz) << 4;
+
+  f32x4 acc[4][8];  // [nt][mt]
+  // fragment registers: A half (4 m tiles x 2 k-steps), W column half 1 (2 n tiles x 2 k-steps) and TWO sets of W column
+  // half 0 (this tile's / the next tile's): 32 + 16 + 32 VGPRs
+  bf16x8 fa[2][4], wy[2][2], wx0[2][2], wx1[2][2];
+
+  auto read_a = [&](const char* sbase, int mh) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      fa[0][t] = *(const bf16x8*)(sbase + rowA + (mh * 4 + t) * 2048 + ch0);
+      fa[1][t] = *(const bf16x8*)(sbase + rowA + (mh * 4 + t) * 2048 + ch1);
+    }
+  };
+  auto read_w = [&](bf16x8 (&dst)[2][2], const char* sbase, int nh) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      dst[0][t] = *(const bf16x8*)(sbase + rowW + (nh * 2 + t) * 2048 + ch0);
+      dst[1][t] = *(const bf16x8*)(sbase + rowW + (nh * 2 + t) * 2048 + ch1);
+    }
+  };
+  // end of a load section: counted DMA wait (VM >= 0), all of this wave's LDS reads retired, then the barrier
+#define OWC_PP_SYNC_L(VM)                                                                         \
+  do {                                                                                            \
+    if constexpr ((VM) >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((VM) < 0 ? 0 : (VM)) : "memory"); \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                               \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+  } while (0)
+  // MFMA section: one C quadrant over the whole K-tile (k-step 0 then 1: every output element stays ONE ascending chain)
+  auto quadrant = [&](const bf16x8 (&wf)[2][2], int mh, int nh) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[nh * 2 + n][mh * 4 + m] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][n], fa[ks][m], acc[nh * 2 + n][mh * 4 + m], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // one K-tile; MODE 0 steady (u + 2 < nk), 1 second to last, 2 last.  wc/wn: this tile's / the next tile's W column-half-0 set
+  auto ktile = [&](auto mode_c, int u, bf16x8 (&wcur)[2][2], bf16x8 (&wnxt)[2][2]) {
+    constexpr int MODE = decltype(mode_c)::value;
+    const char* cur = lds + (u & 1) * STAGE_BYTES;
+    const char* nxt = lds + ((u + 1) & 1) * STAGE_BYTES;
+    // p0
+    read_a(cur, 0);
+    if constexpr (MODE <= 1) issue_a(u + 1, 1);
+    OWC_PP_SYNC_L(-1);
+    quadrant(wcur, 0, 0);
+    // p1
+    read_w(wy, cur, 1);
+    OWC_PP_SYNC_L(-1);
+    quadrant(wy, 0, 1);
+    // p2
+    read_a(cur, 1);
+    if constexpr (MODE == 0) {
+      issue_w(u + 2, 0);
+      OWC_PP_SYNC_L(6);   // W halves of u+1 landed; in flight: A0(u+1), A1(u+1), W0(u+2)
+    } else if constexpr (MODE == 1) {
+      OWC_PP_SYNC_L(4);   // in flight: A0(u+1), A1(u+1)
+    } else {
+      OWC_PP_SYNC_L(-1);
+    }
+    quadrant(wy, 1, 1);
+    // p3
+    if constexpr (MODE <= 1) read_w(wnxt, nxt, 0);
+    if constexpr (MODE == 0) {
+      issue_w(u + 2, 1);
+      issue_a(u + 2, 0);
+      OWC_PP_SYNC_L(6);   // A halves of u+1 landed; in flight: W0(u+2), W1(u+2), A0(u+2)
+    } else if constexpr (MODE == 1) {
+      OWC_PP_SYNC_L(0);
+    } else {
+      OWC_PP_SYNC_L(-1);
+    }
+    quadrant(wcur, 1, 0);
+  };
+
+  // ---- prologue: K-tile 0 entirely, then what p2 / p3 of "tile -1" would have issued for tile 1
+  issue_a(0, 0);
+  issue_a(0, 1);
+  issue_w(0, 0);
+  issue_w(0, 1);
+  issue_w(1, 0);
+  issue_w(1, 1);
+  issue_a(1, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");   // K-tile 0 landed and published
+  __builtin_amdgcn_sched_barrier(0);
+  read_w(wx0, lds, 0);
+  if (wr) {   // group 1 runs one barrier interval behind group 0
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  int u = 0;
+  for (; u + 2 < nk; u += 2) {
+    ktile(I0{}, u, wx0, wx1);
+    ktile(I0{}, u + 1, wx1, wx0);
+  }
+  ktile(I1{}, u, wx0, wx1);
+  ktile(I2{}, u + 1, wx1, wx0);
+  if (!wr) {  // group 0 waits for group 1's last MFMA section: every wave has executed the same number of barriers
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef OWC_PP_SYNC_L
+
+  if (dbg & 4) {  // timing experiment: no epilogue
+    if (acc[0][0][0] == 123.456f) ((float*)Cv)[0] = 1.f;
+    return;
+  }
+  if constexpr (EPI == OWC_EPI_F32) {
+    gemm_epilogue<EPI, 8>(acc, m0 + wr * 128, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
+  } else {
+    // LDS is quiescent: every wave has passed the final barrier with its reads retired and no DMA pending
+    constexpr int CCOLS = EPI == OWC_EPI_SWIGLU ? BT / 2 : BT;
+    gemm_epilogue<EPI, 8>(acc, m0 + wr * 128, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux, lds, CCOLS * 2,
+                          wr * 128, wc * 64);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    store_ctile<8>(lds, BT, CCOLS, (bf16_t*)Cv, ldc, m0, EPI == OWC_EPI_SWIGLU ? (n0 >> 1) : n0, M,
+                   EPI == OWC_EPI_SWIGLU ? (N >> 1) : N, w, l);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Skinny-M variant (M <= 64: greedy decode at the reference's own batch sizes, 1 ... a few dozen sequences).  There the
 // GEMM is a weight STREAM: every byte of W is read once per step, the arithmetic is nothing, and the tiled kernels above
 // leave most CUs idle (the o / down projections of the 7B decoder are 28 tiles wide).  Here ONE WAVE owns 16 rows of W
@@ -574,6 +792,8 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
     if (hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<EPI>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<EPI>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_kernel<EPI>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES) != hipSuccess)
       return OWC_ERR_HIP;
     attr_set = true;
@@ -583,7 +803,11 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
     owc_gemm_profile_end(prof, s);
     return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
   }
-  if (big)
+  if (big && g_pingpong && (K % (2 * BK)) == 0)
+    hipLaunchKernelGGL(gemm_bf16_nt_256pp_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), 2 * STAGE_BYTES, s,
+                       (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
+                       (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, g_gemm_dbg, aux);
+  else if (big)
     hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), 2 * STAGE_BYTES, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
                        (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, g_gemm_dbg, aux);
@@ -699,3 +923,4 @@ void owc_gemm_set_big_min_m(int m) { g_big_min_m = m; }
 void owc_gemm_set_dbg(int v) { g_gemm_dbg = v; }
 void owc_gemm_set_mid_max_tiles(int v) { g_mid_max_tiles = v; }
 void owc_gemm_set_skinny_max_m(int v) { g_skinny_max_m = v; }
+void owc_gemm_set_pingpong(int v) { g_pingpong = v; }

@@ -101,8 +101,41 @@ class SentenceScorer:
         self._lib = _lib.load()
         self._ctx = _lib.ctx(self.dev_index)
 
-    def embed(self, ids, mask) -> torch.Tensor:
-        """ids/mask: int [n, L] (numpy or torch) -> L2-normalised fp32 embeddings [n, hidden] on the device."""
+    def embed(self, ids, mask, packed: bool = True) -> torch.Tensor:
+        """ids/mask: int [n, L] (numpy or torch) -> L2-normalised fp32 embeddings [n, hidden] on the device.
+        `packed` (default): only the tokens with mask == 1 become rows (`owc_bert_embed_packed`) - identical results, no work
+        on padding; the layout (token list, position ids, sequence offsets) is integer bookkeeping done on the host, where
+        the tokenizer's output lives anyway.  `packed=False` runs the padded `owc_bert_embed`."""
+        if not packed:
+            return self._embed_padded(ids, mask)
+        ids_h = ids.cpu().numpy() if isinstance(ids, torch.Tensor) else np.asarray(ids)
+        mask_h = (mask.cpu().numpy() if isinstance(mask, torch.Tensor) else np.asarray(mask)) != 0
+        n, L = ids_h.shape
+        H = self.w.cfg["hidden_size"]
+        out = torch.empty((n, H), dtype=F32, device=self.device)
+        lens = mask_h.sum(1).astype(np.int64)
+        for i0 in range(0, n, self.max_batch):   # batches of whole sequences
+            i1 = min(n, i0 + self.max_batch)
+            m = mask_h[i0:i1]
+            T = int(m.sum())
+            if T == 0:
+                out[i0:i1] = float("nan")   # no token at all: the reference divides 0 by a zero norm (_text.py:202)
+                continue
+            tok_ids = np.ascontiguousarray(ids_h[i0:i1][m], dtype=np.int32)
+            tok_pos = np.ascontiguousarray(np.broadcast_to(np.arange(L, dtype=np.int32), m.shape)[m])
+            seq_start = np.concatenate([[0], np.cumsum(lens[i0:i1])]).astype(np.int32)
+            d_ids, d_pos, d_start = (torch.from_numpy(a).to(self.device, non_blocking=True) for a in (tok_ids, tok_pos, seq_start))
+            nb = self._lib.owc_bert_packed_workspace_bytes(C.byref(self.w.c), T)
+            if self._ws is None or self._ws.numel() < nb:
+                self._ws = None
+                self._ws = torch.empty(int(nb), dtype=torch.uint8, device=self.device)
+            rc = self._lib.owc_bert_embed_packed(self._ctx, C.byref(self.w.c), d_ids.data_ptr(), d_pos.data_ptr(), d_start.data_ptr(),
+                                                 i1 - i0, T, int(lens[i0:i1].max()), out[i0:i1].data_ptr(), self._ws.data_ptr(),
+                                                 self._ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, self.dev_index)
+        return out
+
+    def _embed_padded(self, ids, mask) -> torch.Tensor:
         if isinstance(ids, np.ndarray):
             ids = torch.from_numpy(np.ascontiguousarray(ids))
         if isinstance(mask, np.ndarray):

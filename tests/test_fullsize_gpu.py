@@ -137,7 +137,7 @@ def test_full_llava_15_7b_properties(gpu):
 
 def test_full_7b_properties(gpu):
     """BASELINE config #3 at its own dimensions - full Qwen2-VL-7B (3584 / 28 q / 4 kv heads / 18944, 28 layers, random weights),
-    with the bench's own chunking: 240 prompts span two prefill launch groups (65536 packed rows ~ 240 x 272 + the shared
+    with the bench's own chunking: 250 prompts span two prefill launch groups (65536 packed rows hold 240 x 272 + the shared
     prefix) and 136 images span two vision launch groups (131072 tokens = 128 images).  Properties: finite outputs,
     determinism, and batch invariance - a sequence's tokens inside the chunked batch equal the same sequence run alone
     (first / last of each launch group, i.e. across the group boundaries and the batch-size dependent decode kernels)."""
@@ -146,7 +146,7 @@ def test_full_7b_properties(gpu):
     d = DIMS["qwen2-vl-7b"]
     eng = Qwen2VLEngine(Qwen2VLWeights.random(d, gpu, seed=5))
     g = torch.Generator(device=gpu).manual_seed(1)
-    n_img, n = 136, 240
+    n_img, n = 136, 250
     pix = torch.randn((n_img * 1024, 1176), generator=g, device=gpu, dtype=torch.bfloat16)
     emb_img = eng.encode_images(pix, [(1, 32, 32)] * n_img)          # two vision launch groups (128 + 8 images)
     assert emb_img.shape == (n_img * 256, d.d_model) and bool(torch.isfinite(emb_img.float()).all())
@@ -164,6 +164,6 @@ def test_full_7b_properties(gpu):
     assert bool(torch.isfinite(logits.float()).all())
     again = eng.generate(ids, emb_img, grids, 6, img_rows=rows)
     assert torch.equal(batch, again)                                   # deterministic
-    for b in (0, 120, 238, 239):                                       # 238 / 239: the second prefill launch group
+    for b in (0, 120, 239, 240, 249):                                  # 240.. : the second prefill launch group
         single = eng.generate([ids[b]], emb_img, [grids[b]], 6, img_rows=[rows[b]])
         assert torch.equal(single[0], batch[b]), (b, single[0].tolist(), batch[b].tolist())

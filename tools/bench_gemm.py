@@ -96,21 +96,23 @@ def main():
         return ab(dev, next((a for a in sys.argv[1:] if not a.startswith("--")), None), knob.encode())
     only = next((a for a in sys.argv[1:] if not a.startswith("--")), None)
     m_over = next((int(a[4:]) for a in sys.argv[1:] if a.startswith("--m=")), 0)  # e.g. --m=131072: the vision launch group
+    swiglu = "--epi=swiglu" in sys.argv   # the epilogue the model's gate/up launch really uses (C is [M, N/2])
+    epi = ops.EPI_SWIGLU if swiglu else ops.EPI_NONE
+    iters = next((int(a[8:]) for a in sys.argv[1:] if a.startswith("--iters=")), 10)
     for name, m, n, k in SHAPES:
         if only and not name.startswith(only):
             continue
         m = m_over or m
         a = torch.randn(m, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
-        out = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+        out = torch.empty(m, n // 2 if swiglu else n, dtype=torch.bfloat16, device=dev)
         for _ in range(3):
-            ops.gemm_bf16(a, w, out=out)
+            ops.gemm_bf16(a, w, out=out, epilogue=epi)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        iters = 10
         e0.record()
         for _ in range(iters):
-            ops.gemm_bf16(a, w, out=out)
+            ops.gemm_bf16(a, w, out=out, epilogue=epi)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
