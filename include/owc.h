@@ -336,7 +336,7 @@ int owc_bert_embed(owc_ctx* ctx, const owc_bert_weights* w, const int32_t* ids, 
 
 /* The same encoder over PACKED rows: only the tokens with attention_mask == 1 are rows (tok_ids / tok_pos: int32[T], tok_pos =
  * the token's column in the padded matrix = its BERT position id; sequence s owns rows [seq_start[s], seq_start[s+1]),
- * seq_start: int32[n + 1]; max_len = longest sequence).  Identical results to owc_bert_embed: in the reference
+ * seq_start: int32[n + 1]; max_len = longest sequence).  Same results as owc_bert_embed (to fp32 rounding, tested <= 1e-6): in the reference
  * (`padding=True`, _text.py:193-196) padded positions are masked out as keys and weigh 0 in the pooling, so their rows feed
  * nothing; here they are simply not computed (labels of 2..16 tokens padded to 16 are ~45 % padding). */
 size_t owc_bert_packed_workspace_bytes(const owc_bert_weights* w, int T);

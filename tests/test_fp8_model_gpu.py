@@ -46,12 +46,10 @@ def test_fp8_generate_matches_fp8_oracle(setup, gpu):
     o_toks, o_logits = Q.generate(w, cfg, ids, pix, grid, 6, bf16=True, return_logits=True, fp8=fp8)
     assert np.abs(logits - o_logits[0]).max() <= 0.10 * np.abs(o_logits[0]).max()
     assert np.abs(logits - o_logits[0]).mean() <= 0.02 * np.abs(o_logits[0]).max()
-    for j in range(6):
-        top2 = np.sort(o_logits[j])[-2:]
-        if top2[1] - top2[0] > 0.20 * np.abs(o_logits[j]).max():
-            assert toks[j] == o_toks[j], (j, toks, o_toks)
-        else:
-            break
+    # free-running tokens up to the first near-tie; every step under teacher forcing: tests/test_decode_parity_gpu.py
+    margins = [np.sort(o_logits[j])[-1] - np.sort(o_logits[j])[-2] > 0.20 * np.abs(o_logits[j]).max() for j in range(6)]
+    n_sure = margins.index(False) if False in margins else 6
+    assert np.array_equal(toks[:n_sure], o_toks[:n_sure]), (toks, o_toks)
 
 
 def test_fp8_vs_bf16_agreement(setup, gpu):

@@ -68,13 +68,12 @@ def test_generate_matches_oracle_and_hf(setup, gpu):
     _close(logits, o_logits[0], 0.03)
     _close(logits, g["bf16_logits"][0], 0.05)
     _close(logits, g["f32_logits"][0], 0.05)
+    # free-running tokens equal HF's up to the first near-tie; every step is asserted under teacher forcing in
+    # tests/test_decode_parity_gpu.py
     ref = g["f32_logits"]
-    for j in range(8):
-        top2 = np.sort(ref[j])[-2:]
-        if top2[1] - top2[0] > 0.06 * np.abs(ref[j]).max():
-            assert toks[j] == g["f32_tokens"][j], (j, toks, g["f32_tokens"])
-        else:
-            break
+    margins = [np.sort(ref[j])[-1] - np.sort(ref[j])[-2] > 0.06 * np.abs(ref[j]).max() for j in range(8)]
+    n_sure = margins.index(False) if False in margins else 8
+    assert np.array_equal(toks[:n_sure], g["f32_tokens"][:n_sure]), (toks, g["f32_tokens"])
 
 
 def test_batched_equals_single(setup, gpu):
@@ -147,10 +146,9 @@ def test_next_generate_matches_oracle_and_hf(setup_next, gpu):
     _close(logits, o_logits[0], 0.03)
     _close(logits, g["bf16_logits"][0], 0.05)
     _close(logits, g["f32_logits"][0], 0.05)
+    # free-running tokens equal HF's up to the first near-tie; every step is asserted under teacher forcing in
+    # tests/test_decode_parity_gpu.py
     ref = g["f32_logits"]
-    for j in range(8):
-        top2 = np.sort(ref[j])[-2:]
-        if top2[1] - top2[0] > 0.06 * np.abs(ref[j]).max():
-            assert toks[j] == g["f32_tokens"][j], (j, toks, g["f32_tokens"])
-        else:
-            break
+    margins = [np.sort(ref[j])[-1] - np.sort(ref[j])[-2] > 0.06 * np.abs(ref[j]).max() for j in range(8)]
+    n_sure = margins.index(False) if False in margins else 8
+    assert np.array_equal(toks[:n_sure], g["f32_tokens"][:n_sure]), (toks, g["f32_tokens"])

@@ -60,14 +60,12 @@ def test_generate_matches_oracle_and_hf(setup, gpu, case):
     _close(logits, o_logits[0], 0.03)
     _close(logits, g[f"{case}_bf16_logits"][0], 0.05)
     _close(logits, g[f"{case}_f32_logits"][0], 0.05)
-    # token parity wherever the decision is not a near-tie
+    # free-running tokens: identical to HF's up to the first near-tie (after it the continuations may legitimately differ);
+    # EVERY step is asserted under teacher forcing in tests/test_decode_parity_gpu.py
     ref = g[f"{case}_f32_logits"]
-    for j in range(8):
-        top2 = np.sort(ref[j])[-2:]
-        if top2[1] - top2[0] > 0.06 * np.abs(ref[j]).max():
-            assert toks[j] == g[f"{case}_f32_tokens"][j], (j, toks, g[f"{case}_f32_tokens"])
-        else:
-            break  # after a near-tie the continuations may legitimately diverge
+    margins = [np.sort(ref[j])[-1] - np.sort(ref[j])[-2] > 0.06 * np.abs(ref[j]).max() for j in range(8)]
+    n_sure = margins.index(False) if False in margins else 8
+    assert n_sure >= 1 and np.array_equal(toks[:n_sure], g[f"{case}_f32_tokens"][:n_sure]), (toks, g[f"{case}_f32_tokens"])
 
 
 def test_batched_equals_single(setup, gpu):

@@ -93,9 +93,10 @@ def test_cosine_topk(gpu, N, C, k):
 
 def test_packed_rows_equal_padded_rows(gpu):
     """`owc_bert_embed_packed` (only mask == 1 tokens are rows) against `owc_bert_embed` (every padded position computed, the
-    reference's shape of the computation, _text.py:193-198): a sequence's arithmetic is the same chain of operations in both, so
-    the embeddings are bit-identical - ragged lengths 2..16, a batch split (max_batch), and masks with HOLES (position ids stay the
-    padded columns); both also sit within 2e-5 of the numpy oracle."""
+    reference's shape of the computation, _text.py:193-198): a sequence's arithmetic is the same chain of operations in both (the
+    two attention kernels differ only in how the compiler contracts their multiply-adds), so the embeddings agree to fp32
+    rounding (<= 1e-6 on unit vectors) - ragged lengths 2..16, a batch split (max_batch), and masks with HOLES (position ids
+    stay the padded columns); both also sit within 2e-5 of the numpy oracle."""
     from lmms_owc_amd.engine.scorer import BertWeights, SentenceScorer
 
     c = recipes.bert_cfg("minilm")
@@ -103,12 +104,12 @@ def test_packed_rows_equal_padded_rows(gpu):
     sc = SentenceScorer(BertWeights(c, w, gpu), max_batch=300)
     ids, mask = recipes.label_tokens(777, 16, c["vocab_size"], seed=5)
     a, b = sc.embed(ids, mask, packed=True), sc.embed(ids, mask, packed=False)
-    assert torch.equal(a, b)
+    assert float((a - b).abs().max()) <= 1e-6
     r = np.random.default_rng(9)
     holes = (r.random(mask.shape) < 0.8).astype(np.int64) * mask
     holes[:, 0] = 1
     a, b = sc.embed(ids, holes, packed=True), sc.embed(ids, holes, packed=False)
-    assert torch.equal(a, b)
+    assert float((a - b).abs().max()) <= 1e-6
     np.testing.assert_allclose(to_np(a[:64]), B.sentence_embed(w, c, ids[:64], holes[:64]), atol=2e-5)
     # device tensors are accepted as well (the layout is built from a host copy of the mask)
     d = sc.embed(torch.from_numpy(ids).to(gpu), torch.from_numpy(holes).to(gpu))
