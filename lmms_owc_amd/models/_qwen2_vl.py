@@ -115,6 +115,9 @@ class Qwen2VL(Model):
         self._pool = ThreadPoolExecutor(max_workers=self._prep_threads)
         self._prep_thread = ThreadPoolExecutor(max_workers=1)
         self._lookahead = 2
+        import threading
+
+        self._pinned_free, self._pinned_lock = [], threading.Lock()
 
     # ------------------------------------------------------------------ loading
     def load_model(self) -> None:
@@ -300,11 +303,29 @@ class Qwen2VL(Model):
             j = i
             while j < len(images) and images[j].shape == images[i].shape:
                 j += 1
-            buf = torch.empty((j - i, *images[i].shape), dtype=torch.uint8, pin_memory=True)
+            buf = self._pinned_take((j - i, *images[i].shape))
             np.stack(images[i:j], out=buf.numpy())
             groups.append(buf)
             i = j
         return {"prompts": prompts, "grids": grids_per_prompt, "groups": groups, "max_new": max_new, "n": len(chunk)}
+
+    def _pinned_take(self, shape: tuple) -> torch.Tensor:
+        """Pinned staging buffer for one same-size image run: reused across chunks (page-locking a fresh GB per chunk costs
+        more than copying into it)."""
+        n = int(np.prod(shape))
+        with self._pinned_lock:
+            for i, t in enumerate(self._pinned_free):
+                if t.numel() >= n:
+                    return self._pinned_free.pop(i)[:n].view(shape)
+        return torch.empty(n, dtype=torch.uint8, pin_memory=True).view(shape)
+
+    def _pinned_give(self, bufs: list) -> None:
+        with self._pinned_lock:
+            for b in bufs:
+                base = b._base if b._base is not None else b
+                self._pinned_free.append(base.reshape(-1))
+            self._pinned_free.sort(key=lambda t: t.numel())
+            del self._pinned_free[:-6]   # keep the six largest
 
     def _generate_rows(self, requests: list) -> list[np.ndarray]:
         """Token rows (cut at EOS) per request, in request order.  Chunks of `batch_size` requests flow through a two-stage
@@ -318,12 +339,8 @@ class Qwen2VL(Model):
 
         reordered = utils.Collator([reg.args for reg in requests], _collate, grouping=True)
         chunks = list(reordered.get_batched(n=self.batch_size, batch_fn=None))
-        if chunks and len(chunks[0]) >= 64:
-            # ramp-up: the very first chunk has nothing to hide its host preparation behind, so it is cut into 1/8, 1/8, 1/4, 1/2 -
-            # the GPU starts after an eighth of a chunk is ready and every later piece is prepared under the previous one
-            first, n0 = chunks[0], len(chunks[0])
-            cuts = [0, n0 // 8, n0 // 4, n0 // 2, n0]
-            chunks = [first[a:b] for a, b in zip(cuts[:-1], cuts[1:])] + chunks[1:]
+        # (a ramp-up of the first chunk - 1/8, 1/8, 1/4, 1/2 so that the GPU starts early - was measured and removed: the
+        # small pieces run the decoder at a fraction of its large-batch rate, which costs more than the exposed preparation)
         tok = self._tokenizer
         pad = tok.pad_token_id if tok.pad_token_id is not None else 0
         rows: list[np.ndarray] = []
@@ -331,8 +348,9 @@ class Qwen2VL(Model):
         nxt = 0
 
         def finish(item) -> None:
-            host, ev = item
-            ev.synchronize()
+            host, ev, groups = item
+            ev.synchronize()          # the chunk's GPU work is complete: its staging buffers can be reused
+            self._pinned_give(groups)
             for r in host.numpy():
                 stop = np.flatnonzero(r == tok.eos_token_id)
                 rows.append(r[: stop[0]].copy() if len(stop) else r.copy())
@@ -351,7 +369,7 @@ class Qwen2VL(Model):
             host.copy_(out, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            inflight.append((host, ev))
+            inflight.append((host, ev, prep["groups"]))
             if len(inflight) > 1:
                 finish(inflight.popleft())
         while inflight:

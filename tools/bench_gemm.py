@@ -65,6 +65,10 @@ def ab(dev, only, knob=b"gemm_big_min_m"):
 
 def main():
     dev = torch.device("cuda:0")
+    for a in sys.argv[1:]:   # --set=gemm_pingpong=0 : owc_tuning_set before anything runs
+        if a.startswith("--set="):
+            k, v = a[6:].split("=")
+            assert _lib.load().owc_tuning_set(k.encode(), int(v)) == 0, k
     if "--dbg" in sys.argv:  # timing experiments (--vals=0,512,4): 0 normal, 1 no DMA, 2 DMA re-reads K-tiles 0/1 (L2 hits), 4 no epilogue, 512 direct epilogue stores
         lib = _lib.load()
         only = next((a for a in sys.argv[1:] if not a.startswith("--")), None)
