@@ -29,7 +29,10 @@ int owc_tuning_set(const char* name, int value) {
     owc_gemm_fp8_set_skinny_max_m(value);
   }
   else if (!strcmp(name, "gemm_big_min_m")) owc_gemm_set_big_min_m(value);
-  else if (!strcmp(name, "gemm_pingpong")) owc_gemm_set_pingpong(value);
+  else if (!strcmp(name, "gemm_pingpong")) {
+    owc_gemm_set_pingpong(value);
+    owc_gemm_fp8_set_pingpong(value);
+  }
   else if (!strcmp(name, "gemm_dbg")) owc_gemm_set_dbg(value);
   else if (!strcmp(name, "attn_dbg")) owc_attn_set_dbg(value);
   else if (!strcmp(name, "prefill_prune_last")) owc_llm_set_prune_last(value);

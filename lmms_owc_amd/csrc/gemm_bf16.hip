@@ -819,12 +819,14 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
         (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
         vset = true;
       }
       if (var == 1) OWC_PP_LAUNCH(1);
       else if (var == 2) OWC_PP_LAUNCH(2);
       else if (var == 4) OWC_PP_LAUNCH(4);
       else if (var == 8) OWC_PP_LAUNCH(8);
+      else if (var == 3) OWC_PP_LAUNCH(3);
       else OWC_PP_LAUNCH(0);
     } else {
       OWC_PP_LAUNCH(0);

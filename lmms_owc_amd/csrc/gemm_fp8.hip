@@ -22,6 +22,7 @@ constexpr int BT = 256, BKB = 128;                 // tile edge, K-tile in BYTES
 constexpr int OP_BYTES = BT * BKB;                 // 32 KiB per operand per stage
 constexpr int STAGE_BYTES = 2 * OP_BYTES;
 constexpr int GROUP_M2 = 4;
+int g_fp8_pingpong = 1;       // follows the "gemm_pingpong" knob
 int g_fp8_skinny_max_m = 64;  // follows the "gemm_skinny_max_m" knob
 int g_fp8_mid_max_tiles = 128;  // fewer 256x256 tiles than this -> 64x64 tiles (follows "gemm_mid_max_tiles": 0 disables)
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;
@@ -274,6 +275,183 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256_kernel(
 }
 
 
+// ---- ping-pong variant of the 256x256x128 kernel: the schedule of gemm_bf16_nt_256pp_kernel (gemm_bf16.hip: two waves per SIMD
+// alternate MFMA / load roles, counted vmcnt(6), half-tile LDS-DMA) with the arithmetic swapped: a K-tile is 128 fp8 elements =
+// the same 128-byte rows and LDS image, a lane's operand is 32 consecutive K bytes (two swizzled ds_read_b128), one scaled MFMA
+// per 16x16 tile per K-tile, so a C quadrant (4 m tiles x 2 n tiles) is 8 MFMAs of 32 cycles = the bf16 quadrant's 256 cycles.
+// Same ascending chain per output element: bit-identical to gemm_fp8_nt_256_kernel.  Requires at least two K-tiles.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_fp8_nt_256pp_kernel(
+    const uint8_t* __restrict__ A, long lda, const float* __restrict__ SA, const uint8_t* __restrict__ W, long ldw,
+    const float* __restrict__ SW, const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv, long ldc,
+    int M, int N, int K, int tiles_m, int tiles_n, owc_gemm_aux aux) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int nblk = tiles_m * tiles_n;
+  const int nk = K / BKB;
+  int m0, n0;
+  {
+    const int bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int width = GROUP_M2 * tiles_n;
+    const int group = lid / width;
+    const int first_m = group * GROUP_M2;
+    const int gsize = min(tiles_m - first_m, GROUP_M2);
+    m0 = (first_m + (lid % width) % gsize) * BT;
+    n0 = ((lid % width) / gsize) * BT;
+  }
+  const char* abase = (const char*)(A + (long)m0 * lda);
+  const char* wbase = (const char*)(W + (long)n0 * ldw);
+  unsigned aoff[2][2], woff[2][2];   // half h, piece j -> rows 128h + 16w + 8j .. +8
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = 128 * h + 16 * w + 8 * j + (l >> 3);
+      const int c = (l & 7) ^ ((row >> 1) & 7);
+      aoff[h][j] = (unsigned)((long)min(row, M - 1 - m0) * lda + c * 16);
+      woff[h][j] = (unsigned)((long)min(row, N - 1 - n0) * ldw + c * 16);
+    }
+  auto issue_a = [&](int kt, int h) {
+    char* dst = lds + (kt & 1) * STAGE_BYTES + (128 * h + 16 * w) * 128;
+    const long kb = (long)kt * BKB;
+    glds16(abase + kb + aoff[h][0], dst);
+    glds16(abase + kb + aoff[h][1], dst + 1024);
+  };
+  auto issue_w = [&](int kt, int h) {
+    char* dst = lds + (kt & 1) * STAGE_BYTES + OP_BYTES + (128 * h + 16 * w) * 128;
+    const long kb = (long)kt * BKB;
+    glds16(wbase + kb + woff[h][0], dst);
+    glds16(wbase + kb + woff[h][1], dst + 1024);
+  };
+  const int wr = w >> 2, wc = w & 3;
+  const int fr = l & 15, fq = l >> 4;
+  const int swz = (fr >> 1) & 7;
+  const int rowA = (wr * 128 + fr) * 128;
+  const int rowW = OP_BYTES + (wc * 64 + fr) * 128;
+  const int chlo = (fq ^ swz) << 4, chhi = ((4 + fq) ^ swz) << 4;   // the operand byte pairing of gemm_fp8_nt_256_kernel
+
+  f32x4 acc[4][8];  // [nt][mt]
+  i32x8 fa[4], wy[2], wx[2];   // (a third W set as in the bf16 kernel spills here: the column-half-0 set is re-read in p0 instead)
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  auto rd = [&](i32x8& dst, const char* p) {
+    const i32x4 lo = *(const i32x4*)(p + chlo), hi = *(const i32x4*)(p + chhi);
+    dst = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto read_a = [&](const char* sbase, int mh) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) rd(fa[t], sbase + rowA + (mh * 4 + t) * 2048);
+  };
+  auto read_w = [&](i32x8 (&dst)[2], const char* sbase, int nh) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) rd(dst[t], sbase + rowW + (nh * 2 + t) * 2048);
+  };
+#define OWC_PP_SYNC_L(VM)                                                                         \
+  do {                                                                                            \
+    if constexpr ((VM) >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((VM) < 0 ? 0 : (VM)) : "memory"); \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                               \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+  } while (0)
+  auto quadrant = [&](const i32x8 (&wf)[2], int mh, int nh) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        acc[nh * 2 + n][mh * 4 + m] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[n], fa[m], acc[nh * 2 + n][mh * 4 + m],
+                                                                                         0, 0, 0, 0x7f, 0, 0x7f);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto ktile = [&](auto mode_c, int u) {
+    constexpr int MODE = decltype(mode_c)::value;   // 0 steady, 1 second to last, 2 last K-tile
+    const char* cur = lds + (u & 1) * STAGE_BYTES;
+    read_w(wx, cur, 0);
+    read_a(cur, 0);
+    if constexpr (MODE <= 1) issue_a(u + 1, 1);
+    OWC_PP_SYNC_L(-1);
+    quadrant(wx, 0, 0);
+    read_w(wy, cur, 1);
+    OWC_PP_SYNC_L(-1);
+    quadrant(wy, 0, 1);
+    read_a(cur, 1);
+    if constexpr (MODE == 0) {
+      issue_w(u + 2, 0);
+      OWC_PP_SYNC_L(6);
+    } else if constexpr (MODE == 1) {
+      OWC_PP_SYNC_L(4);
+    } else {
+      OWC_PP_SYNC_L(-1);
+    }
+    quadrant(wy, 1, 1);
+    if constexpr (MODE == 0) {
+      issue_w(u + 2, 1);
+      issue_a(u + 2, 0);
+      OWC_PP_SYNC_L(6);
+    } else if constexpr (MODE == 1) {
+      OWC_PP_SYNC_L(0);
+    } else {
+      OWC_PP_SYNC_L(-1);
+    }
+    quadrant(wx, 1, 0);
+  };
+  issue_a(0, 0);
+  issue_a(0, 1);
+  issue_w(0, 0);
+  issue_w(0, 1);
+  issue_w(1, 0);
+  issue_w(1, 1);
+  issue_a(1, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  if (wr) {
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  int u = 0;
+  for (; u + 2 < nk; ++u) ktile(I0{}, u);
+  ktile(I1{}, u);
+  ktile(I2{}, u + 1);
+  if (!wr) {
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef OWC_PP_SYNC_L
+  {
+    f32x4 swv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) swv[nt] = *(const f32x4*)(SW + min(n0 + wc * 64 + nt * 16 + fq * 4, N - 4));
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const float sa = SA[min(m0 + wr * 128 + mt * 16 + fr, M - 1)];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[nt][mt][e] = acc[nt][mt][e] * sa * swv[nt][e];
+    }
+  }
+  constexpr int CCOLS = EPI == OWC_EPI_SWIGLU ? BT / 2 : BT;
+  gemm_epilogue<EPI, 8>(acc, m0 + wr * 128, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux, lds, CCOLS * 2, wr * 128,
+                        wc * 64);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  store_ctile<8>(lds, BT, CCOLS, (bf16_t*)Cv, ldc, m0, EPI == OWC_EPI_SWIGLU ? (n0 >> 1) : n0, M,
+                 EPI == OWC_EPI_SWIGLU ? (N >> 1) : N, w, l);
+}
+
+
 // ---- 64x64x128 variant for the in-between shapes (M above the skinny kernel's 64 rows, too few 256x256 tiles for the 256 CUs:
 // fp8 decode at batch 65 .. ~1000, single-prompt prefill).  The fp8 twin of gemm_bf16_nt_64_kernel: 4 waves, wave w owns rows
 // [16w, 16w+16) x 64 columns, one scaled MFMA per n tile per K-tile, 32 KiB LDS, same ascending chain (bit-identical).
@@ -476,6 +654,8 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)gemm_fp8_nt_256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_fp8_nt_256pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS_BYTES) != hipSuccess)
       return OWC_ERR_HIP;
     attr_set = true;
@@ -494,9 +674,14 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
     owc_gemm_profile_end(prof, s);
     return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
   }
-  hipLaunchKernelGGL(gemm_fp8_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), LDS_BYTES, s,
-                     (const uint8_t*)A, lda, sa, (const uint8_t*)W, ldw, sw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C,
-                     ldc, M, N, K, tiles_m, tiles_n, aux);
+  if (g_fp8_pingpong && K >= 2 * BKB)
+    hipLaunchKernelGGL(gemm_fp8_nt_256pp_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), LDS_BYTES, s,
+                       (const uint8_t*)A, lda, sa, (const uint8_t*)W, ldw, sw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C,
+                       ldc, M, N, K, tiles_m, tiles_n, aux);
+  else
+    hipLaunchKernelGGL(gemm_fp8_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), LDS_BYTES, s,
+                       (const uint8_t*)A, lda, sa, (const uint8_t*)W, ldw, sw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C,
+                       ldc, M, N, K, tiles_m, tiles_n, aux);
   owc_gemm_profile_end(prof, s);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
@@ -504,6 +689,7 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
 }  // namespace
 
 void owc_gemm_fp8_set_skinny_max_m(int v) { g_fp8_skinny_max_m = v; }
+void owc_gemm_fp8_set_pingpong(int v) { g_fp8_pingpong = v; }
 void owc_gemm_fp8_set_mid_max_tiles(int v) { g_fp8_mid_max_tiles = v ? 128 : 0; }
 
 int owc_launch_quant_rows_fp8(const void* X, long ldx, void* Q, long ldq, float* S, int rows, int cols, hipStream_t st) {

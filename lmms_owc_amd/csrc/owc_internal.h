@@ -76,6 +76,7 @@ void owc_gemm_set_dbg(int v);
 void owc_gemm_set_mid_max_tiles(int v);
 void owc_gemm_set_skinny_max_m(int v);
 void owc_gemm_set_pingpong(int v);
+void owc_gemm_fp8_set_pingpong(int v);
 void owc_gemm_fp8_set_skinny_max_m(int v);
 void owc_gemm_fp8_set_mid_max_tiles(int v);
 int owc_launch_gemm_bf16_aux(const void* A, long lda, const void* W, long ldw, const void* bias,

@@ -15,7 +15,14 @@ SHAPES = [("7b.qkv", 18304, 4608, 3584), ("7b.gateup", 18304, 37888, 3584), ("7b
 
 def main():
     dev = torch.device("cuda:0")
-    only = sys.argv[1] if len(sys.argv) > 1 else None
+    from lmms_owc_amd import _lib
+
+    for a in sys.argv[1:]:   # --set=gemm_pingpong=0
+        if a.startswith("--set="):
+            k, v = a[6:].split("=")
+            assert _lib.load().owc_tuning_set(k.encode(), int(v)) == 0
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    only = args[0] if args else None
     for name, m, n, k in SHAPES:
         if only and name != only:
             continue

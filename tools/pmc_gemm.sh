@@ -9,7 +9,7 @@ TAG=${1:-r02}
 ROOT=$(pwd)
 export TMPDIR=/tmp
 SHAPE="7b.gateup --m=65536 --epi=swiglu --iters=4"
-declare -A GROUPS=(
+declare -A CGROUPS=(
   [fetch]="FETCH_SIZE"
   [write]="WRITE_SIZE"
   [tcc]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
@@ -23,7 +23,7 @@ for K in pp ls; do
   for G in fetch write tcc sq grbm; do
     OUT=$ROOT/gpurun_out/pmc_${TAG}_${K}_${G}
     rm -rf $OUT
-    (cd /tmp && rocprofv3 --pmc ${GROUPS[$G]} --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/tools/bench_gemm.py $SHAPE $SET) > $OUT.log 2>&1
+    (cd /tmp && rocprofv3 --pmc ${CGROUPS[$G]} --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/tools/bench_gemm.py $SHAPE $SET) > $OUT.log 2>&1
     DIRS="$DIRS $OUT"
   done
   python3 tools/pmc_traffic_summary.py --kernel $KN --tag ${TAG}_gateup_swiglu_${K} \
