@@ -447,8 +447,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
 //
 // Staging: an operand K-tile (256 rows x 128 B) is two half-tiles of 128 rows; wave w stages rows 16w..16w+15 of each
 // half (2 LDS-DMA instructions).  Schedule for K-tile u (phases p0..p3), buffers = u & 1:
-//   p0  read A(rows half 0 of the wave tile, u)  [8 ds_read_b128]   issue A half 1 of u+1
-//   p1  read W(cols half 1, u)                   [4]
+//   p0  read A(rows half 0 of the wave tile, u)  [8 ds_read_b128]
+//   p1  read W(cols half 1, u)                   [4]                issue A half 1 of u+1
 //   p2  read A(rows half 1, u)                   [8]                issue W half 0 of u+2      wait: W(u+1) landed
 //   p3  read W(cols half 0, u+1) -> other set    [4]                issue W half 1, A half 0 of u+2   wait: A(u+1) landed
 // Each wait is a counted vmcnt(6) (three half-tiles stay in flight) at the END of a load section; the data is read one
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
 // exact counts.  Requires K % 128 == 0 (an even number of K-tiles: the W fragment sets alternate between two register
 // blocks so that p3 can fetch the next tile's set while this tile's is still in use).
 // ------------------------------------------------------------------------------------------------
-template <int EPI, int VAR = 0>   // VAR: experiment bits (1 no setprio, 2 A half 1 issued in p1, 4 GROUP_M 8, 8 lgkmcnt after the barrier)
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
     const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
     const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv, long ldc, int M, int N, int K,
@@ -476,11 +476,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    constexpr int GM = (VAR & 4) ? 8 : GROUP_M2;
-    const int width = GM * tiles_n;
+    const int width = GROUP_M2 * tiles_n;
     const int group = lid / width;
-    const int first_m = group * GM;
-    const int gsize = min(tiles_m - first_m, GM);
+    const int first_m = group * GROUP_M2;
+    const int gsize = min(tiles_m - first_m, GROUP_M2);
     m0 = (first_m + (lid % width) % gsize) * BT;
     n0 = ((lid % width) / gsize) * BT;
   }
@@ -540,13 +539,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
 #define OWC_PP_SYNC_L(VM)                                                                         \
   do {                                                                                            \
     if constexpr ((VM) >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((VM) < 0 ? 0 : (VM)) : "memory"); \
-    if constexpr (VAR & 8) asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");         \
-    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                          \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                               \
     __builtin_amdgcn_sched_barrier(0);                                                            \
   } while (0)
   // MFMA section: one C quadrant over the whole K-tile (k-step 0 then 1: every output element stays ONE ascending chain)
   auto quadrant = [&](const bf16x8 (&wf)[2][2], int mh, int nh) {
-    if constexpr (!(VAR & 1)) __builtin_amdgcn_s_setprio(1);
+    // (no s_setprio around the MFMA group: the partner wave is in its load section and needs the issue slots - measured
+    // +0.5..1.5 % without, tools/bench_gemm.py A-B)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -555,7 +554,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
         for (int m = 0; m < 4; ++m)
           acc[nh * 2 + n][mh * 4 + m] =
               __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][n], fa[ks][m], acc[nh * 2 + n][mh * 4 + m], 0, 0, 0);
-    if constexpr (!(VAR & 1)) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -567,12 +565,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
     const char* nxt = lds + ((u + 1) & 1) * STAGE_BYTES;
     // p0
     read_a(cur, 0);
-    if constexpr (MODE <= 1 && !(VAR & 2)) issue_a(u + 1, 1);
     OWC_PP_SYNC_L(-1);
     quadrant(wcur, 0, 0);
     // p1
     read_w(wy, cur, 1);
-    if constexpr (MODE <= 1 && (VAR & 2)) issue_a(u + 1, 1);
+    if constexpr (MODE <= 1) issue_a(u + 1, 1);
     OWC_PP_SYNC_L(-1);
     quadrant(wy, 0, 1);
     // p2
@@ -796,7 +793,7 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<EPI>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_kernel<EPI, 0>,
+        hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_kernel<EPI>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES) != hipSuccess)
       return OWC_ERR_HIP;
     attr_set = true;
@@ -806,33 +803,10 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
     owc_gemm_profile_end(prof, s);
     return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
   }
-  if (big && g_pingpong && (K % (2 * BK)) == 0) {
-#define OWC_PP_LAUNCH(V)                                                                                          \
-  hipLaunchKernelGGL((gemm_bf16_nt_256pp_kernel<EPI, V>), dim3(tiles_m * tiles_n), dim3(512), 2 * STAGE_BYTES, s,     \
-                     (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C, ldc, \
-                     M, N, K, tiles_m, tiles_n, g_gemm_dbg & 0xffff, aux)
-    const int var = g_gemm_dbg >> 16;
-    if constexpr (EPI == OWC_EPI_NONE) {   // experiment variants exist for the plain epilogue only (tools/bench_gemm.py --dbg)
-      static bool vset = false;
-      if (!vset) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-        vset = true;
-      }
-      if (var == 1) OWC_PP_LAUNCH(1);
-      else if (var == 2) OWC_PP_LAUNCH(2);
-      else if (var == 4) OWC_PP_LAUNCH(4);
-      else if (var == 8) OWC_PP_LAUNCH(8);
-      else if (var == 3) OWC_PP_LAUNCH(3);
-      else OWC_PP_LAUNCH(0);
-    } else {
-      OWC_PP_LAUNCH(0);
-    }
-#undef OWC_PP_LAUNCH
-  }
+  if (big && g_pingpong && (K % (2 * BK)) == 0)
+    hipLaunchKernelGGL(gemm_bf16_nt_256pp_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), 2 * STAGE_BYTES, s,
+                       (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
+                       (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, g_gemm_dbg, aux);
   else if (big)
     hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), 2 * STAGE_BYTES, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
