@@ -499,7 +499,10 @@ def pil_leg(engine, dims, host_u8, B: int, T: int, device, sync) -> dict:
     sync()
     dtp = time.perf_counter() - t0
     assert len(answers) == n and all(isinstance(a, str) for a in answers)
+    first = lm.last_timing.get("first_chunk_prep_s", 0.0)
     return {"seconds": dtp, "images": n, "batch_size": bs, "prep_threads": lm._prep_threads, "host_cores": os.cpu_count(),
+            "first_chunk_prep_s": first,   # exposed once per generate_until call (a task), whatever its length
+            "images_per_s_after_first_prep": n / max(dtp - first, 1e-9),   # what a long task converges to (per rank)
             "what": "PIL 448x448 (uniform-noise pixels) -> JPEG round trip + smart_resize/bicubic + tokenise on the host pool -> pinned "
                     "H2D -> patchify -> vision tower -> prefill -> 16 greedy tokens -> detokenised strings; chunk k+1 is prepared while "
                     "chunk k runs on the GPU"}

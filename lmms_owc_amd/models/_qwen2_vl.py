@@ -287,24 +287,31 @@ class Qwen2VL(Model):
         max_new = int(gen_kwargs.get("max_new_tokens", 128))
         if gen_kwargs.get("temperature", 0) not in (0, 0.0) or gen_kwargs.get("num_beams", 1) != 1:
             raise NotImplementedError("the HIP decoder implements greedy decoding (temperature 0, 1 beam)")
-        visuals_per_doc = [doc_to_visual[0](self.task_dict[task][split][did]) for did in doc_ids]
-        flat = [v for vs in visuals_per_doc for v in vs]
-        prepared = iter(list(self._pool.map(lambda v: imageproc.prepare_image(v, self._min_pixels, self._max_pixels), flat)))
+        docs = self.task_dict[task][split]
+
+        def fetch(did):   # image fetch (file open + decode in the reference's tasks) AND preparation run on the pool workers
+            return [imageproc.prepare_image(v, self._min_pixels, self._max_pixels) for v in doc_to_visual[0](docs[did])]
+
+        arrs_per_doc = list(self._pool.map(fetch, doc_ids))
         images, grids_per_prompt, prompts = [], [], []
-        for ctx, visuals in zip(contexts, visuals_per_doc):
-            arrs = [next(prepared) for _ in visuals]
+        cache: dict = {}   # a task asks every image the same question: one tokenisation per distinct (question, image-token counts)
+        for ctx, arrs in zip(contexts, arrs_per_doc):
             grids = [(1, a.shape[1] // 14, a.shape[2] // 14) for a in arrs]
             images += arrs
             grids_per_prompt.append(grids)
-            prompts.append(self._prompt_ids(ctx.replace("<image>", ""), [g[1] * g[2] // 4 for g in grids]))
-        # same-size runs share one patchify launch; each run is staged in pinned memory
+            key = (ctx, tuple(g[1] * g[2] // 4 for g in grids))
+            if key not in cache:
+                cache[key] = self._prompt_ids(ctx.replace("<image>", ""), list(key[1]))
+            prompts.append(cache[key])
+        # same-size runs share one patchify launch; each run is staged in pinned memory (parallel copies: memcpy drops the GIL)
         groups, i = [], 0
         while i < len(images):
             j = i
             while j < len(images) and images[j].shape == images[i].shape:
                 j += 1
             buf = self._pinned_take((j - i, *images[i].shape))
-            np.stack(images[i:j], out=buf.numpy())
+            dst = buf.numpy()
+            list(self._pool.map(lambda k, i=i, dst=dst: np.copyto(dst[k - i], images[k]), range(i, j)))
             groups.append(buf)
             i = j
         return {"prompts": prompts, "grids": grids_per_prompt, "groups": groups, "max_new": max_new, "n": len(chunk)}
@@ -355,11 +362,17 @@ class Qwen2VL(Model):
                 stop = np.flatnonzero(r == tok.eos_token_id)
                 rows.append(r[: stop[0]].copy() if len(stop) else r.copy())
 
+        import time
+
+        t_begin = time.perf_counter()
+        self.last_timing = {"chunks": len(chunks)}
         for k in range(len(chunks)):
             while nxt < len(chunks) and len(ahead) < self._lookahead:
                 ahead.append(self._prep_thread.submit(self._prepare_chunk, chunks[nxt]))
                 nxt += 1
             prep = ahead.popleft().result()
+            if k == 0:   # nothing hides the first chunk's host preparation; every later chunk is prepared under GPU work
+                self.last_timing["first_chunk_prep_s"] = time.perf_counter() - t_begin
             emb = None
             if prep["groups"]:
                 emb = self._model.encode_images(self._pixel_values(prep["groups"]), [g for gs in prep["grids"] for g in gs])
@@ -374,6 +387,7 @@ class Qwen2VL(Model):
                 finish(inflight.popleft())
         while inflight:
             finish(inflight.popleft())
+        self.last_timing["total_s"] = time.perf_counter() - t_begin
         return reordered.get_original(rows)
 
     def _pixel_values(self, images: list) -> torch.Tensor:
