@@ -58,7 +58,8 @@ const char* owc_last_error(const owc_ctx* ctx);
 /* A-B / tuning knobs (process-wide; the same switches owc_init reads from the environment):
  * "gemm_big_min_m" (OWC_GEMM_BIG_MIN_M), "gemm_skinny_max_m" (0 disables the weight-streaming small-M kernel), "gemm_mid_max_tiles"
  * (0 disables the 64x64-tile kernel), "gemm_dbg"
- * (OWC_GEMM_DBG), "attn_dbg" (OWC_ATTN_DBG), "prefill_prune_last" (0: owc_llm_prefill runs the last layer's attention / o-proj /
+ * (OWC_GEMM_DBG), "attn_dbg" (OWC_ATTN_DBG), "gemm_pingpong" (0: the lock-step 256x256 kernels, 1 = default: bf16 ping-pong
+ * kernel, 2: the fp8 ping-pong kernel too), "prefill_prune_last" (0: owc_llm_prefill runs the last layer's attention / o-proj /
  * MLP on every row instead of the last-token rows only -- same logits bit for bit, tested), "bert_bf16x3" (0: owc_bert_embed runs
  * its linears on the exact f32-input MFMA instead of the three-piece bf16 split).
  * Returns OWC_ERR_ARG for an unknown name.  Measurement aid only: no reference counterpart. */

@@ -197,3 +197,36 @@ def test_gemm_mid_kernel_bit_identical_to_128_tiles(gpu, m, n, k):
     for x, y in zip(*outs):
         assert torch.equal(x, y)
     assert_bf16_close(to_np(outs[0][0]), _oracle(a, w, b), atol=1e-4)
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(4096, 4096, 4096, "none"), (2048, 37888, 3584, "swiglu"), (32768, 1280, 1280, "residual"),
+                                       (1100, 13000, 384, "none"), (65536, 1280, 256, "quick_gelu"), (3000, 5120, 5120, "f32")])
+def test_pingpong_kernel_bit_identical_to_lockstep_race_screen(gpu, m, n, k, epi):
+    """The ping-pong 256x256 kernel (two waves per SIMD alternate MFMA / load roles; counted vmcnt + one-phase-later reads are
+    its only ordering) against the lock-step kernel on the same operands: every output element is the same ascending MFMA
+    chain, so the results must be BIT-identical - repeated 25 times per shape (a mis-ordered LDS-DMA / ds_read shows up as
+    rare wrong tiles, not as a tolerance drift), on ragged M / N edges, the shortest legal K (2 K-tiles: prologue + peeled tail
+    only), 4, 6 and 80 K-tiles, and every epilogue family."""
+    from lmms_owc_amd import _lib, ops
+
+    lib = _lib.load()
+    a = bf16_randn((m, k), 70 + (m % 97), device=gpu)
+    w = bf16_randn((n, k), 71, 0.05, device=gpu)
+    b = bf16_randn((n,), 72, device=gpu)
+    r = bf16_randn((m, n), 73, device=gpu) if epi == "residual" else None
+    code = {"none": _lib.EPI_NONE, "swiglu": _lib.EPI_SWIGLU, "residual": _lib.EPI_RESIDUAL, "quick_gelu": _lib.EPI_QUICK_GELU,
+            "f32": _lib.EPI_F32}[epi]
+    run = lambda: ops.gemm_bf16(a, w, None if epi == "swiglu" else b, epilogue=code, residual=r)  # noqa: E731
+    try:
+        assert lib.owc_tuning_set(b"gemm_pingpong", 0) == 0
+        ref = run()
+        assert lib.owc_tuning_set(b"gemm_pingpong", 1) == 0
+        bad = 0
+        for _ in range(25):
+            bad += int(not torch.equal(run(), ref))
+    finally:
+        lib.owc_tuning_set(b"gemm_pingpong", 1)
+        _lib.load().owc_tuning_set(b"gemm_pingpong", 1)
+    assert bad == 0, f"{bad} / 25 launches differ from the lock-step kernel"
+    if epi == "none":
+        assert_bf16_close(to_np(ref[:256]), _oracle(a[:256], w, b), atol=1e-4)
