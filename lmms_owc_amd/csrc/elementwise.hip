@@ -215,15 +215,31 @@ __global__ __launch_bounds__(256) void mrope_kv_kernel(
     return;
   }
   bf16x8 oa, ob;
+  if (((sec0 | sec1) & 7) == 0) {
+    // the section boundaries are multiples of 8 (Qwen2-VL: [16, 24, 24]): the thread's 8 dims share one position stream, so the
+    // table rows come in as four 16-byte loads instead of sixteen scalar gathers
+    const int stream = (i0 < sec0) ? 0 : ((i0 < sec0 + sec1) ? 1 : 2);
+    const long row = (long)pos3[stream * pos_stride + t] * 64 + i0;
+    const f32x4 c0 = *(const f32x4*)(cos_t + row), c1 = *(const f32x4*)(cos_t + row + 4);
+    const f32x4 s0v = *(const f32x4*)(sin_t + row), s1v = *(const f32x4*)(sin_t + row + 4);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int i = i0 + e;
-    const int stream = (i < sec0) ? 0 : ((i < sec0 + sec1) ? 1 : 2);
-    const int pos = pos3[stream * pos_stride + t];
-    const float c = cos_t[pos * 64 + i], s = sin_t[pos * 64 + i];
-    const float x1 = bf2f(a[e]), x2 = bf2f(b[e]);
-    oa[e] = f2bf(rbf(x1 * c) + rbf(-x2 * s));
-    ob[e] = f2bf(rbf(x2 * c) + rbf(x1 * s));
+    for (int e = 0; e < 8; ++e) {
+      const float c = e < 4 ? c0[e & 3] : c1[e & 3], s = e < 4 ? s0v[e & 3] : s1v[e & 3];
+      const float x1 = bf2f(a[e]), x2 = bf2f(b[e]);
+      oa[e] = f2bf(rbf(x1 * c) + rbf(-x2 * s));
+      ob[e] = f2bf(rbf(x2 * c) + rbf(x1 * s));
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = i0 + e;
+      const int stream = (i < sec0) ? 0 : ((i < sec0 + sec1) ? 1 : 2);
+      const int pos = pos3[stream * pos_stride + t];
+      const float c = cos_t[pos * 64 + i], s = sin_t[pos * 64 + i];
+      const float x1 = bf2f(a[e]), x2 = bf2f(b[e]);
+      oa[e] = f2bf(rbf(x1 * c) + rbf(-x2 * s));
+      ob[e] = f2bf(rbf(x2 * c) + rbf(x1 * s));
+    }
   }
   if (h < n_q) {
     *(bf16x8*)(p + i0) = oa;
