@@ -65,7 +65,7 @@ def pruned_flops_per_image(d, prompts_per_chunk: int) -> float:
     return float(last_layer + shared_rows * per_row)
 
 
-def cpu_baseline_lmm(dims, device, seed: int, new_tokens: int, pix_dev, hip_tokens, n_images: int) -> dict:
+def cpu_baseline_lmm(dims, device, seed: int, new_tokens: int, pix_dev, hip_tokens, n_images: int, engine=None) -> dict:
     """The reference's CPU path: HF Qwen2VLForConditionalGeneration.generate, batch 1, greedy (src/models/_qwen2_vl.py:308-329),
     on the SAME seeded weights (`random_param`, regenerated per HF parameter name and copied to the host) and the SAME
     pixel_values / prompt ids as the HIP run's first `n_images` images; its tokens are compared with the HIP tokens."""
@@ -108,19 +108,29 @@ def cpu_baseline_lmm(dims, device, seed: int, new_tokens: int, pix_dev, hip_toke
     inp = torch.from_numpy(ids.astype(np.int64))[None]
     mm = (inp == d.image_token_id).int()
     grid = torch.tensor([[1, 32, 32]])
-    times, same_first, same_all = [], 0, 0
+    times, same_first, same_all, logit_err = [], 0, 0, []
     with torch.no_grad():
         for i in range(n_images):
             pix = pix_dev[i * 1024:(i + 1) * 1024].cpu()
             t0 = time.perf_counter()
             gen = model.generate(input_ids=inp, attention_mask=torch.ones_like(inp), pixel_values=pix, image_grid_thw=grid,
                                  mm_token_type_ids=mm, do_sample=False, num_beams=1, max_new_tokens=new_tokens,
-                                 min_new_tokens=new_tokens, use_cache=True, pad_token_id=0)
+                                 min_new_tokens=new_tokens, use_cache=True, pad_token_id=0, return_dict_in_generate=True,
+                                 output_logits=True)
             times.append(time.perf_counter() - t0)
-            new = gen[0, inp.shape[1]:].tolist()
+            new = gen.sequences[0, inp.shape[1]:].tolist()
             hip = [int(t) for t in hip_tokens[i].tolist()]
             same_first += int(new[0] == hip[0])
             same_all += int(new == hip)
+            if engine is not None and gen.logits is not None:
+                # full-size logit parity: the HIP engine teacher-forced on HF's continuation, every step against HF's CPU logits
+                emb = engine.encode_images(pix_dev[i * 1024:(i + 1) * 1024], [(1, 32, 32)])
+                _, sl = engine.generate([ids], emb, [[(1, 32, 32)]], new_tokens, forced_tokens=np.asarray(new)[None],
+                                        return_step_logits=True)
+                sl = sl[:, 0].float().cpu()
+                for j, ref in enumerate(gen.logits):
+                    ref = ref[0].float()
+                    logit_err.append(float((sl[j] - ref).abs().max() / ref.abs().max()))
     del model
     best = float(np.mean(times[1:])) if len(times) > 1 else float(times[0])
     import transformers
@@ -129,6 +139,9 @@ def cpu_baseline_lmm(dims, device, seed: int, new_tokens: int, pix_dev, hip_toke
             "sample": f"{n_images} image(s) 448x448 = the HIP run's first images (same pixel_values, prompt ids and seeded weights), batch 1, "
                       f"bf16, transformers {transformers.__version__} Qwen2VLForConditionalGeneration.generate on CPU (greedy, {new_tokens} "
                       f"new tokens); mean of images after the first; per-image s = {[round(t, 2) for t in times]}",
+            "logits_vs_hip": {"steps_compared": len(logit_err), "worst_rel_err": max(logit_err) if logit_err else None,
+                              "mean_rel_err": float(np.mean(logit_err)) if logit_err else None,
+                              "what": "max |HIP - HF| / max |HF| per step, HIP engine teacher-forced on HF's tokens (full 7B, same weights)"},
             "tokens_vs_hip": {"images": n_images, "first_token_equal": same_first, "all_tokens_equal": same_all,
                               "note": "random weights give near-flat logits over a 152k vocabulary: a near-tie may flip under a different "
                                       "fp32 summation order (parity is asserted by the teacher-forced tests, not here)"}}
@@ -463,7 +476,7 @@ def main() -> None:
                                                "kernel_ms_total": b16["ms"], "launches": b16["launches"]}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"] = cpu_baseline_lmm(dims, device, 1234, T, pix, out, args.cpu_images)
+                result["cpu_baseline"] = cpu_baseline_lmm(dims, device, 1234, T, pix, out, args.cpu_images, engine)
                 result["cpu_baseline_label_cosine"] = cpu_baseline_scorer(4096, L)
             except Exception as e:  # the baseline must never sink the measurement
                 result["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "reference",

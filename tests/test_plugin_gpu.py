@@ -365,3 +365,32 @@ def test_fp8_decoder_through_the_plugin(gpu, model_type, name):
     assert lm.model.w.llm.weight_dtype == 0
     with pytest.raises(ValueError):
         get_model("custom-model", model_type=model_type, model_name_or_path=f"synthetic:{name}", decoder_dtype="int4")
+
+
+def test_token_records_equal_strings_and_pipeline_chunks(gpu):
+    """`generate_until_tokens` + `decode_tokens` (the fixed-width records of the end-of-task RCCL gather) give exactly the strings
+    `generate_until` returns; the double-buffered chunk pipeline (preparation thread + pinned staging reuse + deferred token
+    read-back + quarter-first-chunk ramp) returns the same answers for every batch size, in request order."""
+    from lmms_owc_amd.models import get_model
+    from lmms_owc_amd.tasks import load_task
+
+    task = load_task("synthetic:300:56x84:3")      # 300 requests: batch 256 takes the ramp (64 + 192) and a 44-request tail
+    outs = {}
+    for bs in (7, 256):
+        lm = get_model("custom-model", model_type="qwen2-vl", model_name_or_path="synthetic:tiny", batch_size=bs)
+        lm.task_dict[task.task_name] = task.dataset
+        task.build_all_requests(limit=None, rank=0, world_size=1)
+        outs[bs] = lm.generate_until(task.instances)
+        assert lm.last_timing["chunks"] == (43 if bs == 7 else 3)
+    assert outs[7] == outs[256] and len(outs[7]) == 300
+    task.build_all_requests(limit=None, rank=0, world_size=1)
+    mat, n = lm.generate_until_tokens(task.instances)
+    assert mat.shape[0] == 300 and mat.dtype == np.int32 and n.shape == (300,)
+    assert lm.decode_tokens([mat[i, : n[i]] for i in range(300)]) == outs[7]
+    # a second plug-in around the SAME engine (no second weight set) answers identically
+    from lmms_owc_amd.models._qwen2_vl import ByteTokenizer, Qwen2VL
+
+    twin = Qwen2VL.from_engine(lm._model, ByteTokenizer(), batch_size=64)
+    twin.task_dict[task.task_name] = task.dataset
+    task.build_all_requests(limit=None, rank=0, world_size=1)
+    assert twin.generate_until(task.instances) == outs[7]
