@@ -489,7 +489,7 @@ def main() -> None:
         raise SystemExit("batch invariance check failed (the JSON line above carries the measurement)")
 
 
-def pil_leg(engine, dims, host_u8, B: int, T: int, device, sync) -> dict:
+def pil_leg(engine, dims, host_u8, B: int, T: int, device, sync, lm=None) -> dict:
     """PIL images -> `Qwen2VL.generate_until` -> strings on the engine of the main leg (same weights): 2 chunks of B images (the
     engine's own batch), so that the second chunk's host preparation overlaps the first chunk's GPU work; the first chunk's
     preparation has nothing to hide behind and is inside the timed region."""
@@ -502,7 +502,8 @@ def pil_leg(engine, dims, host_u8, B: int, T: int, device, sync) -> dict:
     arr = host_u8[:B].permute(0, 2, 3, 1).contiguous().numpy()            # HWC uint8 (uniform noise: the slowest JPEG case)
     docs = [{"visual": Image.fromarray(arr[i % len(arr)], "RGB"), "target": f"class_{i % 10}"} for i in range(n)]
     task = ClassificationTask("bench", docs, generation_kwargs={"max_new_tokens": T, "do_sample": False})
-    lm = Qwen2VL.from_engine(engine, ByteTokenizer(), batch_size=bs, eos_token_id=-1)
+    if lm is None:
+        lm = Qwen2VL.from_engine(engine, ByteTokenizer(), batch_size=bs, eos_token_id=-1)
     lm.task_dict["bench"] = task.dataset
     task.build_all_requests(limit=None, rank=0, world_size=1)
     warm = task.instances[: min(8, n)]                                  # warm the worker pool / pinned allocator on their own
