@@ -597,16 +597,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
     quadrant(wcur, 1, 0);
   };
 
-  // ---- intra-XCD stagger (experiment, dbg bits 14-15): the 32 CUs of an XCD run equal tiles in lock-step, so their epilogues hit the
-  // XCD's memory-side write path together (measured: ~6 us for 32 x 128 KB = that path's rate, not the CU's).  Delaying the
-  // first-round block of CU c of its XCD by c x delta ONCE spreads the bursts over a few microseconds for the whole launch, while
-  // the CUs stay within a few K-tiles of each other, i.e. inside what the 4 MiB L2 still holds of the shared panels.
-  if ((dbg & 0xC000) && blockIdx.x < 256) {
-    const unsigned per = ((dbg >> 14) & 3) * 10u;   // 0.1 / 0.2 / 0.3 us per CU (s_memrealtime ticks of 10 ns)
-    const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 31) * per;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(2);
-  }
   // ---- prologue: K-tile 0 entirely, then what p2 / p3 of "tile -1" would have issued for tile 1
   issue_a(0, 0);
   issue_a(0, 1);
