@@ -79,8 +79,8 @@ int owc_gemm_profile_read(owc_ctx* ctx, double* total_ms, double* total_flops, i
 enum owc_prof_kind {
   OWC_PROF_GEMM_BF16 = 0,     /* owc_gemm_bf16 and every bf16 Linear of the model drivers */
   OWC_PROF_GEMM_FP8 = 1,      /* owc_gemm_fp8 (fp8 decoder projections) */
-  OWC_PROF_ATTN_NONCAUSAL = 2, /* owc_attention_bf16, causal = 0 (vision tower / CLIP) */
-  OWC_PROF_ATTN_CAUSAL = 3,   /* owc_attention_bf16, causal = 1 (decoder prefill and decode steps) */
+  OWC_PROF_ATTN_VISION = 2,   /* owc_attention_bf16 with head_dim != 128 (Qwen2-VL vision tower 80, CLIP 64) */
+  OWC_PROF_ATTN_DECODER = 3,  /* owc_attention_bf16 with head_dim 128 (decoder: causal prefill and the decode-step mapping) */
   OWC_PROF_SCORER_GEMM = 4,   /* the sentence encoder's linears (owc_bert_embed) */
   OWC_PROF_COSINE_TOPK = 5,   /* cosine_topk_kernel */
   OWC_PROF_KINDS = 6

@@ -338,7 +338,9 @@ int launch(const void* Q, long q_ts, long q_hs, const void* K, long k_ts, long k
     attr_set = true;
   }
   // sequence lengths live on the device: the launch is recorded with work 0 and priced by the caller (include/owc.h)
-  const int prof = owc_gemm_profile_begin(0.0, CAUSAL ? OWC_PROF_ATTN_CAUSAL : OWC_PROF_ATTN_NONCAUSAL, st);
+  // class by head_dim: 128 = the decoder (causal prefill AND the decode-step mapping, which runs the non-causal template),
+  // 80 / 64 / 32 = the vision towers
+  const int prof = owc_gemm_profile_begin(0.0, HD == 128 ? OWC_PROF_ATTN_DECODER : OWC_PROF_ATTN_VISION, st);
   hipLaunchKernelGGL((attn_fwd_kernel<HD, CAUSAL>), dim3(n_pairs * nqb), dim3(256), lds_bytes, st,
                      (const bf16_t*)Q, q_ts, q_hs, (const bf16_t*)K, k_ts, k_hs, (const bf16_t*)V,
                      v_ts, v_hs, (bf16_t*)O, o_ts, o_hs, q_start, o_start, k_start, seq_len, q_len, n_heads,
