@@ -14,7 +14,7 @@ Multi-GPU: one process per GPU, no data-path collective.  The r
 `gather_object` calls per task (`_engine.py:298-315`); here every rank contributes a FIXED-WIDTH int32 record per document,
 
     { doc_id, n, payload[width] }      payload = generated token ids (models with `generate_until_tokens`: the ids go
-                                        device -> RCCL -> rank 0 and are detokenised there) or the UTF-8 bytes of the
+                                        to rank 0 over RCCL and are detokenised there) or the UTF-8 bytes of the
                                         JSON-encoded answer (any other `Model` plug-in, multi-round tuples included),
 
 all ranks pad their shard to the largest shard (sizes follow from the shard function; the record width is agreed by one
@@ -120,13 +120,15 @@ def gather_answers(lm, reqs: list, resps, sizes: list[int], rank: int, world: in
     else:
         mat, nb = _pack_bytes(list(resps))
         payload, n = torch.from_numpy(mat), torch.from_numpy(nb)
-    # RCCL moves device memory (the token ids never visit the host before the gather); gloo (CPU tests) host memory
+    # RCCL moves device memory, gloo (CPU tests) host memory
     device = torch.device(lm.device) if dist is not None and dist.get_backend() == "nccl" else torch.device("cpu")
     width = torch.tensor([payload.shape[1] if payload.ndim == 2 and payload.shape[0] else 0], dtype=torch.int64, device=device)
     if dist is not None:
         dist.all_reduce(width, op=dist.ReduceOp.MAX)   # the widest record of any rank (8 bytes; a rank may own no document)
     W = max(int(width.item()), 1)
     rows = max(sizes)
+    if rows == 0:   # no rank owns a document (limit 0 / empty task)
+        return {} if rank == 0 else None
     rec = torch.zeros((rows, 2 + W), dtype=torch.int32, device=device)
     k = len(reqs)
     if k:

@@ -377,12 +377,17 @@ def test_token_records_equal_strings_and_pipeline_chunks(gpu):
     task = load_task("synthetic:300:56x84:3")      # 300 requests: batch 256 takes the ramp (64 + 192) and a 44-request tail
     outs = {}
     for bs in (7, 256):
-        lm = get_model("custom-model", model_type="qwen2-vl", model_name_or_path="synthetic:tiny", batch_size=bs)
+        lm = get_model("custom-model", model_type="qwen2-vl", model_name_or_path="synthetic:tiny", batch_size=bs, engine_batch=0)
         lm.task_dict[task.task_name] = task.dataset
         task.build_all_requests(limit=None, rank=0, world_size=1)
         outs[bs] = lm.generate_until(task.instances)
         assert lm.last_timing["chunks"] == (43 if bs == 7 else 3)
     assert outs[7] == outs[256] and len(outs[7]) == 300
+    # engine_batch="auto" (the default): batch_size is only a lower bound, the whole task fits one engine pass - same answers
+    auto = get_model("custom-model", model_type="qwen2-vl", model_name_or_path="synthetic:tiny", batch_size=1)
+    auto.task_dict[task.task_name] = task.dataset
+    task.build_all_requests(limit=None, rank=0, world_size=1)
+    assert auto.engine_batch(8) >= 300 and auto.generate_until(task.instances) == outs[7] and auto.last_timing["chunks"] == 2
     task.build_all_requests(limit=None, rank=0, world_size=1)
     mat, n = lm.generate_until_tokens(task.instances)
     assert mat.shape[0] == 300 and mat.dtype == np.int32 and n.shape == (300,)
