@@ -447,12 +447,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
 //
 // Staging: an operand K-tile (256 rows x 128 B) is two half-tiles of 128 rows; wave w stages rows 16w..16w+15 of each
 // half (2 LDS-DMA instructions).  Schedule for K-tile u (phases p0..p3), buffers = u & 1:
-//   p0  read A(rows half 0 of the wave tile, u)  [8 ds_read_b128]   issue A half 0 of u+1
+//   p0  read A(rows half 0 of the wave tile, u)  [8 ds_read_b128]
 //   p1  read W(cols half 1, u)                   [4]                issue A half 1 of u+1
-//   p2  read A(rows half 1, u)                   [8]                issue W half 0 of u+2      wait vmcnt(6): W(u+1) landed
-//   p3  read W(cols half 0, u+1) -> other set    [4]                issue W half 1 of u+2      wait vmcnt(4): A(u+1) landed
-// (one half-tile = 2 LDS-DMA instructions per phase; two or three half-tiles stay in flight across every wait.)  Each wait sits
-// at the END of a load section; the data is read one
+//   p2  read A(rows half 1, u)                   [8]                issue W half 0 of u+2      wait: W(u+1) landed
+//   p3  read W(cols half 0, u+1) -> other set    [4]                issue W half 1, A half 0 of u+2   wait: A(u+1) landed
+// Each wait is a counted vmcnt(6) (three half-tiles stay in flight) at the END of a load section; the data is read one
 // phase later (RAW: counted wait -> barrier -> read, for both groups); a region is restaged at the earliest one phase
 // after its last read, whose lgkmcnt(0) also sits before the barrier (WAR).  The tail (last two K-tiles) is peeled with
 // exact counts.  Requires K % 128 == 0 (an even number of K-tiles: the W fragment sets alternate between two register
@@ -566,7 +565,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
     const char* nxt = lds + ((u + 1) & 1) * STAGE_BYTES;
     // p0
     read_a(cur, 0);
-    if constexpr (MODE <= 1) issue_a(u + 1, 0);
     OWC_PP_SYNC_L(-1);
     quadrant(wcur, 0, 0);
     // p1
@@ -589,7 +587,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
     if constexpr (MODE <= 1) read_w(wnxt, nxt, 0);
     if constexpr (MODE == 0) {
       issue_w(u + 2, 1);
-      OWC_PP_SYNC_L(4);   // A halves of u+1 landed; in flight: W0(u+2), W1(u+2)
+      issue_a(u + 2, 0);
+      OWC_PP_SYNC_L(6);   // A halves of u+1 landed; in flight: W0(u+2), W1(u+2), A0(u+2)
     } else if constexpr (MODE == 1) {
       OWC_PP_SYNC_L(0);
     } else {
@@ -605,11 +604,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
   issue_w(0, 1);
   issue_w(1, 0);
   issue_w(1, 1);
+  issue_a(1, 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // K-tile 0 landed and published
+  asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");   // K-tile 0 landed and published
   __builtin_amdgcn_sched_barrier(0);
   read_w(wx0, lds, 0);
   if (wr) {   // group 1 runs one barrier interval behind group 0
