@@ -67,9 +67,14 @@ class LLaVA(Model):
     def __init__(self, model_name_or_path: str = "llava-hf/llava-1.5-7b-hf", attn_implementation: str | None = None,
                  chat_template: str | None = None, use_cache: bool = True, batch_size: int = 1, device_map: str = "auto",
                  dtype: str | torch.dtype = "bfloat16", load_in_8bit: bool = False, load_in_4bit: bool = False,
-                 decoder_dtype: str = "bf16", **kwargs) -> None:
-        if decoder_dtype not in ("bf16", "fp8"):  # the one kwarg beyond the reference's: fp8 decoder projections
+                 decoder_dtype: str = "bf16", engine_batch: int | str = "auto", **kwargs) -> None:
+        # two kwargs beyond the reference's: fp8 decoder projections and `engine_batch` - `batch_size` is a
+        # lower bound, tokens are batch-invariant (see Qwen2VL.__init__): "auto" = what fits in HBM (<= 512), n = exactly n, 0 = off
+        if decoder_dtype not in ("bf16", "fp8"):
             raise ValueError("decoder_dtype must be 'bf16' or 'fp8'")
+        if engine_batch != "auto" and (not isinstance(engine_batch, int) or engine_batch < 0):
+            raise ValueError("engine_batch must be 'auto' or an integer >= 0")
+        self._engine_batch_arg = engine_batch
         self._decoder_dtype = decoder_dtype
         self._model_name_or_path = model_name_or_path
         self._attn_implementation = attn_implementation  # accepted; attention is always the fused HIP kernel
@@ -106,6 +111,21 @@ class LLaVA(Model):
         self._pool = ThreadPoolExecutor(max_workers=8)
         self._model = LlavaEngine(weights)
         self._processor = self._tokenizer
+
+    def engine_batch(self, max_new_tokens: int = 64) -> int:
+        """Requests per engine pass (see Qwen2VL.engine_batch): KV cache + projected features for the largest image the
+        processor produces (5 anyres views, or one 336-px view), a quarter of the free HBM, at most 512."""
+        arg = self._engine_batch_arg
+        if arg == 0:
+            return self.batch_size
+        if arg != "auto":
+            return max(self.batch_size, int(arg))
+        d = self._dims
+        views = 5 if d.grid_pinpoints else 1
+        tokens = views * d.tokens + 128 + int(max_new_tokens)
+        per_req = (d.n_layers * 2 * d.n_kv_heads * d.head_dim * 2) * tokens + views * d.tokens * (d.d_model * 2 + d.v_embed * 24)
+        free, _ = torch.cuda.mem_get_info(self._device)
+        return max(self.batch_size, min(512, int(0.25 * free / per_req)))
 
     def loglikelihood(self, requests: list) -> list[tuple[float, bool]]:
         raise NotImplementedError("loglikelihood is outside the accelerated path (SURVEY.md §8f: generation only)")
@@ -175,7 +195,8 @@ class LLaVA(Model):
             return -len(tok.encode(x[0], add_special_tokens=False)), x[0]
 
         reordered = utils.Collator([reg.args for reg in requests], _collate, grouping=True)
-        for chunk in reordered.get_batched(n=self.batch_size, batch_fn=None):
+        max_new_all = max([int(r.args[1].get("max_new_tokens", 1024)) for r in requests] + [1])
+        for chunk in reordered.get_batched(n=self.engine_batch(max_new_all), batch_fn=None):
             contexts, all_gen_kwargs, doc_to_visual, doc_ids, tasks, splits = zip(*chunk, strict=True)
             task, split = tasks[0], splits[0]
             for g in all_gen_kwargs:   # the reference (batch size 1) pops it from EVERY request's own dict, which is what the
