@@ -499,12 +499,21 @@ def pil_leg(engine, dims, host_u8, B: int, T: int, device, sync, lm=None) -> dic
     from lmms_owc_amd.models._qwen2_vl import ByteTokenizer, Qwen2VL
     from lmms_owc_amd.tasks import ClassificationTask
 
+    class BenchTokenizer(ByteTokenizer):
+        """The main leg's 286-token prompt (14 text ids + image placeholders + 16 text ids): a byte tokenizer would spell the
+        question out one token per character (~360 tokens) and the two legs would not do the same work per image."""
+
+        def chat_ids(self, question: str, n_image_tokens: list[int]) -> list[int]:
+            ids = prompt_ids(self.image_pad)
+            assert n_image_tokens == [S_IMG]
+            return [int(t) for t in ids]
+
     n, bs = 3 * B, B
     arr = host_u8[:B].permute(0, 2, 3, 1).contiguous().numpy()            # HWC uint8 (uniform noise: the slowest JPEG case)
     docs = [{"visual": Image.fromarray(arr[i % len(arr)], "RGB"), "target": f"class_{i % 10}"} for i in range(n)]
     task = ClassificationTask("bench", docs, generation_kwargs={"max_new_tokens": T, "do_sample": False})
     if lm is None:
-        lm = Qwen2VL.from_engine(engine, ByteTokenizer(), batch_size=bs, eos_token_id=-1)
+        lm = Qwen2VL.from_engine(engine, BenchTokenizer(), batch_size=bs, eos_token_id=-1)
     lm.task_dict["bench"] = task.dataset
     task.build_all_requests(limit=None, rank=0, world_size=1)
     warm = task.instances[: min(8, n)]                                  # warm the worker pool / pinned allocator on their own

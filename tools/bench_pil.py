@@ -47,11 +47,8 @@ def main():
         for si in a.switch_interval.split(","):
             os.environ["OWC_PREP_THREADS"] = th
             sys.setswitchinterval(float(si))
-            from lmms_owc_amd.models._qwen2_vl import ByteTokenizer, Qwen2VL
-
-            lm = Qwen2VL.from_engine(engine, ByteTokenizer(), batch_size=B, eos_token_id=-1)
-            for rep in ("cold", "warm pinned pool"):
-                r = bench.pil_leg(engine, dims, host_u8, B, T, device, torch.cuda.synchronize, lm=lm)
+            for rep in ("cold",):
+                r = bench.pil_leg(engine, dims, host_u8, B, T, device, torch.cuda.synchronize)
                 print(f"threads {th} switchinterval {si} [{rep}]: {r['images'] / r['seconds']:.1f} images/s ({r['images'] / r['seconds'] / eng:.3f} of "
                       f"engine), first prep {r['first_chunk_prep_s']:.2f} s, chunks {r['chunks']}", flush=True)
 
