@@ -281,13 +281,22 @@ def main() -> None:
         return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # test hook (never set by the driver): OWC_BENCH_SHARE_GPU=1 lets the ranks of a multi-rank run share cuda:0 with gloo
+    # collectives, so that the N > 1 code path can be exercised on a 1-GPU box (RCCL refuses two ranks on one device)
+    share = os.environ.get("OWC_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    cdev = torch.device("cpu") if share else device   # where the timing scalars of the collectives live
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
 
     from lmms_owc_amd import _lib
     from lmms_owc_amd import build as owc_build
@@ -352,10 +361,10 @@ def main() -> None:
     lib.owc_gemm_profile_enable(ctx, 0)
     fp8_run = args.decoder_dtype == "fp8"
     assert out.shape == (B, T)
-    tall = torch.tensor([dt_local], device=device, dtype=torch.float64)
+    tall = torch.tensor([dt_local], device=cdev, dtype=torch.float64)
     per_rank_dt = [dt_local]
     if dist is not None:
-        gathered = torch.empty(world, device=device, dtype=torch.float64)
+        gathered = torch.empty(world, device=cdev, dtype=torch.float64)
         dist.all_gather_into_tensor(gathered, tall)
         per_rank_dt = gathered.tolist()
     dt = max(per_rank_dt)                       # max over ranks
@@ -380,7 +389,7 @@ def main() -> None:
     emb_h = engine.encode_images(pix_h, flat_grids)
     engine.generate(prompts, emb_h, grids, T, eos_token_id=-1, pad_token_id=0).cpu()
     sync()
-    pcie_dt = torch.tensor([time.perf_counter() - p0], device=device, dtype=torch.float64)
+    pcie_dt = torch.tensor([time.perf_counter() - p0], device=cdev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(pcie_dt, op=dist.ReduceOp.MAX)
     pcie_images_per_s = world * B / float(pcie_dt.item())
@@ -392,7 +401,7 @@ def main() -> None:
     if not args.no_pil_leg:
         pil = pil_leg(engine, dims, host_u8, B, T, device, sync)
         if dist is not None:
-            t = torch.tensor([pil["seconds"]], device=device, dtype=torch.float64)
+            t = torch.tensor([pil["seconds"]], device=cdev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             pil["seconds"] = float(t.item())
         pil["images_per_s"] = world * pil["images"] / pil["seconds"]
@@ -420,7 +429,7 @@ def main() -> None:
     for _ in range(args.steps):
         tv, ti, paired = score()
     sync()
-    sdt = torch.tensor([time.perf_counter() - s0], device=device, dtype=torch.float64)
+    sdt = torch.tensor([time.perf_counter() - s0], device=cdev, dtype=torch.float64)
     sprof = read_profile() if rank == 0 else None
     lib.owc_gemm_profile_enable(ctx, 0)
     if dist is not None:

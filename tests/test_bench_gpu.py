@@ -1,0 +1,39 @@
+"""bench.py's N > 1 code path on real hardware.
+
+An 8-GPU node is the driver's to launch; a gpurun box has ONE GPU.  The test hook OWC_BENCH_SHARE_GPU=1 (bench.py) puts both ranks
+of a --gpus 2 run on cuda:0 with gloo collectives (RCCL refuses two ranks on one device), so that everything after the rendezvous
+- per-rank weights and inputs, the barrier-bracketed timed region, the gather of per-rank times, max-over-ranks, the whole-job
+value, the scorer / PCIe legs' reductions and rank 0's JSON line - runs on the HIP engine exactly as it will with 8 ranks.
+"""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_two_ranks_share_one_gpu(gpu):
+    env = dict(os.environ, OWC_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--model", "2b", "--batch", "64", "--steps", "2", "--warmup", "1",
+           "--scorer-labels", "4096", "--no-cpu-baseline", "--no-pil-leg"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout       # rank 0 prints ONE line, rank 1 none
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["images_per_gpu_per_step"] == 64 and out["config"]["parallelism"] == "dp2" and out["rccl_world_size"] == 2
+    # whole-job value = both ranks' images over the max-over-ranks time
+    assert abs(out["value"] - 128 / (out["ms_per_step"] / 1e3)) <= 1e-3 * out["value"]
+    assert len(out["per_rank_images_per_s"]) == 2 and all(v > 0 for v in out["per_rank_images_per_s"])
+    assert out["value"] <= sum(out["per_rank_images_per_s"]) * (1 + 1e-6)
+    assert out["batch_invariance_check"].startswith("ok")
+    assert out["roofline"]["launches"] > 0 and 0 < out["roofline"]["frac"] < 1     # rank 0's launches only
+    assert out["label_cosine_per_sec"] > 0 and out["images_per_s_from_host_uint8"] > 0
