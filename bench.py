@@ -265,6 +265,8 @@ def main() -> None:
                     help="run the model's nominal forward: full last prefill layer on every row and no shared-prefix segment "
                          "(same tokens bit for bit; shows what the two dead-work eliminations are worth)")
     ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
+                    help="owc_tuning_set(KNOB, VALUE) before anything runs (A-B experiments; recorded in config.tuning)")
     ap.add_argument("--dry-run", action="store_true", help="launcher + rendezvous check on CPU (gloo); stops before HIP init")
     ap.add_argument("--one-gpu-value", type=float, default=None,
                     help="images/s of the 1-GPU run: adds scaling_efficiency = value / (N * this) to the line")
@@ -306,6 +308,9 @@ def main() -> None:
             owc_build.build(verbose=False)
     if dist is not None:
         dist.barrier()
+    for kv in args.tune:
+        name, val = kv.split("=")
+        _lib.check(_lib.load().owc_tuning_set(name.encode(), int(val)), 0)
     from lmms_owc_amd.engine.qwen2vl import DIMS, Qwen2VLEngine, Qwen2VLWeights
     from lmms_owc_amd.engine.scorer import MINILM_L6, BertWeights, SentenceScorer
 
@@ -455,7 +460,8 @@ def main() -> None:
             "config": {"workload": f"Qwen2-VL-{args.model.upper()}{' (fp8 decoder)' if fp8_run else ''} open-world classify: {B} synthetic 448x448 images per GPU per step "
                                    f"(1024 patches -> 256 image tokens), prompt S=286, {T} forced greedy tokens, seeded random "
                                    "weights of the real architecture; images strided across ranks, no data-path collective",
-                       "images_per_gpu_per_step": B, "prompt_tokens": 286, "new_tokens": T, "parallelism": f"dp{world}"},
+                       "images_per_gpu_per_step": B, "prompt_tokens": 286, "new_tokens": T, "parallelism": f"dp{world}",
+                       **({"tuning": args.tune} if args.tune else {})},
             "per_rank_images_per_s": [B * args.steps / t for t in per_rank_dt],
             "rccl_world_size": dist.get_world_size() if dist is not None else 1,
             "batch_invariance_check": "ok: image 0's tokens inside the batch == the same image run alone" if invariant else

@@ -190,6 +190,25 @@ def check(rc: int, device: int = 0) -> None:
         raise OwcError(f"libowc_hip status {rc}: {msg.decode() if msg else '?'}")
 
 
+def h2d(a, device, dtype=None) -> "torch.Tensor":
+    """Host array (numpy, or a CPU tensor in pageable memory) -> device tensor, asynchronously on the current stream and SAFELY.
+
+    `torch.from_numpy(tmp).to(device, non_blocking=True)` is neither: from pageable memory the runtime may read the source after
+    the call returned, and a temporary's bytes are recycled by the next numpy allocation - the device then receives whatever the
+    host wrote there later (seen as a batch-invariance failure only when a second process delayed the copy queue).  Here the bytes
+    are first copied into a block of torch's caching PINNED-host allocator; the non_blocking copy records an event for that block,
+    and the allocator does not hand it out again before the event has passed, so the temporary can be dropped at once.  No host
+    synchronisation, so the launch thread keeps running ahead of the GPU."""
+    import numpy as np
+
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=dtype))
+    if t.numel() == 0:
+        return torch.empty(t.shape, dtype=t.dtype, device=device)
+    if not t.is_pinned():
+        t = t.contiguous().pin_memory()
+    return t.to(device, non_blocking=True)
+
+
 def stream_ptr() -> int:
     import torch
 

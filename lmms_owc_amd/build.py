@@ -9,9 +9,11 @@ from __future__ import annotations
 import concurrent.futures as cf
 import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
+import tempfile
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
@@ -50,6 +52,48 @@ def _digest(src: Path) -> str:
     return h.hexdigest()
 
 
+# Instruction forms that must not ship (checked on the disassembly of every object, see _lint):
+#  * packed fp32 multiply / add / fma whose LOW result takes src0's low and src1's HIGH half (`op_sel:[0,1...]`): on gfx950 the low
+#    result is wrong in lanes 48-63 whenever another wave of the SIMD is executing MFMAs (measured: tools/probes/probe_load_after_mfma.hip,
+#    0.03 % of executions under a dense MFMA burst, never with one wave per SIMD or without MFMAs; the other op_sel forms the kernels use
+#    were measured clean).  The compiler's SLP vectoriser forms it from scalar code (it did in the fused RoPE epilogue), so this is a
+#    property of the OBJECT, not of the source.
+FORBIDDEN_ISA = [(re.compile(r"\bv_pk_(?:mul|add|fma)_f32\b.*\bop_sel:\[0,1[\],]"), "packed fp32 op with op_sel:[0,1] (gfx950: wrong low result in lanes 48-63 beside MFMAs)")]
+
+
+def _objdump() -> str:
+    for cand in (Path(_hipcc()).resolve().parent.parent / "lib" / "llvm" / "bin" / "llvm-objdump", Path("/opt/rocm/lib/llvm/bin/llvm-objdump")):
+        if cand.exists():
+            return str(cand)
+    w = shutil.which("llvm-objdump")
+    if w:
+        return w
+    raise RuntimeError("llvm-objdump not found: the objects cannot be checked for forbidden instruction forms")
+
+
+def _lint(obj: Path, has_kernels: bool) -> None:
+    """Disassemble the gfx950 code object inside `obj` and refuse FORBIDDEN_ISA."""
+    with tempfile.TemporaryDirectory() as td:
+        tmp = Path(td) / obj.name
+        shutil.copy(obj, tmp)
+        subprocess.run([_objdump(), "--offloading", str(tmp)], capture_output=True, text=True, check=True)
+        cos = [f for f in Path(td).iterdir() if "amdgcn" in f.name]
+        if not cos:
+            if has_kernels:
+                raise RuntimeError(f"{obj.name}: no gfx950 code object found inside the object file")
+            return   # a host-only translation unit (api.hip, the model drivers)
+        text = subprocess.run([_objdump(), "-d", str(cos[0])], capture_output=True, text=True, check=True).stdout
+    fn, hits = "?", []
+    for line in text.splitlines():
+        if line.endswith(">:"):
+            fn = line.split("<")[-1][:-2]
+        for rx, why in FORBIDDEN_ISA:
+            if rx.search(line):
+                hits.append(f"{fn}: {line.strip()}  <- {why}")
+    if hits:
+        raise RuntimeError(f"{obj.name} contains {len(hits)} forbidden instruction(s):\n  " + "\n  ".join(hits[:8]))
+
+
 def _compile(src: Path, force: bool) -> Path:
     obj = OBJ / (src.stem + ".o")
     stamp = OBJ / (src.stem + ".sha")
@@ -60,6 +104,7 @@ def _compile(src: Path, force: bool) -> Path:
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src.name}:\n{res.stdout}\n{res.stderr}")
+    _lint(obj, "__global__" in src.read_text())
     stamp.write_text(dig)
     return obj
 

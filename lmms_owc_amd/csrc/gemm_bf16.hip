@@ -44,7 +44,8 @@ GemmProfile g_prof;
 int g_gemm_dbg = 0;       // timing-experiment knob (OWC_GEMM_DBG / owc_tuning_set "gemm_dbg"), results are garbage unless 0 or 512:
                           // 1 no DMA, 2 DMA re-reads K-tiles 0/1 (all L2 hits), 4 no epilogue, 512 direct (un-staged) epilogue stores,
                           // 2048 no per-K-tile barrier, 4096 no DMA wait at the barrier
-int g_skinny_max_m = 64;   // M at and below which the weight-streaming skinny kernel runs (0 disables: A-B knob "gemm_skinny_max_m")
+int g_skinny_max_m = 32;   // M at and below which the weight-streaming skinny kernel runs (0 disables: A-B knob "gemm_skinny_max_m"; up to 64 is legal):
+                           // measured on the 7B decode step, ms: M = 33 6.4 skinny / 6.9 64x64 tiles, 40 7.0 / 6.7, 48 7.5 / 6.9, 64 9.8 / 6.6
 int g_mid_max_tiles = 256;  // fewer 128x128 tiles than this -> 64x64 tiles (0 disables: A-B knob "gemm_mid_max_tiles")
 int g_big_min_tiles = 192;  // fewer 256x256 tiles than this -> use the 128x128 kernel
 int g_pingpong = 1;       // 256x256 launches with K % 128 == 0 use the ping-pong kernel (A-B knob "gemm_pingpong", 0 = lock-step kernel)
@@ -157,20 +158,25 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
 
 
 // ------------------------------------------------------------------------------------------------
-// 64x64x64 variant for the in-between shapes (M above the skinny kernel's 64 rows but too few 128x128 tiles to occupy the 256
-// CUs: decode at batch 65-512, the prefill of a single prompt).  4 waves, wave w owns rows [16w, 16w+16) x all 64 columns (one m
-// tile x four n tiles, so the shared epilogue applies with MT = 1); 32 KiB of LDS per block, five blocks per CU.  Same ascending
-// K accumulation chain as every other kernel here (bit-identical results), K tails from the zero page.
+// 64x64x64 variant for the in-between shapes (M above the skinny kernel's rows but too few 128x128 tiles to occupy the 256 CUs:
+// decode at batch 33-512, the prefill of a single prompt).  4 waves, wave w owns rows [16w, 16w+16) x all 64 columns (one m tile x
+// four n tiles, so the shared epilogue applies with MT = 1).  These launches are weight streams with ONE block per CU or less (the
+// o / down projections of the 7B decoder are 56 x M/64 tiles), so what matters is bytes in flight per block: a ring of NS64 = 4
+// stages of 16 KiB (LDS-DMA), three of them in flight behind a counted vmcnt, ONE raw barrier per K-tile (round 1: two stages and a
+// __syncthreads, i.e. vmcnt(0), per K-tile: 16 KiB in flight, 0.65 TB/s on the 7B down projection at batch 256).  Same ascending K
+// accumulation chain as every other kernel here (bit-identical results), K tails from the zero page.
 // ------------------------------------------------------------------------------------------------
 constexpr int B64 = 64;
 constexpr int TILE64_BYTES = B64 * BK * 2;  // 8 KiB per operand tile
+// stages (A + W tile each): 4 (64 KiB, two blocks per CU) unless the launch has more blocks than 2 per CU and at most 3 per CU, where
+// 3 stages (48 KiB) keep it to one round (the 7B gate/up projection at M <= 64 is 592 blocks)
 
-template <int EPI>
+template <int EPI, int NS64>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
     const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
     const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv,
     long ldc, int M, int N, int K, const void* __restrict__ zeros, int tiles_m, int tiles_n, owc_gemm_aux aux) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];  // [buf][A|W][64 rows][128 B]
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // [stage][A|W][64 rows][128 B]
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
@@ -198,6 +204,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
     wsrc[j] = (const char*)(W + (long)min(n0 + row, N - 1) * ldw + c * 8);
   }
   const int nk = (K + BK - 1) / BK;
+  // always 4 LDS-DMA instructions per wave and stage, also past the end of K (zero page: an L2 hit nobody reads), so that the
+  // counted waits below hold on every iteration
   auto stage = [&](int buf, int kt) {
     char* la = lds + buf * (2 * TILE64_BYTES) + w * 2048;
     char* lw = la + TILE64_BYTES;
@@ -217,12 +225,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
   f32x4 acc[4][1];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  stage(0, 0);
-  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NS64 - 1; ++i) stage(i, i);
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* la = lds + cur * (2 * TILE64_BYTES);
+    // this wave's pieces of stage kt have landed (the 4 * (NS64 - 2) newer ones may fly); the barrier publishes everybody's and
+    // tells that every wave is done reading stage kt - 1, whose slot the next DMA overwrites
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (NS64 - 2)) : "memory");
+    stage((kt + NS64 - 1) % NS64, kt + NS64 - 1);
+    const char* la = lds + (kt % NS64) * (2 * TILE64_BYTES);
     const char* lw = la + TILE64_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -233,8 +243,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa, acc[nt][0], 0, 0, 0);
     }
-    __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued zero-page pieces, before the block's LDS goes away
   gemm_epilogue<EPI, 1>(acc, m0 + w * 16, n0, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
 }
 
@@ -791,6 +801,8 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<EPI>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_bf16_nt_64_kernel<EPI, 4>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * TILE64_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<EPI>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_kernel<EPI>,
@@ -813,9 +825,14 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
                        (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, g_gemm_dbg, aux);
   else if (g_mid_max_tiles > 0 && tiles_m * tiles_n < g_mid_max_tiles) {  // too few 128x128 tiles for 256 CUs: 64x64 tiles
     const int tm64 = (M + B64 - 1) / B64, tn64 = (N + B64 - 1) / B64;
-    hipLaunchKernelGGL(gemm_bf16_nt_64_kernel<EPI>, dim3(tm64 * tn64), dim3(256), 4 * TILE64_BYTES, s,
-                       (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
-                       (const bf16_t*)R, ldr, C, ldc, M, N, K, zeros, tm64, tn64, aux);
+    if (tm64 * tn64 > 512 && tm64 * tn64 <= 768)
+      hipLaunchKernelGGL((gemm_bf16_nt_64_kernel<EPI, 3>), dim3(tm64 * tn64), dim3(256), 3 * 2 * TILE64_BYTES, s,
+                         (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
+                         (const bf16_t*)R, ldr, C, ldc, M, N, K, zeros, tm64, tn64, aux);
+    else
+      hipLaunchKernelGGL((gemm_bf16_nt_64_kernel<EPI, 4>), dim3(tm64 * tn64), dim3(256), 4 * 2 * TILE64_BYTES, s,
+                         (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
+                         (const bf16_t*)R, ldr, C, ldc, M, N, K, zeros, tm64, tn64, aux);
   } else
     hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
@@ -922,5 +939,5 @@ int owc_gemm_profile_collect(double* total_ms, double* total_flops, long* launch
 void owc_gemm_set_big_min_m(int m) { g_big_min_m = m; }
 void owc_gemm_set_dbg(int v) { g_gemm_dbg = v; }
 void owc_gemm_set_mid_max_tiles(int v) { g_mid_max_tiles = v; }
-void owc_gemm_set_skinny_max_m(int v) { g_skinny_max_m = v; }
+void owc_gemm_set_skinny_max_m(int v) { g_skinny_max_m = v < 0 ? 32 : v; }  // negative: back to the default
 void owc_gemm_set_pingpong(int v) { g_pingpong = v; }

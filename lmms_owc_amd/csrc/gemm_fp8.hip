@@ -688,7 +688,7 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
 
 }  // namespace
 
-void owc_gemm_fp8_set_skinny_max_m(int v) { g_fp8_skinny_max_m = v; }
+void owc_gemm_fp8_set_skinny_max_m(int v) { g_fp8_skinny_max_m = v < 0 ? 64 : v; }  // negative: back to the default
 void owc_gemm_fp8_set_pingpong(int v) { g_fp8_pingpong = v; }
 void owc_gemm_fp8_set_mid_max_tiles(int v) { g_fp8_mid_max_tiles = v ? 128 : 0; }
 

@@ -304,7 +304,7 @@ class Qwen2VLEngine:
         return self._ws
 
     def _i32(self, a) -> torch.Tensor:
-        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.device, non_blocking=True)
+        return _lib.h2d(a, self.device, np.int32)
 
     # -- vision tower ------------------------------------------------------------------
     def encode_images(self, pixel_values: torch.Tensor, grid_thw) -> torch.Tensor:

@@ -124,7 +124,7 @@ class SentenceScorer:
             tok_ids = np.ascontiguousarray(ids_h[i0:i1][m], dtype=np.int32)
             tok_pos = np.ascontiguousarray(np.broadcast_to(np.arange(L, dtype=np.int32), m.shape)[m])
             seq_start = np.concatenate([[0], np.cumsum(lens[i0:i1])]).astype(np.int32)
-            d_ids, d_pos, d_start = (torch.from_numpy(a).to(self.device, non_blocking=True) for a in (tok_ids, tok_pos, seq_start))
+            d_ids, d_pos, d_start = (_lib.h2d(a, self.device) for a in (tok_ids, tok_pos, seq_start))
             nb = self._lib.owc_bert_packed_workspace_bytes(C.byref(self.w.c), T)
             if self._ws is None or self._ws.numel() < nb:
                 self._ws = None

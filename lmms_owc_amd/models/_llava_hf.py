@@ -18,7 +18,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from .. import utils
+from .. import _lib, utils
 from ..engine.llava import DIMS, NEXT_PINPOINTS, LlavaDims, LlavaEngine, LlavaWeights
 from . import imageproc
 from ._api import register_model
@@ -214,7 +214,7 @@ class LLaVA(Model):
             sizes = [p[1] for p in prepared]
             feats, rows = None, []
             if prepared:
-                u8 = torch.from_numpy(np.concatenate([p[0] for p in prepared])).to(self._device, non_blocking=True)
+                u8 = _lib.h2d(np.concatenate([p[0] for p in prepared]), self._device)
                 feats = eng.encode_views(eng.patchify(u8, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD))
                 rows = eng.feature_rows(views_per_image, sizes)
             prompts, rows_per_prompt, cur = [], [], 0

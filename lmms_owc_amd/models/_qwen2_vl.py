@@ -15,7 +15,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from .. import ops, utils
+from .. import _lib, ops, utils
 from ..engine.qwen2vl import DIMS, Qwen2VLDims, Qwen2VLEngine, Qwen2VLWeights
 from . import imageproc
 from ._api import register_model
@@ -444,7 +444,7 @@ class Qwen2VL(Model):
         r0 = 0
         for g in groups:
             n = g.shape[0] * (g.shape[2] // 14) * (g.shape[3] // 14)
-            ops.patchify_u8(g.to(self._device, non_blocking=True), imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD,
+            ops.patchify_u8(_lib.h2d(g, self._device), imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD,
                             out=pix[r0:r0 + n])
             r0 += n
         return pix

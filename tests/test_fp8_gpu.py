@@ -123,7 +123,7 @@ def test_gemm_fp8_skinny_kernel(gpu, m, epi):
     try:
         tiled = run(xq, xs, r)
     finally:
-        lib.owc_tuning_set(b"gemm_skinny_max_m", 64)
+        lib.owc_tuning_set(b"gemm_skinny_max_m", -1)
     assert torch.equal(out, tiled)
     assert torch.equal(run(xq[:1], xs[:1], None if r is None else r[:1])[0], out[0])
     if epi == "bias":

@@ -7,6 +7,7 @@ from oracle import np_ops
 from tests.util import assert_bf16_close, bf16_randn, to_np
 
 pytestmark = pytest.mark.gpu
+SKINNY_MAX_M = -1   # "gemm_skinny_max_m" < 0 restores the library's defaults (tests that move the knob put it back)
 
 SHAPES = [
     # (M, N, K): ragged M / N, K tails (K % 64 != 0), patch-embed K = 1176
@@ -164,6 +165,7 @@ def test_gemm_skinny_kernel(gpu, m, epi):
         else:
             run = lambda x: ops.gemm_bf16(x, w, b)  # noqa: E731
             want, atol = y, 1e-4
+    lib.owc_tuning_set(b"gemm_skinny_max_m", 64)   # every MT variant of the kernel, whatever the dispatch default is
     out = to_np(run(a))
     assert_bf16_close(out, want, ulps=4.0, min_exact=0.80, atol=atol)
     # the tiled kernel on the same operands (skinny kernel switched off)
@@ -171,7 +173,7 @@ def test_gemm_skinny_kernel(gpu, m, epi):
     try:
         tiled = to_np(run(a))
     finally:
-        lib.owc_tuning_set(b"gemm_skinny_max_m", 64)
+        lib.owc_tuning_set(b"gemm_skinny_max_m", SKINNY_MAX_M)
     assert np.array_equal(out, tiled)
     # row 0 alone gives the same bits as row 0 inside the batch
     assert np.array_equal(to_np(run(a[:1]))[0], out[0])
@@ -197,6 +199,39 @@ def test_gemm_mid_kernel_bit_identical_to_128_tiles(gpu, m, n, k):
     for x, y in zip(*outs):
         assert torch.equal(x, y)
     assert_bf16_close(to_np(outs[0][0]), _oracle(a, w, b), atol=1e-4)
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(256, 3584, 18944, "residual"), (64, 4736, 3584, "swiglu"), (130, 512, 128, "none"),
+                                       (70, 264, 64, "none"), (300, 1216, 1176, "quick_gelu"), (512, 3584, 3584, "residual")])
+def test_gemm_mid_kernel_race_screen(gpu, m, n, k, epi):
+    """The 64x64 kernel's 4-stage LDS-DMA ring (counted vmcnt + one raw barrier per K-tile are its only ordering) against the
+    128x128 kernel on the same operands, 20 times per shape: 296 K-tiles (the 7B down projection at decode batch 256), fewer K-tiles
+    than stages (1 and 2: the over-issued zero-page pieces), a ragged K tail, ragged M / N, SwiGLU.  Bit-identical every time."""
+    from lmms_owc_amd import _lib, ops
+
+    lib = _lib.load()
+    a = bf16_randn((m, k), 80 + (m % 97), device=gpu)
+    w = bf16_randn((n, k), 81, 0.05, device=gpu)
+    b = bf16_randn((n,), 82, device=gpu)
+    r = bf16_randn((m, n), 83, device=gpu)
+    E = {"none": _lib.EPI_NONE, "residual": _lib.EPI_RESIDUAL, "swiglu": _lib.EPI_SWIGLU, "quick_gelu": _lib.EPI_QUICK_GELU}[epi]
+
+    def run():
+        if epi == "swiglu":
+            return ops.gemm_bf16(a, w, None, epilogue=E)
+        return ops.gemm_bf16(a, w, b, epilogue=E, residual=r if epi == "residual" else None)
+
+    lib.owc_tuning_set(b"gemm_skinny_max_m", 0)
+    try:
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 0)
+        want = run()
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 1 << 30)
+        for i in range(20):
+            got = run()
+            assert torch.equal(got, want), (i, (got != want).sum().item())
+    finally:
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 256)
+        lib.owc_tuning_set(b"gemm_skinny_max_m", SKINNY_MAX_M)
 
 
 @pytest.mark.parametrize("m,n,k,epi", [(4096, 4096, 4096, "none"), (2048, 37888, 3584, "swiglu"), (32768, 1280, 1280, "residual"),

@@ -1,4 +1,5 @@
-"""Per-token decode latency of the 7B decoder at small batch sizes (the reference's default is batch size 1)."""
+"""Per-token decode latency of the 7B decoder at small batch sizes (the reference's default is batch size 1).
+usage: bench_decode_latency.py <model> <batches> [bf16|fp8] [knob=value ...]"""
 import sys
 import time
 from pathlib import Path
@@ -15,6 +16,12 @@ if len(sys.argv) > 3:  # decoder dtype: bf16 | fp8
     import dataclasses
 
     d = dataclasses.replace(d, decoder_dtype=sys.argv[3])
+for kv in sys.argv[4:]:  # knob=value ... (owc_tuning_set)
+    from lmms_owc_amd import _lib
+
+    name, val = kv.split("=")
+    _lib.check(_lib.load().owc_tuning_set(name.encode(), int(val)), 0)
+    print("knob", name, val, flush=True)
 eng = Qwen2VLEngine(Qwen2VLWeights.random(d, dev, seed=1))
 r = np.random.default_rng(0)
 for B in ([int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (1, 4, 16, 64, 256)):

@@ -69,6 +69,37 @@ def main():
         if a.startswith("--set="):
             k, v = a[6:].split("=")
             assert _lib.load().owc_tuning_set(k.encode(), int(v)) == 0, k
+    sweep = next((a[8:] for a in sys.argv[1:] if a.startswith("--sweep=")), None)
+    if sweep:  # --sweep=<knob>:v1,v2,... [--m=<rows>] [prefix]: the values of one knob interleaved in one process, median of 5 rounds
+        lib = _lib.load()
+        knob, vals = sweep.split(":")
+        vals = [int(v) for v in vals.split(",")]
+        only = next((a for a in sys.argv[1:] if not a.startswith("--")), None)
+        m_over = next((int(a[4:]) for a in sys.argv[1:] if a.startswith("--m=")), 0)
+        for name, m, n, k in SHAPES:
+            if only and not name.startswith(only):
+                continue
+            m = m_over or m
+            a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+            w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+            out = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            res = {}
+            for rnd in range(6):
+                for v in vals:
+                    assert lib.owc_tuning_set(knob.encode(), v) == 0
+                    for _ in range(2):
+                        ops.gemm_bf16(a, w, out=out)
+                    e0.record()
+                    for _ in range(10):
+                        ops.gemm_bf16(a, w, out=out)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if rnd:
+                        res.setdefault(v, []).append(e0.elapsed_time(e1) / 10 * 1e3)
+            print(f"{name:18s} M={m:6d} N={n:6d} K={k:6d}  [{knob}] " + "  ".join(
+                f"{v}: {sorted(r)[len(r) // 2]:7.1f} us ({2.0 * m * n * k / sorted(r)[len(r) // 2] / 1e6:6.0f} TF)" for v, r in res.items()), flush=True)
+        return
     if "--dbg" in sys.argv:  # timing experiments (--vals=0,512,4): 0 normal, 1 no DMA, 2 DMA re-reads K-tiles 0/1 (L2 hits), 4 no epilogue, 512 direct epilogue stores
         lib = _lib.load()
         only = next((a for a in sys.argv[1:] if not a.startswith("--")), None)
