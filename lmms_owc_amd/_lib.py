@@ -190,23 +190,33 @@ def check(rc: int, device: int = 0) -> None:
         raise OwcError(f"libowc_hip status {rc}: {msg.decode() if msg else '?'}")
 
 
-def h2d(a, device, dtype=None) -> "torch.Tensor":
-    """Host array (numpy, or a CPU tensor in pageable memory) -> device tensor, asynchronously on the current stream and SAFELY.
+_h2d_pending: list = []   # (event, host tensor) of copies the stream may not have executed yet
 
-    `torch.from_numpy(tmp).to(device, non_blocking=True)` is neither: from pageable memory the runtime may read the source after
-    the call returned, and a temporary's bytes are recycled by the next numpy allocation - the device then receives whatever the
-    host wrote there later (seen as a batch-invariance failure only when a second process delayed the copy queue).  Here the bytes
-    are first copied into a block of torch's caching PINNED-host allocator; the non_blocking copy records an event for that block,
-    and the allocator does not hand it out again before the event has passed, so the temporary can be dropped at once.  No host
-    synchronisation, so the launch thread keeps running ahead of the GPU."""
+
+def h2d(a, device, dtype=None) -> "torch.Tensor":
+    """Host array (numpy, or a CPU tensor) -> device tensor on the current stream, without a host synchronisation and without
+    depending on what the runtime does with pageable memory.
+
+    `torch.from_numpy(tmp).to(device, non_blocking=True)` on a temporary is only safe if the runtime has read the source before the
+    call returns.  ROCm 7.2 does (the call stages the bytes: its host time grows with the size like a memcpy, tools/bench_h2d.py), but
+    nothing here should hinge on that: the source tensor - and through it the numpy buffer - is kept referenced until an event
+    recorded behind the copy has passed, so its bytes can be neither freed nor recycled earlier.  (Going through torch's pinned-host
+    cache instead costs 0.3-0.4 ms per MB on this platform - writes into pinned memory are slow - and took the label-cosine leg from
+    670 k to 215 k labels/s.)"""
     import numpy as np
 
     t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=dtype))
     if t.numel() == 0:
         return torch.empty(t.shape, dtype=t.dtype, device=device)
-    if not t.is_pinned():
-        t = t.contiguous().pin_memory()
-    return t.to(device, non_blocking=True)
+    t = t.contiguous()
+    out = t.to(device, non_blocking=True)
+    with _lock:
+        while _h2d_pending and _h2d_pending[0][0].query():
+            _h2d_pending.pop(0)
+        ev = torch.cuda.Event()
+        ev.record()
+        _h2d_pending.append((ev, t))
+    return out
 
 
 def stream_ptr() -> int:

@@ -14,3 +14,8 @@ run "8 v_pk_fma_f32 op_sel_hi:[1,0,0]" $B '-DFIRST_USE="v_pk_fma_f32 %1, %0, %4,
 run "9 v_pk_add_f32 op_sel:[0,1] op_sel_hi:[0,0]" $B '-DFIRST_USE="v_pk_add_f32 %1, %0, %4 op_sel:[0,1] op_sel_hi:[0,0]"' '-DWANT_LO=(want+5.0f)' '-DWANT_HI=(want+3.0f)'
 run "10 v_pk_mul_f32 op_sel:[0,1] (hi default)" $B '-DFIRST_USE="v_pk_mul_f32 %1, %0, %4 op_sel:[0,1]"' '-DWANT_LO=(want*5.0f)' '-DWANT_HI=((want+0.25f)*5.0f)'
 run "11 v_pk_mul_f32 op_sel:[1,0]" $B '-DFIRST_USE="v_pk_mul_f32 %1, %0, %4 op_sel:[1,0]"' '-DWANT_LO=((want+0.25f)*3.0f)' '-DWANT_HI=((want+0.25f)*5.0f)'
+for g in "s_nop 3" "s_nop 15" "v_nop\\n\\tv_nop"; do
+  run "form 5 after a gap of [$g] behind the s_waitcnt" $B "-DGAP=\"$g\\n\\t\""
+done
+echo "-- form 5 with ONE block (one wave per SIMD) per CU:"; $B 2>/dev/null && /tmp/probe_load 40 160000 | sed 's/.*wrong by lane quarter 0..3 //; s/| copy.*//'
+echo "-- form 5 without MFMAs:"; /tmp/probe_load 0 0 | sed 's/.*wrong by lane quarter 0..3 //; s/| copy.*//'
