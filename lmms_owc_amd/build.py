@@ -53,12 +53,13 @@ def _digest(src: Path) -> str:
 
 
 # Instruction forms that must not ship (checked on the disassembly of every object, see _lint):
-#  * packed fp32 multiply / add / fma whose LOW result takes src0's low and src1's HIGH half (`op_sel:[0,1...]`): on gfx950 the low
-#    result is wrong in lanes 48-63 whenever another wave of the SIMD is executing MFMAs (measured: tools/probes/probe_load_after_mfma.hip,
+#  * packed fp32 multiply / add / fma whose LOW result takes src0's low half and the HIGH half of src1 or src2 (`op_sel:[0,1]`,
+#    `[0,1,x]`, `[0,0,1]`): on gfx950 the low result is wrong in lanes 48-63 whenever another wave of the SIMD is executing MFMAs (measured: tools/probes/probe_load_after_mfma.hip,
 #    0.03 % of executions under a dense MFMA burst, never with one wave per SIMD or without MFMAs; the other op_sel forms the kernels use
 #    were measured clean).  The compiler's SLP vectoriser forms it from scalar code (it did in the fused RoPE epilogue), so this is a
 #    property of the OBJECT, not of the source.
-FORBIDDEN_ISA = [(re.compile(r"\bv_pk_(?:mul|add|fma)_f32\b.*\bop_sel:\[0,1[\],]"), "packed fp32 op with op_sel:[0,1] (gfx950: wrong low result in lanes 48-63 beside MFMAs)")]
+FORBIDDEN_ISA = [(re.compile(r"\bv_pk_(?:mul|add|fma)_f32\b.*\bop_sel:\[0(?:,0)*,1"),
+                  "packed fp32 op with op_sel:[0,..,1] (gfx950: wrong low result in lanes 48-63 beside MFMAs)")]
 
 
 def _objdump() -> str:

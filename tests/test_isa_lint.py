@@ -31,9 +31,16 @@ def _obj(tmp_path: Path, name: str, text: str) -> Path:
     return obj
 
 
+FMA = BAD.replace("f32x2* o) {", "f32x2* o) {\n  f32x2 zz = o[threadIdx.x];").replace(
+    'v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0]" : "=v"(r) : "v"(x), "v"(y)',
+    'v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1]" : "=v"(r) : "v"(x), "v"(y), "v"(zz)')
+
+
 def test_lint_rejects_the_forbidden_form_and_accepts_its_neighbour(tmp_path):
     with pytest.raises(RuntimeError, match=r"op_sel:\[0,1\]"):
         owc_build._lint(_obj(tmp_path, "bad", BAD), True)
+    with pytest.raises(RuntimeError, match=r"op_sel:\[0,0,1\]"):
+        owc_build._lint(_obj(tmp_path, "fma", FMA), True)     # src2's high half for the low result: measured wrong as well
     owc_build._lint(_obj(tmp_path, "good", GOOD), True)   # the broadcast form the kernels do use (measured clean)
 
 
