@@ -16,13 +16,15 @@ if len(sys.argv) > 3:  # decoder dtype: bf16 | fp8
     import dataclasses
 
     d = dataclasses.replace(d, decoder_dtype=sys.argv[3])
-for kv in sys.argv[4:]:  # knob=value ... (owc_tuning_set)
+for kv in [a for a in sys.argv[4:] if "=" in a]:  # knob=value ... (owc_tuning_set); the word "graph" turns the hipGraph decode on
     from lmms_owc_amd import _lib
 
     name, val = kv.split("=")
     _lib.check(_lib.load().owc_tuning_set(name.encode(), int(val)), 0)
     print("knob", name, val, flush=True)
-eng = Qwen2VLEngine(Qwen2VLWeights.random(d, dev, seed=1))
+graph = any(a == "graph" for a in sys.argv[4:])
+eng = Qwen2VLEngine(Qwen2VLWeights.random(d, dev, seed=1), graph_decode=graph)
+print("graph_decode", graph, flush=True)
 r = np.random.default_rng(0)
 for B in ([int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (1, 4, 16, 64, 256)):
     prompts = [r.integers(1000, 30000, 286).astype(np.int32) for _ in range(B)]
