@@ -42,7 +42,7 @@ struct GemmProfile {
 };
 GemmProfile g_prof;
 int g_gemm_dbg = 0;       // timing-experiment knob (OWC_GEMM_DBG / owc_tuning_set "gemm_dbg"), results are garbage unless 0 or 512:
-                          // 1 no DMA, 2 DMA re-reads K-tiles 0/1 (all L2 hits), 4 no epilogue, 512 direct (un-staged) epilogue stores,
+                          // 1 no DMA, 2 DMA re-reads K-tiles 0/1 (all L2 hits), 4 no epilogue, 512 direct (un-staged) epilogue stores, 1024 streaming C stores (results unchanged),
                           // 2048 no per-K-tile barrier, 4096 no DMA wait at the barrier
 int g_skinny_max_m = 32;   // M at and below which the weight-streaming skinny kernel runs (0 disables: A-B knob "gemm_skinny_max_m"; up to 64 is legal):
                            // measured on the 7B decode step, ms: M = 33 6.4 skinny / 6.9 64x64 tiles, 40 7.0 / 6.7, 48 7.5 / 6.9, 64 9.8 / 6.6
@@ -654,8 +654,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
     gemm_epilogue<EPI, 8>(acc, m0 + wr * 128, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux, lds, CCOLS * 2,
                           wr * 128, wc * 64);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    store_ctile<8>(lds, BT, CCOLS, (bf16_t*)Cv, ldc, m0, EPI == OWC_EPI_SWIGLU ? (n0 >> 1) : n0, M,
-                   EPI == OWC_EPI_SWIGLU ? (N >> 1) : N, w, l);
+    if (dbg & 1024)   // streaming (non-temporal) C stores: set by launch() for outputs far larger than the caches
+      store_ctile<8, true>(lds, BT, CCOLS, (bf16_t*)Cv, ldc, m0, EPI == OWC_EPI_SWIGLU ? (n0 >> 1) : n0, M,
+                           EPI == OWC_EPI_SWIGLU ? (N >> 1) : N, w, l);
+    else
+      store_ctile<8>(lds, BT, CCOLS, (bf16_t*)Cv, ldc, m0, EPI == OWC_EPI_SWIGLU ? (n0 >> 1) : n0, M,
+                     EPI == OWC_EPI_SWIGLU ? (N >> 1) : N, w, l);
   }
 }
 
@@ -815,10 +819,15 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
     owc_gemm_profile_end(prof, s);
     return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
   }
-  if (big && g_pingpong && (K % (2 * BK)) == 0)
+  if (big && g_pingpong && (K % (2 * BK)) == 0) {
+    // C far larger than L2 + Infinity Cache (256 MB): stream it out (`global_store ... nt`) instead of evicting the operand panels the
+    // XCD's L2 is sharing: +0.3...3 % per launch on the path's shapes (vit.proj 1154 -> 1192 TFLOP/s, gate/up 1459 -> 1480), never
+    // slower; a small C (decode steps) stays cacheable for the kernel that reads it next
+    const int flags = g_gemm_dbg | ((size_t)M * (size_t)N * 2 > ((size_t)512 << 20) ? 1024 : 0);
     hipLaunchKernelGGL(gemm_bf16_nt_256pp_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), 2 * STAGE_BYTES, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
-                       (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, g_gemm_dbg, aux);
+                       (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, flags, aux);
+  }
   else if (big)
     hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), 2 * STAGE_BYTES, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,

@@ -163,7 +163,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
 
 // Second half of the LDS-staged epilogue: the block's output tile (rows x cols bf16, pitch = cols * 2 bytes) leaves LDS as
 // whole rows - a wave-instruction covers 64 lanes x 16 B = 1 KiB of consecutive row segments.
-template <int WAVES>
+template <int WAVES, bool NT = false>
 __device__ __forceinline__ void store_ctile(const char* ctile, int rows, int cols, bf16_t* C, long ldc, int m0, int n0,
                                             int M, int Ncols, int w, int l) {
   const int lpr = cols >> 3;            // lanes per row (16-byte chunks)
@@ -176,7 +176,10 @@ __device__ __forceinline__ void store_ctile(const char* ctile, int rows, int col
   for (int it = 0; it < rows_per_wave / rpi; ++it) {
     const int r = w * rows_per_wave + it * rpi + r_in;
     const bf16x8 v = *(const bf16x8*)(ctile + r * (cols * 2) + ((c ^ (r & 7)) << 4));
-    if (m0 + r < M && n < Ncols) *(bf16x8*)(C + (long)(m0 + r) * ldc + n) = v;
+    if (m0 + r < M && n < Ncols) {
+      if constexpr (NT) __builtin_nontemporal_store(v, (bf16x8*)(C + (long)(m0 + r) * ldc + n));
+      else *(bf16x8*)(C + (long)(m0 + r) * ldc + n) = v;
+    }
   }
 }
 
