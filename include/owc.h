@@ -56,7 +56,7 @@ int owc_init(int device, owc_ctx** out);
 int owc_destroy(owc_ctx* ctx);
 const char* owc_last_error(const owc_ctx* ctx);
 /* A-B / tuning knobs (process-wide; the same switches owc_init reads from the environment):
- * "gemm_big_min_m" (OWC_GEMM_BIG_MIN_M), "gemm_skinny_max_m" (0 disables the weight-streaming small-M kernel, a negative value restores the defaults), "gemm_mid_max_tiles"
+ * "gemm_big_min_m" (OWC_GEMM_BIG_MIN_M), "gemm_big_min_tiles" (fewest 256x256 tiles for which the 256x256 kernels run; negative = default 144), "gemm_skinny_max_m" (0 disables the weight-streaming small-M kernel, a negative value restores the defaults), "gemm_mid_max_tiles"
  * (0 disables the 64x64-tile kernel), "gemm_dbg"
  * (OWC_GEMM_DBG), "attn_dbg" (OWC_ATTN_DBG), "gemm_pingpong" (0: the lock-step 256x256 kernels, 1 = default: bf16 ping-pong
  * kernel, 2: the fp8 ping-pong kernel too), "prefill_prune_last" (0: owc_llm_prefill runs the last layer's attention / o-proj /

@@ -29,6 +29,7 @@ int owc_tuning_set(const char* name, int value) {
     owc_gemm_fp8_set_skinny_max_m(value);
   }
   else if (!strcmp(name, "gemm_big_min_m")) owc_gemm_set_big_min_m(value);
+  else if (!strcmp(name, "gemm_big_min_tiles")) owc_gemm_set_big_min_tiles(value);
   else if (!strcmp(name, "gemm_pingpong")) {  // 0: lock-step kernels, 1 (default): bf16 ping-pong, 2: the fp8 ping-pong kernel as well
     owc_gemm_set_pingpong(value != 0);
     owc_gemm_fp8_set_pingpong(value >= 2);

@@ -75,6 +75,7 @@ void owc_gemm_set_big_min_m(int m);
 void owc_gemm_set_dbg(int v);
 void owc_gemm_set_mid_max_tiles(int v);
 void owc_gemm_set_skinny_max_m(int v);
+void owc_gemm_set_big_min_tiles(int v);
 void owc_gemm_set_pingpong(int v);
 void owc_gemm_fp8_set_pingpong(int v);
 void owc_gemm_fp8_set_skinny_max_m(int v);

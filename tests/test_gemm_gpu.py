@@ -19,7 +19,7 @@ SHAPES = [
     (1024, 3840, 1280),
     (513, 2048, 8960),
     (64, 1280, 5120),
-    # >= 192 tiles of 256x256 and K % 64 == 0 -> the 256x256 quadrant-pipelined kernel (full and ragged tiles)
+    # >= 144 tiles of 256x256 and K % 64 == 0 -> the 256x256 quadrant-pipelined kernel (full and ragged tiles)
     (4096, 3072, 1280),
     (4000, 3080, 1344),
     (3700, 4096, 64),
