@@ -49,7 +49,7 @@ int g_skinny_max_m = 32;   // M at and below which the weight-streaming skinny k
 int g_mid_max_tiles = 256;  // fewer 128x128 tiles than this -> 64x64 tiles (0 disables: A-B knob "gemm_mid_max_tiles")
 int g_big_min_tiles = 144;  // fewer 256x256 tiles than this -> use the 128x128 kernel (measured: 160-162 tiles 256x256 +24...40 %, 126 tiles -3...8 %; knob "gemm_big_min_tiles")
 int g_pingpong = 1;       // 256x256 launches with K % 128 == 0 use the ping-pong kernel (A-B knob "gemm_pingpong", 0 = lock-step kernel)
-int g_big_min_m = 1024;  // M at and above which the 256x128 3-stage kernel is used (OWC_GEMM_BIG_MIN_M)
+int g_big_min_m = 256;   // M at and above which the 256x256 kernels may run (OWC_GEMM_BIG_MIN_M / knob "gemm_big_min_m"; round 1: 1024)
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
@@ -797,7 +797,10 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
            long ldr, void* C, long ldc, int M, int N, int K, const void* zeros, hipStream_t s,
            const owc_gemm_aux& aux) {
   // 256x256 tiles need enough of them to fill the 256 CUs (one block per CU); otherwise 128x128 (2 per CU)
-  const bool big = M >= g_big_min_m && N >= BT && (K % BK) == 0 &&
+  // ... and, below 1024 rows, only when padding M to 256 wastes at most an eighth of the tile rows (measured on the 7B gate/up
+  // projection: M = 256 / 512 / 768 135 -> 81 / 198 -> 155 / 255 -> 163 us against the 128x128 kernel, M = 384 138 -> 149 us)
+  const int pad256 = (M + BT - 1) / BT * BT - M;
+  const bool big = M >= g_big_min_m && (M >= 1024 || pad256 * 8 <= M) && N >= BT && (K % BK) == 0 &&
                    (long)((M + BT - 1) / BT) * ((N + BT - 1) / BT) >= g_big_min_tiles;
   const int tiles_m = big ? (M + BT - 1) / BT : (M + BM - 1) / BM;
   const int tiles_n = big ? (N + BT - 1) / BT : (N + BN - 1) / BN;
