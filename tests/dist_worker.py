@@ -54,7 +54,14 @@ class TokenStubModel(StubModel):
 
 def main():
     world = int(os.environ["WORLD_SIZE"])
-    if world > 1:
+    backend = os.environ.get("OWC_TEST_BACKEND", "gloo")   # "nccl" (= RCCL): tests/test_rccl_gpu.py, also with ONE rank
+    if backend == "nccl":
+        import torch
+
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        StubModel.device = f"cuda:{torch.cuda.current_device()}"
+    elif world > 1:
         dist.init_process_group("gloo")
     docs = [{"visual": f"img{i}.jpg", "target": f"class_{i % 4}"} for i in range(11)]
     metrics = [{"metric": "exact_match", "aggregation": "mean", "ignore_case": True, "regexes_to_ignore": [",", "\\$"]},
@@ -75,7 +82,7 @@ def main():
         tracker.save_results_aggregated(results=res, samples=samples, datetime_str=date)
         for name in res["configs"]:
             tracker.save_results_samples(task_name=name, samples=samples[name])
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
