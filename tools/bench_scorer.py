@@ -1,5 +1,5 @@
 """The label-cosine leg alone, swept over the class count (C in {100, 397, 1000, 10000}) and the label count.
-usage: python tools/bench_scorer.py [classes=100,397,1000,10000] [labels=65536]"""
+usage: python tools/bench_scorer.py [classes=100,397,1000,10000] [labels=65536] [knob=value ...]"""
 import sys
 import time
 from pathlib import Path
@@ -11,6 +11,10 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from lmms_owc_amd.engine.scorer import MINILM_L6, BertWeights, SentenceScorer  # noqa: E402
 
 args = dict(a.split("=") for a in sys.argv[1:])
+for k in [k for k in args if k not in ("classes", "labels")]:   # anything else: owc_tuning_set(knob, value), e.g. bert_w3=0
+    from lmms_owc_amd import _lib
+    _lib.check(_lib.load().owc_tuning_set(k.encode(), int(args[k])), 0)
+    print("knob", k, args[k], flush=True)
 classes = [int(c) for c in args.get("classes", "100,397,1000,10000").split(",")]
 n_lab, L = int(args.get("labels", 65536)), 16
 dev = torch.device("cuda:0")
