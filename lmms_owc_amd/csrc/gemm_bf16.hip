@@ -506,17 +506,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
       aoff[h][j] = (unsigned)((long)min(row, M - 1 - m0) * lda * 2 + c * 16);
       woff[h][j] = (unsigned)((long)min(row, N - 1 - n0) * ldw * 2 + c * 16);
     }
+  // The K-tile's base is pinned in SGPRs (opaque to the compiler, which otherwise builds a 64-bit per-lane address with a
+  // v_lshl_add_u64 in front of every LDS-DMA instruction: 24 of them per 128 MFMAs, and vector work beside MFMAs is paid in full -
+  // tools/probes/probe_mfma_valu_overlap.hip): the DMA then takes the scalar-base + 32-bit lane-offset form, 0 VALU per piece.
   auto issue_a = [&](int kt, int h) {  // A half-tile h of K-tile kt -> buffer kt & 1
     char* dst = lds + (kt & 1) * STAGE_BYTES + (128 * h + 16 * w) * 128;
-    const long kb = (long)kt * (BK * 2);
-    glds16(abase + kb + aoff[h][0], dst);
-    glds16(abase + kb + aoff[h][1], dst + 1024);
+    const char* ab = abase + (long)kt * (BK * 2);
+    asm volatile("" : "+s"(ab), "+v"(aoff[h][0]), "+v"(aoff[h][1]));   // the zero-extension must not be hoisted either
+    glds16(ab + aoff[h][0], dst);
+    glds16(ab + aoff[h][1], dst + 1024);
   };
   auto issue_w = [&](int kt, int h) {
     char* dst = lds + (kt & 1) * STAGE_BYTES + OP_BYTES + (128 * h + 16 * w) * 128;
-    const long kb = (long)kt * (BK * 2);
-    glds16(wbase + kb + woff[h][0], dst);
-    glds16(wbase + kb + woff[h][1], dst + 1024);
+    const char* wb = wbase + (long)kt * (BK * 2);
+    asm volatile("" : "+s"(wb), "+v"(woff[h][0]), "+v"(woff[h][1]));
+    glds16(wb + woff[h][0], dst);
+    glds16(wb + woff[h][1], dst + 1024);
   };
 
   const int wr = w >> 2, wc = w & 3;

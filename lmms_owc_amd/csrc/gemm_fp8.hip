@@ -150,20 +150,27 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256_kernel(
     aoff[j] = (unsigned)((long)min(row, M - 1 - m0) * lda + c * 16);
     woff[j] = (unsigned)((long)min(row, N - 1 - n0) * ldw + c * 16);
   }
+  // K-tile bases pinned in SGPRs and the lane offsets kept 32-bit at the point of use: the DMA takes the scalar-base + lane-offset form
+  // instead of a v_lshl_add_u64 per piece (vector work beside MFMAs is paid in full, see gemm_bf16.hip)
   auto stage = [&](int buf, int kt) {
     char* la = lds + buf * STAGE_BYTES + w * 4096;
-    const long kb = (long)kt * BKB;
+    const char* ab = abase + (long)kt * BKB;
+    const char* wb = wbase + (long)kt * BKB;
+    asm volatile("" : "+s"(ab), "+s"(wb));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      glds16(abase + kb + aoff[j], la + j * 1024);
-      glds16(wbase + kb + woff[j], la + OP_BYTES + j * 1024);
+      asm volatile("" : "+v"(aoff[j]), "+v"(woff[j]));
+      glds16(ab + aoff[j], la + j * 1024);
+      glds16(wb + woff[j], la + OP_BYTES + j * 1024);
     }
   };
   auto stage_piece = [&](int buf, int kt, int j) {
     char* la = lds + buf * STAGE_BYTES + w * 4096;
-    const long kb = (long)kt * BKB;
-    glds16(abase + kb + aoff[j], la + j * 1024);
-    glds16(wbase + kb + woff[j], la + OP_BYTES + j * 1024);
+    const char* ab = abase + (long)kt * BKB;
+    const char* wb = wbase + (long)kt * BKB;
+    asm volatile("" : "+s"(ab), "+s"(wb), "+v"(aoff[j]), "+v"(woff[j]));
+    glds16(ab + aoff[j], la + j * 1024);
+    glds16(wb + woff[j], la + OP_BYTES + j * 1024);
   };
 
   const int wr = w >> 2, wc = w & 3;
