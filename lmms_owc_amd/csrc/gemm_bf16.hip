@@ -55,7 +55,9 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 constexpr int GROUP_M = 8;
 
-template <int EPI>
+// KTAIL = false (K % 64 == 0): no per-piece predicate / select, and the LDS-DMA takes the scalar-base + 32-bit lane-offset form (the loop
+// then holds no vector instruction but the MFMAs: vector work beside MFMAs is paid in full, tools/probes/probe_mfma_valu_overlap.hip).
+template <int EPI, bool KTAIL>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
     const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
     const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv,
@@ -96,17 +98,37 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
   }
   const int nk = (K + BK - 1) / BK;
 
+  const char* abase = (const char*)(A + (long)m0 * lda);
+  const char* wbase = (const char*)(W + (long)n0 * ldw);
+  unsigned aoff[4], woff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    aoff[j] = (unsigned)(asrc[j] - abase);
+    woff[j] = (unsigned)(wsrc[j] - wbase);
+  }
   auto stage = [&](int buf, int kt) {
     char* la = lds + buf * (2 * TILE_BYTES) + w * 4096;
     char* lw = la + TILE_BYTES;
     const int k0 = kt * BK;
+    if constexpr (KTAIL) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool ok = (k0 + kchunk[j]) < K;
-      const void* ga = ok ? (const void*)(asrc[j] + (long)k0 * 2) : zeros;
-      const void* gw = ok ? (const void*)(wsrc[j] + (long)k0 * 2) : zeros;
-      glds16(ga, la + j * 1024);
-      glds16(gw, lw + j * 1024);
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = (k0 + kchunk[j]) < K;
+        const void* ga = ok ? (const void*)(asrc[j] + (long)k0 * 2) : zeros;
+        const void* gw = ok ? (const void*)(wsrc[j] + (long)k0 * 2) : zeros;
+        glds16(ga, la + j * 1024);
+        glds16(gw, lw + j * 1024);
+      }
+    } else {
+      const char* ab = abase + (long)k0 * 2;
+      const char* wb = wbase + (long)k0 * 2;
+      asm volatile("" : "+s"(ab), "+s"(wb));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        asm volatile("" : "+v"(aoff[j]), "+v"(woff[j]));
+        glds16(ab + aoff[j], la + j * 1024);
+        glds16(wb + woff[j], lw + j * 1024);
+      }
     }
   };
 
@@ -171,7 +193,7 @@ constexpr int TILE64_BYTES = B64 * BK * 2;  // 8 KiB per operand tile
 // stages (A + W tile each): 4 (64 KiB, two blocks per CU) unless the launch has more blocks than 2 per CU and at most 3 per CU, where
 // 3 stages (48 KiB) keep it to one round (the 7B gate/up projection at M <= 64 is 592 blocks)
 
-template <int EPI, int NS64>
+template <int EPI, int NS64, bool KTAIL>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
     const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
     const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv,
@@ -206,15 +228,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
   const int nk = (K + BK - 1) / BK;
   // always 4 LDS-DMA instructions per wave and stage, also past the end of K (zero page: an L2 hit nobody reads), so that the
   // counted waits below hold on every iteration
+  const char* abase = (const char*)(A + (long)m0 * lda);
+  const char* wbase = (const char*)(W + (long)n0 * ldw);
+  unsigned aoff[2], woff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    aoff[j] = (unsigned)(asrc[j] - abase);
+    woff[j] = (unsigned)(wsrc[j] - wbase);
+  }
   auto stage = [&](int buf, int kt) {
     char* la = lds + buf * (2 * TILE64_BYTES) + w * 2048;
     char* lw = la + TILE64_BYTES;
     const int k0 = kt * BK;
+    if constexpr (KTAIL) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const bool ok = (k0 + kchunk[j]) < K;
-      glds16(ok ? (const void*)(asrc[j] + (long)k0 * 2) : zeros, la + j * 1024);
-      glds16(ok ? (const void*)(wsrc[j] + (long)k0 * 2) : zeros, lw + j * 1024);
+      for (int j = 0; j < 2; ++j) {
+        const bool ok = (k0 + kchunk[j]) < K;
+        glds16(ok ? (const void*)(asrc[j] + (long)k0 * 2) : zeros, la + j * 1024);
+        glds16(ok ? (const void*)(wsrc[j] + (long)k0 * 2) : zeros, lw + j * 1024);
+      }
+    } else {   // K % 64 == 0; the pieces issued past the end of K (the ring's over-issue) re-read the last K-tile: nobody reads them
+      const long kk = (long)min(k0, K - BK) * 2;
+      const char* ab = abase + kk;
+      const char* wb = wbase + kk;
+      asm volatile("" : "+s"(ab), "+s"(wb));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        asm volatile("" : "+v"(aoff[j]), "+v"(woff[j]));
+        glds16(ab + aoff[j], la + j * 1024);
+        glds16(wb + woff[j], lw + j * 1024);
+      }
     }
   };
   const int fr = l & 15, fq = l >> 4;
@@ -811,9 +854,13 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
   const int tiles_n = big ? (N + BT - 1) / BT : (N + BN - 1) / BN;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<EPI>,
+    if (hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<EPI, true>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemm_bf16_nt_64_kernel<EPI, 4>,
+        hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<EPI, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_bf16_nt_64_kernel<EPI, 4, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * TILE64_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_bf16_nt_64_kernel<EPI, 4, false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * TILE64_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<EPI>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES) != hipSuccess ||
@@ -842,18 +889,25 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
                        (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, g_gemm_dbg, aux);
   else if (g_mid_max_tiles > 0 && tiles_m * tiles_n < g_mid_max_tiles) {  // too few 128x128 tiles for 256 CUs: 64x64 tiles
     const int tm64 = (M + B64 - 1) / B64, tn64 = (N + B64 - 1) / B64;
-    if (tm64 * tn64 > 512 && tm64 * tn64 <= 768)
-      hipLaunchKernelGGL((gemm_bf16_nt_64_kernel<EPI, 3>), dim3(tm64 * tn64), dim3(256), 3 * 2 * TILE64_BYTES, s,
-                         (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
-                         (const bf16_t*)R, ldr, C, ldc, M, N, K, zeros, tm64, tn64, aux);
-    else
-      hipLaunchKernelGGL((gemm_bf16_nt_64_kernel<EPI, 4>), dim3(tm64 * tn64), dim3(256), 4 * 2 * TILE64_BYTES, s,
-                         (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
-                         (const bf16_t*)R, ldr, C, ldc, M, N, K, zeros, tm64, tn64, aux);
+#define OWC_L64(NS_, KT_)                                                                                                  \
+  hipLaunchKernelGGL((gemm_bf16_nt_64_kernel<EPI, NS_, KT_>), dim3(tm64 * tn64), dim3(256), NS_ * 2 * TILE64_BYTES, s,        \
+                     (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C, ldc, M, N,   \
+                     K, zeros, tm64, tn64, aux)
+    const bool ktail = (K % BK) != 0;
+    if (tm64 * tn64 > 512 && tm64 * tn64 <= 768) { if (ktail) OWC_L64(3, true); else OWC_L64(3, false); }
+    else { if (ktail) OWC_L64(4, true); else OWC_L64(4, false); }
+#undef OWC_L64
   } else
-    hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, s,
-                       (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
-                       (const bf16_t*)R, ldr, C, ldc, M, N, K, zeros, tiles_m, tiles_n, aux);
+  {
+    if ((K % BK) != 0)
+      hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI, true>), dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, s,
+                         (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
+                         (const bf16_t*)R, ldr, C, ldc, M, N, K, zeros, tiles_m, tiles_n, aux);
+    else
+      hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI, false>), dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, s,
+                         (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
+                         (const bf16_t*)R, ldr, C, ldc, M, N, K, zeros, tiles_m, tiles_n, aux);
+  }
   owc_gemm_profile_end(prof, s);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
