@@ -265,3 +265,27 @@ def test_pingpong_kernel_bit_identical_to_lockstep_race_screen(gpu, m, n, k, epi
     assert bad == 0, f"{bad} / 25 launches differ from the lock-step kernel"
     if epi == "none":
         assert_bf16_close(to_np(ref[:256]), _oracle(a[:256], w, b), atol=1e-4)
+
+
+@pytest.mark.parametrize("name,n,k,epi", [("qkv", 4608, 3584, "bias"), ("o", 3584, 3584, "residual"), ("gateup", 37888, 3584, "swiglu"),
+                                          ("down", 3584, 18944, "residual"), ("vit.fc1", 5120, 1280, "quick_gelu"), ("vit.patch", 1280, 1176, "none")])
+def test_row0_bits_do_not_depend_on_m(gpu, name, n, k, epi):
+    """Batch invariance at the op: row 0 of a projection of the 7B decoder / vision tower must be the same bits whether 1 or 18 304 rows
+    ride along - i.e. whichever of the weight-streaming, 64x64-ring, 128x128 and 256x256 ping-pong kernels (with or without K tail) the
+    dispatch picks at that M: every threshold of `launch()` is crossed here (32 | 33, 64 | 65, 255 | 256 with the padding rule at 384,
+    1023 | 1024, 144 tiles of 256x256)."""
+    from lmms_owc_amd import _lib, ops
+
+    ms = [1, 8, 32, 33, 64, 65, 128, 255, 256, 286, 384, 512, 1023, 1024, 2048, 18304]
+    a = bf16_randn((max(ms), k), 90, device=gpu)
+    w = bf16_randn((n, k), 91, 0.05, device=gpu)
+    b = bf16_randn((n,), 92, device=gpu)
+    r = bf16_randn((max(ms), n), 93, device=gpu)
+    E = {"bias": _lib.EPI_NONE, "none": _lib.EPI_NONE, "residual": _lib.EPI_RESIDUAL, "swiglu": _lib.EPI_SWIGLU, "quick_gelu": _lib.EPI_QUICK_GELU}[epi]
+    ref = None
+    for m in ms:
+        out = ops.gemm_bf16(a[:m], w, None if epi in ("none", "swiglu") else b, epilogue=E, residual=r[:m] if epi == "residual" else None)
+        row = out[0].clone()
+        if ref is None:
+            ref = row
+        assert torch.equal(row, ref), (name, m, int((row != ref).sum()))
