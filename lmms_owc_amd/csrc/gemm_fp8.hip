@@ -461,7 +461,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256pp_kernel(
 
 // ---- 64x64x128 variant for the in-between shapes (M above the skinny kernel's 64 rows, too few 256x256 tiles for the 256 CUs:
 // fp8 decode at batch 65 .. ~1000, single-prompt prefill).  The fp8 twin of gemm_bf16_nt_64_kernel: 4 waves, wave w owns rows
-// [16w, 16w+16) x 64 columns, one scaled MFMA per n tile per K-tile, 32 KiB LDS, same ascending chain (bit-identical).
+// [16w, 16w+16) x 64 columns, one scaled MFMA per n tile per K-tile, a four-stage LDS-DMA ring (64 KiB), same ascending chain (bit-identical).
 constexpr int B64 = 64;
 constexpr int TILE64_BYTES = B64 * BKB;  // 8 KiB per operand tile
 
@@ -484,23 +484,33 @@ __global__ __launch_bounds__(256) void gemm_fp8_nt_64_kernel(
   const int first_m = group * 8;
   const int gsize = min(tiles_m - first_m, 8);
   const int m0 = (first_m + (lid % width) % gsize) * B64, n0 = ((lid % width) / gsize) * B64;
-  const char* asrc[2];
-  const char* wsrc[2];
+  // staging: wave w moves rows [16w, 16w+16) of both tiles, 2 pieces of 8 rows; scalar tile bases + 32-bit lane offsets (the DMA's
+  // scalar-base form: no vector address arithmetic in the loop)
+  const char* abase = (const char*)(A + (long)m0 * lda);
+  const char* wbase = (const char*)(W + (long)n0 * ldw);
+  unsigned aoff[2], woff[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int row = 16 * w + 8 * j + (l >> 3);
     const int c = (l & 7) ^ ((row >> 1) & 7);
-    asrc[j] = (const char*)(A + (long)min(m0 + row, M - 1) * lda + c * 16);
-    wsrc[j] = (const char*)(W + (long)min(n0 + row, N - 1) * ldw + c * 16);
+    aoff[j] = (unsigned)((long)min(row, M - 1 - m0) * lda + c * 16);
+    woff[j] = (unsigned)((long)min(row, N - 1 - n0) * ldw + c * 16);
   }
   const int nk = K / BKB;
+  // ring of NS8 stages like gemm_bf16_nt_64_kernel: NS8 - 1 K-tiles in flight behind a counted vmcnt, one raw barrier per K-tile
+  // (round 1: two stages and a full drain per K-tile); the pieces issued past the end of K re-read the last K-tile (nobody reads them)
+  constexpr int NS8 = 4;
   auto stage = [&](int buf, int kt) {
     char* la = lds + buf * (2 * TILE64_BYTES) + w * 2048;
-    const long kb = (long)kt * BKB;
+    const long kb = (long)min(kt, nk - 1) * BKB;
+    const char* ab = abase + kb;
+    const char* wb = wbase + kb;
+    asm volatile("" : "+s"(ab), "+s"(wb));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      glds16(asrc[j] + kb, la + j * 1024);
-      glds16(wsrc[j] + kb, la + TILE64_BYTES + j * 1024);
+      asm volatile("" : "+v"(aoff[j]), "+v"(woff[j]));
+      glds16(ab + aoff[j], la + j * 1024);
+      glds16(wb + woff[j], la + TILE64_BYTES + j * 1024);
     }
   };
   const int fr = l & 15, fq = l >> 4;
@@ -514,20 +524,20 @@ __global__ __launch_bounds__(256) void gemm_fp8_nt_64_kernel(
   f32x4 acc[4][1];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  stage(0, 0);
-  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NS8 - 1; ++i) stage(i, i);
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* la = lds + cur * (2 * TILE64_BYTES);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (NS8 - 2)) : "memory");
+    stage((kt + NS8 - 1) % NS8, kt + NS8 - 1);
+    const char* la = lds + (kt % NS8) * (2 * TILE64_BYTES);
     const i32x8 fa = rd(la + (w * 16 + fr) * 128);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const i32x8 fw = rd(la + TILE64_BYTES + (nt * 16 + fr) * 128);
       acc[nt][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw, fa, acc[nt][0], 0, 0, 0, 0x7f, 0, 0x7f);
     }
-    __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   {
     const float sa = SA[min(m0 + w * 16 + fr, M - 1)];
 #pragma unroll
@@ -663,7 +673,9 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
     if (hipFuncSetAttribute((const void*)gemm_fp8_nt_256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)gemm_fp8_nt_256pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            LDS_BYTES) != hipSuccess)
+                            LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_fp8_nt_64_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            8 * TILE64_BYTES) != hipSuccess)
       return OWC_ERR_HIP;
     attr_set = true;
   }
@@ -676,7 +688,7 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
   }
   if (g_fp8_mid_max_tiles > 0 && tiles_m * tiles_n < g_fp8_mid_max_tiles) {  // too few 256x256 tiles for the 256 CUs
     const int tm64 = (M + B64 - 1) / B64, tn64 = (N + B64 - 1) / B64;
-    hipLaunchKernelGGL(gemm_fp8_nt_64_kernel<EPI>, dim3(tm64 * tn64), dim3(256), 4 * TILE64_BYTES, s, (const uint8_t*)A, lda, sa,
+    hipLaunchKernelGGL(gemm_fp8_nt_64_kernel<EPI>, dim3(tm64 * tn64), dim3(256), 8 * TILE64_BYTES, s, (const uint8_t*)A, lda, sa,
                        (const uint8_t*)W, ldw, sw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C, ldc, M, N, K, tm64, tn64, aux);
     owc_gemm_profile_end(prof, s);
     return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;

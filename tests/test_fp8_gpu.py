@@ -150,3 +150,31 @@ def test_gemm_fp8_tile_sizes_bit_identical(gpu, m, n, k, epi):
         outs.append(ops.gemm_fp8(xq, xs, wq, ws, bias, epilogue=e, residual=r))
     lib.owc_tuning_set(b"gemm_mid_max_tiles", 256)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(256, 8192, 29568, "res"), (130, 1024, 128, "bias"), (70, 520, 256, "bias"), (512, 2048, 8192, "swiglu")])
+def test_gemm_fp8_mid_kernel_race_screen(gpu, m, n, k, epi):
+    """The fp8 64x64 kernel's four-stage LDS-DMA ring (counted vmcnt + one raw barrier per K-tile) against the 256x256 kernel, 15 times
+    per shape: 231 K-tiles (the 72B down projection at decode batch 256), 1 and 2 K-tiles (fewer than stages: the over-issued pieces),
+    ragged M / N, SwiGLU.  Bit-identical every time."""
+    from lmms_owc_amd import _lib, ops
+
+    lib = _lib.load()
+    x = bf16_randn((m, k), 180 + m, 1.0, gpu)
+    w = bf16_randn((n, k), 181, 0.05, gpu)
+    xq, xs = ops.quantize_rows_fp8(x)
+    wq, ws = ops.quantize_rows_fp8(w)
+    bias = bf16_randn((n,), 5, 0.5, gpu) if epi == "bias" else None
+    r = bf16_randn((m, n), 9, 1.0, gpu) if epi == "res" else None
+    e = {"bias": _lib.EPI_NONE, "res": _lib.EPI_RESIDUAL, "swiglu": _lib.EPI_SWIGLU}[epi]
+    try:
+        lib.owc_tuning_set(b"gemm_skinny_max_m", 0)
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 0)
+        want = ops.gemm_fp8(xq, xs, wq, ws, bias, epilogue=e, residual=r)
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 256)
+        for i in range(15):
+            got = ops.gemm_fp8(xq, xs, wq, ws, bias, epilogue=e, residual=r)
+            assert torch.equal(got, want), (i, int((got != want).sum()))
+    finally:
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 256)
+        lib.owc_tuning_set(b"gemm_skinny_max_m", -1)
