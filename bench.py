@@ -556,7 +556,7 @@ def load_traffic(args, engine, B: int) -> dict | None:
     literal.  Only when this run contains that launch class: 7B, one full 65536-row prefill group, no tuning knob, bf16."""
     if args.model != "7b" or B < 256 or engine.prefill_chunk_tokens != 65536 or args.nominal_forward:
         return None
-    if any(k.startswith("OWC_GEMM_") for k in os.environ):
+    if any(k.startswith("OWC_GEMM_") for k in os.environ) or args.tune:
         return None
     cands = sorted((ROOT / "profiles").glob("r*_pmc_gemm_traffic*.json"))
     if not cands:

@@ -2,7 +2,7 @@
 # rocprofv3 PMC passes on the step's largest GEMM launch class (7B gate/up at the prefill launch-group size, SwiGLU epilogue:
 # what owc_llm_prefill really launches), one counter group per pass (MI355X_MICROARCH.md "rocprofv3 PMC slots"), for the
 # ping-pong kernel (default) and the lock-step kernel (--set=gemm_pingpong=0).  Run on the GPU box from the repo root:
-#   bash tools/pmc_gemm.sh r02
+#   bash tools/pmc_gemm.sh r02 ["pp" | "ls" | "pp ls"]
 # writes gpurun_out/pmc_<tag>_<kernel>_<group>/ and profiles/<tag>_<kernel>_pmc_{raw.csv,gemm_traffic.json}
 set -u
 TAG=${1:-r02}
@@ -16,7 +16,7 @@ declare -A CGROUPS=(
   [sq]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAVES"
   [grbm]="GRBM_GUI_ACTIVE"
 )
-for K in pp ls; do
+for K in ${2:-pp ls}; do
   SET=""; KN="gemm_bf16_nt_256pp_kernel"
   if [ $K = ls ]; then SET="--set=gemm_pingpong=0"; KN="gemm_bf16_nt_256_kernel"; fi
   DIRS=""
