@@ -55,16 +55,21 @@ enum owc_epilogue {
 int owc_init(int device, owc_ctx** out);
 int owc_destroy(owc_ctx* ctx);
 const char* owc_last_error(const owc_ctx* ctx);
-/* A-B / tuning knobs (process-wide; the same switches owc_init reads from the environment):
- * "gemm_big_min_m" (OWC_GEMM_BIG_MIN_M), "gemm_big_min_tiles" (fewest 256x256 tiles for which the 256x256 kernels run; negative = default 144), "gemm_skinny_max_m" (0 disables the weight-streaming small-M kernel, a negative value restores the defaults), "gemm_mid_max_tiles"
- * (0 disables the 64x64-tile kernel), "gemm_dbg"
- * (OWC_GEMM_DBG), "attn_dbg" (OWC_ATTN_DBG), "gemm_pingpong" (0: the lock-step 256x256 kernels, 1 = default: bf16 ping-pong
- * kernel, 2: the fp8 ping-pong kernel too), "prefill_prune_last" (0: owc_llm_prefill runs the last layer's attention / o-proj /
- * MLP on every row instead of the last-token rows only -- same logits bit for bit, tested), "bert_bf16x3" (0: owc_bert_embed runs
- * its linears on the exact f32-input MFMA instead of the three-piece bf16 split).
+/* A-B / tuning knobs (process-wide; the library reads NO environment variable - every switch goes through this call):
+ * "gemm_big_min_m", "gemm_big_min_tiles" (fewest 256x256 tiles for which the 256x256 kernels run; negative = default 144),
+ * "gemm_skinny_max_m" (0 disables the weight-streaming small-M kernel, a negative value restores the defaults),
+ * "gemm_mid_max_tiles" (0 disables the 64x64-tile kernel), "gemm_pingpong" (0: the lock-step 256x256 kernels, 1 = default: bf16
+ * ping-pong kernel, 2: the fp8 ping-pong kernel too), "prefill_prune_last" (0: owc_llm_prefill runs the last layer's attention /
+ * o-proj / MLP on every row instead of the last-token rows only -- same logits bit for bit, tested), "bert_bf16x3" (0:
+ * owc_bert_embed runs its linears on the exact f32-input MFMA instead of the three-piece bf16 split), "decode_fuse" (0: the
+ * decode step runs the separate RMSNorm / M-RoPE + KV-write kernels instead of the fused ones -- same bits, tested).
+ * Every knob above selects between kernels that return the SAME results.  The timing-only experiment knobs "gemm_dbg" /
+ * "attn_dbg" (parts of a kernel switched off to price them; outputs are garbage) exist only in libowc_hip_timing.so, which
+ * `python -m lmms_owc_amd.build --timing` builds with -DOWC_TIMING_KNOBS for tools/; the product library does not know them.
  * Returns OWC_ERR_ARG for an unknown name.  Measurement aid only: no reference counterpart. */
 int owc_tuning_set(const char* name, int value);
 int owc_abi_version(void); /* bumped whenever a signature in this header changes */
+int owc_has_timing_knobs(void); /* 0 in the product library; 1 in the -DOWC_TIMING_KNOBS build that tools/ load */
 
 /* ---- measurement hooks (bench.py roofline leg) ------------------------------------------------ */
 /* When enabled, every owc_gemm_bf16 / owc_gemm_fp8 launch (also inside the model drivers) is bracketed by a

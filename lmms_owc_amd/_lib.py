@@ -19,6 +19,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "libowc_hip.so"
 _lock = threading.Lock()
 _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
+_timing_ok = False
 
 ABI_VERSION = 11
 
@@ -98,6 +99,7 @@ class BertWeights(C.Structure):
 # name -> (restype, argtypes); every symbol include/owc.h declares
 SIGNATURES: dict[str, tuple] = {
     "owc_abi_version": (i32, []),
+    "owc_has_timing_knobs": (i32, []),
     "owc_tuning_set": (i32, [C.c_char_p, i32]),
     "owc_init": (i32, [i32, C.POINTER(vp)]),
     "owc_destroy": (i32, [vp]),
@@ -146,6 +148,16 @@ def lib_path() -> Path:
     return _LIB_PATH
 
 
+def use_timing_library() -> None:
+    """tools/ only: load libowc_hip_timing.so (the -DOWC_TIMING_KNOBS build, `python -m lmms_owc_amd.build --timing`) instead of
+    the product library.  Must be called before the first `load()`; nothing in the package calls it."""
+    global _LIB_PATH, _timing_ok
+    if _lib is not None:
+        raise OwcError("use_timing_library() must come before the first load()")
+    _LIB_PATH = _LIB_PATH.with_name("libowc_hip_timing.so")
+    _timing_ok = True
+
+
 def load() -> C.CDLL:
     """Load libowc_hip.so; raises (loudly) if it has not been built or lacks a symbol."""
     global _lib
@@ -163,6 +175,8 @@ def load() -> C.CDLL:
                 fn.argtypes = args
             if lib.owc_abi_version() != ABI_VERSION:
                 raise OwcError("libowc_hip.so ABI version mismatch: rebuild the extension")
+            if lib.owc_has_timing_knobs() and not _timing_ok:
+                raise OwcError(f"{_LIB_PATH} was built with -DOWC_TIMING_KNOBS: that build is for tools/ only, rebuild the product library")
             _lib = lib
         return _lib
 

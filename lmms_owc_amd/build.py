@@ -20,6 +20,10 @@ ROOT = Path(__file__).resolve().parent
 CSRC = ROOT / "csrc"
 OBJ = CSRC / "build"
 LIB = ROOT / "libowc_hip.so"
+# second library for tools/ only: the same sources with -DOWC_TIMING_KNOBS (timing experiments that switch parts of a kernel off;
+# the product library has those branches compiled out and does not know the knob names)
+OBJ_TIMING = CSRC / "build_timing"
+LIB_TIMING = ROOT / "libowc_hip_timing.so"
 ARCH = "gfx950"
 
 
@@ -30,8 +34,8 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: libowc_hip.so cannot be built")
 
 
-def _flags() -> list[str]:
-    return [
+def _flags(timing: bool = False) -> list[str]:
+    return ([] if not timing else ["-DOWC_TIMING_KNOBS"]) + [
         f"--offload-arch={ARCH}",
         "-O3",
         "-std=c++17",
@@ -43,9 +47,9 @@ def _flags() -> list[str]:
     ]
 
 
-def _digest(src: Path) -> str:
+def _digest(src: Path, timing: bool = False) -> str:
     h = hashlib.sha256()
-    h.update(" ".join(_flags()).encode())
+    h.update(" ".join(_flags(timing)).encode())
     for hdr in sorted(list(CSRC.glob("*.h")) + list((ROOT.parent / "include").glob("*.h"))):
         h.update(hdr.read_bytes())
     h.update(src.read_bytes())
@@ -95,13 +99,14 @@ def _lint(obj: Path, has_kernels: bool) -> None:
         raise RuntimeError(f"{obj.name} contains {len(hits)} forbidden instruction(s):\n  " + "\n  ".join(hits[:8]))
 
 
-def _compile(src: Path, force: bool) -> Path:
-    obj = OBJ / (src.stem + ".o")
-    stamp = OBJ / (src.stem + ".sha")
-    dig = _digest(src)
+def _compile(src: Path, force: bool, timing: bool = False) -> Path:
+    objdir = OBJ_TIMING if timing else OBJ
+    obj = objdir / (src.stem + ".o")
+    stamp = objdir / (src.stem + ".sha")
+    dig = _digest(src, timing)
     if not force and obj.exists() and stamp.exists() and stamp.read_text() == dig:
         return obj
-    cmd = [_hipcc(), *_flags(), "-c", str(src), "-o", str(obj)]
+    cmd = [_hipcc(), *_flags(timing), "-c", str(src), "-o", str(obj)]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src.name}:\n{res.stdout}\n{res.stderr}")
@@ -110,27 +115,29 @@ def _compile(src: Path, force: bool) -> Path:
     return obj
 
 
-def build(force: bool = False, verbose: bool = True) -> Path:
-    """Compile every csrc/*.hip for gfx950 and link libowc_hip.so next to this file."""
-    OBJ.mkdir(parents=True, exist_ok=True)
+def build(force: bool = False, verbose: bool = True, timing: bool = False) -> Path:
+    """Compile every csrc/*.hip for gfx950 and link libowc_hip.so next to this file (`timing`: libowc_hip_timing.so, the
+    -DOWC_TIMING_KNOBS build tools/ load for timing experiments - never the product)."""
+    objdir, lib = (OBJ_TIMING, LIB_TIMING) if timing else (OBJ, LIB)
+    objdir.mkdir(parents=True, exist_ok=True)
     srcs = sorted(CSRC.glob("*.hip"))
     if not srcs:
         raise RuntimeError("no HIP sources found")
-    before = {s: (OBJ / (s.stem + ".o")).stat().st_mtime_ns if (OBJ / (s.stem + ".o")).exists() else 0 for s in srcs}
+    before = {s: (objdir / (s.stem + ".o")).stat().st_mtime_ns if (objdir / (s.stem + ".o")).exists() else 0 for s in srcs}
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), srcs))
-    changed = any((OBJ / (s.stem + ".o")).stat().st_mtime_ns != before[s] for s in srcs)
-    if changed or force or not LIB.exists():
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+        objs = list(ex.map(lambda s: _compile(s, force, timing), srcs))
+    changed = any((objdir / (s.stem + ".o")).stat().st_mtime_ns != before[s] for s in srcs)
+    if changed or force or not lib.exists():
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(lib), *map(str, objs)]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"link failed:\n{res.stdout}\n{res.stderr}")
         if verbose:
-            print(f"[owc build] linked {LIB} from {len(objs)} objects", file=sys.stderr)
+            print(f"[owc build] linked {lib} from {len(objs)} objects", file=sys.stderr)
     elif verbose:
-        print(f"[owc build] {LIB.name} up to date", file=sys.stderr)
-    return LIB
+        print(f"[owc build] {lib.name} up to date", file=sys.stderr)
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, timing="--timing" in sys.argv)

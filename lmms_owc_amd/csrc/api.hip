@@ -18,6 +18,14 @@ extern "C" {
 
 int owc_abi_version(void) { return 11; }
 
+int owc_has_timing_knobs(void) {   // 1 only in libowc_hip_timing.so (tools/); the product library answers 0
+#ifdef OWC_TIMING_KNOBS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 int owc_tuning_set(const char* name, int value) {
   if (!name) return OWC_ERR_ARG;
   if (!strcmp(name, "gemm_mid_max_tiles")) {
@@ -34,8 +42,10 @@ int owc_tuning_set(const char* name, int value) {
     owc_gemm_set_pingpong(value != 0);
     owc_gemm_fp8_set_pingpong(value >= 2);
   }
+#ifdef OWC_TIMING_KNOBS   // timing-only experiments: the product library does not know these names (OWC_ERR_ARG)
   else if (!strcmp(name, "gemm_dbg")) owc_gemm_set_dbg(value);
   else if (!strcmp(name, "attn_dbg")) owc_attn_set_dbg(value);
+#endif
   else if (!strcmp(name, "prefill_prune_last")) owc_llm_set_prune_last(value);
   else if (!strcmp(name, "bert_bf16x3")) owc_bert_set_x3(value);
   else return OWC_ERR_ARG;
@@ -44,15 +54,6 @@ int owc_tuning_set(const char* name, int value) {
 
 static int g_ctx_device = -1;  // one context per process (one process per GPU): kernel attributes, knobs and the profile recording
                                // are process-wide, so a second device in the same process is refused instead of half-working
-
-static void debug_knob_from_env(const char* env, void (*set)(int)) {
-  const char* e = getenv(env);
-  if (!e) return;
-  const int v = atoi(e);
-  set(v);
-  if (v != 0)  // these knobs switch parts of a kernel OFF for timing experiments: results are garbage
-    fprintf(stderr, "[libowc_hip] WARNING: %s=%d is a TIMING-ONLY debug knob - outputs of this process are NOT valid results\n", env, v);
-}
 
 int owc_init(int device, owc_ctx** out) {
   if (out == nullptr) return OWC_ERR_ARG;
@@ -65,9 +66,10 @@ int owc_init(int device, owc_ctx** out) {
     delete ctx;
     return OWC_ERR_HIP;
   }
-  if (const char* e = getenv("OWC_GEMM_BIG_MIN_M")) owc_gemm_set_big_min_m(atoi(e));  // tuning / A-B knob
-  debug_knob_from_env("OWC_GEMM_DBG", owc_gemm_set_dbg);  // timing-only experiments (loud on stderr when set)
-  debug_knob_from_env("OWC_ATTN_DBG", owc_attn_set_dbg);
+  // (no environment variable is read here: every knob goes through owc_tuning_set, i.e. through the caller's own code)
+#ifdef OWC_TIMING_KNOBS
+  fprintf(stderr, "[libowc_hip] this is the TIMING-KNOB build (tools/ only): `gemm_dbg` / `attn_dbg` can switch parts of a kernel off\n");
+#endif
   g_ctx_device = device;
   *out = ctx;
   return OWC_OK;

@@ -19,7 +19,7 @@
 
 namespace {
 
-int g_attn_dbg = 0;  // timing experiment (owc_tuning_set "attn_dbg"): 1 = no K/V DMA in the loop
+int g_attn_dbg = 0;  // timing experiment (owc_tuning_set "attn_dbg", -DOWC_TIMING_KNOBS build only): 1 = no K/V DMA in the loop
 
 constexpr int QB = 128;  // query rows per block
 constexpr int KB = 64;   // keys per tile
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
 
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
-    if (t + 1 < ntiles && !(dbg & 1)) stage(cur ^ 1, t + 1);
+    if (t + 1 < ntiles && !OWC_TK(dbg & 1)) stage(cur ^ 1, t + 1);
     const char* kt_ = lds + cur * (2 * C::TILE);
     const char* vt_ = kt_ + C::TILE;
     if (active) {
@@ -376,4 +376,4 @@ int owc_launch_attention(const void* Q, long q_ts, long q_hs, const void* K, lon
   return OWC_ERR_SHAPE;
 }
 
-void owc_attn_set_dbg(int v) { g_attn_dbg = v; }
+void owc_attn_set_dbg(int v) { g_attn_dbg = OWC_TK(true) ? v : 0; }

@@ -496,13 +496,14 @@ int owc_cosine_topk(owc_ctx* ctx, const float* preds, const float* classes, cons
   }
   if (top_val || top_idx) {
     if (!top_val || !top_idx || k <= 0 || k > TOPK_MAX) OWC_FAIL(ctx, OWC_ERR_ARG, "owc_cosine_topk: 1 <= k <= 16 with both outputs");
+    if (D != 384 && D != 768 && D != 64) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_cosine_topk: D must be 384, 768 or 64");
     const dim3 grid((N + 63) / 64);
-    const int prof = owc_gemm_profile_begin(2.0 * (double)N * (double)C * (double)D, OWC_PROF_COSINE_TOPK, st);
+    const int prof = owc_gemm_profile_begin(2.0 * (double)N * (double)C * (double)D, OWC_PROF_COSINE_TOPK, st);  // after validation: never unmatched
     switch (D) {
       case 384: hipLaunchKernelGGL(cosine_topk_kernel<24>, grid, dim3(256), 0, st, preds, classes, N, C, k, top_val, top_idx); break;
       case 768: hipLaunchKernelGGL(cosine_topk_kernel<48>, grid, dim3(256), 0, st, preds, classes, N, C, k, top_val, top_idx); break;
       case 64: hipLaunchKernelGGL(cosine_topk_kernel<4>, grid, dim3(256), 0, st, preds, classes, N, C, k, top_val, top_idx); break;
-      default: OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_cosine_topk: D must be 384, 768 or 64");
+      default: break;   // unreachable (validated above)
     }
     owc_gemm_profile_end(prof, st);
   }

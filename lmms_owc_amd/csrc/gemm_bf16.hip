@@ -41,7 +41,7 @@ struct GemmProfile {
   size_t used = 0;
 };
 GemmProfile g_prof;
-int g_gemm_dbg = 0;       // timing-experiment knob (OWC_GEMM_DBG / owc_tuning_set "gemm_dbg"), results are garbage unless 0 or 512:
+int g_gemm_dbg = 0;       // timing-experiment knob (owc_tuning_set "gemm_dbg" of the -DOWC_TIMING_KNOBS build only), results are garbage unless 0 or 512:
                           // 1 no DMA, 2 DMA re-reads K-tiles 0/1 (all L2 hits), 4 no epilogue, 512 direct (un-staged) epilogue stores, 1024 streaming C stores (results unchanged),
                           // 2048 no per-K-tile barrier, 4096 no DMA wait at the barrier
 int g_skinny_max_m = 32;   // M at and below which the weight-streaming skinny kernel runs (0 disables: A-B knob "gemm_skinny_max_m"; up to 64 is legal):
@@ -49,7 +49,7 @@ int g_skinny_max_m = 32;   // M at and below which the weight-streaming skinny k
 int g_mid_max_tiles = 256;  // fewer 128x128 tiles than this -> 64x64 tiles (0 disables: A-B knob "gemm_mid_max_tiles")
 int g_big_min_tiles = 144;  // fewer 256x256 tiles than this -> use the 128x128 kernel (measured: 160-162 tiles 256x256 +24...40 %, 126 tiles -3...8 %; knob "gemm_big_min_tiles")
 int g_pingpong = 1;       // 256x256 launches with K % 128 == 0 use the ping-pong kernel (A-B knob "gemm_pingpong", 0 = lock-step kernel)
-int g_big_min_m = 256;   // M at and above which the 256x256 kernels may run (OWC_GEMM_BIG_MIN_M / knob "gemm_big_min_m"; round 1: 1024)
+int g_big_min_m = 256;   // M at and above which the 256x256 kernels may run (knob "gemm_big_min_m"; round 1: 1024)
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
@@ -273,7 +273,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
   for (int kt = 0; kt < nk; ++kt) {
     // this wave's pieces of stage kt have landed (the 4 * (NS64 - 2) newer ones may fly); the barrier publishes everybody's and
     // tells that every wave is done reading stage kt - 1, whose slot the next DMA overwrites
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (NS64 - 2)) : "memory");
+    // (lgkmcnt(0): this wave's own ds_reads of stage kt - 1 have retired too - the MFMAs consumed them long ago, so it costs
+    // nothing, and the WAR guarantee then holds in the source instead of resting on the compiler's placement of its waits)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 * (NS64 - 2)) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
     stage((kt + NS64 - 1) % NS64, kt + NS64 - 1);
     const char* la = lds + (kt % NS64) * (2 * TILE64_BYTES);
     const char* lw = la + TILE64_BYTES;
@@ -450,8 +453,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
     // every LDS read of stage kt by this wave has completed (lgkmcnt(0), issued >= one phase ago) and its DMA
     // pieces of stage kt+1 have landed (issued a whole K-tile ago); the barrier publishes stage kt+1 and proves
     // stage kt's buffer is no longer read by anyone.
-    if (dbg & 2048) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // timing experiment: no barrier
-    else if (dbg & 4096) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // timing experiment: no DMA wait
+    if (OWC_TK(dbg & 2048)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // timing experiment: no barrier
+    else if (OWC_TK(dbg & 4096)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // timing experiment: no DMA wait
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (kt + 1 < nk) {
       read_a(xa, nxt, 0, ch0);  // next K-tile, phase 1
@@ -459,10 +462,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
     }
     // phase 4: rows 0-63, k-step 1 — with the DMA of stage kt+2 (into stage kt's buffer, free since the barrier)
     // interleaved between its MFMA groups
-    phase_dma(ya, wk1, 0, kt & 1, (dbg & 2) ? (kt & 1) : kt + 2, kt + 2 < nk && !(dbg & 1));  // dbg 2: re-read K-tiles 0/1 (all L2 hits)
+    phase_dma(ya, wk1, 0, kt & 1, OWC_TK(dbg & 2) ? (kt & 1) : kt + 2, kt + 2 < nk && !OWC_TK(dbg & 1));  // dbg 2: re-read K-tiles 0/1 (all L2 hits)
   }
 
-  if (dbg & 4) {  // timing experiment: no epilogue
+  if (OWC_TK(dbg & 4)) {  // timing experiment: no epilogue
     if (acc[0][0][0] == 123.456f) ((float*)Cv)[0] = 1.f;
     return;
   }
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(
   } else {
     // LDS is quiescent here (every wave passed the last K-tile's barrier with lgkmcnt(0); no DMA is pending): the two
     // stage buffers become the 256 x 256 (SWIGLU: 256 x 128) bf16 image of the output tile
-    if (dbg & 512) {
+    if (OWC_TK(dbg & 512)) {
       gemm_epilogue<EPI, 8>(acc, m0 + wr * 128, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
       return;
     }
@@ -690,7 +693,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
   }
 #undef OWC_PP_SYNC_L
 
-  if (dbg & 4) {  // timing experiment: no epilogue
+  if (OWC_TK(dbg & 4)) {  // timing experiment: no epilogue
     if (acc[0][0][0] == 123.456f) ((float*)Cv)[0] = 1.f;
     return;
   }
@@ -1008,7 +1011,7 @@ int owc_gemm_profile_collect(double* total_ms, double* total_flops, long* launch
 }
 
 void owc_gemm_set_big_min_m(int m) { g_big_min_m = m; }
-void owc_gemm_set_dbg(int v) { g_gemm_dbg = v; }
+void owc_gemm_set_dbg(int v) { g_gemm_dbg = OWC_TK(true) ? v : 0; }
 void owc_gemm_set_mid_max_tiles(int v) { g_mid_max_tiles = v; }
 void owc_gemm_set_big_min_tiles(int v) { g_big_min_tiles = v < 0 ? 144 : v; }
 void owc_gemm_set_skinny_max_m(int v) { g_skinny_max_m = v < 0 ? 32 : v; }  // negative: back to the default

@@ -527,7 +527,8 @@ __global__ __launch_bounds__(256) void gemm_fp8_nt_64_kernel(
 #pragma unroll
   for (int i = 0; i < NS8 - 1; ++i) stage(i, i);
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (NS8 - 2)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 * (NS8 - 2)) : "memory");   // lgkmcnt(0): WAR on the slot restaged next, in the source
+    __builtin_amdgcn_sched_barrier(0);
     stage((kt + NS8 - 1) % NS8, kt + NS8 - 1);
     const char* la = lds + (kt % NS8) * (2 * TILE64_BYTES);
     const i32x8 fa = rd(la + (w * 16 + fr) * 128);

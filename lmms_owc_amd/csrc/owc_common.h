@@ -16,6 +16,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define OWC_WAVE 64
 
+// Timing-only experiment knobs (parts of a kernel switched OFF to price them: results are garbage) exist only in the second
+// library `python -m lmms_owc_amd.build --timing` builds for tools/ (libowc_hip_timing.so, -DOWC_TIMING_KNOBS).  In the product
+// library the branches below are dead code and `owc_tuning_set("gemm_dbg" | "attn_dbg")` is an unknown knob.
+#ifdef OWC_TIMING_KNOBS
+#define OWC_TK(cond) (cond)
+#else
+#define OWC_TK(cond) false
+#endif
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 

@@ -202,7 +202,10 @@ def evaluate(lm, task_dict: dict, limit: int | float | None = None, log_samples:
             if log_samples:
                 target = task.doc_to_target(doc)
                 example = {
-                    "doc_id": req.doc_id, "doc": {k: v for k, v in doc.items() if "image" not in k}, "target": target,
+                    # the reference's filter (`_engine.py:263`) plus: values that JSON cannot carry are dropped (a decoded PIL
+                    # image under `visual` would be written as its repr, memory address included; the reference's rows hold a path)
+                    "doc_id": req.doc_id,
+                    "doc": {k: v for k, v in doc.items() if "image" not in k and isinstance(v, _SERIALIZABLE)}, "target": target,
                     "arguments": [a for a in req.args if isinstance(a, _SERIALIZABLE)],
                     "resps": [req.resps], "filtered_resps": [req.filtered_resps["none"]],
                     # the reference hashes `requests[0].doc`, which its TaskInstance never sets (tasks/_manager.py:881 `# doc=doc`):

@@ -124,8 +124,12 @@ class LLaVA(Model):
         views = 5 if d.grid_pinpoints else 1
         tokens = views * d.tokens + 128 + int(max_new_tokens)
         per_req = (d.n_layers * 2 * d.n_kv_heads * d.head_dim * 2) * tokens + views * d.tokens * (d.d_model * 2 + d.v_embed * 24)
-        free, _ = torch.cuda.mem_get_info(self._device)
-        return max(self.batch_size, min(512, int(0.25 * free / per_req)))
+        cache = self.__dict__.setdefault("_auto_batch", {})   # once per max_new_tokens (see Qwen2VL.engine_batch)
+        if max_new_tokens not in cache:
+            free, _ = torch.cuda.mem_get_info(self._device)
+            free += torch.cuda.memory_reserved(self._device) - torch.cuda.memory_allocated(self._device)
+            cache[max_new_tokens] = max(self.batch_size, min(512, int(0.25 * free / per_req)))
+        return cache[max_new_tokens]
 
     def loglikelihood(self, requests: list) -> list[tuple[float, bool]]:
         raise NotImplementedError("loglikelihood is outside the accelerated path (SURVEY.md §8f: generation only)")

@@ -128,8 +128,15 @@ class Qwen2VL(Model):
         tokens = self._max_pixels // 784 + 64 + int(max_new_tokens)
         per_req = (d.n_layers * 2 * d.n_kv_heads * d.head_dim * 2) * tokens + (self._max_pixels // 196) * 1176 * 2 \
             + (self._max_pixels // 784) * d.d_model * 2
-        free, _ = torch.cuda.mem_get_info(self._device)
-        return max(self.batch_size, min(2048, int(0.25 * free / per_req)))
+        # computed ONCE per max_new_tokens: after the first task torch's caching allocator holds the KV cache and workspaces,
+        # `mem_get_info` would report them as used and later tasks would get a smaller batch, new chunk sizes and new allocations.
+        # What torch has reserved but not allocated is reusable by the next pass, so it counts as free.
+        cache = self.__dict__.setdefault("_auto_batch", {})
+        if max_new_tokens not in cache:
+            free, _ = torch.cuda.mem_get_info(self._device)
+            free += torch.cuda.memory_reserved(self._device) - torch.cuda.memory_allocated(self._device)
+            cache[max_new_tokens] = max(self.batch_size, min(2048, int(0.25 * free / per_req)))
+        return cache[max_new_tokens]
 
     def _start_workers(self) -> None:
         import os
@@ -346,6 +353,8 @@ class Qwen2VL(Model):
             i = j
         return {"prompts": prompts, "grids": grids_per_prompt, "groups": groups, "max_new": max_new, "n": len(chunk)}
 
+    PINNED_POOL_BYTES = 4 << 30   # retained (idle) pinned staging per rank; buffers in flight are bounded by the look-ahead
+
     def _pinned_take(self, shape: tuple) -> torch.Tensor:
         """Pinned staging buffer for one same-size image run: reused across chunks (page-locking a fresh GB per chunk costs
         more than copying into it)."""
@@ -362,7 +371,9 @@ class Qwen2VL(Model):
                 base = b._base if b._base is not None else b
                 self._pinned_free.append(base.reshape(-1))
             self._pinned_free.sort(key=lambda t: t.numel())
-            del self._pinned_free[:-6]   # keep the six largest
+            del self._pinned_free[:-6]   # keep the six largest ...
+            while len(self._pinned_free) > 1 and sum(t.numel() for t in self._pinned_free) > self.PINNED_POOL_BYTES:
+                del self._pinned_free[0]   # ... within a byte cap: page-locked host memory is per rank, eight ranks share a host
 
     def _generate_rows(self, requests: list) -> list[np.ndarray]:
         """Token rows (cut at EOS) per request, in request order.  Chunks of `batch_size` requests flow through a two-stage

@@ -6,8 +6,10 @@ first near-tie (after it the continuations may legitimately differ), so here the
 fed the reference's tokens (`forced_tokens`), returns every step's logits (`return_step_logits`), and EVERY step is
 compared with
 
-* the bf16 numpy oracle run on the same forced continuation  (<= 3 % of max |logit|; fp8 decoder: 10 %),
-* HF's own bf16 and fp32 runs of the same weights from tests/golden (<= 5 %),
+* the bf16 numpy oracle run on the same forced continuation  (<= 2 % of max |logit| - observed 0.9-1.5 %; fp8 decoder: 10 %),
+* HF's own bf16 and fp32 runs of the same weights from tests/golden (<= 2.5 % - observed 0.8-1.5 %),
+* HF's own bf16-vs-fp32 gap: the HIP logits are no farther from HF's fp32 run than 1.5 x what HF's bf16 run is
+  (`check_within_hf_bf16_noise`: worst step, mean over steps, and per step),
 
 and the engine's argmax must equal the reference token at every step whose top-2 margin exceeds twice the bound
 (`continue` on a near-tie, never `break`); on a near-tie the engine's token must still be one of the reference's
@@ -25,11 +27,15 @@ import torch
 
 from oracle import qwen2vl_np as Q
 from tests import recipes
-from tests.util import check_forced_steps, to_np
+from tests.util import check_forced_steps, check_within_hf_bf16_noise, to_np
 
 pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).parent / "golden"
 BF16 = torch.bfloat16
+# max |HIP - ref| / max |ref| per step.  Observed on MI355X (gpurun_out/r3_parity_baseline.log): 0.9-1.5 % against the bf16 numpy oracle
+# and against HF's bf16 / fp32 runs, at tiny size and at every config width; HF's own bf16-vs-fp32 gap on the goldens is 1.0-1.3 %.
+ORACLE_BOUND = 0.02
+HF_BOUND = 0.025
 
 
 # ---------------------------------------------------------------- Qwen2-VL tiny (HF goldens, 8 steps)
@@ -58,10 +64,11 @@ def test_qwen_every_step_vs_oracle_and_hf(qwen_tiny, gpu, case):
     toks, logits = eng.generate([ids], emb, [grid], T, forced_tokens=ref_tok[None], return_step_logits=True)
     toks, logits = to_np(toks)[0].astype(int), to_np(logits)[:, 0]
     _, o_logits = Q.generate(w, cfg, ids, pix, grid, T, bf16=True, return_logits=True, forced_tokens=ref_tok)
-    n = check_forced_steps(logits, toks, o_logits, None, 0.03, f"qwen-{case} oracle")
-    n += check_forced_steps(logits, toks, g[f"{case}_bf16_logits"], ref_tok, 0.05, f"qwen-{case} hf-bf16", margin_frac=0.06)
-    n += check_forced_steps(logits, toks, g[f"{case}_f32_logits"], ref_tok, 0.05, f"qwen-{case} hf-f32", margin_frac=0.06)
+    n = check_forced_steps(logits, toks, o_logits, None, ORACLE_BOUND, f"qwen-{case} oracle")
+    n += check_forced_steps(logits, toks, g[f"{case}_bf16_logits"], ref_tok, HF_BOUND, f"qwen-{case} hf-bf16")
+    n += check_forced_steps(logits, toks, g[f"{case}_f32_logits"], ref_tok, HF_BOUND, f"qwen-{case} hf-f32")
     assert n >= 3 * 4   # steps with a decisive margin, per reference (the others are asserted as near-top picks)
+    check_within_hf_bf16_noise(logits, g[f"{case}_bf16_logits"], g[f"{case}_f32_logits"], f"qwen-{case}")
 
 
 def test_qwen_fp8_every_step_vs_fp8_oracle(qwen_tiny, gpu):
@@ -106,9 +113,11 @@ def test_llava_every_step_vs_oracle_and_hf(gpu):
     toks, logits = eng.generate_from_features([ids], feats, [rows], T, forced_tokens=ref_tok[None], return_step_logits=True)
     toks, logits = to_np(toks)[0].astype(int), to_np(logits)[:, 0]
     _, o_logits = L.generate(w, cfg, ids, pix, T, bf16=True, return_logits=True, forced_tokens=ref_tok)
-    check_forced_steps(logits, toks, o_logits, None, 0.03, "llava oracle")
-    check_forced_steps(logits, toks, g["bf16_logits"], ref_tok, 0.05, "llava hf-bf16", margin_frac=0.06)
-    check_forced_steps(logits, toks, g["f32_logits"], ref_tok, 0.05, "llava hf-f32", margin_frac=0.06)
+    n = check_forced_steps(logits, toks, o_logits, None, ORACLE_BOUND, "llava oracle")
+    n += check_forced_steps(logits, toks, g["bf16_logits"], ref_tok, HF_BOUND, "llava hf-bf16")
+    n += check_forced_steps(logits, toks, g["f32_logits"], ref_tok, HF_BOUND, "llava hf-f32")
+    assert n >= 3 * 3   # this golden's top-2 margins exceed 5 % on 4 of its 8 steps
+    check_within_hf_bf16_noise(logits, g["bf16_logits"], g["f32_logits"], "llava")
 
 
 def test_llava_next_every_step_vs_oracle_and_hf(gpu):
@@ -130,10 +139,11 @@ def test_llava_next_every_step_vs_oracle_and_hf(gpu):
     toks, logits = to_np(toks)[0].astype(int), to_np(logits)[:, 0]
     _, o_logits = L.generate(w, cfg, ids, pix, T, bf16=True, return_logits=True, image_sizes=sizes, views_per_image=views,
                              forced_tokens=ref_tok)
-    check_forced_steps(logits, toks, o_logits, None, 0.03, "llava-next oracle")
-    n = check_forced_steps(logits, toks, g["bf16_logits"], ref_tok, 0.05, "llava-next hf-bf16", margin_frac=0.06)
-    n += check_forced_steps(logits, toks, g["f32_logits"], ref_tok, 0.05, "llava-next hf-f32", margin_frac=0.06)
+    check_forced_steps(logits, toks, o_logits, None, ORACLE_BOUND, "llava-next oracle")
+    n = check_forced_steps(logits, toks, g["bf16_logits"], ref_tok, HF_BOUND, "llava-next hf-bf16")
+    n += check_forced_steps(logits, toks, g["f32_logits"], ref_tok, HF_BOUND, "llava-next hf-f32")
     assert n >= 2 * 7   # this golden is decisive on 7 of its 8 steps
+    check_within_hf_bf16_noise(logits, g["bf16_logits"], g["f32_logits"], "llava-next")
 
 
 # ---------------------------------------------------------------- decoder width slices: every decode GEMM kernel
@@ -149,11 +159,16 @@ WIDTHS = {
 _W_CACHE: dict = {}   # one entry: the numpy weights of the most recent width (the 72B-width slice is 7 GB of fp32)
 
 
-def _slice(name, gpu, decoder_dtype="bf16"):
-    """2 decoder layers at the named model's widths + a 1-block miniature vision tower (the vision tower is width-tested in
-    tests/test_fullsize_gpu.py); vocab 2048 keeps the numpy oracle in seconds."""
-    from lmms_owc_amd.engine.qwen2vl import Qwen2VLDims, Qwen2VLEngine, Qwen2VLWeights
+OUTLIER_ROWS, OUTLIER_SCALE, OUTLIER_SEED = 16, 4.0, 97
 
+
+def _slice_weights(name):
+    """cfg + numpy weights of the 2-layer slice (CPU only: also used by tools/slice_margins.py to count the decisive steps the
+    ORACLE's logits offer before a GPU ever runs).  Random N(0, sigma) lm_head rows give near-flat logits over the vocabulary -
+    top-2 margins of 0-2 % of max |logit|, so a token comparison would almost never bind.  OUTLIER_ROWS vocabulary rows are
+    therefore scaled by OUTLIER_SCALE (same rows for the oracle and the engine: it is one weight dict): the winner is then
+    decided among those candidates with margins of typically 10-40 %, i.e. >= 4 of 6 steps per sequence are decisive and
+    the token assertion is real.  The relative logit error is unchanged by the scaling (numerator and max |logit| scale alike)."""
     d, hq, hkv, ff, bias = WIDTHS[name]
     cfg = Q.Cfg(vision=Q.VisionCfg(depth=1, embed_dim=160, num_heads=2, mlp_ratio=4.0, hidden_size=d),
                 text=Q.TextCfg(hidden_size=d, num_hidden_layers=2, num_attention_heads=hq, num_key_value_heads=hkv,
@@ -165,8 +180,21 @@ def _slice(name, gpu, decoder_dtype="bf16"):
             for k in list(w):
                 if "self_attn" in k and k.endswith("bias"):
                     w[k] = np.zeros_like(w[k])
+        rows = np.random.default_rng(OUTLIER_SEED).choice(np.arange(1, 1900), OUTLIER_ROWS, replace=False)
+        head = w["lm_head.weight"].copy()
+        head[rows] *= OUTLIER_SCALE          # a power of two: the scaled rows stay bf16-representable
+        w["lm_head.weight"] = head
         _W_CACHE[name] = w
-    w = _W_CACHE[name]
+    return cfg, _W_CACHE[name]
+
+
+def _slice(name, gpu, decoder_dtype="bf16"):
+    """2 decoder layers at the named model's widths + a 1-block miniature vision tower (the vision tower is width-tested in
+    tests/test_fullsize_gpu.py); vocab 2048 keeps the numpy oracle in seconds."""
+    from lmms_owc_amd.engine.qwen2vl import Qwen2VLDims, Qwen2VLEngine, Qwen2VLWeights
+
+    d, hq, hkv, ff, bias = WIDTHS[name]
+    cfg, w = _slice_weights(name)
     dims = Qwen2VLDims(v_depth=1, v_embed=160, v_heads=2, v_mlp=640, n_layers=2, d_model=d, n_q_heads=hq, n_kv_heads=hkv,
                        d_ff=ff, vocab=2048, tie_embeddings=False, image_token_id=2000, max_positions=512, max_grid=64,
                        decoder_dtype=decoder_dtype)
@@ -186,8 +214,10 @@ def _slice_case(cfg, B, n_check, seed):
     return prompts, pick, check
 
 
-def _run_slice(name, gpu, B, T, decoder_dtype="bf16", frac=0.03, mean_frac=None):
-    cfg, w, eng = _slice(name, gpu, decoder_dtype)
+def _slice_refs(name, B, T, decoder_dtype="bf16"):
+    """The oracle's side of a slice case (CPU only): images, prompts, the forced continuation and, for the 3 checked sequences,
+    the oracle's tokens + logits of every step."""
+    cfg, w = _slice_weights(name)
     fp8 = None
     if decoder_dtype == "fp8":
         from oracle import fp8_np as F
@@ -197,7 +227,6 @@ def _run_slice(name, gpu, B, T, decoder_dtype="bf16", frac=0.03, mean_frac=None)
         fp8 = _W_CACHE[name + "/fp8"]
     grid = [(1, 4, 4)]
     pixs = [recipes.pixel_values(grid, 50 + i) for i in range(3)]
-    emb = eng.encode_images(torch.from_numpy(np.concatenate(pixs)).to(BF16).to(gpu), grid * 3)   # 3 images x 4 rows
     prompts, pick, check = _slice_case(cfg, B, 3, seed=B)
     r = np.random.default_rng(B + 1)
     forced = r.integers(1, 1900, (B, T))
@@ -206,14 +235,24 @@ def _run_slice(name, gpu, B, T, decoder_dtype="bf16", frac=0.03, mean_frac=None)
         o_toks, o_logits = Q.generate(w, cfg, prompts[b], pixs[pick[b]], grid, T, bf16=True, return_logits=True, fp8=fp8)
         forced[b] = o_toks
         refs[b] = (o_toks, o_logits)
+    return cfg, grid, pixs, prompts, pick, check, forced, refs
+
+
+def _run_slice(name, gpu, B, T, decoder_dtype="bf16", frac=0.02, mean_frac=None, min_decisive=4):
+    """Every checked sequence must offer - and pass - at least `min_decisive` token comparisons with a decisive margin."""
+    _, _, eng = _slice(name, gpu, decoder_dtype)
+    cfg, grid, pixs, prompts, pick, check, forced, refs = _slice_refs(name, B, T, decoder_dtype)
+    emb = eng.encode_images(torch.from_numpy(np.concatenate(pixs)).to(BF16).to(gpu), grid * 3)   # 3 images x 4 rows
     rows = [4 * int(pick[b]) + np.arange(4) for b in range(B)]
     toks, logits = eng.generate(prompts, emb, [grid] * B, T, img_rows=rows, forced_tokens=forced, return_step_logits=True)
     toks = to_np(toks).astype(int)
-    n = 0
+    counts = []
     for b in check:
-        n += check_forced_steps(to_np(logits[:, b]), toks[b], refs[b][1], refs[b][0], frac, f"{name} B={B} seq {b}",
-                                mean_frac=mean_frac)
-    return n
+        n = check_forced_steps(to_np(logits[:, b]), toks[b], refs[b][1], refs[b][0], frac, f"{name} B={B} seq {b}",
+                               mean_frac=mean_frac)
+        assert n >= min_decisive, f"{name} B={B} seq {b}: only {n} of {T} steps had a decisive top-2 margin (want >= {min_decisive})"
+        counts.append(n)
+    return counts
 
 
 @pytest.mark.parametrize("B", [8, 200, 1280])
@@ -232,4 +271,4 @@ def test_config_width_decode_steps(gpu, name, B):
 @pytest.mark.parametrize("B", [8, 130])
 def test_72b_width_fp8_decode_steps(gpu, B):
     """Config #5's fp8 decoder at 72B widths (K = 8192 / 29568 per-token scales): fp8 engine vs the numpy fp8 decoder."""
-    _run_slice("72b", gpu, B, 6, decoder_dtype="fp8", frac=0.10, mean_frac=0.02)
+    _run_slice("72b", gpu, B, 6, decoder_dtype="fp8", frac=0.10, mean_frac=0.02, min_decisive=FP8_MIN_DECISIVE)

@@ -66,3 +66,28 @@ def test_fractional_limit_is_ceiled_like_the_reference(pipeline):
 
     res = simple_evaluate(model="stand-in", task_objects={"toytask": F.toy_task()}, limit=0.1, model_object=F.StandInModel())
     assert res["n-samples"]["toytask"] == {"original": 11, "effective": 2} and len(res["samples"]["toytask"]) == 2
+
+
+def test_decoded_image_in_doc_never_reaches_the_samples_file(pipeline, tmp_path):
+    """Docs of this repo may carry the decoded image under `visual` (the reference's rows hold a path there): the sample
+    record keeps JSON-serialisable values only, so two runs write identical files and no object repr / address leaks."""
+    import json
+
+    from PIL import Image
+
+    from lmms_owc_amd.engine.evaluate import simple_evaluate
+    from lmms_owc_amd.engine.tracker import EngineTracker
+
+    texts = []
+    for run in range(2):
+        task = F.toy_task()
+        for d in task.docs:
+            d["visual"] = Image.new("RGB", (8, 8))   # a fresh object (fresh address) per run
+        res = simple_evaluate(model="stand-in", task_objects={"toytask": task}, limit=3, model_object=F.StandInModel(), datetime_str=F.DATE)
+        tr = EngineTracker(output_path=str(tmp_path / f"run{run}"))
+        tr.save_results_samples(task_name="toytask", samples=res["samples"]["toytask"])
+        (f,) = (tmp_path / f"run{run}").rglob("*_samples_*.jsonl")
+        texts.append(f.read_text())
+    assert texts[0] == texts[1] and "PIL" not in texts[0] and " at 0x" not in texts[0]
+    for line in texts[0].splitlines():
+        assert "visual" not in json.loads(line)["doc"] and "target" in json.loads(line)["doc"]

@@ -77,6 +77,25 @@ def test_cabi_exports_every_declared_symbol():
     assert _lib.load().owc_abi_version() == _lib.ABI_VERSION
 
 
+def test_product_library_has_no_timing_knobs_and_reads_no_environment():
+    """The timing-only experiment knobs (parts of a kernel switched off: garbage results) are compiled out of libowc_hip.so -
+    `owc_tuning_set` does not know their names - and the library reads no environment variable (csrc/ has no getenv): an
+    OWC_*_DBG variable left in a shell cannot touch an evaluation run.  They live in libowc_hip_timing.so (tools/ only)."""
+    from lmms_owc_amd import _lib
+
+    lib = _lib.load()
+    assert lib.owc_has_timing_knobs() == 0
+    for knob in (b"gemm_dbg", b"attn_dbg"):
+        assert lib.owc_tuning_set(knob, 0) != 0, knob
+    assert lib.owc_tuning_set(b"gemm_pingpong", 1) == 0        # the result-preserving A-B knobs stay
+    for f in (ROOT / "lmms_owc_amd" / "csrc").glob("*.h*"):
+        assert "getenv" not in f.read_text(), f.name
+    from lmms_owc_amd import build as owc_build
+
+    dyn = subprocess.run([owc_build._objdump(), "-T", str(_lib.lib_path())], capture_output=True, text=True, check=True).stdout
+    assert "owc_tuning_set" in dyn and "getenv" not in dyn     # the shared object does not even import getenv
+
+
 def test_product_path_fails_loudly_without_gpu_or_extension(tmp_path, monkeypatch):
     import torch
 

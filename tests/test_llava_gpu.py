@@ -39,8 +39,10 @@ def setup(gpu):
     return cfg, w, eng, np.load(GOLD / "llava_tiny.npz")
 
 
-def _close(got, ref, frac):
-    assert np.abs(got - ref).max() <= frac * np.abs(ref).max(), (np.abs(got - ref).max(), np.abs(ref).max())
+def _close(got, ref, frac, tag=""):
+    from tests.util import assert_rel_close
+
+    assert_rel_close(got, ref, frac, tag or "model-level")
 
 
 def _feats(eng, pix, gpu):

@@ -49,3 +49,25 @@ def test_topk_contains_paired():
     assert (idx[:7, 0] == np.arange(7)).all()
     np.testing.assert_allclose(val[:7, 0], 1.0, atol=1e-6)
     assert (np.diff(val, axis=1) <= 0).all()
+
+
+def test_ragged_256_labels_at_minilm_size():
+    """256 ragged labels (lengths 2..16) through the REFERENCE's encode_sentence_bert / semantic_similarity /
+    mean_average_semantic_similarity at full MiniLM-L6 size (tools/gen_golden.py scorer_ragged)."""
+    g = np.load(GOLD / "scorer_minilm256.npz")
+    meta = json.loads((GOLD / "scorer_minilm256.json").read_text())
+    c = recipes.bert_cfg("minilm")
+    w = recipes.bert_weights(c, meta["weights_seed"])
+    s_r, s_p = (int(x) for x in g["label_seeds"])
+    ids_r, mask_r = recipes.label_tokens(meta["n"], meta["L"], c["vocab_size"], seed=s_r)
+    ids_p, mask_p = recipes.label_tokens(meta["n"], meta["L"], c["vocab_size"], seed=s_p)
+    assert len(set(mask_r.sum(1).tolist())) >= 12   # really ragged
+    zr, zp = B.sentence_embed(w, c, ids_r, mask_r), B.sentence_embed(w, c, ids_p, mask_p)
+    np.testing.assert_allclose(zr, g["ref_embeds"], atol=2e-6)
+    np.testing.assert_allclose(zp, g["pred_embeds"], atol=2e-6)
+    cos = B.paired_cosine(zr, zp)
+    np.testing.assert_allclose(cos, g["semantic_similarity_none"], atol=2e-6)
+    np.testing.assert_allclose(cos.mean(), g["semantic_similarity_mean"], atol=2e-6)
+    got = B.mean_average(g["semantic_similarity_none"])
+    for k, v in meta["mean_average"].items():
+        assert abs(got[k] - v) < 1e-6

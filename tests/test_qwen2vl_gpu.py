@@ -32,8 +32,10 @@ def setup(gpu):
     return cfg, w, eng, np.load(GOLD / "qwen2vl_tiny.npz")
 
 
-def _close(got, ref, frac):
-    assert np.abs(got - ref).max() <= frac * np.abs(ref).max(), (np.abs(got - ref).max(), np.abs(ref).max())
+def _close(got, ref, frac, tag=""):
+    from tests.util import assert_rel_close
+
+    assert_rel_close(got, ref, frac, tag or "model-level")
 
 
 @pytest.mark.parametrize("case", ["a", "b"])

@@ -31,6 +31,33 @@ def test_embed_matches_reference_golden(gpu, kind, n, L):
     np.testing.assert_allclose(cos, g[f"{kind}_semantic_similarity_none"], atol=2e-5)
 
 
+def test_ragged_256_labels_match_reference_golden(gpu):
+    """256 ragged labels (2..16 tokens) at full MiniLM-L6 size against the REFERENCE's own CPU-fp32 output
+    (tests/golden/scorer_minilm256.npz): packed rows, a batch split in the middle (max_batch 100), paired cosine, the mean and
+    the threshold masses of mean_average_semantic_similarity (/root/reference/src/data/metrics/_group.py:392-458, :537-544)."""
+    import json
+
+    from lmms_owc_amd.engine.scorer import BertWeights, SentenceScorer
+
+    g = np.load(GOLD / "scorer_minilm256.npz")
+    meta = json.loads((GOLD / "scorer_minilm256.json").read_text())
+    c = recipes.bert_cfg("minilm")
+    s_r, s_p = (int(x) for x in g["label_seeds"])
+    ids_r, mask_r = recipes.label_tokens(meta["n"], meta["L"], c["vocab_size"], seed=s_r)
+    ids_p, mask_p = recipes.label_tokens(meta["n"], meta["L"], c["vocab_size"], seed=s_p)
+    for max_batch in (100, 16384):
+        sc = SentenceScorer(BertWeights(c, recipes.bert_weights(c, meta["weights_seed"]), gpu), max_batch=max_batch)
+        zr, zp = sc.embed(ids_r, mask_r), sc.embed(ids_p, mask_p)
+        np.testing.assert_allclose(to_np(zr), g["ref_embeds"], atol=2e-5)
+        np.testing.assert_allclose(to_np(zp), g["pred_embeds"], atol=2e-5)
+        cos = to_np(sc.paired_cosine(zr, zp))
+        np.testing.assert_allclose(cos, g["semantic_similarity_none"], atol=2e-5)
+        assert abs(float(cos.mean()) - float(g["semantic_similarity_mean"])) <= 2e-5
+        got = B.mean_average(cos)   # threshold masses: a pure function of the cosines (the oracle's helper as the checker)
+        for k, v in meta["mean_average"].items():
+            assert abs(got[k] - v) <= 1.0 / meta["n"] + 1e-6, k   # a cosine within 2e-5 of a threshold may land on either side
+
+
 def test_bf16x3_linears_match_the_exact_f32_mfma(gpu):
     """The encoder's linears run as three-piece bf16 splits of the fp32 operands (6 bf16 MFMAs per block, gemm_f32.hip); the
     exact f32-input MFMA kernel stays selectable.  Both must sit within the golden tolerance, and within 2e-6 of each other."""

@@ -7,6 +7,13 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from lmms_owc_amd import _lib, ops  # noqa: E402
 
+# timing experiments (`gemm_dbg` / `attn_dbg`: parts of a kernel switched off) exist only in the -DOWC_TIMING_KNOBS build
+if any(a.startswith(("--dbg", "--timing")) or "_dbg" in a for a in sys.argv[1:]):
+    from lmms_owc_amd import build as _owc_build
+
+    _owc_build.build(verbose=False, timing=True)
+    _lib.use_timing_library()
+
 SHAPES = [
     ("vit.qkv", 32768, 3840, 1280),
     ("vit.proj", 32768, 1280, 1280),

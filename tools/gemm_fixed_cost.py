@@ -7,6 +7,10 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from lmms_owc_amd import _lib, ops  # noqa: E402
+from lmms_owc_amd import build as _owc_build  # noqa: E402
+
+_owc_build.build(verbose=False, timing=True)   # `gemm_dbg` exists only in the -DOWC_TIMING_KNOBS build
+_lib.use_timing_library()
 
 dev = torch.device("cuda:0")
 lib = _lib.load()

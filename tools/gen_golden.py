@@ -178,6 +178,44 @@ def import_reference():
     return metrics, text_mod, utils
 
 
+def gen_scorer_ragged():
+    """The reference's own encode_sentence_bert / semantic_similarity on 256 RAGGED labels at full MiniLM-L6 size (lengths uniform
+    2..16, mixed `str` / `[str]` wrapping): the 8-label `minilm` case of gen_scorer() is one padded batch; this one is what a task's
+    prediction column looks like.  Written to its own file (scorer_minilm256.npz) so the existing vectors stay byte-identical."""
+    metrics, text_mod, _ = import_reference()
+    c = recipes.bert_cfg("minilm")
+    w = recipes.bert_weights(c, 1234)
+    text_mod.sentence_bert_model = hf_bert(c, w)
+    text_mod.sentence_bert_processor = IdTokenizer()
+    n, L = 256, 16
+    ids_r, mask_r = recipes.label_tokens(n, L, c["vocab_size"], seed=31)
+    ids_p, mask_p = recipes.label_tokens(n, L, c["vocab_size"], seed=32)
+    to_text = lambda ids, mask: [" ".join(str(int(t)) for t, m in zip(r, mk) if m) for r, mk in zip(ids, mask)]  # noqa: E731
+    refs, preds = to_text(ids_r, mask_r), to_text(ids_p, mask_p)
+    out = {}
+    saved = torch.cuda.is_available
+    torch.cuda.is_available = lambda: False   # the reference's CPU fp32 branch (_text.py:165-170)
+    try:
+        b = text_mod.encode_sentence_bert({"text": list(refs)}, input_column="text")
+        out["ref_embeds"] = np.array(b["text_sentence_bert_embeds"], dtype=np.float32)
+        b = text_mod.encode_sentence_bert({"text": list(preds)}, input_column="text")
+        out["pred_embeds"] = np.array(b["text_sentence_bert_embeds"], dtype=np.float32)
+        items = [(r, [p]) if i % 2 else ([r], p) for i, (r, p) in enumerate(zip(refs, preds))]
+        ss = metrics.get_metric_info("semantic_similarity")
+        out["semantic_similarity_none"] = np.array(ss.group_fn(ss.builder_fn(items), reduce="none"), dtype=np.float32)
+        out["semantic_similarity_mean"] = np.array(ss.group_fn(ss.builder_fn(items), reduce="mean"), dtype=np.float32)
+        ma = metrics.get_metric_info("mean_average_semantic_similarity")
+        mean_average = ma.group_fn(ma.builder_fn(items), reduce="mean")   # dict: threshold -> mass, + their mean
+    finally:
+        torch.cuda.is_available = saved
+    out["label_seeds"] = np.array([31, 32])
+    np.savez_compressed(GOLD / "scorer_minilm256.npz", **out)
+    (GOLD / "scorer_minilm256.json").write_text(json.dumps({"versions": versions(), "n": n, "L": L, "weights_seed": 1234,
+                                                            "mean_average": mean_average,
+                                                            "what": "reference encode_sentence_bert + semantic_similarity, CPU fp32"}, indent=1))
+    print("scorer ragged golden:", {k: v.shape for k, v in out.items()})
+
+
 class IdTokenizer:
     """Stand-in for AutoTokenizer: a label is a string of space-separated token ids (no tokenizer files offline)."""
 
@@ -520,3 +558,5 @@ if __name__ == "__main__":
         gen_qwen()
     if "scorer" in which:
         gen_scorer()
+    if "scorer_ragged" in which:
+        gen_scorer_ragged()

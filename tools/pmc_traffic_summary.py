@@ -28,6 +28,8 @@ def main() -> None:
     ap.add_argument("--shape", default="")
     ap.add_argument("--alg-bytes", default="", help="A=..,W=..,C=.. algorithmic bytes of one launch")
     ap.add_argument("--command", default="")
+    ap.add_argument("--seq", type=int, default=None, help="measurement sequence number (bench.py reads the highest one of a kernel); "
+                                                          "default: one more than the highest under profiles/")
     ap.add_argument("passes", nargs="+")
     a = ap.parse_args()
     acc, cnt = collections.defaultdict(float), collections.Counter()
@@ -50,7 +52,10 @@ def main() -> None:
         wr = csv.writer(fh)
         wr.writerow(header)
         wr.writerows(raw_rows)
-    out = {"kernel": a.kernel, "shape": a.shape, "command": a.command, "launches_per_counter": dict(cnt),
+    seq = a.seq
+    if seq is None:
+        seq = 1 + max([json.loads(f.read_text()).get("seq", -1) for f in (ROOT / "profiles").glob("r*_pmc_gemm_traffic*.json")] + [-1])
+    out = {"seq": seq, "kernel": a.kernel, "shape": a.shape, "command": a.command, "launches_per_counter": dict(cnt),
            "per_launch": per, "raw_csv": str(raw.relative_to(ROOT))}
     if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
         fetch, write = 2.0 * per["FETCH_SIZE"] * 1024.0, per["WRITE_SIZE"] * 1024.0

@@ -1,0 +1,27 @@
+"""CPU check of the width-slice parity cases (tests/test_decode_parity_gpu.py): how many steps of each checked sequence have a
+DECISIVE top-2 margin in the ORACLE's logits (> 2 x the logit bound), i.e. how many token comparisons the GPU test will bind on.
+Run after changing OUTLIER_* or the case seeds:   python tools/slice_margins.py [name ...]"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from tests import test_decode_parity_gpu as T  # noqa: E402
+
+CASES = [("2b", 8, 8, "bf16"), ("2b", 200, 8, "bf16"), ("2b", 1280, 8, "bf16"), ("7b", 8, 6, "bf16"), ("7b", 300, 6, "bf16"),
+         ("yi34b", 8, 6, "bf16"), ("yi34b", 130, 6, "bf16"), ("72b", 8, 6, "bf16"), ("72b", 130, 6, "bf16"),
+         ("72b", 8, 6, "fp8"), ("72b", 130, 6, "fp8")]
+only = set(sys.argv[1:])
+for name, B, steps, dt in CASES:
+    if only and name not in only and dt not in only:
+        continue
+    t0 = time.time()
+    frac = 0.10 if dt == "fp8" else 0.02
+    *_, check, forced, refs = T._slice_refs(name, B, steps, dt)
+    for b in check:
+        lg = np.asarray(refs[b][1], np.float32)
+        m = [float((np.sort(x)[-1] - np.sort(x)[-2]) / np.abs(x).max()) for x in lg]
+        print(f"{name:6s} {dt} B={B:5d} seq {b:5d}: decisive (> {2 * frac:.2f}) {sum(x > 2 * frac for x in m)} / {steps}   margins {np.round(m, 3)}  tokens {list(refs[b][0])}", flush=True)
+    print(f"   ({time.time() - t0:.1f} s)")
