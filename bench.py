@@ -41,11 +41,11 @@ RENDEZVOUS_FAILED = 75   # exit code of a rank whose init_process_group failed (
 PEAK_FP8_TFLOPS = 5000.0   # dense fp8 (block-scaled f8f6f4 MFMA) peak, same source
 
 
-def flops_per_image(d, new_tokens: int) -> float:
-    """SURVEY.md §8(d) algorithmic FLOPs per 448x448 image (causal attention counted at 1/2)."""
-    P, Dv, Lv, S = 1024, d.v_embed, d.v_depth, S_TEXT_BEFORE + S_IMG + S_TEXT_AFTER
+def flops_per_image(d, new_tokens: int, patches: int = 1024) -> float:
+    """SURVEY.md §8(d) algorithmic FLOPs per image of `patches` 14x14 patches (448x448: 1024; causal attention counted at 1/2)."""
+    P, Dv, Lv, S = patches, d.v_embed, d.v_depth, S_TEXT_BEFORE + patches // 4 + S_TEXT_AFTER
     f_vit = 2 * P * d.patch_k * Dv + Lv * (8 * P * Dv * Dv + 4 * P * P * Dv + 4 * P * Dv * d.v_mlp) \
-        + 2 * 256 * (4 * Dv) ** 2 + 2 * 256 * 4 * Dv * d.d_model
+        + 2 * (P // 4) * (4 * Dv) ** 2 + 2 * (P // 4) * 4 * Dv * d.d_model
     H, KV, hd, dm, ff, L, V = d.n_q_heads, d.n_kv_heads, d.head_dim, d.d_model, d.d_ff, d.n_layers, d.vocab
     f_pre = L * (2 * S * dm * (H + 2 * KV) * hd + 2 * S * H * hd * dm + 2 * S * S * H * hd + 6 * S * dm * ff) + 2 * dm * V
     # the first new token comes out of the prefill logits: T new tokens need T - 1 single-token forwards
@@ -197,10 +197,96 @@ def cpu_baseline_scorer(n_labels: int, L: int) -> dict:
             "sample": f"{n_labels} labels x {L} tokens, HF BertModel fp32 CPU batches of 1024 + paired bmm"}
 
 
-def prompt_ids(image_token_id: int) -> np.ndarray:
+def prompt_ids(image_token_id: int, n_image_tokens: int = S_IMG) -> np.ndarray:
     r = np.random.default_rng(1234)
-    return np.concatenate([r.integers(1000, 150000, S_TEXT_BEFORE), np.full(S_IMG, image_token_id),
+    return np.concatenate([r.integers(1000, 150000, S_TEXT_BEFORE), np.full(n_image_tokens, image_token_id),
                            r.integers(1000, 150000, S_TEXT_AFTER)]).astype(np.int32)
+
+
+# ---- real-size workload (BASELINE config #3: Food-101 + DTD + Flowers-102; none of them is 448x448).  There are no dataset files
+# offline, so the (height, width) distributions are modelled on the datasets' published sizing rules - stated here, seeded, and
+# only ever used for the extra `--image-sizes` leg (never `value`):
+#   food101:    "rescaled to a maximum side length of 512": mostly 512x512, the rest 4:3 / 3:2 landscape or portrait
+#   dtd:        "sizes range between 300x300 and 640x640": both sides uniform in [300, 640]
+#   flowers102: "smallest side 500": the other side uniform in [500, 1000], landscape or portrait
+def _sizes_food101(r, n):
+    table = [(512, 512)] * 12 + [(384, 512)] * 3 + [(512, 384)] * 2 + [(341, 512), (512, 341), (306, 512)]
+    return [table[i] for i in r.integers(0, len(table), n)]
+
+
+def _sizes_dtd(r, n):
+    return [(int(h), int(w)) for h, w in r.integers(300, 641, (n, 2))]
+
+
+def _sizes_flowers102(r, n):
+    out = []
+    for long_side, portrait in zip(r.integers(500, 1001, n), r.random(n) < 0.35):
+        out.append((int(long_side), 500) if portrait else (500, int(long_side)))
+    return out
+
+
+DATASET_SIZES = {"food101": _sizes_food101, "dtd": _sizes_dtd, "flowers102": _sizes_flowers102}
+
+
+def ragged_leg(engine, dims, name: str, n: int, T: int, steps: int, device, sync, min_pixels: int = 4 * 784, max_pixels: int = 1024 * 784) -> dict:
+    """The reference resizes every image inside [min_pixels, max_pixels] (`_qwen2_vl.py:64-65, 299-305`) -> 64...1024 image tokens
+    per image.  `n` images with the dataset's size distribution -> smart_resize (two stages, like `imageproc.prepare_image`) ->
+    uint8 uniform pixels -> owc_patchify_u8 -> ragged vision launch groups -> prompts of 14 + n_tok + 16 tokens (unequal lengths:
+    KV slots sized by the longest, shared 14-token prefix) -> `T` greedy tokens."""
+    from lmms_owc_amd import ops as owc_ops
+    from lmms_owc_amd.models import imageproc
+
+    r = np.random.default_rng(4321)
+    sizes = DATASET_SIZES[name](r, n)
+    grids = []
+    for h, w in sizes:
+        h1, w1 = imageproc.smart_resize(h, w, 28, 4 * 28 * 28, 16384 * 28 * 28)         # qwen_vl_utils.fetch_image
+        h2, w2 = imageproc.smart_resize(h1, w1, 28, min_pixels, max_pixels)             # the HF processor
+        grids.append((1, h2 // 14, w2 // 14))
+    gen = torch.Generator(device=device).manual_seed(99)
+    by_size: dict = {}
+    for i, g in enumerate(grids):
+        by_size.setdefault(g, []).append(i)
+    pieces = [None] * n
+    for (_, gh, gw), idx in by_size.items():   # one patchify launch per distinct size (outside the timed region)
+        u8 = torch.randint(0, 256, (len(idx), 3, gh * 14, gw * 14), generator=gen, device=device, dtype=torch.uint8)
+        pv = owc_ops.patchify_u8(u8, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD)
+        for j, i in enumerate(idx):
+            pieces[i] = pv[j * gh * gw:(j + 1) * gh * gw]
+    pix = torch.cat(pieces)
+    del pieces
+    n_tok = [g[1] * g[2] // 4 for g in grids]
+    prompts = [prompt_ids(dims.image_token_id, t) for t in n_tok]
+    gpp = [[g] for g in grids]
+
+    def step():
+        emb = engine.encode_images(pix, grids)
+        return engine.generate(prompts, emb, gpp, T, eos_token_id=-1, pad_token_id=0).cpu()
+
+    out = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    sync()
+    dt = (time.perf_counter() - t0) / steps
+    # property checks outside the timed region: determinism, and a short + a long image alone == inside the ragged batch
+    again = step()
+    lo, hi = int(np.argmin(n_tok)), int(np.argmax(n_tok))
+    inv = bool(torch.equal(again, out))
+    for i in (lo, hi):
+        row0 = sum(g[1] * g[2] for g in grids[:i])
+        emb1 = engine.encode_images(pix[row0:row0 + grids[i][1] * grids[i][2]], [grids[i]])
+        solo = engine.generate([prompts[i]], emb1, [gpp[i]], T, eos_token_id=-1, pad_token_id=0).cpu()
+        inv = inv and bool(torch.equal(solo[0], out[i]))
+    flops = float(sum(flops_per_image(dims, T, g[1] * g[2]) for g in grids))
+    return {"dataset_size_model": name, "images": n, "seconds_per_pass": dt, "images_per_s": n / dt, "image_tokens_per_s": sum(n_tok) / dt,
+            "image_tokens_per_image": {"min": min(n_tok), "mean": float(np.mean(n_tok)), "max": max(n_tok)},
+            "distinct_grids": len(by_size), "prompt_tokens": {"min": 30 + min(n_tok), "max": 30 + max(n_tok)},
+            "model_flops_per_image_mean": flops / n, "mfma_frac_end_to_end_nominal": flops / dt / (PEAK_BF16_TFLOPS * 1e12),
+            "deterministic_and_batch_invariant": inv,
+            "what": "seeded (height, width) model of the dataset's published sizing rule -> smart_resize within [3136, 802816] px -> "
+                    "ragged cu_seqlens vision launch groups + unequal prompts (shared 14-token prefix); uniform-noise pixels; never `value`"}
 
 
 def self_launch(n: int) -> int:
@@ -303,6 +389,11 @@ def main() -> None:
     ap.add_argument("--prefill-chunk", type=int, default=None, help="packed prefill rows per launch group (engine default if unset)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pil-leg", action="store_true", help="skip the PIL -> generate_until -> strings leg")
+    ap.add_argument("--no-decode-leg", action="store_true", help="skip the HBM-regime decode leg (decode step at batch 1 / 32 / 128)")
+    ap.add_argument("--image-sizes", default=None, choices=sorted(DATASET_SIZES),
+                    help="extra leg (never `value`): images of the dataset's real size distribution through smart_resize "
+                         "(64...1024 image tokens per image, ragged vision / prefill launch groups); reports images/s and image-tokens/s")
+    ap.add_argument("--ragged-images", type=int, default=1024, help="images of the --image-sizes leg")
     ap.add_argument("--nominal-forward", action="store_true",
                     help="run the model's nominal forward: full last prefill layer on every row and no shared-prefix segment "
                          "(same tokens bit for bit; shows what the two dead-work eliminations are worth)")
@@ -470,6 +561,22 @@ def main() -> None:
         pil["images_per_s"] = world * pil["images"] / pil["seconds"]
     del host_u8
 
+    # ---- HBM-regime decode leg (never `value`): ms per decode step at the reference's batch size and mid batches
+    decode_leg = None
+    if rank == 0 and not args.no_decode_leg:
+        decode_leg = decode_regime_leg(engine, dims)
+    if dist is not None:
+        dist.barrier()
+
+    ragged = None
+    if args.image_sizes:
+        ragged = ragged_leg(engine, dims, args.image_sizes, args.ragged_images, T, max(1, args.steps - 1), device, sync)
+        if dist is not None:
+            t = torch.tensor([ragged["seconds_per_pass"]], device=cdev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ragged["seconds_per_pass"] = float(t.item())
+            ragged["images_per_s"] = world * ragged["images"] / ragged["seconds_per_pass"]
+
     # ---- scorer leg: label-cosine/s (embed predictions + cosine top-5 against resident class embeddings)
     n_lab, L = args.scorer_labels, 16
     scorer = SentenceScorer(BertWeights.random(MINILM_L6, device, seed=7), max_batch=16384)
@@ -540,6 +647,8 @@ def main() -> None:
                          "launches": g["launches"], "kernel_ms_total": g["ms"], "share_of_step_time": g["ms"] * 1e-3 / time_or(dt),
                          "method": "HIP events around every launch of the timed region on the launch stream; achieved = sum(2MNK) / sum(t)"},
             "roofline_attention": attention_rooflines(prof, dims, B, T, args.steps, dt),
+            "roofline_decode": decode_leg,
+            "real_image_sizes": ragged,
             "roofline_label_cosine": scorer_rooflines(sprof, n_lab, args.scorer_classes, 5, args.steps, float(sdt.item())),
         }
         if args.one_gpu_value:
@@ -569,6 +678,8 @@ def main() -> None:
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if ragged is not None and not ragged["deterministic_and_batch_invariant"]:
+        raise SystemExit("ragged leg: determinism / batch invariance failed (the JSON line above carries the measurement)")
     if not invariant:
         raise SystemExit("batch invariance check failed (the JSON line above carries the measurement)")
     if parity_failure:
@@ -649,22 +760,72 @@ def load_traffic(args, engine, B: int) -> dict | None:
             "raw_counters": d.get("raw_csv")}
 
 
+PEAK_HBM_GBS = 8000.0   # HBM3E peak, MI355X_MICROARCH.md (about 6.3 TB/s is what a pure stream achieves)
+
+
 def attention_rooflines(prof: dict, d, B: int, T: int, steps: int, dt: float) -> dict:
-    """Roofline objects of the two attention launch classes of the timed region (HIP events inside the library; the launcher
-    cannot see the device-side lengths, so the algorithmic FLOPs are priced here from the workload's shapes)."""
+    """Roofline objects of the THREE attention launch classes of the timed region (HIP events inside the library; the launcher
+    cannot see the device-side lengths, so the algorithmic work is priced here from the workload's shapes):
+    vision (non-causal, MFMA-bound), causal prefill (MFMA-bound), decode (one query row per q head over the sequence's whole
+    KV cache: HBM-bound, priced in bytes = the K and V rows it streams)."""
     S = S_TEXT_BEFORE + S_IMG + S_TEXT_AFTER
     vis = steps * B * d.v_depth * 4.0 * 1024 * 1024 * d.v_embed                      # QK^T + PV, non-causal, per image per layer
     pre = steps * B * d.n_layers * 2.0 * S * S * d.n_q_heads * d.head_dim            # causal: half of 4 S^2 H hd
-    dec = steps * B * d.n_layers * sum(4.0 * (S + i) * d.n_q_heads * d.head_dim for i in range(T - 1))
+    kv_row = 2.0 * d.n_kv_heads * d.head_dim * 2                                     # K + V bytes of one token in one layer
+    dec_bytes = steps * B * d.n_layers * sum(kv_row * (S + i + 1) for i in range(T - 1))   # step i reads the S + i + 1 cached rows
     out = {}
     for name, kind, flops, kernel in (("vision", "attn_vision", vis, "attn_fwd_kernel<80,false>"),
-                                      ("decoder", "attn_decoder", pre + dec, "attn_fwd_kernel<128,*> (causal prefill + decode steps)")):
+                                      ("prefill", "attn_prefill", pre, "attn_fwd_kernel<128,true> (causal GQA prefill, S = 286)")):
         p = prof[kind]
         tf = flops / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
         out[name] = {"bound": "mfma", "kernel": kernel, "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": tf / PEAK_BF16_TFLOPS, "traffic": None, "launches": p["launches"], "kernel_ms_total": p["ms"],
                      "share_of_step_time": p["ms"] * 1e-3 / time_or(dt)}
+    p = prof["attn_decode"]
+    gbs = dec_bytes / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else 0.0
+    out["decode"] = {"bound": "hbm", "kernel": "attn_fwd_kernel<128,false> (decode mapping: rows = the G q heads of a kv group)",
+                     "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                     "algorithmic_bytes": "K + V rows of the sequence's cache, once per kv head per step: 2 * n_kv_heads * 128 * 2 B per token per layer",
+                     "launches": p["launches"], "kernel_ms_total": p["ms"], "share_of_step_time": p["ms"] * 1e-3 / time_or(dt)}
     return out
+
+
+def decode_regime_leg(engine, dims, batches=(1, 32, 128), s_prompt: int = 286, t_short: int = 2, t_long: int = 18) -> dict:
+    """The HBM-bound regime of the greedy decode loop (SURVEY.md section 8d "Bound": a decode step streams every decoder weight once
+    whatever the batch, so below the ridge B ~ 312 it is a weight stream): ms per token-step of the bench's own engine at the
+    reference's batch size (1) and at mid batches, from the difference of a `t_long`- and a `t_short`-token generate on text-only
+    prompts of S = 286 tokens.  Algorithmic bytes per step = the decoder layers' weights + lm_head (each read once) + the K/V
+    rows of every sequence (2 KB per token per layer for 7B) - NOT the embedding table (B rows of it) and not the vision tower."""
+    d = dims
+    wbytes = 2.0 * (d.n_layers * (d.d_model * (d.n_q_heads + 2 * d.n_kv_heads) * d.head_dim + d.n_q_heads * d.head_dim * d.d_model
+                                  + 3 * d.d_model * d.d_ff) + d.vocab * d.d_model)
+    if getattr(d, "decoder_dtype", "bf16") == "fp8":   # fp8 decoder projections: 1 byte per layer weight, lm_head stays bf16
+        wbytes = wbytes - (wbytes - 2.0 * d.vocab * d.d_model) / 2
+    r = np.random.default_rng(0)
+    rows = []
+    for B in batches:
+        prompts = [r.integers(1000, 30000, s_prompt).astype(np.int32) for _ in range(B)]
+        none = [[] for _ in prompts]
+        ts = {}
+        for T in (t_short, t_long):
+            engine.generate(prompts, None, none, T)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                engine.generate(prompts, None, none, T)
+            torch.cuda.synchronize()
+            ts[T] = (time.perf_counter() - t0) / 3
+        per_step = (ts[t_long] - ts[t_short]) / (t_long - t_short)
+        kv = B * d.n_layers * 2.0 * d.n_kv_heads * d.head_dim * 2 * (s_prompt + (t_short + t_long) / 2.0)   # mean cached rows over the steps
+        rows.append({"batch": B, "ms_per_step": per_step * 1e3, "bytes_per_step": wbytes + kv, "achieved": (wbytes + kv) / per_step / 1e9,
+                     "frac": (wbytes + kv) / per_step / 1e9 / PEAK_HBM_GBS, "tokens_per_s": B / per_step})
+    head = rows[0]
+    return {"bound": "hbm", "kernel": "one greedy decode step (owc_llm_decode_step: 28 layers of weight-streaming GEMMs + KV-cache attention + lm_head)",
+            "achieved": head["achieved"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": head["frac"], "traffic": None,
+            "batch": head["batch"], "ms_per_step": head["ms_per_step"], "by_batch": rows,
+            "weight_bytes_per_step": wbytes,
+            "method": f"(t({t_long} new tokens) - t({t_short} new tokens)) / {t_long - t_short} on text-only prompts of {s_prompt} tokens, 3 repeats each, "
+                      "host clock around synchronised generates (every generate is >= 50 ms); `achieved` = the reference's own batch size (1)"}
 
 
 def scorer_rooflines(sprof: dict, n_lab: int, n_cls: int, k: int, steps: int, sdt: float) -> dict:

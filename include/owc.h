@@ -85,10 +85,13 @@ enum owc_prof_kind {
   OWC_PROF_GEMM_BF16 = 0,     /* owc_gemm_bf16 and every bf16 Linear of the model drivers */
   OWC_PROF_GEMM_FP8 = 1,      /* owc_gemm_fp8 (fp8 decoder projections) */
   OWC_PROF_ATTN_VISION = 2,   /* owc_attention_bf16 with head_dim != 128 (Qwen2-VL vision tower 80, CLIP 64) */
-  OWC_PROF_ATTN_DECODER = 3,  /* owc_attention_bf16 with head_dim 128 (decoder: causal prefill and the decode-step mapping) */
+  OWC_PROF_ATTN_PREFILL = 3,  /* owc_attention_bf16 with head_dim 128, causal (decoder prefill; MFMA-bound) + the last prefill layer's
+                                 last-token launch */
   OWC_PROF_SCORER_GEMM = 4,   /* the sentence encoder's linears (owc_bert_embed) */
   OWC_PROF_COSINE_TOPK = 5,   /* cosine_topk_kernel */
-  OWC_PROF_KINDS = 6
+  OWC_PROF_ATTN_DECODE = 6,   /* owc_attention_bf16 with head_dim 128, non-causal: the decode-step mapping (one query row per q head
+                                 over the whole KV cache of the sequence; HBM-bound: it streams the cache) */
+  OWC_PROF_KINDS = 7
 };
 int owc_profile_read(owc_ctx* ctx, int n_kinds, double* total_ms, double* total_work, int64_t* launches);
 

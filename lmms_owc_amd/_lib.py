@@ -141,7 +141,7 @@ SIGNATURES: dict[str, tuple] = {
     "owc_profile_read": (i32, [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
-PROF_KINDS = ("gemm_bf16", "gemm_fp8", "attn_vision", "attn_decoder", "scorer_gemm", "cosine_topk")   # enum owc_prof_kind
+PROF_KINDS = ("gemm_bf16", "gemm_fp8", "attn_vision", "attn_prefill", "scorer_gemm", "cosine_topk", "attn_decode")   # enum owc_prof_kind
 
 
 def lib_path() -> Path:

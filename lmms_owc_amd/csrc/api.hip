@@ -46,6 +46,8 @@ int owc_tuning_set(const char* name, int value) {
   else if (!strcmp(name, "gemm_dbg")) owc_gemm_set_dbg(value);
   else if (!strcmp(name, "attn_dbg")) owc_attn_set_dbg(value);
 #endif
+  else if (!strcmp(name, "gemm_ring8")) owc_gemm_set_ring8(value);
+  else if (!strcmp(name, "gemm_skinny_deep")) owc_gemm_set_skinny_deep(value);
   else if (!strcmp(name, "prefill_prune_last")) owc_llm_set_prune_last(value);
   else if (!strcmp(name, "bert_bf16x3")) owc_bert_set_x3(value);
   else return OWC_ERR_ARG;

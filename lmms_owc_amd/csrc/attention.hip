@@ -21,6 +21,8 @@ namespace {
 
 int g_attn_dbg = 0;  // timing experiment (owc_tuning_set "attn_dbg", -DOWC_TIMING_KNOBS build only): 1 = no K/V DMA in the loop
 
+int g_attn_class_prefill = 0;  // set by owc_llm_prefill around its non-causal last-token launch (profile class only)
+
 constexpr int QB = 128;  // query rows per block
 constexpr int KB = 64;   // keys per tile
 
@@ -338,9 +340,10 @@ int launch(const void* Q, long q_ts, long q_hs, const void* K, long k_ts, long k
     attr_set = true;
   }
   // sequence lengths live on the device: the launch is recorded with work 0 and priced by the caller (include/owc.h)
-  // class by head_dim: 128 = the decoder (causal prefill AND the decode-step mapping, which runs the non-causal template),
-  // 80 / 64 / 32 = the vision towers
-  const int prof = owc_gemm_profile_begin(0.0, HD == 128 ? OWC_PROF_ATTN_DECODER : OWC_PROF_ATTN_VISION, st);
+  // class: head_dim 128 causal = decoder prefill, head_dim 128 non-causal = the decode-step mapping (a KV-cache stream) unless the
+  // prefill driver says otherwise (its last layer's last-token launch), 80 / 64 / 32 = the vision towers
+  const int cls = HD != 128 ? OWC_PROF_ATTN_VISION : (CAUSAL || g_attn_class_prefill) ? OWC_PROF_ATTN_PREFILL : OWC_PROF_ATTN_DECODE;
+  const int prof = owc_gemm_profile_begin(0.0, cls, st);
   hipLaunchKernelGGL((attn_fwd_kernel<HD, CAUSAL>), dim3(n_pairs * nqb), dim3(256), lds_bytes, st,
                      (const bf16_t*)Q, q_ts, q_hs, (const bf16_t*)K, k_ts, k_hs, (const bf16_t*)V,
                      v_ts, v_hs, (bf16_t*)O, o_ts, o_hs, q_start, o_start, k_start, seq_len, q_len, n_heads,
@@ -376,4 +379,5 @@ int owc_launch_attention(const void* Q, long q_ts, long q_hs, const void* K, lon
   return OWC_ERR_SHAPE;
 }
 
+void owc_attn_class_prefill(int on) { g_attn_class_prefill = on; }
 void owc_attn_set_dbg(int v) { g_attn_dbg = OWC_TK(true) ? v : 0; }

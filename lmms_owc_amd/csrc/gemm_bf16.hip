@@ -48,6 +48,8 @@ int g_skinny_max_m = 32;   // M at and below which the weight-streaming skinny k
                            // measured on the 7B decode step, ms: M = 33 6.4 skinny / 6.9 64x64 tiles, 40 7.0 / 6.7, 48 7.5 / 6.9, 64 9.8 / 6.6
 int g_mid_max_tiles = 256;  // fewer 128x128 tiles than this -> 64x64 tiles (0 disables: A-B knob "gemm_mid_max_tiles")
 int g_big_min_tiles = 144;  // fewer 256x256 tiles than this -> use the 128x128 kernel (measured: 160-162 tiles 256x256 +24...40 %, 126 tiles -3...8 %; knob "gemm_big_min_tiles")
+int g_ring8 = 1;          // 64x64-tile launches of at most one block per CU use a ring of 8 stages (128 KiB LDS) instead of 4 (knob "gemm_ring8")
+int g_skinny_deep = 1;    // deeper register rings in the weight-streaming skinny kernel (knob "gemm_skinny_deep")
 int g_pingpong = 1;       // 256x256 launches with K % 128 == 0 use the ping-pong kernel (A-B knob "gemm_pingpong", 0 = lock-step kernel)
 int g_big_min_m = 256;   // M at and above which the 256x256 kernels may run (knob "gemm_big_min_m"; round 1: 1024)
 
@@ -835,8 +837,13 @@ bool launch_skinny(const void* A, long lda, const void* W, long ldw, const void*
                      ldw, (const bf16_t*)bias, (const bf16_t*)R, ldr, (bf16_t*)C, ldc, M, N, K)
     constexpr int NT_ = EPI == OWC_EPI_SWIGLU ? 2 : 1;
     // super-steps in flight per wave: 16 VGPRs each per (n tile + m tile), about 192 VGPRs of ring in all
-    if (M <= 16) OWC_SK(1, 12 / (NT_ + 1)); else if (M <= 32) OWC_SK(2, 12 / (NT_ + 2)); else if (M <= 48) OWC_SK(3, 12 / (NT_ + 3));
-    else OWC_SK(4, 2);
+    if (g_skinny_deep) {
+      if (M <= 16) OWC_SK(1, 18 / (NT_ + 1)); else if (M <= 32) OWC_SK(2, 18 / (NT_ + 2)); else if (M <= 48) OWC_SK(3, 18 / (NT_ + 3));
+      else OWC_SK(4, 3);
+    } else {
+      if (M <= 16) OWC_SK(1, 12 / (NT_ + 1)); else if (M <= 32) OWC_SK(2, 12 / (NT_ + 2)); else if (M <= 48) OWC_SK(3, 12 / (NT_ + 3));
+      else OWC_SK(4, 2);
+    }
 #undef OWC_SK
     return true;
   }
@@ -865,6 +872,8 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * TILE64_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)gemm_bf16_nt_64_kernel<EPI, 4, false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * TILE64_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_bf16_nt_64_kernel<EPI, 8, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * TILE64_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<EPI>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_kernel<EPI>,
@@ -897,7 +906,8 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
                      (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C, ldc, M, N,   \
                      K, zeros, tm64, tn64, aux)
     const bool ktail = (K % BK) != 0;
-    if (tm64 * tn64 > 512 && tm64 * tn64 <= 768) { if (ktail) OWC_L64(3, true); else OWC_L64(3, false); }
+    if (g_ring8 && !ktail && tm64 * tn64 <= 256 && K >= 8 * BK) OWC_L64(8, false);   // one block per CU at most: spend the LDS on bytes in flight
+    else if (tm64 * tn64 > 512 && tm64 * tn64 <= 768) { if (ktail) OWC_L64(3, true); else OWC_L64(3, false); }
     else { if (ktail) OWC_L64(4, true); else OWC_L64(4, false); }
 #undef OWC_L64
   } else
@@ -1016,3 +1026,5 @@ void owc_gemm_set_mid_max_tiles(int v) { g_mid_max_tiles = v; }
 void owc_gemm_set_big_min_tiles(int v) { g_big_min_tiles = v < 0 ? 144 : v; }
 void owc_gemm_set_skinny_max_m(int v) { g_skinny_max_m = v < 0 ? 32 : v; }  // negative: back to the default
 void owc_gemm_set_pingpong(int v) { g_pingpong = v; }
+void owc_gemm_set_ring8(int v) { g_ring8 = v; }
+void owc_gemm_set_skinny_deep(int v) { g_skinny_deep = v; }

@@ -77,6 +77,8 @@ void owc_gemm_set_mid_max_tiles(int v);
 void owc_gemm_set_skinny_max_m(int v);
 void owc_gemm_set_big_min_tiles(int v);
 void owc_gemm_set_pingpong(int v);
+void owc_gemm_set_ring8(int v);
+void owc_gemm_set_skinny_deep(int v);
 void owc_gemm_fp8_set_pingpong(int v);
 void owc_gemm_fp8_set_skinny_max_m(int v);
 void owc_gemm_fp8_set_mid_max_tiles(int v);
@@ -84,6 +86,7 @@ int owc_launch_gemm_bf16_aux(const void* A, long lda, const void* W, long ldw, c
                              const void* R, long ldr, void* C, long ldc, int M, int N, int K, int epi,
                              const void* zeros, hipStream_t s, const owc_gemm_aux* aux);
 void owc_attn_set_dbg(int v);
+void owc_attn_class_prefill(int on);  // profile class of the next non-causal head_dim-128 launches
 void owc_llm_set_prune_last(int v);
 int owc_launch_clip_patchify(const uint8_t* img, void* out, long ldo, int kpad, int n_img, int S,
                              const float* mean, const float* stdv, hipStream_t st);

@@ -156,9 +156,12 @@ static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache
       // the last token sees every key of its sequence: the decode mapping below, one "sequence" per output
       int32_t *qs_l = idx3, *os_l = idx3 + owc_align256((size_t)n_seq * 4) / 4, *ql_l = os_l + owc_align256((size_t)n_seq * 4) / 4;
       OWC_TRY(owc_launch_last_rows_prep(last_index, qs_l, os_l, ql_l, n_out, Hq + 2 * Hkv, Hq, G, st));
-      OWC_TRY(owc_launch_attention(qkv, hd, (long)G * hd, kc, hd, (long)cache->s_max * hd, vc, hd,
-                                   (long)cache->s_max * hd, attn, hd, (long)G * hd, qs_l, os_l,
-                                   k_start, k_len, ql_l, n_out, Hkv, 1, hd, G, 0, scale, st));
+      owc_attn_class_prefill(1);
+      const int rc_tail = owc_launch_attention(qkv, hd, (long)G * hd, kc, hd, (long)cache->s_max * hd, vc, hd,
+                                               (long)cache->s_max * hd, attn, hd, (long)G * hd, qs_l, os_l,
+                                               k_start, k_len, ql_l, n_out, Hkv, 1, hd, G, 0, scale, st);
+      owc_attn_class_prefill(0);
+      OWC_TRY(rc_tail);
       OWC_TRY(owc_launch_gather_rows(x, d, last_index, xl, d, n_out, d, st));
       M = n_out;
       xr = xl;

@@ -160,6 +160,12 @@ _W_CACHE: dict = {}   # one entry: the numpy weights of the most recent width (t
 
 
 OUTLIER_ROWS, OUTLIER_SCALE, OUTLIER_SEED = 16, 4.0, 97
+OUTLIER_BOUND = 0.03          # the scaled rows' own logit bound (see tests/util.check_forced_steps); decisive margin = 2 x this
+FP8_BOUND, FP8_OUTLIER_BOUND = 0.10, 0.12
+
+
+def outlier_rows() -> np.ndarray:
+    return np.random.default_rng(OUTLIER_SEED).choice(np.arange(1, 1900), OUTLIER_ROWS, replace=False)
 
 
 def _slice_weights(name):
@@ -167,8 +173,9 @@ def _slice_weights(name):
     ORACLE's logits offer before a GPU ever runs).  Random N(0, sigma) lm_head rows give near-flat logits over the vocabulary -
     top-2 margins of 0-2 % of max |logit|, so a token comparison would almost never bind.  OUTLIER_ROWS vocabulary rows are
     therefore scaled by OUTLIER_SCALE (same rows for the oracle and the engine: it is one weight dict): the winner is then
-    decided among those candidates with margins of typically 10-40 %, i.e. >= 4 of 6 steps per sequence are decisive and
-    the token assertion is real.  The relative logit error is unchanged by the scaling (numerator and max |logit| scale alike)."""
+    decided among those candidates with margins of typically 10-40 %, i.e. 3-6 of 6 steps per sequence are decisive and
+    the token assertion is real.  The ordinary rows keep their statistic and bound (2 % of their own max |logit|); the scaled
+    rows get their own bound (their error is the same hidden-state noise times the scale over a handful of rows)."""
     d, hq, hkv, ff, bias = WIDTHS[name]
     cfg = Q.Cfg(vision=Q.VisionCfg(depth=1, embed_dim=160, num_heads=2, mlp_ratio=4.0, hidden_size=d),
                 text=Q.TextCfg(hidden_size=d, num_hidden_layers=2, num_attention_heads=hq, num_key_value_heads=hkv,
@@ -180,9 +187,8 @@ def _slice_weights(name):
             for k in list(w):
                 if "self_attn" in k and k.endswith("bias"):
                     w[k] = np.zeros_like(w[k])
-        rows = np.random.default_rng(OUTLIER_SEED).choice(np.arange(1, 1900), OUTLIER_ROWS, replace=False)
         head = w["lm_head.weight"].copy()
-        head[rows] *= OUTLIER_SCALE          # a power of two: the scaled rows stay bf16-representable
+        head[outlier_rows()] *= OUTLIER_SCALE          # a power of two: the scaled rows stay bf16-representable
         w["lm_head.weight"] = head
         _W_CACHE[name] = w
     return cfg, _W_CACHE[name]
@@ -238,8 +244,12 @@ def _slice_refs(name, B, T, decoder_dtype="bf16"):
     return cfg, grid, pixs, prompts, pick, check, forced, refs
 
 
-def _run_slice(name, gpu, B, T, decoder_dtype="bf16", frac=0.02, mean_frac=None, min_decisive=4):
-    """Every checked sequence must offer - and pass - at least `min_decisive` token comparisons with a decisive margin."""
+def _run_slice(name, gpu, B, T, decoder_dtype="bf16", frac=ORACLE_BOUND, special_frac=OUTLIER_BOUND, mean_frac=None, min_decisive=3,
+               min_total=None):
+    """Every checked sequence must offer - and pass - at least `min_decisive` token comparisons with a decisive margin (top-2
+    margin of the ORACLE's logits > 2 x the scaled rows' bound = 6 %; fp8: 24 %), the three sequences together at least
+    `min_total` (default: 10 of 18).  What the oracle offers is known before a GPU runs: `python tools/slice_margins.py`
+    (bf16: 3-8 decisive steps per sequence, 11-21 per case; fp8: 1-4 per sequence, 5-8 per case)."""
     _, _, eng = _slice(name, gpu, decoder_dtype)
     cfg, grid, pixs, prompts, pick, check, forced, refs = _slice_refs(name, B, T, decoder_dtype)
     emb = eng.encode_images(torch.from_numpy(np.concatenate(pixs)).to(BF16).to(gpu), grid * 3)   # 3 images x 4 rows
@@ -249,9 +259,11 @@ def _run_slice(name, gpu, B, T, decoder_dtype="bf16", frac=0.02, mean_frac=None,
     counts = []
     for b in check:
         n = check_forced_steps(to_np(logits[:, b]), toks[b], refs[b][1], refs[b][0], frac, f"{name} B={B} seq {b}",
-                               mean_frac=mean_frac)
+                               mean_frac=mean_frac, special_cols=outlier_rows(), special_frac=special_frac)
         assert n >= min_decisive, f"{name} B={B} seq {b}: only {n} of {T} steps had a decisive top-2 margin (want >= {min_decisive})"
         counts.append(n)
+    min_total = (10 * 3 * T) // 18 if min_total is None else min_total
+    assert sum(counts) >= min_total, f"{name} B={B}: {counts} decisive steps, want >= {min_total} of {3 * T}"
     return counts
 
 
@@ -271,4 +283,5 @@ def test_config_width_decode_steps(gpu, name, B):
 @pytest.mark.parametrize("B", [8, 130])
 def test_72b_width_fp8_decode_steps(gpu, B):
     """Config #5's fp8 decoder at 72B widths (K = 8192 / 29568 per-token scales): fp8 engine vs the numpy fp8 decoder."""
-    _run_slice("72b", gpu, B, 6, decoder_dtype="fp8", frac=0.10, mean_frac=0.02, min_decisive=FP8_MIN_DECISIVE)
+    _run_slice("72b", gpu, B, 6, decoder_dtype="fp8", frac=FP8_BOUND, special_frac=FP8_OUTLIER_BOUND, mean_frac=0.02, min_decisive=1,
+               min_total=5)

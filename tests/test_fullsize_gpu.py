@@ -43,7 +43,7 @@ def test_vision_slice_full_width(slice_model, gpu):
     for i in (0, 15):
         ref = Q.vit_forward(w, cfg, pix[i * 1024:(i + 1) * 1024], grid[:1], bf16=True)
         got = out[i * 256:(i + 1) * 256]
-        assert np.abs(got - ref).max() <= 0.03 * np.abs(ref).max(), (i, np.abs(got - ref).max(), np.abs(ref).max())
+        assert np.abs(got - ref).max() <= 0.02 * np.abs(ref).max(), (i, np.abs(got - ref).max(), np.abs(ref).max())
         assert np.abs(got - ref).mean() <= 0.004 * np.abs(ref).max()
 
 
@@ -58,7 +58,7 @@ def test_decoder_slice_full_width(slice_model, gpu):
 
     o_toks, o_logits = Q.generate(w, cfg, ids, pix, grid, 4, bf16=True, return_logits=True)
     toks, logits = eng.generate([ids], emb, [grid], 4, forced_tokens=o_toks[None], return_step_logits=True)
-    check_forced_steps(to_np(logits)[:, 0], to_np(toks)[0].astype(int), o_logits, o_toks, 0.03, "2b-width slice, S = 286")
+    check_forced_steps(to_np(logits)[:, 0], to_np(toks)[0].astype(int), o_logits, o_toks, 0.02, "2b-width slice, S = 286")
 
 
 def test_full_2b_properties(gpu):
@@ -106,7 +106,7 @@ def test_llava_clip_slice_full_width(gpu):
     out = to_np(eng.encode_views(torch.from_numpy(p).to(torch.bfloat16).to(gpu))).reshape(4, 577, 4096)[:, 1:]
     for i in (0, 3):  # views are independent; the oracle on two of them (numpy time)
         ref = L.project(w, L.clip_features(w, cfg, pix[i:i + 1], bf16=True), bf16=True)[0]
-        assert np.abs(out[i] - ref).max() <= 0.03 * np.abs(ref).max(), (i, np.abs(out[i] - ref).max(), np.abs(ref).max())
+        assert np.abs(out[i] - ref).max() <= 0.02 * np.abs(ref).max(), (i, np.abs(out[i] - ref).max(), np.abs(ref).max())
         assert np.abs(out[i] - ref).mean() <= 0.004 * np.abs(ref).max()
 
 
@@ -165,3 +165,55 @@ def test_full_7b_properties(gpu):
     for b in (0, 120, 239, 240, 249):                                  # 240.. : the second prefill launch group
         single = eng.generate([ids[b]], emb_img, [grids[b]], 6, img_rows=[rows[b]])
         assert torch.equal(single[0], batch[b]), (b, single[0].tolist(), batch[b].tolist())
+
+
+def test_full_7b_properties_ragged(gpu):
+    """BASELINE config #3 on the datasets' REAL image sizes: the reference resizes every image inside [min_pixels, max_pixels]
+    (/root/reference/src/models/_qwen2_vl.py:64-65, 299-305), so a Food-101 / DTD / Flowers-102 batch holds 64...1024 image
+    tokens per image - ragged `cu_seqlens` in the vision tower, prompts of unequal length in the prefill (KV slots sized by the
+    longest, the 14 shared text tokens prefilled once) and in every decode step's KV attention.  Full Qwen2-VL-7B, random
+    weights; 200 images of mixed grids (4x4 patches ... 64x64, incl. non-square and the 200:1-ish thin ones) spanning two vision
+    launch groups and two prefill launch groups.  Properties: finite outputs, determinism, and batch invariance of both the
+    image embeddings and the greedy tokens (an image / a prompt alone == inside the ragged, chunked batch)."""
+    from lmms_owc_amd.engine.qwen2vl import DIMS, Qwen2VLEngine, Qwen2VLWeights
+    from lmms_owc_amd.models import imageproc
+
+    d = DIMS["qwen2-vl-7b"]
+    eng = Qwen2VLEngine(Qwen2VLWeights.random(d, gpu, seed=5), vit_chunk_tokens=65536, prefill_chunk_tokens=32768)
+    r = np.random.default_rng(11)
+    # (height, width) in pixels -> the processor's own resize rule -> patch grids
+    sizes = [(512, 512)] * 40 + [(384, 512)] * 20 + [(int(h), int(w)) for h, w in r.integers(300, 641, (60, 2))] \
+        + [(500, int(w)) for w in r.integers(500, 1001, 40)] + [(int(h), 500) for h in r.integers(500, 1001, 30)] \
+        + [(56, 56), (28, 140), (2000, 1500), (896, 896), (100, 3000), (640, 480), (90, 70), (1024, 768), (30, 30), (448, 448)]
+    order = r.permutation(len(sizes))
+    grids = []
+    for i in order:
+        h, w = sizes[i]
+        h1, w1 = imageproc.smart_resize(h, w, 28, 4 * 28 * 28, 16384 * 28 * 28)
+        h2, w2 = imageproc.smart_resize(h1, w1, 28, 4 * 784, 1024 * 784)
+        grids.append((1, h2 // 14, w2 // 14))
+    n = len(grids)
+    lens = [g[1] * g[2] for g in grids]
+    n_tok = [t // 4 for t in lens]
+    assert min(n_tok) <= 8 and max(n_tok) >= 1000 and len(set(grids)) > 60        # really ragged, both extremes present
+    assert sum(lens) > 2 * 65536 // 2 and sum(30 + t for t in n_tok) > 32768     # > 1 vision group, > 1 prefill group
+    g = torch.Generator(device=gpu).manual_seed(1)
+    pix = torch.randn((sum(lens), 1176), generator=g, device=gpu, dtype=torch.bfloat16)
+    emb = eng.encode_images(pix, grids)
+    assert emb.shape == (sum(n_tok), d.d_model) and bool(torch.isfinite(emb.float()).all())
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    estarts = np.concatenate([[0], np.cumsum(n_tok)])
+    probe = sorted({0, n - 1, int(np.argmin(n_tok)), int(np.argmax(n_tok)), n // 2, n // 3})
+    for i in probe:   # an image alone == inside the ragged launch groups
+        solo = eng.encode_images(pix[starts[i]:starts[i + 1]], [grids[i]])
+        assert torch.equal(solo, emb[estarts[i]:estarts[i + 1]]), i
+    head = r.integers(1000, 150000, 14)
+    ids = [np.concatenate([head, np.full(n_tok[i], d.image_token_id), r.integers(1000, 150000, 10 + i % 9)]) for i in range(n)]
+    gpp = [[gr] for gr in grids]
+    assert eng._common_prefix(ids, 0, n) == 14
+    batch, logits = eng.generate(ids, emb, gpp, 5, return_logits=True)
+    assert bool(torch.isfinite(logits.float()).all())
+    assert torch.equal(batch, eng.generate(ids, emb, gpp, 5))            # deterministic
+    for i in probe:   # a prompt alone (no shared-prefix segment, its own KV slot size) == inside the batch
+        single = eng.generate([ids[i]], emb[estarts[i]:estarts[i + 1]], [gpp[i]], 5)
+        assert torch.equal(single[0], batch[i]), (i, grids[i], single[0].tolist(), batch[i].tolist())

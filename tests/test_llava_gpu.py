@@ -39,6 +39,8 @@ def setup(gpu):
     return cfg, w, eng, np.load(GOLD / "llava_tiny.npz")
 
 
+# model-level bounds: 2 % of max |ref| against the bf16 numpy oracle, 2.5 % against HF's bf16 / fp32 runs (observed on MI355X:
+# 0.4-1.1 %; HF's own bf16-vs-fp32 gap on these goldens is 1.0-1.3 %)
 def _close(got, ref, frac, tag=""):
     from tests.util import assert_rel_close
 
@@ -54,9 +56,9 @@ def test_clip_features_match_oracle_and_hf(setup, gpu):
     pix = recipes.clip_pixels(2, cfg.vision.image_size)
     out = to_np(_feats(eng, pix, gpu)).reshape(2, eng.d.tokens, -1)[:, 1:].reshape(-1, cfg.text.hidden_size)
     want = L.project(w, L.clip_features(w, cfg, pix, bf16=True), bf16=True).reshape(-1, cfg.text.hidden_size)
-    _close(out, want, 0.03)
-    _close(out, g["bf16_feats"], 0.04)
-    _close(out, g["f32_feats"], 0.05)
+    _close(out, want, 0.02)
+    _close(out, g["bf16_feats"], 0.025)
+    _close(out, g["f32_feats"], 0.025)
 
 
 def test_generate_matches_oracle_and_hf(setup, gpu):
@@ -67,9 +69,9 @@ def test_generate_matches_oracle_and_hf(setup, gpu):
     toks, logits = eng.generate_from_features([ids], _feats(eng, pix, gpu), [rows], 8, return_logits=True)
     toks, logits = to_np(toks)[0].astype(int), to_np(logits)[0]
     o_toks, o_logits = L.generate(w, cfg, ids, pix, 8, bf16=True, return_logits=True)
-    _close(logits, o_logits[0], 0.03)
-    _close(logits, g["bf16_logits"][0], 0.05)
-    _close(logits, g["f32_logits"][0], 0.05)
+    _close(logits, o_logits[0], 0.02)
+    _close(logits, g["bf16_logits"][0], 0.025)
+    _close(logits, g["f32_logits"][0], 0.025)
     # free-running tokens equal HF's up to the first near-tie; every step is asserted under teacher forcing in
     # tests/test_decode_parity_gpu.py
     ref = g["f32_logits"]
@@ -139,15 +141,15 @@ def test_next_generate_matches_oracle_and_hf(setup_next, gpu):
     rows = eng.feature_rows(views, sizes)
     assert [len(r) for r in rows] == g["n_tok"].tolist()
     packed = to_np(feats)[np.concatenate(rows)]
-    _close(packed, g["bf16_feats"], 0.04)
-    _close(packed, g["f32_feats"], 0.05)
+    _close(packed, g["bf16_feats"], 0.025)
+    _close(packed, g["f32_feats"], 0.025)
     ids = g["ids"]
     toks, logits = eng.generate_from_features([ids], feats, [np.concatenate(rows)], 8, return_logits=True)
     toks, logits = to_np(toks)[0].astype(int), to_np(logits)[0]
     o_toks, o_logits = L.generate(w, cfg, ids, pix, 8, bf16=True, return_logits=True, image_sizes=sizes, views_per_image=views)
-    _close(logits, o_logits[0], 0.03)
-    _close(logits, g["bf16_logits"][0], 0.05)
-    _close(logits, g["f32_logits"][0], 0.05)
+    _close(logits, o_logits[0], 0.02)
+    _close(logits, g["bf16_logits"][0], 0.025)
+    _close(logits, g["f32_logits"][0], 0.025)
     # free-running tokens equal HF's up to the first near-tie; every step is asserted under teacher forcing in
     # tests/test_decode_parity_gpu.py
     ref = g["f32_logits"]

@@ -180,6 +180,16 @@ def test_embed_argmax_patchify(gpu):
     logits[2, 700] = 50.0  # tie -> lowest index
     got = ops.argmax_bf16(logits)
     assert np.array_equal(to_np(got).astype(int), np.argmax(to_np(logits), -1))
+    # the real vocabulary (152 064 = 19 008 chunks of 8: the 4-way unrolled part, the remainder loop) and a ragged one with a
+    # scalar tail; ties planted across thread / unroll / wave boundaries must resolve to the LOWEST index
+    for V in (152064, 152064 - 3, 8 * 1024 * 4 + 8):
+        logits = bf16_randn((5, V), 4, 1.0, gpu)
+        logits[1, [7, 8 * 1024 + 7, V - 1]] = 60.0
+        logits[2, [V - 1, V - 2]] = 60.0
+        logits[3, [8 * 4096 - 1, 8 * 4096]] = 60.0
+        logits[4, 0] = 60.0
+        got = to_np(ops.argmax_bf16(logits)).astype(int)
+        assert np.array_equal(got, np.argmax(to_np(logits), -1)), (V, got)
 
     g = torch.Generator().manual_seed(0)
     im = torch.randint(0, 256, (2, 3, 56, 84), generator=g, dtype=torch.uint8)

@@ -350,18 +350,26 @@ def test_multi_round_generation(gpu, scorer):
 
 @pytest.mark.parametrize("model_type,name", [("qwen2-vl", "tiny"), ("llava", "tiny-next")])
 def test_fp8_decoder_through_the_plugin(gpu, model_type, name):
-    """`--model_args decoder_dtype=fp8`: the plug-ins build the e4m3fn decoder; answers are batch-invariant and mostly agree with bf16."""
+    """`--model_args decoder_dtype=fp8`: the plug-ins build the e4m3fn decoder; answers are batch-invariant and their FIRST generated
+    token (same context on both sides) agrees with the bf16 decoder's for most documents (random-weight miniatures: logits are
+    near-flat, the model-level bar of tests/test_fp8_model_gpu.py is 75 % top-1 agreement over 32 prompts; here 12 documents)."""
     from lmms_owc_amd.models import get_model
     from lmms_owc_amd.tasks import load_task
 
-    task = load_task("synthetic:6:70x120:3")
-    task.build_all_requests(limit=None, rank=0, world_size=1)
+    task = load_task("synthetic:12:70x120:3")
     outs = {}
     for key, kw in {"fp8_1": dict(decoder_dtype="fp8", batch_size=1), "fp8_4": dict(decoder_dtype="fp8", batch_size=4), "bf16": dict(batch_size=4)}.items():
         lm = get_model("custom-model", model_type=model_type, model_name_or_path=f"synthetic:{name}", **kw)
         lm.task_dict[task.task_name] = task.dataset
-        outs[key] = lm.generate_until(task.instances)
-    assert outs["fp8_1"] == outs["fp8_4"] and len(outs["fp8_4"]) == 6
+        task.build_all_requests(limit=None, rank=0, world_size=1)
+        outs[key] = [r[:1].tolist() for r in lm._generate_rows(task.instances)] if hasattr(lm, "_generate_rows") else None
+        task.build_all_requests(limit=None, rank=0, world_size=1)
+        outs[key + "_text"] = lm.generate_until(task.instances)
+    assert outs["fp8_1_text"] == outs["fp8_4_text"] and len(outs["fp8_4_text"]) == 12
+    if outs["bf16"] is not None:
+        agree = np.mean([a == b for a, b in zip(outs["fp8_4"], outs["bf16"])])
+        print(f"[fp8-plugin] {model_type}: first-token agreement with the bf16 decoder {agree:.2f} over {len(outs['bf16'])} documents")
+        assert agree >= 0.5, (agree, outs["fp8_4"], outs["bf16"])
     assert lm.model.w.llm.weight_dtype == 0
     with pytest.raises(ValueError):
         get_model("custom-model", model_type=model_type, model_name_or_path=f"synthetic:{name}", decoder_dtype="int4")

@@ -32,6 +32,8 @@ def setup(gpu):
     return cfg, w, eng, np.load(GOLD / "qwen2vl_tiny.npz")
 
 
+# model-level bounds: 2 % of max |ref| against the bf16 numpy oracle, 2.5 % against HF's bf16 / fp32 runs (observed on MI355X:
+# 0.4-1.1 %; HF's own bf16-vs-fp32 gap on these goldens is 1.0-1.3 %)
 def _close(got, ref, frac, tag=""):
     from tests.util import assert_rel_close
 
@@ -44,9 +46,9 @@ def test_vit_matches_oracle_and_hf(setup, gpu, case):
     grid = [tuple(r) for r in g[f"{case}_grid"].tolist()]
     pix = recipes.pixel_values(grid, 7)
     out = to_np(eng.encode_images(torch.from_numpy(pix).to(torch.bfloat16).to(gpu), grid))
-    _close(out, Q.vit_forward(w, cfg, pix, grid, bf16=True), 0.03)
-    _close(out, g[f"{case}_bf16_vit"], 0.04)   # HF bf16 (CPU) run of the same weights
-    _close(out, g[f"{case}_f32_vit"], 0.05)    # HF fp32
+    _close(out, Q.vit_forward(w, cfg, pix, grid, bf16=True), 0.02)
+    _close(out, g[f"{case}_bf16_vit"], 0.025)   # HF bf16 (CPU) run of the same weights
+    _close(out, g[f"{case}_f32_vit"], 0.025)    # HF fp32
 
 
 @pytest.mark.parametrize("case", ["a", "b"])
@@ -59,9 +61,9 @@ def test_generate_matches_oracle_and_hf(setup, gpu, case):
     toks, logits = eng.generate([ids], emb, [grid], 8, return_logits=True)
     toks, logits = to_np(toks)[0].astype(int), to_np(logits)[0]
     o_toks, o_logits = Q.generate(w, cfg, ids, pix, grid, 8, bf16=True, return_logits=True)
-    _close(logits, o_logits[0], 0.03)
-    _close(logits, g[f"{case}_bf16_logits"][0], 0.05)
-    _close(logits, g[f"{case}_f32_logits"][0], 0.05)
+    _close(logits, o_logits[0], 0.02)
+    _close(logits, g[f"{case}_bf16_logits"][0], 0.025)
+    _close(logits, g[f"{case}_f32_logits"][0], 0.025)
     # free-running tokens: identical to HF's up to the first near-tie (after it the continuations may legitimately differ);
     # EVERY step is asserted under teacher forcing in tests/test_decode_parity_gpu.py
     ref = g[f"{case}_f32_logits"]

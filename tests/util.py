@@ -24,22 +24,39 @@ def assert_bf16_close(got: np.ndarray, want: np.ndarray, ulps=2.0, min_exact=0.9
     assert exact >= min_exact, f"only {exact:.4f} bit-exact"
 
 
-def check_forced_steps(got_logits, got_toks, ref_logits, ref_toks, frac, tag, mean_frac=None, margin_frac=None) -> int:
+def check_forced_steps(got_logits, got_toks, ref_logits, ref_toks, frac, tag, mean_frac=None, margin_frac=None,
+                       special_cols=None, special_frac=None) -> int:
     """Teacher-forced decode parity: EVERY step j of `got_logits` [T, V] is within `frac` * max |ref_logits[j]| of the
     reference's step-j logits (both conditional on the same forced continuation).  Token rule per step: where the
-    reference's top-2 margin exceeds `margin_frac` (default 2 * frac) * max|ref| the engine's argmax must equal the reference's (`ref_toks[j]`,
-    or argmax(ref_logits[j]) when None); on a near-tie the engine's token must still score within that margin of the
-    reference's maximum.  Never stops at a near-tie.  Returns the number of steps whose token was asserted equal."""
+    reference's top-2 margin exceeds `margin_frac` (default 2 * the largest logit bound in force) * max|ref| the engine's argmax
+    must equal the reference's (`ref_toks[j]`, or argmax(ref_logits[j]) when None); on a near-tie the engine's token must still
+    score within that margin of the reference's maximum.  Never stops at a near-tie.  Returns the number of steps whose token
+    was asserted equal.
+
+    `special_cols` (vocabulary rows a test scaled up to create decisive margins, tests/test_decode_parity_gpu.py): the ordinary
+    columns are then held to `frac` of THEIR OWN max |ref| (the statistic and bound of the unscaled case), the few scaled columns
+    to `special_frac` of the global max |ref| (their error is the same hidden-state noise times the scale, over a handful of rows
+    that also set the maximum: a heavier tail, observed up to 2.4 % where the ordinary columns sit at 1.0-1.5 %)."""
     got_logits, ref_logits = np.asarray(got_logits, np.float32), np.asarray(ref_logits, np.float32)
     assert got_logits.shape == ref_logits.shape, (got_logits.shape, ref_logits.shape)
-    decisive, worst = 0, 0.0
-    margin_frac = 2 * frac if margin_frac is None else margin_frac
+    decisive, worst, worst_sp = 0, 0.0, 0.0
+    main = np.ones(ref_logits.shape[1], bool)
+    if special_cols is not None:
+        main[np.asarray(special_cols)] = False
+        assert special_frac is not None
+    if margin_frac is None:
+        margin_frac = 2 * (max(frac, special_frac) if special_cols is not None else frac)
     for j in range(ref_logits.shape[0]):
         ref, got = ref_logits[j], got_logits[j]
         scale = np.abs(ref).max()
-        err = np.abs(got - ref).max()
-        worst = max(worst, float(err / scale))
-        assert err <= frac * scale, f"{tag}: step {j} logits off by {err / scale:.4f} of max|logit| (bound {frac})"
+        scale_main = np.abs(ref[main]).max()
+        err = np.abs(got - ref)[main].max()
+        worst = max(worst, float(err / scale_main))
+        assert err <= frac * scale_main, f"{tag}: step {j} logits off by {err / scale_main:.4f} of max|logit| (bound {frac})"
+        if special_cols is not None:
+            err_sp = np.abs(got - ref)[~main].max()
+            worst_sp = max(worst_sp, float(err_sp / scale))
+            assert err_sp <= special_frac * scale, f"{tag}: step {j} scaled rows off by {err_sp / scale:.4f} of max|logit| (bound {special_frac})"
         if mean_frac is not None:
             assert np.abs(got - ref).mean() <= mean_frac * scale, f"{tag}: step {j} mean logit error"
         want = int(ref_toks[j]) if ref_toks is not None else int(np.argmax(ref))
@@ -49,8 +66,9 @@ def check_forced_steps(got_logits, got_toks, ref_logits, ref_toks, frac, tag, me
             decisive += 1
         else:
             assert ref[int(got_toks[j])] >= top2[1] - margin_frac * scale, f"{tag}: step {j} picked a non-candidate token"
-    print(f"[forced-steps] {tag}: {ref_logits.shape[0]} steps, worst logit error {worst:.4f} of max|logit| (bound {frac}), "
-          f"{decisive} decisive token steps")
+    sp = f", scaled rows {worst_sp:.4f} (bound {special_frac})" if special_cols is not None else ""
+    print(f"[forced-steps] {tag}: {ref_logits.shape[0]} steps, worst logit error {worst:.4f} of max|logit| (bound {frac}){sp}, "
+          f"{decisive} decisive token steps (margin > {margin_frac})")
     return decisive
 
 

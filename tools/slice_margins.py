@@ -18,7 +18,7 @@ for name, B, steps, dt in CASES:
     if only and name not in only and dt not in only:
         continue
     t0 = time.time()
-    frac = 0.10 if dt == "fp8" else 0.02
+    frac = T.FP8_OUTLIER_BOUND if dt == "fp8" else T.OUTLIER_BOUND   # the decisive margin is 2 x the scaled rows' bound
     *_, check, forced, refs = T._slice_refs(name, B, steps, dt)
     for b in check:
         lg = np.asarray(refs[b][1], np.float32)
