@@ -139,6 +139,18 @@ int owc_mrope_kv_write(owc_ctx* ctx, void* qkv, int64_t ld, const int32_t* pos3,
                        const int32_t* tok_slot, const int32_t* tok_idx, int T, int n_q_heads,
                        int n_kv_heads, int s_max, int mrope_sec0, int mrope_sec1, void* stream);
 
+/* One DECODE step's attention for B sequences in a single launch (head_dim 128): rotate q and k of the fed token with the rope
+ * table row pos[b] (a generated token's three M-RoPE streams are equal: plain 1-D rope), write the rotated k row and the v row
+ * into the KV cache at row write_idx[b] of slot[b], then attend the G = n_q / n_kv query heads of every kv group over the
+ * k_len[b] cached rows (the new one included).  qkv: [B][(n_q + 2 n_kv) * 128] as the fused projection leaves it (NOT modified);
+ * caches: [slot][n_kv][s_max][128]; out: [B][n_q * 128].  Equals owc_mrope_kv_write + owc_attention_bf16 in the decode
+ * mapping: identical cache rows, attention output within the rounding of P (the four waves of a block split the keys and merge
+ * their partial softmax results in a fixed order).  Replaces HF apply_multimodal_rotary_pos_emb (:180-222), the cache
+ * update and Qwen2VLAttention's sdpa (:508-556) for a generated token. */
+int owc_decode_attention(owc_ctx* ctx, const void* qkv, int64_t ld, const int32_t* pos, const float* cos_t, const float* sin_t,
+                         void* k_cache, void* v_cache, const int32_t* slot, const int32_t* write_idx, const int32_t* k_len,
+                         void* out, int64_t ldo, int B, int n_q_heads, int n_kv_heads, int s_max, float scale, void* stream);
+
 /* softmax(Q K^T * scale [+ causal mask]) V for packed variable-length sequences (flash-style).
  * Element (seq b, head h, row i, dim d) lives at
  *   Q: Q + (q_start[b] + i) * q_ts + h * q_hs + d        K/V: K + (k_start[b] + j) * k_ts + (h / kv_group) * k_hs + d

@@ -21,7 +21,7 @@ _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
 _timing_ok = False
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = range(6)
 
@@ -111,6 +111,7 @@ SIGNATURES: dict[str, tuple] = {
     "owc_rope_table": (i32, [vp, vp, vp, i32, i32, i32, f32, i32, vp]),
     "owc_vision_rope": (i32, [vp, vp, i64, vp, vp, vp, i32, i32, i32, vp]),
     "owc_mrope_kv_write": (i32, [vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "owc_decode_attention": (i32, [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, vp]),
     "owc_attention_bf16": (i32, [vp, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, vp,
                                  i32, i32, i32, i32, i32, i32, f32, vp]),
     "owc_quantize_rows_fp8": (i32, [vp, vp, i64, vp, i64, vp, i32, i32, vp]),

@@ -16,7 +16,7 @@
 
 extern "C" {
 
-int owc_abi_version(void) { return 11; }
+int owc_abi_version(void) { return 12; }
 
 int owc_has_timing_knobs(void) {   // 1 only in libowc_hip_timing.so (tools/); the product library answers 0
 #ifdef OWC_TIMING_KNOBS
@@ -46,8 +46,8 @@ int owc_tuning_set(const char* name, int value) {
   else if (!strcmp(name, "gemm_dbg")) owc_gemm_set_dbg(value);
   else if (!strcmp(name, "attn_dbg")) owc_attn_set_dbg(value);
 #endif
-  else if (!strcmp(name, "gemm_ring8")) owc_gemm_set_ring8(value);
   else if (!strcmp(name, "gemm_skinny_deep")) owc_gemm_set_skinny_deep(value);
+  else if (!strcmp(name, "decode_fuse")) owc_llm_set_decode_fuse(value);
   else if (!strcmp(name, "prefill_prune_last")) owc_llm_set_prune_last(value);
   else if (!strcmp(name, "bert_bf16x3")) owc_bert_set_x3(value);
   else return OWC_ERR_ARG;
@@ -149,6 +149,15 @@ int owc_attention_bf16(owc_ctx* ctx, const void* Q, int64_t q_ts, int64_t q_hs, 
       owc_launch_attention(Q, q_ts, q_hs, K, k_ts, k_hs, V, v_ts, v_hs, O, o_ts, o_hs, q_start, o_start,
                            k_start, seq_len, q_len, n_seq, n_heads, kv_group, head_dim, max_q_len, causal,
                            scale, ST(stream)));
+}
+
+int owc_decode_attention(owc_ctx* ctx, const void* qkv, int64_t ld, const int32_t* pos, const float* cos_t, const float* sin_t,
+                         void* k_cache, void* v_cache, const int32_t* slot, const int32_t* write_idx, const int32_t* k_len,
+                         void* out, int64_t ldo, int B, int n_q_heads, int n_kv_heads, int s_max, float scale, void* stream) {
+  if (!ctx || !qkv || !pos || !cos_t || !sin_t || !k_cache || !v_cache || !slot || !write_idx || !k_len || !out) return OWC_ERR_ARG;
+  RET(ctx, "owc_decode_attention",
+      owc_launch_attn_decode_fused(qkv, ld, pos, cos_t, sin_t, k_cache, v_cache, slot, write_idx, k_len, out, ldo, B, n_q_heads,
+                                   n_kv_heads, s_max, scale, ST(stream)));
 }
 
 int owc_embed_tokens(owc_ctx* ctx, const int32_t* ids, const int32_t* img_index, const void* table,

@@ -183,7 +183,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     if (t + 1 < ntiles && !OWC_TK(dbg & 1)) stage(cur ^ 1, t + 1);
     const char* kt_ = lds + cur * (2 * C::TILE);
     const char* vt_ = kt_ + C::TILE;
-    if (active) {
+    // causal: a tile whose first key lies beyond the LAST row of this wave is masked for all 32 rows - it would add exp2(-inf) = 0
+    // to every sum and leave the running maximum alone, so skipping it changes no bit (the wave still stages and meets the
+    // barriers).  S = 286 prompts in 128-row blocks: 29 instead of 37 wave-tiles per prompt and head.
+    if (active && (!CAUSAL || t * KB <= qb * QB + w * 32 + 31 + coff)) {
 
     // ---- S^T = K . Q^T ----
     f32x4 s[4][2];
@@ -352,6 +355,252 @@ int launch(const void* Q, long q_ts, long q_hs, const void* K, long k_ts, long k
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Decode step (round 3): M-RoPE of the new token + KV-cache write + attention over the sequence's cache in ONE launch.
+//
+// A decode step used to be  mrope_kv_kernel (rotate q and k of the fed token, write k / v into the cache: ~6 us of launch and
+// latency per layer at small batch) followed by attn_fwd_kernel in its "decode mapping" (the G q heads of a kv group are the
+// query rows of one block) - where only ONE of the block's four waves had rows and walked the key tiles one after the other
+// behind two block barriers per tile (12.6 us per layer at batch 1 for 286 keys: with the launch before it, 13 % of the step).
+// Here a block is still one (sequence, kv head) pair, but
+//   * the four waves SPLIT THE KEYS: wave w owns the 64-key tiles w, w + 4, ... and runs its own online softmax over them, with
+//     no block barrier in the loop; the partial (max, sum, O) of the waves are merged in wave order through LDS - a fixed
+//     order, so the result of a sequence does not depend on what else is in the batch;
+//   * K fragments go global -> registers (every K byte is used by exactly one wave: LDS staging would only add a hop), V tiles
+//     go through wave-private LDS (16 KiB, LDS-DMA) because the O^T = V^T . P^T product needs the transposing LDS read;
+//   * the wave that owns the LAST tile rotates the fed token's k with the rope table, writes that k row and the v row into
+//     the cache and waits for the stores before it loads its tiles, so the new key is simply part of its last tile;
+//   * every wave rotates the G query rows in registers (a rotary pair (i, i + 64) lives in the same lane: k-steps ks and ks + 2).
+// Arithmetic and rounding points are those of mrope_kv_kernel + attn_fwd_kernel (rope: bf16(bf16(x cos) + bf16(rot sin)) with
+// the bf16-rounded table; scores fp32, P rounded to bf16 before P.V); only the order in which partial softmax results are
+// combined differs.  HF: apply_multimodal_rotary_pos_emb (:180-222; three equal position streams for a generated token, i.e.
+// plain 1-D rope), Qwen2VLAttention.forward (:508-556).
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int DEC_VTILE = KB * 256;  // one V tile: 64 keys x 256 B
+
+__global__ __launch_bounds__(256) void attn_decode_fused_kernel(
+    const bf16_t* __restrict__ qkv, long ld, const int* __restrict__ pos, const float* __restrict__ cos_t,
+    const float* __restrict__ sin_t, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, const int* __restrict__ slot,
+    const int* __restrict__ write_idx, const int* __restrict__ k_len, bf16_t* __restrict__ O, long ldo, int n_q, int n_kv,
+    int s_max, float scale_log2e) {
+  using C = Cfg<128>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // [4 waves][2 buffers][V tile 16 KiB]; reused for the merge
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int fr = l & 15, g = l >> 4;
+  const int b = blockIdx.x / n_kv, hk = blockIdx.x % n_kv;
+  const int G = n_q / n_kv;
+  const int L = k_len[b];                       // keys, the fed token's included
+  const int widx = write_idx[b];
+  const long row0 = ((long)slot[b] * n_kv + hk) * s_max;   // first cache row of this (sequence, kv head)
+  bf16_t* Kseq = kc + row0 * 128;
+  bf16_t* Vseq = vc + row0 * 128;
+  const int ntiles = (L + KB - 1) / KB;
+  const bf16_t* tok = qkv + (long)b * ld;
+  const long trow = (long)pos[b] * 64;          // rope table row of the fed token
+
+  // ---- the owner of the last tile: rope(k), cache write of k and v (lanes 0-7: one rotary pair of 8-dim chunks each; lanes 8-23: v)
+  if (w == ((ntiles - 1) & 3)) {
+    if (l < 8) {
+      const bf16_t* kp = tok + (long)(n_q + hk) * 128;
+      const bf16x8 a = *(const bf16x8*)(kp + l * 8), bb = *(const bf16x8*)(kp + l * 8 + 64);
+      const f32x4 c0 = *(const f32x4*)(cos_t + trow + l * 8), c1 = *(const f32x4*)(cos_t + trow + l * 8 + 4);
+      const f32x4 s0 = *(const f32x4*)(sin_t + trow + l * 8), s1 = *(const f32x4*)(sin_t + trow + l * 8 + 4);
+      bf16x8 oa, ob;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float c = e < 4 ? c0[e & 3] : c1[e & 3], sn = e < 4 ? s0[e & 3] : s1[e & 3];
+        const float x1 = bf2f(a[e]), x2 = bf2f(bb[e]);
+        oa[e] = f2bf(rbf(x1 * c) + rbf(-x2 * sn));
+        ob[e] = f2bf(rbf(x2 * c) + rbf(x1 * sn));
+      }
+      bf16_t* dst = Kseq + (long)widx * 128;
+      *(bf16x8*)(dst + l * 8) = oa;
+      *(bf16x8*)(dst + l * 8 + 64) = ob;
+    } else if (l < 24) {
+      const bf16_t* vp = tok + (long)(n_q + n_kv + hk) * 128;
+      *(bf16x8*)(Vseq + (long)widx * 128 + (l - 8) * 8) = *(const bf16x8*)(vp + (l - 8) * 8);
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // the two rows are in L2 before this wave's tile loads are issued (gfx9: vmcnt counts stores)
+  }
+
+  // ---- Q fragments of the G query heads (lane = query column fr, clamped), rotated in registers
+  bf16x8 qf[4];
+  {
+    const bf16_t* qp = tok + (long)(hk * G + min(fr, G - 1)) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + (ks * 4 + g) * 8);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {   // chunk c = 4 ks + g < 8 pairs with chunk c + 8 = k-step ks + 2, same lane
+      const int i0 = (ks * 4 + g) * 8;
+      const f32x4 c0 = *(const f32x4*)(cos_t + trow + i0), c1 = *(const f32x4*)(cos_t + trow + i0 + 4);
+      const f32x4 s0 = *(const f32x4*)(sin_t + trow + i0), s1 = *(const f32x4*)(sin_t + trow + i0 + 4);
+      bf16x8 oa, ob;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float c = e < 4 ? c0[e & 3] : c1[e & 3], sn = e < 4 ? s0[e & 3] : s1[e & 3];
+        const float x1 = bf2f(qf[ks][e]), x2 = bf2f(qf[ks + 2][e]);
+        oa[e] = f2bf(rbf(x1 * c) + rbf(-x2 * sn));
+        ob[e] = f2bf(rbf(x2 * c) + rbf(x1 * sn));
+      }
+      qf[ks] = oa;
+      qf[ks + 2] = ob;
+    }
+  }
+
+  f32x4 o[C::DT];
+#pragma unroll
+  for (int d = 0; d < C::DT; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float mrun = -1e30f, lrun = 0.f;
+
+  char* vbuf = lds + w * (2 * DEC_VTILE);
+  // V tile t -> this wave's LDS buffer: 16 pieces of 1 KiB (4 keys x 256 B each), rows clamped at the ragged end, the 16-byte
+  // chunk order of a row XOR-swizzled with (key & 7) << 1 like the block-staged kernel above
+  auto stage_v = [&](int buf, int t) {
+    char* base = vbuf + buf * DEC_VTILE;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int key = p * 4 + (l >> 4), posc = l & 15;
+      const int c = posc ^ ((key & 7) << 1);
+      const bf16_t* src = Vseq + (long)min(t * KB + key, L - 1) * 128 + c * 8;
+      glds16(src, base + p * 1024);
+    }
+  };
+  bf16x8 kf[4][4];
+  auto load_k = [&](int t) {   // K fragments of tile t: lane (fr, g) <- key 16 kt + fr, chunk 4 ks + g
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const bf16_t* kr = Kseq + (long)min(t * KB + kt * 16 + fr, L - 1) * 128 + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *(const bf16x8*)(kr + ks * 32);
+    }
+  };
+  const int vq = fr >> 2, vp = fr & 3;
+
+  int buf = 0;
+  if (w < ntiles) stage_v(0, w);
+  for (int t = w; t < ntiles; t += 4) {
+    load_k(t);
+    if (t + 4 < ntiles) stage_v(buf ^ 1, t + 4);
+    // ---- S^T = K . Q^T (waits for the K fragments only: the V tiles may still fly)
+    f32x4 s[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][ks], qf[ks], s[kt], 0, 0, 0);
+    }
+    if (t * KB + KB > L) {   // ragged last tile (wave-uniform branch)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (t * KB + kt * 16 + g * 4 + r >= L) s[kt][r] = -1e30f;
+    }
+    // ---- online softmax over this wave's keys (lane = query column)
+    float mx = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+    mx = max_over_groups(mx);
+    const float mnew = fmaxf(mrun, mx);
+    const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * scale_log2e);
+    const float neg = -mnew * scale_log2e;
+    mrun = mnew;
+    float sum = 0.f;
+    float x[4][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        x[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] * scale_log2e + neg);
+        sum += x[kt][r];
+      }
+    lrun = lrun * alpha + sum;
+#pragma unroll
+    for (int d = 0; d < C::DT; ++d) {
+      o[d][0] *= alpha;
+      o[d][1] *= alpha;
+      o[d][2] *= alpha;
+      o[d][3] *= alpha;
+    }
+    bf16x8 pf[2];
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pf[sx][r] = f2bf(x[2 * sx][r]);
+        pf[sx][4 + r] = f2bf(x[2 * sx + 1][r]);
+      }
+    // ---- O^T += V^T . P^T : this tile's V pieces have landed (the next tile's 16 may fly)
+    if (t + 4 < ntiles) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* vt_ = vbuf + buf * DEC_VTILE;
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+      const int key0 = sx * 32 + g * 4 + vq;
+      const int key1 = key0 + 16;
+#pragma unroll
+      for (int d = 0; d < C::DT; ++d) {
+        const int ch = 2 * d + (vp >> 1);
+        const int a0 = key0 * 256 + ((ch ^ ((key0 & 7) << 1)) << 4) + (vp & 1) * 8;
+        const int a1 = key1 * 256 + ((ch ^ ((key1 & 7) << 1)) << 4) + (vp & 1) * 8;
+        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vt_ + a0));
+        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vt_ + a1));
+        const bf16x8 vf = (bf16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[sx], o[d], 0, 0, 0);
+      }
+    }
+    buf ^= 1;
+  }
+
+  // ---- merge the four partial results in wave order (LDS reused: every wave is past its last V read after the barrier)
+  float lsum = lrun;
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  __syncthreads();
+  float* mg = (float*)lds;                 // [4 waves][34 values][64 lanes]: m, l, o[8][4]
+  {
+    float* mine = mg + (size_t)w * 34 * 64 + l;
+    mine[0] = mrun;
+    mine[64] = lsum;
+#pragma unroll
+    for (int d = 0; d < C::DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[(2 + d * 4 + r) * 64] = o[d][r];
+  }
+  __syncthreads();
+  if (w == 0 && fr < G) {
+    float M = -1e30f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) M = fmaxf(M, mg[(size_t)k * 34 * 64 + l]);
+    float f[4], Lt = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f[k] = __builtin_amdgcn_exp2f((mg[(size_t)k * 34 * 64 + l] - M) * scale_log2e);   // 0 for a wave without tiles
+      Lt += mg[(size_t)k * 34 * 64 + 64 + l] * f[k];
+    }
+    const float inv = 1.0f / Lt;
+    bf16_t* op = O + (long)b * ldo + (long)(hk * G + fr) * 128 + g * 4;
+#pragma unroll
+    for (int d = 0; d < C::DT; ++d) {
+      bf16x4 ov;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc += mg[(size_t)k * 34 * 64 + (2 + d * 4 + r) * 64 + l] * f[k];
+        ov[r] = f2bf(acc * inv);
+      }
+      *(bf16x4*)(op + d * 16) = ov;
+    }
+  }
+}
+
 }  // namespace
 
 int owc_launch_attention(const void* Q, long q_ts, long q_hs, const void* K, long k_ts, long k_hs,
@@ -377,6 +626,26 @@ int owc_launch_attention(const void* Q, long q_ts, long q_hs, const void* K, lon
   OWC_ATTN_CASE(64)
 #undef OWC_ATTN_CASE
   return OWC_ERR_SHAPE;
+}
+
+// Fused decode step: rope(q, k) of the fed token + KV-cache write + attention (head_dim 128).  `O` rows are [B][n_q * 128].
+int owc_launch_attn_decode_fused(const void* qkv, long ld, const int* pos, const float* cos_t, const float* sin_t, void* kc,
+                                 void* vc, const int* slot, const int* write_idx, const int* k_len, void* O, long ldo, int B,
+                                 int n_q, int n_kv, int s_max, float scale, hipStream_t st) {
+  if (B <= 0 || n_q <= 0 || n_kv <= 0 || (n_q % n_kv) || n_q / n_kv > 16 || (ld & 7) || (ldo & 3)) return OWC_ERR_SHAPE;
+  const int lds_bytes = 4 * 2 * DEC_VTILE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)attn_decode_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+      return OWC_ERR_HIP;
+    attr_set = true;
+  }
+  const int prof = owc_gemm_profile_begin(0.0, OWC_PROF_ATTN_DECODE, st);
+  hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(B * n_kv), dim3(256), lds_bytes, st, (const bf16_t*)qkv, ld, pos, cos_t, sin_t,
+                     (bf16_t*)kc, (bf16_t*)vc, slot, write_idx, k_len, (bf16_t*)O, ldo, n_q, n_kv, s_max,
+                     scale * 1.4426950408889634f);
+  owc_gemm_profile_end(prof, st);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 
 void owc_attn_class_prefill(int on) { g_attn_class_prefill = on; }

@@ -48,8 +48,7 @@ int g_skinny_max_m = 32;   // M at and below which the weight-streaming skinny k
                            // measured on the 7B decode step, ms: M = 33 6.4 skinny / 6.9 64x64 tiles, 40 7.0 / 6.7, 48 7.5 / 6.9, 64 9.8 / 6.6
 int g_mid_max_tiles = 256;  // fewer 128x128 tiles than this -> 64x64 tiles (0 disables: A-B knob "gemm_mid_max_tiles")
 int g_big_min_tiles = 144;  // fewer 256x256 tiles than this -> use the 128x128 kernel (measured: 160-162 tiles 256x256 +24...40 %, 126 tiles -3...8 %; knob "gemm_big_min_tiles")
-int g_ring8 = 1;          // 64x64-tile launches of at most one block per CU use a ring of 8 stages (128 KiB LDS) instead of 4 (knob "gemm_ring8")
-int g_skinny_deep = 1;    // deeper register rings in the weight-streaming skinny kernel (knob "gemm_skinny_deep")
+int g_skinny_deep = 1;    // the skinny kernel's 9-deep ring for long-K launches of at most one wave per CU (knob "gemm_skinny_deep")
 int g_pingpong = 1;       // 256x256 launches with K % 128 == 0 use the ping-pong kernel (A-B knob "gemm_pingpong", 0 = lock-step kernel)
 int g_big_min_m = 256;   // M at and above which the 256x256 kernels may run (knob "gemm_big_min_m"; round 1: 1024)
 
@@ -270,28 +269,58 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
   f32x4 acc[4][1];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // Software-pipelined K loop (round 3).  These launches are one block per CU (or less) with ONE wave per SIMD, so nothing
+  // overlaps unless the wave's own instruction stream does it: with "barrier, DMA issue, 10 ds_reads, 8 MFMAs" in sequence a
+  // K-tile took ~0.30 us (7B down projection at M = 64 ... 256: 88 us for 296 K-tiles whatever M, the ring depth made no
+  // difference - tools/bench_decode_gemms.py) against 0.12 us of matrix-pipe time.  Now the fragments of k-step 1 are read
+  // while the MFMAs of k-step 0 run and the next tile's k-step-0 fragments (and the DMA issue) while those of k-step 1 run; the
+  // slot of tile kt is refilled with tile kt + NS right after the barrier that proves every wave has read it (one tile more
+  // look-ahead than before: NS tiles resident or in flight).  Same ascending accumulation chain per output: bit-identical.
+  // The fragment reads are inline asm with HAND-COUNTED lgkmcnt waits: fragments fetched in one iteration are consumed in the
+  // next, and across the loop back-edge the compiler's own wait insertion falls back to lgkmcnt(0) in front of the first MFMA
+  // group - which would wait for the five reads just issued for the OTHER k-step as well, i.e. no overlap at all.
+  bf16x8 fa0, fa1, fw0[4], fw1[4];
+  auto read_frags = [&](const char* la, int oa, int ow, bf16x8& a, bf16x8 (&wf)[4]) {   // 5 ds_read_b128, in this order
+    const unsigned pa = (unsigned)(size_t)(la + oa), pw = (unsigned)(size_t)(la + ow);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a) : "v"(pa));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[0]) : "v"(pw), "n"(TILE64_BYTES));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[1]) : "v"(pw), "n"(TILE64_BYTES + 2048));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[2]) : "v"(pw), "n"(TILE64_BYTES + 4096));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[3]) : "v"(pw), "n"(TILE64_BYTES + 6144));
+  };
+  const char* lds0 = (const char*)(size_t)(unsigned)(size_t)(lptr_t)lds;   // the 32-bit LDS byte offset of the dynamic segment
 #pragma unroll
-  for (int i = 0; i < NS64 - 1; ++i) stage(i, i);
+  for (int i = 0; i < NS64; ++i) stage(i, i);
+  // tile 0 of this wave has landed (the 4 * (NS64 - 1) newer pieces may fly); the barrier publishes everybody's
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (NS64 - 1)) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  read_frags(lds0, offA0, offW0, fa0, fw0);
   for (int kt = 0; kt < nk; ++kt) {
-    // this wave's pieces of stage kt have landed (the 4 * (NS64 - 2) newer ones may fly); the barrier publishes everybody's and
-    // tells that every wave is done reading stage kt - 1, whose slot the next DMA overwrites
-    // (lgkmcnt(0): this wave's own ds_reads of stage kt - 1 have retired too - the MFMAs consumed them long ago, so it costs
-    // nothing, and the WAR guarantee then holds in the source instead of resting on the compiler's placement of its waits)
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 * (NS64 - 2)) : "memory");
+    const char* cur = lds0 + (kt % NS64) * (2 * TILE64_BYTES);
+    const char* nxt = lds0 + ((kt + 1) % NS64) * (2 * TILE64_BYTES);
+    read_frags(cur, offA1, offW1, fa1, fw1);
+    // the five reads of k-step 0 (issued one MFMA group ago) have returned; the five just issued may still fly
+    asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fa0), "+v"(fw0[0]), "+v"(fw0[1]), "+v"(fw0[2]), "+v"(fw0[3])::"memory");
     __builtin_amdgcn_sched_barrier(0);
-    stage((kt + NS64 - 1) % NS64, kt + NS64 - 1);
-    const char* la = lds + (kt % NS64) * (2 * TILE64_BYTES);
-    const char* lw = la + TILE64_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 fa = *(const bf16x8*)(la + (ks ? offA1 : offA0));
-      bf16x8 fw[4];
+    for (int nt = 0; nt < 4; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[nt], fa0, acc[nt][0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // this wave's pieces of tile kt + 1 have landed (the 4 * (NS64 - 2) newer ones may fly) and its reads of tile kt have
+    // retired (lgkmcnt(0): k-step 1's fragments are in, and it is the WAR guarantee for the slot restaged below); the barrier
+    // publishes tile kt + 1 and proves nobody reads tile kt any more
+    asm volatile("s_waitcnt vmcnt(%5) lgkmcnt(0)\n\ts_barrier"
+                 : "+v"(fa1), "+v"(fw1[0]), "+v"(fw1[1]), "+v"(fw1[2]), "+v"(fw1[3])
+                 : "n"(4 * (NS64 - 2))
+                 : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    stage(kt % NS64, kt + NS64);
+    read_frags(nxt, offA0, offW0, fa0, fw0);   // past the last tile: an over-issued (clamped / zero-page) tile nobody multiplies
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) fw[t] = *(const bf16x8*)(lw + (ks ? offW1 : offW0) + t * 16 * 128);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa, acc[nt][0], 0, 0, 0);
-    }
+    for (int nt = 0; nt < 4; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[nt], fa1, acc[nt][0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa0), "+v"(fw0[0]), "+v"(fw0[1]), "+v"(fw0[2]), "+v"(fw0[3])::"memory");   // the last look-ahead reads
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued zero-page pieces, before the block's LDS goes away
   gemm_epilogue<EPI, 1>(acc, m0 + w * 16, n0, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
 }
@@ -837,9 +866,12 @@ bool launch_skinny(const void* A, long lda, const void* W, long ldw, const void*
                      ldw, (const bf16_t*)bias, (const bf16_t*)R, ldr, (bf16_t*)C, ldc, M, N, K)
     constexpr int NT_ = EPI == OWC_EPI_SWIGLU ? 2 : 1;
     // super-steps in flight per wave: 16 VGPRs each per (n tile + m tile), about 192 VGPRs of ring in all
-    if (g_skinny_deep) {
-      if (M <= 16) OWC_SK(1, 18 / (NT_ + 1)); else if (M <= 32) OWC_SK(2, 18 / (NT_ + 2)); else if (M <= 48) OWC_SK(3, 18 / (NT_ + 3));
-      else OWC_SK(4, 3);
+    // One wave per CU or less and a long K (the 7B down projection: 224 waves x 606 KB): occupancy is no concern, bytes in flight per
+    // wave are - a ring of 9 super-steps (36 KiB of W in flight per wave, accumulators spill into AGPRs, no scratch) instead of 6:
+    // M = 1 / 8 / 16: 32.1 -> 25.4 / 35.4 -> 30.7 / 38.8 -> 36.8 us (5.3 TB/s at M = 1).  Everywhere else the deeper ring LOSES
+    // (gate/up 53 -> 70 us: its 1184 waves want two per SIMD; K = 3584 launches are over before the ring pays), so it stays off there.
+    if (g_skinny_deep && M <= 16 && NT_ == 1 && grid.x <= 256 && K >= 8192) {
+      OWC_SK(1, 9);
     } else {
       if (M <= 16) OWC_SK(1, 12 / (NT_ + 1)); else if (M <= 32) OWC_SK(2, 12 / (NT_ + 2)); else if (M <= 48) OWC_SK(3, 12 / (NT_ + 3));
       else OWC_SK(4, 2);
@@ -872,8 +904,6 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * TILE64_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)gemm_bf16_nt_64_kernel<EPI, 4, false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * TILE64_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemm_bf16_nt_64_kernel<EPI, 8, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * TILE64_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<EPI>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_kernel<EPI>,
@@ -906,8 +936,7 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
                      (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C, ldc, M, N,   \
                      K, zeros, tm64, tn64, aux)
     const bool ktail = (K % BK) != 0;
-    if (g_ring8 && !ktail && tm64 * tn64 <= 256 && K >= 8 * BK) OWC_L64(8, false);   // one block per CU at most: spend the LDS on bytes in flight
-    else if (tm64 * tn64 > 512 && tm64 * tn64 <= 768) { if (ktail) OWC_L64(3, true); else OWC_L64(3, false); }
+    if (tm64 * tn64 > 512 && tm64 * tn64 <= 768) { if (ktail) OWC_L64(3, true); else OWC_L64(3, false); }
     else { if (ktail) OWC_L64(4, true); else OWC_L64(4, false); }
 #undef OWC_L64
   } else
@@ -1026,5 +1055,4 @@ void owc_gemm_set_mid_max_tiles(int v) { g_mid_max_tiles = v; }
 void owc_gemm_set_big_min_tiles(int v) { g_big_min_tiles = v < 0 ? 144 : v; }
 void owc_gemm_set_skinny_max_m(int v) { g_skinny_max_m = v < 0 ? 32 : v; }  // negative: back to the default
 void owc_gemm_set_pingpong(int v) { g_pingpong = v; }
-void owc_gemm_set_ring8(int v) { g_ring8 = v; }
 void owc_gemm_set_skinny_deep(int v) { g_skinny_deep = v; }

@@ -77,7 +77,6 @@ void owc_gemm_set_mid_max_tiles(int v);
 void owc_gemm_set_skinny_max_m(int v);
 void owc_gemm_set_big_min_tiles(int v);
 void owc_gemm_set_pingpong(int v);
-void owc_gemm_set_ring8(int v);
 void owc_gemm_set_skinny_deep(int v);
 void owc_gemm_fp8_set_pingpong(int v);
 void owc_gemm_fp8_set_skinny_max_m(int v);
@@ -88,6 +87,10 @@ int owc_launch_gemm_bf16_aux(const void* A, long lda, const void* W, long ldw, c
 void owc_attn_set_dbg(int v);
 void owc_attn_class_prefill(int on);  // profile class of the next non-causal head_dim-128 launches
 void owc_llm_set_prune_last(int v);
+void owc_llm_set_decode_fuse(int v);
+int owc_launch_attn_decode_fused(const void* qkv, long ld, const int* pos, const float* cos_t, const float* sin_t, void* kc,
+                                 void* vc, const int* slot, const int* write_idx, const int* k_len, void* O, long ldo, int B,
+                                 int n_q, int n_kv, int s_max, float scale, hipStream_t st);
 int owc_launch_clip_patchify(const uint8_t* img, void* out, long ldo, int kpad, int n_img, int S,
                              const float* mean, const float* stdv, hipStream_t st);
 int owc_launch_clip_embed(const void* pe, const void* pos_cls, void* x, int n_img, int tokens, int E,

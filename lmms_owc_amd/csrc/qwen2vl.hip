@@ -108,6 +108,7 @@ size_t owc_llm_workspace_bytes(const owc_llm_weights* w, int T, int n_seq) {
   return b + 1024;
 }
 
+static int g_decode_fuse = 1;  // owc_tuning_set("decode_fuse", 0): decode steps run mrope_kv_kernel + the generic attention kernel (A-B / parity)
 static int g_prune_last = 1;  // owc_tuning_set("prefill_prune_last", 0): full last layer (the A side of the bit-identity test)
 
 // `last_index` != NULL (prefill): only the last token of the first `n_out` sequences feeds the lm_head, so the LAST layer
@@ -148,8 +149,10 @@ static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache
     // self-attention block (HF:601-614)
     OWC_TRY(norm(T, x, L.ln1_w));
     OWC_TRY(linear(T, fp8 ? nullptr : h, d, L.qkv_w, L.qkv_s, L.qkv_b, nullptr, qkv, NQKV, NQKV, d, OWC_EPI_NONE));
-    OWC_TRY(owc_launch_mrope_kv(qkv, NQKV, pos3, pos_stride, w->rope_cos, w->rope_sin, kc, vc, tok_slot,
-                                tok_idx, T, Hq, Hkv, cache->s_max, w->mrope_sec0, w->mrope_sec1, bcast_first, bcast_n, st));
+    const bool fused_decode = decode && g_decode_fuse && hd == 128 && G <= 16;
+    if (!fused_decode)
+      OWC_TRY(owc_launch_mrope_kv(qkv, NQKV, pos3, pos_stride, w->rope_cos, w->rope_sin, kc, vc, tok_slot,
+                                  tok_idx, T, Hq, Hkv, cache->s_max, w->mrope_sec0, w->mrope_sec1, bcast_first, bcast_n, st));
     int M = T;
     void* xr = x;
     if (tail) {
@@ -169,6 +172,10 @@ static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache
       OWC_TRY(owc_launch_attention(qkv, NQKV, hd, kc, hd, (long)cache->s_max * hd, vc, hd,
                                    (long)cache->s_max * hd, attn, (long)Hq * hd, hd, q_start, nullptr,
                                    k_start, k_len, q_len, n_seq, Hq, G, hd, max_q_len, 1, scale, st));
+    } else if (fused_decode) {
+      // rope of the fed token + KV-cache write + attention over the cache in one launch (attention.hip, round 3)
+      OWC_TRY(owc_launch_attn_decode_fused(qkv, NQKV, pos3, w->rope_cos, w->rope_sin, kc, vc, tok_slot, tok_idx, k_len, attn,
+                                           (long)Hq * hd, T, Hq, Hkv, cache->s_max, scale, st));
     } else {
       // one query row per q head: map the G heads of a kv group onto the "rows" of the kernel
       OWC_TRY(owc_launch_attention(qkv, hd, (long)G * hd, kc, hd, (long)cache->s_max * hd, vc, hd,
@@ -284,3 +291,4 @@ int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cac
 }  // extern "C"
 
 void owc_llm_set_prune_last(int v) { g_prune_last = v != 0; }
+void owc_llm_set_decode_fuse(int v) { g_decode_fuse = v != 0; }

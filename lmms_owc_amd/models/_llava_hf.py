@@ -134,8 +134,57 @@ class LLaVA(Model):
     def loglikelihood(self, requests: list) -> list[tuple[float, bool]]:
         raise NotImplementedError("loglikelihood is outside the accelerated path (SURVEY.md §8f: generation only)")
 
-    def generate_until_multi_round(self, requests: list) -> list[str]:
-        raise NotImplementedError("multi-round generation is outside the accelerated path (SURVEY.md §8f)")
+    def generate_until_multi_round(self, requests: list) -> list[tuple]:
+        """Multi-round generation (/root/reference/src/models/_llava_hf.py:394-584; the `*_llamav_o1` task configs).  As the
+        reference warns, this wrapper keeps NO history: every round is an independent single-turn prompt built from what the
+        task's `doc_to_text(doc, round_idx=, previous_round_results=, last_round_info=)` returns for that round - its visuals
+        and its context (`<image>` tokens prepended when the context has none, the same chat template as `generate_until`),
+        greedy, EOS only (`until` is read and never applied, :455-466); the rounds stop at the terminal signal of the FIRST
+        document of a batch (:496); the result per request is the tuple of per-round answers.  Batched over documents; an
+        image that appears in several rounds goes through the host-side resize / anyres tiling once.
+        One deliberate difference: the classification tasks' `doc_to_text_multi_round` returns `visual = None` after round 0
+        (`_caltech101_utils.py:66-72`); the reference then evaluates `list(*visuals)` on `(None,)` and raises TypeError (:500-501),
+        i.e. it cannot finish those tasks with this wrapper.  Here such a round is a text-only prompt."""
+        res: list[tuple] = []
+        tok = self._tokenizer
+
+        def _collate(x):
+            return -len(tok.encode(x[0], add_special_tokens=False)), x[0]
+
+        reordered = utils.Collator([reg.args for reg in requests], _collate, grouping=True)
+        max_new_all = max([int(r.args[1].get("max_new_tokens", 1024)) for r in requests] + [1])
+        for chunk in reordered.get_batched(n=self.engine_batch(max_new_all), batch_fn=None):
+            contexts, all_gen_kwargs, doc_to_visual, doc_to_text, doc_ids, tasks, splits = zip(*chunk, strict=True)
+            task, split = tasks[0], splits[0]
+            gen_kwargs = dict(all_gen_kwargs[0])
+            until = gen_kwargs.pop("until", None)
+            if until is not None and not isinstance(until, (str, list)):
+                raise ValueError(f"Expected `gen_kwargs['until']` to be of type Union[str,list] but got {type(until)}")
+            for g in all_gen_kwargs:
+                g.pop("until", None)
+            max_new = int(gen_kwargs.get("max_new_tokens", 1024))
+            if gen_kwargs.get("temperature", 0) not in (0, 0.0) or gen_kwargs.get("num_beams", 1) != 1:
+                raise NotImplementedError("the HIP decoder implements greedy decoding (temperature 0, 1 beam)")
+            docs = [self.task_dict[task][split][did] for did in doc_ids]
+            visuals_per_doc = [list(doc_to_visual[0](d)) for d in docs]
+            contexts = list(contexts)
+            feature_cache: dict = {}            # id(PIL image) -> (views uint8, original size): a round's repeat is not re-encoded
+            round_results: list[list[str]] = []  # [round][doc]
+            round_idx = 0
+            while True:
+                if round_idx:
+                    outs = [doc_to_text[0](d, round_idx=round_idx, previous_round_results=[r[i] for r in round_results],
+                                           last_round_info=None) for i, d in enumerate(docs)]
+                    if outs[0][2]:   # terminal signal of the first document of the batch (:496)
+                        break
+                    visuals_per_doc = [list(o[0]) if o[0] is not None else [] for o in outs]
+                    contexts = [o[1] for o in outs]
+                rows = self._generate_chunk(contexts, visuals_per_doc, max_new, feature_cache)
+                round_results.append(self.decode_tokens(rows))
+                round_idx += 1
+            res.extend(zip(*round_results, strict=True))
+            self.cache_hook.add_partial("generate_until_multi_round", (contexts[0], gen_kwargs), round_results)
+        return reordered.get_original(res)
 
     # ------------------------------------------------------------------ prompt building
     def _render(self, context: str) -> str:
@@ -191,9 +240,43 @@ class LLaVA(Model):
     def decode_tokens(self, rows: list) -> list[str]:
         return self._tokenizer.batch_decode([np.asarray(r) for r in rows], skip_special_tokens=True)
 
+    def _generate_chunk(self, contexts, visuals_per_doc, max_new: int, feature_cache: dict | None = None) -> list[np.ndarray]:
+        """One engine pass: single-turn prompts (context + that document's images) -> greedy token rows cut at EOS."""
+        eng, tok = self._model, self._tokenizer
+        flat = [v for vs in visuals_per_doc for v in vs]
+        if feature_cache is None:
+            prepared = list(self._pool.map(self._views, flat))  # PIL resampling releases the GIL
+        else:
+            new = [v for v in {id(v): v for v in flat}.values() if id(v) not in feature_cache]
+            for v, p in zip(new, self._pool.map(self._views, new)):
+                feature_cache[id(v)] = (v, p)               # the image object is kept alive with its id
+            prepared = [feature_cache[id(v)][1] for v in flat]
+        views_per_image = [p[0].shape[0] for p in prepared]
+        sizes = [p[1] for p in prepared]
+        feats, rows = None, []
+        if prepared:
+            u8 = _lib.h2d(np.concatenate([p[0] for p in prepared]), self._device)
+            feats = eng.encode_views(eng.patchify(u8, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD))
+            rows = eng.feature_rows(views_per_image, sizes)
+        prompts, rows_per_prompt, cur = [], [], 0
+        for ctx, visuals in zip(contexts, visuals_per_doc):
+            mine = rows[cur:cur + len(visuals)]
+            cur += len(visuals)
+            if DEFAULT_IMAGE_TOKEN not in ctx:  # e.g. classification prompts carry no image token (:324-327, :506-509)
+                ctx = f"{' '.join([DEFAULT_IMAGE_TOKEN] * len(visuals))}\n{ctx}"
+            prompts.append(self._prompt_ids(ctx, [len(r) for r in mine]))
+            rows_per_prompt.append(np.concatenate(mine) if mine else np.zeros(0, np.int64))
+        eos = tok.eos_token_id
+        out = eng.generate_from_features(prompts, feats, rows_per_prompt, max_new, eos_token_id=eos, pad_token_id=eos).cpu().numpy()
+        res = []
+        for r in out:
+            stop = np.flatnonzero(r == eos)
+            res.append(r[: stop[0]] if len(stop) else r)
+        return res
+
     def _generate_rows(self, requests: list) -> list[np.ndarray]:
         res: list[np.ndarray] = []
-        d, eng, tok = self._dims, self._model, self._tokenizer
+        tok = self._tokenizer
 
         def _collate(x):
             return -len(tok.encode(x[0], add_special_tokens=False)), x[0]
@@ -212,29 +295,7 @@ class LLaVA(Model):
                 raise NotImplementedError("the HIP decoder implements greedy decoding (temperature 0, 1 beam)")
 
             visuals_per_doc = [doc_to_visual[0](self.task_dict[task][split][did]) for did in doc_ids]
-            flat = [v for vs in visuals_per_doc for v in vs]
-            prepared = list(self._pool.map(self._views, flat))  # PIL resampling releases the GIL
-            views_per_image = [p[0].shape[0] for p in prepared]
-            sizes = [p[1] for p in prepared]
-            feats, rows = None, []
-            if prepared:
-                u8 = _lib.h2d(np.concatenate([p[0] for p in prepared]), self._device)
-                feats = eng.encode_views(eng.patchify(u8, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD))
-                rows = eng.feature_rows(views_per_image, sizes)
-            prompts, rows_per_prompt, cur = [], [], 0
-            for ctx, visuals in zip(contexts, visuals_per_doc):
-                mine = rows[cur:cur + len(visuals)]
-                cur += len(visuals)
-                if DEFAULT_IMAGE_TOKEN not in ctx:  # e.g. classification prompts carry no image token (:324-327)
-                    ctx = f"{' '.join([DEFAULT_IMAGE_TOKEN] * len(visuals))}\n{ctx}"
-                prompts.append(self._prompt_ids(ctx, [len(r) for r in mine]))
-                rows_per_prompt.append(np.concatenate(mine) if mine else np.zeros(0, np.int64))
-
-            eos = tok.eos_token_id
-            out = eng.generate_from_features(prompts, feats, rows_per_prompt, max_new, eos_token_id=eos, pad_token_id=eos).cpu().numpy()
-            for r in out:
-                stop = np.flatnonzero(r == eos)
-                res.append(r[: stop[0]] if len(stop) else r)
+            res.extend(self._generate_chunk(contexts, visuals_per_doc, max_new))
         return reordered.get_original(res)
 
 

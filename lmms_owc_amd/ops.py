@@ -143,6 +143,17 @@ def attention(q, q_ts, q_hs, k, k_ts, k_hs, v, v_ts, v_hs, out, o_ts, o_hs, q_st
     return out
 
 
+def decode_attention(qkv, pos, cos, sin, k_cache, v_cache, slot, write_idx, k_len, n_q, n_kv, s_max, scale, out=None):
+    """One decode step's rope + KV-cache write + attention for B sequences (owc_decode_attention); returns [B, n_q * 128]."""
+    b = qkv.shape[0]
+    if out is None:
+        out = torch.empty((b, n_q * 128), dtype=BF16, device=qkv.device)
+    _call("owc_decode_attention", _dev(qkv), qkv.data_ptr(), qkv.stride(0), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+          k_cache.data_ptr(), v_cache.data_ptr(), slot.data_ptr(), write_idx.data_ptr(), k_len.data_ptr(), out.data_ptr(),
+          out.stride(0), b, n_q, n_kv, s_max, float(scale))
+    return out
+
+
 def embed_tokens(ids, img_index, table, img_embeds):
     out = torch.empty((ids.numel(), table.shape[1]), dtype=BF16, device=table.device)
     _call("owc_embed_tokens", _dev(table), ids.data_ptr(), ptr(img_index), table.data_ptr(), ptr(img_embeds),

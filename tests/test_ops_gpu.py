@@ -164,6 +164,56 @@ def test_attention_decode_mapping(gpu):
         assert np.abs(got[b] - want).max() <= 0.02 * np.abs(want).max() + 1e-3
 
 
+@pytest.mark.parametrize("Hq,Hkv", [(12, 2), (28, 4), (64, 8), (8, 8)])
+def test_decode_attention_fused_equals_the_two_kernel_path(gpu, Hq, Hkv):
+    """owc_decode_attention (rope + KV-cache write + attention of a decode step in one launch, the four waves of a block splitting
+    the keys) against owc_mrope_kv_write + owc_attention_bf16 in the decode mapping: the cache rows it writes are the SAME BITS,
+    nothing else in the caches is touched, the attention output agrees within the rounding of P and with the fp32 reference;
+    key counts 1 ... 700 cross every tile / wave-ownership edge (1, 63, 64, 65, 128, 129, 255, 256, 257, 320)."""
+    from lmms_owc_amd import ops
+
+    hd, s_max = 128, 704
+    G = Hq // Hkv
+    klen = np.array([1, 2, 63, 64, 65, 128, 129, 255, 256, 257, 320, 500, 700])
+    B = len(klen)
+    r = np.random.default_rng(Hq)
+    slot = r.permutation(B + 2)[:B]                  # slots are not the batch index
+    pos = r.integers(0, 2000, B)
+    qkv = bf16_randn((B, (Hq + 2 * Hkv) * hd), 4, 1.0, gpu)
+    kc0 = bf16_randn((B + 2, Hkv, s_max, hd), 5, 1.0, gpu)
+    vc0 = bf16_randn((B + 2, Hkv, s_max, hd), 6, 1.0, gpu)
+    cos, sin = ops.rope_table(2048, 64, 128, 1e6, True, gpu)
+    widx = klen - 1
+    # reference path: mrope_kv (rotates q in place, writes the k / v rows) + the generic kernel in the decode mapping
+    qkv_a, kc_a, vc_a = qkv.clone(), kc0.clone(), vc0.clone()
+    ops.mrope_kv_write_(qkv_a, i32(pos, gpu), cos, sin, kc_a, vc_a, i32(slot, gpu), i32(widx, gpu), Hq, Hkv, s_max, 16, 24, pos_stride=0)
+    out_a = torch.zeros((B, Hq * hd), dtype=torch.bfloat16, device=gpu)
+    ar = np.arange(B)
+    ops.attention(qkv_a, hd, G * hd, kc_a, hd, s_max * hd, vc_a, hd, s_max * hd, out_a, hd, G * hd, i32(ar * (Hq + 2 * Hkv), gpu),
+                  i32(slot * Hkv * s_max, gpu), i32(klen, gpu), n_seq=B, n_heads=Hkv, kv_group=1, head_dim=hd, max_q_len=G,
+                  causal=False, scale=hd ** -0.5, o_start=i32(ar * Hq, gpu), q_len=i32(np.full(B, G), gpu))
+    # fused path
+    kc_b, vc_b = kc0.clone(), vc0.clone()
+    out_b = ops.decode_attention(qkv, i32(pos, gpu), cos, sin, kc_b, vc_b, i32(slot, gpu), i32(widx, gpu), i32(klen, gpu),
+                                 Hq, Hkv, s_max, hd ** -0.5)
+    assert torch.equal(kc_a, kc_b) and torch.equal(vc_a, vc_b)           # same rows, same bits, nothing else touched
+    assert not torch.equal(kc_b, kc0)
+    a, b = to_np(out_a), to_np(out_b)
+    assert np.abs(a - b).max() <= 0.01 * np.abs(a).max() + 1e-3, np.abs(a - b).max()
+    qn = to_np(qkv_a)[:, :Hq * hd].reshape(B, Hq, hd)                    # rotated q
+    kn, vn = to_np(kc_b), to_np(vc_b)
+    for i in range(B):
+        kk = np.repeat(kn[slot[i], :, :klen[i]], G, 0)
+        vv = np.repeat(vn[slot[i], :, :klen[i]], G, 0)
+        want = _attn_ref(qn[i][:, None, :], kk, vv, False)[:, 0]
+        got = b[i].reshape(Hq, hd)
+        assert np.abs(got - want).max() <= 0.02 * np.abs(want).max() + 1e-3, (i, klen[i])
+    # a sequence's result does not depend on its neighbours: the last sequence alone, bit for bit
+    one = ops.decode_attention(qkv[B - 1:], i32(pos[B - 1:], gpu), cos, sin, kc0.clone(), vc0.clone(), i32(slot[B - 1:], gpu),
+                               i32(widx[B - 1:], gpu), i32(klen[B - 1:], gpu), Hq, Hkv, s_max, hd ** -0.5)
+    assert torch.equal(one[0], out_b[B - 1])
+
+
 def test_embed_argmax_patchify(gpu):
     from lmms_owc_amd import ops
 
@@ -183,7 +233,7 @@ def test_embed_argmax_patchify(gpu):
     # the real vocabulary (152 064 = 19 008 chunks of 8: the 4-way unrolled part, the remainder loop) and a ragged one with a
     # scalar tail; ties planted across thread / unroll / wave boundaries must resolve to the LOWEST index
     for V in (152064, 152064 - 3, 8 * 1024 * 4 + 8):
-        logits = bf16_randn((5, V), 4, 1.0, gpu)
+        logits = bf16_randn((5, 152064), 4, 1.0, gpu)[:, :V]   # row stride stays a multiple of 8 elements (16-byte loads)
         logits[1, [7, 8 * 1024 + 7, V - 1]] = 60.0
         logits[2, [V - 1, V - 2]] = 60.0
         logits[3, [8 * 4096 - 1, 8 * 4096]] = 60.0

@@ -348,6 +348,41 @@ def test_multi_round_generation(gpu, scorer):
     assert len(smp) == 4 and len(smp[0]["filtered_resps"][0]) == 3 and "semantic_similarity,none" in res["results"]["synthetic"]
 
 
+@pytest.mark.parametrize("name", ["tiny", "tiny-next"])
+def test_llava_multi_round_generation(gpu, scorer, name):
+    """LLaVA.generate_until_multi_round (/root/reference/src/models/_llava_hf.py:394-584): NO history - every round is an
+    independent single-turn prompt of that round's (visuals, context); a tuple of per-round answers per document, independent
+    of the batch size; round 0 equals `generate_until` on the same request; a later round whose `doc_to_text` returns no visual
+    equals `generate_until` on a text-only request with that round's question; the evaluate loop scores the last round."""
+    from lmms_owc_amd.engine.evaluate import simple_evaluate
+    from lmms_owc_amd.models import get_model
+    from lmms_owc_amd.pipelines import text
+    from lmms_owc_amd.tasks import ClassificationTask, load_task
+
+    text.set_sentence_bert(scorer, HashTokenizer())
+    task = load_task("synthetic-mr:5:70x120:3")
+    outs = []
+    for bs in (1, 3):
+        lm = get_model("custom-model", model_type="llava", model_name_or_path=f"synthetic:{name}", batch_size=bs, engine_batch=0)
+        lm.task_dict[task.task_name] = task.dataset
+        task.build_all_requests(limit=None, rank=0, world_size=1)
+        outs.append(lm.generate_until_multi_round(task.instances))
+    assert outs[0] == outs[1] and len(outs[0]) == 5 and all(isinstance(o, tuple) and len(o) == 3 for o in outs[0])
+    # the same rounds as single-turn requests: round 0 with the image, rounds 1 and 2 text-only
+    for rnd, with_image in ((0, True), (1, False), (2, False)):
+        single = ClassificationTask("synthetic", task.docs, generation_kwargs={"max_new_tokens": 6, "do_sample": False})
+        single.prompt = task.prompts[rnd]
+        if not with_image:
+            single.doc_to_visual = lambda doc: []
+        lm.task_dict["synthetic"] = single.dataset
+        single.build_all_requests(limit=None, rank=0, world_size=1)
+        assert lm.generate_until(single.instances) == [o[rnd] for o in outs[0]], rnd
+    res = simple_evaluate(model="custom-model", model_args=f"model_type=llava,model_name_or_path=synthetic:{name}", tasks=["synthetic-mr:4:56x56:2"],
+                          batch_size=2, limit=4)
+    smp = res["samples"]["synthetic"]
+    assert len(smp) == 4 and len(smp[0]["filtered_resps"][0]) == 3 and "semantic_similarity,none" in res["results"]["synthetic"]
+
+
 @pytest.mark.parametrize("model_type,name", [("qwen2-vl", "tiny"), ("llava", "tiny-next")])
 def test_fp8_decoder_through_the_plugin(gpu, model_type, name):
     """`--model_args decoder_dtype=fp8`: the plug-ins build the e4m3fn decoder; answers are batch-invariant and their FIRST generated
