@@ -44,8 +44,13 @@ PEAK_FP8_TFLOPS = 5000.0   # dense fp8 (block-scaled f8f6f4 MFMA) peak, same sou
 def flops_per_image(d, new_tokens: int, patches: int = 1024) -> float:
     """SURVEY.md §8(d) algorithmic FLOPs per image of `patches` 14x14 patches (448x448: 1024; causal attention counted at 1/2)."""
     P, Dv, Lv, S = patches, d.v_embed, d.v_depth, S_TEXT_BEFORE + patches // 4 + S_TEXT_AFTER
-    f_vit = 2 * P * d.patch_k * Dv + Lv * (8 * P * Dv * Dv + 4 * P * P * Dv + 4 * P * Dv * d.v_mlp) \
-        + 2 * (P // 4) * (4 * Dv) ** 2 + 2 * (P // 4) * 4 * Dv * d.d_model
+    if getattr(d, "v_variant", 0) == 1:   # Qwen2.5-VL: gated MLP (3 matrices), window attention (<= 64 keys) except in the full-attention blocks
+        n_full = len(d.v_fullatt)
+        attn = n_full * 4 * P * P * Dv + (Lv - n_full) * 4 * P * min(P, 64) * Dv
+        f_vit = 2 * P * d.patch_k * Dv + Lv * (8 * P * Dv * Dv + 6 * P * Dv * d.v_mlp) + attn
+    else:
+        f_vit = 2 * P * d.patch_k * Dv + Lv * (8 * P * Dv * Dv + 4 * P * P * Dv + 4 * P * Dv * d.v_mlp)
+    f_vit += 2 * (P // 4) * (4 * Dv) ** 2 + 2 * (P // 4) * 4 * Dv * d.d_model
     H, KV, hd, dm, ff, L, V = d.n_q_heads, d.n_kv_heads, d.head_dim, d.d_model, d.d_ff, d.n_layers, d.vocab
     f_pre = L * (2 * S * dm * (H + 2 * KV) * hd + 2 * S * H * hd * dm + 2 * S * S * H * hd + 6 * S * dm * ff) + 2 * dm * V
     # the first new token comes out of the prefill logits: T new tokens need T - 1 single-token forwards
@@ -378,7 +383,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default="7b", choices=["2b", "7b", "72b"])
+    ap.add_argument("--model", default="7b", choices=["2b", "7b", "72b", "2.5-7b", "2.5-3b"],
+                    help="Qwen2-VL size (default 7b = the model the metric is quoted on); 2.5-* = Qwen2.5-VL (window-attention vision tower)")
     ap.add_argument("--batch", type=int, default=2048, help="images per GPU per step")
     ap.add_argument("--new-tokens", type=int, default=16)
     ap.add_argument("--decoder-dtype", default="bf16", choices=["bf16", "fp8"],
@@ -453,8 +459,10 @@ def main() -> None:
     from lmms_owc_amd.engine.qwen2vl import DIMS, Qwen2VLEngine, Qwen2VLWeights
     from lmms_owc_amd.engine.scorer import MINILM_L6, BertWeights, SentenceScorer
 
-    key = f"qwen2-vl-{args.model}"
+    key = f"qwen2.5-vl-{args.model[4:]}" if args.model.startswith("2.5-") else f"qwen2-vl-{args.model}"
     dims = DIMS[key]
+    if dims.v_variant == 1:
+        args.no_cpu_baseline = True   # the CPU leg builds HF's Qwen2-VL class; Qwen2.5-VL parity lives in tests/ (HF goldens)
     if args.decoder_dtype != "bf16":
         import dataclasses
 
@@ -619,7 +627,7 @@ def main() -> None:
         peak = PEAK_FP8_TFLOPS if fp8_run else PEAK_BF16_TFLOPS
         traffic = None if fp8_run else load_traffic(args, engine, B)
         result = {
-            "metric": f"images/sec (whole node) Qwen2-VL-{args.model.upper()} open-world classify; label-cosine/sec",
+            "metric": f"images/sec (whole node) {'Qwen2.5-VL-' + args.model[4:].upper() if args.model.startswith('2.5-') else 'Qwen2-VL-' + args.model.upper()} open-world classify; label-cosine/sec",
             "value": images_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if not fp8_run else "fp8-e4m3 decoder projections (per-token / per-channel scales), bf16 elsewhere", "data": "synthetic",
@@ -770,6 +778,8 @@ def attention_rooflines(prof: dict, d, B: int, T: int, steps: int, dt: float) ->
     KV cache: HBM-bound, priced in bytes = the K and V rows it streams)."""
     S = S_TEXT_BEFORE + S_IMG + S_TEXT_AFTER
     vis = steps * B * d.v_depth * 4.0 * 1024 * 1024 * d.v_embed                      # QK^T + PV, non-causal, per image per layer
+    if getattr(d, "v_variant", 0) == 1:   # Qwen2.5-VL: 64-key windows except in the full-attention blocks
+        vis = steps * B * 4.0 * 1024 * d.v_embed * (len(d.v_fullatt) * 1024 + (d.v_depth - len(d.v_fullatt)) * 64)
     pre = steps * B * d.n_layers * 2.0 * S * S * d.n_q_heads * d.head_dim            # causal: half of 4 S^2 H hd
     kv_row = 2.0 * d.n_kv_heads * d.head_dim * 2                                     # K + V bytes of one token in one layer
     dec_bytes = steps * B * d.n_layers * sum(kv_row * (S + i + 1) for i in range(T - 1))   # step i reads the S + i + 1 cached rows

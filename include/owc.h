@@ -216,6 +216,14 @@ typedef struct owc_vit_weights {
   const void *merger_ln_w, *merger_ln_b, *merger_fc1_w, *merger_fc1_b, *merger_fc2_w, *merger_fc2_b;
   const float *rope_cos, *rope_sin; /* [rope_positions][head_dim/4] from owc_rope_table(dim = head_dim/2) */
   int32_t rope_positions;
+  /* variant 0: Qwen2-VL (LayerNorm blocks, fc1 -> quick_gelu -> fc2).
+   * variant 1: Qwen2.5-VL (HF modeling_qwen2_5_vl.py:294-323, :137-150): RMSNorm blocks and merger norm (the *_b norm pointers are
+   *   NULL), gated MLP down(silu(gate(x)) * up(x)) with biases - fc1_w / fc1_b hold the gate and up rows INTERLEAVED in groups of 16
+   *   ([g0..g15, u0..u15, g16.., ...], the layout of OWC_EPILOGUE_SWIGLU) with `mlp_hidden` = the intermediate size zero-padded to a
+   *   multiple of 128 (3420 -> 3456: zero rows give silu(0) * 0 = 0 and meet zero columns of fc2_w = down_proj, exactly), and
+   *   WINDOW attention: layer i attends inside the windows unless bit i of `fullatt_mask` is set (owc_vit25_forward). */
+  int32_t variant;
+  uint64_t fullatt_mask;
 } owc_vit_weights;
 
 size_t owc_vit_workspace_bytes(const owc_vit_weights* w, int T);
@@ -229,6 +237,18 @@ int owc_vit_forward(owc_ctx* ctx, const owc_vit_weights* w, const void* pixel_va
                     const int32_t* pos_hw, const int32_t* seq_start, const int32_t* seq_len,
                     int n_img, int T, int max_len, int max_pos_hw, void* out, void* workspace, size_t ws_bytes,
                     void* stream);
+
+/* Qwen2_5_VisionTransformerPretrainedModel.forward (HF modeling_qwen2_5_vl.py:408-470), as the reference loads it for the
+ * `qwen2.5-vl-*` registry names (src/models/_qwen2_vl.py:106-115): patch embed -> rows re-ordered so that the 2x2 token groups of
+ * one 112-pixel window are contiguous (`tok_index[T]`: the source row of every window-ordered row; integer bookkeeping of
+ * transformers/vision_utils.get_vision_window_index, done by the host) -> blocks with window / full attention -> RMSNorm merger
+ * -> `out` rows back in the ORIGINAL order (`out_index[T / merge_unit]`: the window-ordered merged row of every output row, i.e.
+ * argsort(window_index)).  pos_hw is given in window order; seq_start / seq_len describe the images (an image's rows stay
+ * contiguous), win_start / win_len the windows (at most 64 patches each). */
+int owc_vit25_forward(owc_ctx* ctx, const owc_vit_weights* w, const void* pixel_values, int64_t ld_pix,
+                      const int32_t* pos_hw, const int32_t* tok_index, const int32_t* out_index, const int32_t* seq_start,
+                      const int32_t* seq_len, int n_img, int max_len, const int32_t* win_start, const int32_t* win_len, int n_win,
+                      int max_win_len, int T, int max_pos_hw, void* out, void* workspace, size_t ws_bytes, void* stream);
 
 /* ---- model level: LLaVA image branch (CLIP ViT + projector) -------------------------------- */
 /* Replaces LlavaModel.get_image_features (HF modeling_llava.py:144-189) as reached from the reference's

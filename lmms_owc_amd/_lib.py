@@ -47,6 +47,7 @@ class VitWeights(C.Structure):
         ("merger_ln_w", vp), ("merger_ln_b", vp), ("merger_fc1_w", vp), ("merger_fc1_b", vp),
         ("merger_fc2_w", vp), ("merger_fc2_b", vp),
         ("rope_cos", vp), ("rope_sin", vp), ("rope_positions", C.c_int32),
+        ("variant", C.c_int32), ("fullatt_mask", C.c_uint64),
     ]
 
 
@@ -122,6 +123,7 @@ SIGNATURES: dict[str, tuple] = {
     "owc_patchify_u8": (i32, [vp, vp, vp, i64, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp]),
     "owc_vit_workspace_bytes": (sz, [C.POINTER(VitWeights), i32]),
     "owc_vit_forward": (i32, [vp, C.POINTER(VitWeights), vp, i64, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "owc_vit25_forward": (i32, [vp, C.POINTER(VitWeights), vp, i64, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "owc_clip_workspace_bytes": (sz, [C.POINTER(ClipWeights), i32]),
     "owc_clip_forward": (i32, [vp, C.POINTER(ClipWeights), vp, i64, i32, vp, vp, sz, vp]),
     "owc_clip_patchify_u8": (i32, [vp, vp, vp, i64, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp]),

@@ -21,6 +21,7 @@ namespace {
 
 int g_attn_dbg = 0;  // timing experiment (owc_tuning_set "attn_dbg", -DOWC_TIMING_KNOBS build only): 1 = no K/V DMA in the loop
 
+int g_decode_nbuf1_min_blocks = 256;  // fused decode attention: launches with more blocks than this use one V buffer per wave (knob "decode_attn_nbuf1")
 int g_attn_class_prefill = 0;  // set by owc_llm_prefill around its non-causal last-token launch (profile class only)
 
 constexpr int QB = 128;  // query rows per block
@@ -54,7 +55,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     long k_hs, const bf16_t* __restrict__ V, long v_ts, long v_hs, bf16_t* __restrict__ O, long o_ts,
     long o_hs, const int* __restrict__ q_start, const int* __restrict__ o_start,
     const int* __restrict__ k_start, const int* __restrict__ seq_len, const int* __restrict__ q_len, int n_heads, int kv_group, int nqb,
-    int n_pairs, float scale_log2e, int dbg) {
+    int n_pairs, float scale_log2e, int dbg, int qrows) {
+  // `qrows` (<= QB, a multiple of 32): query rows per block.  128 except for causal launches, where the rows of the longest
+  // sequence are spread EVENLY over its blocks (272 prompt rows: 3 x 96 instead of 128 + 128 + 16 - the block of 16 rows streamed
+  // five key tiles for one wave); a row's result does not depend on the block or wave that holds it (same key tiles, same order).
   using C = Cfg<HD>;
   extern __shared__ __attribute__((aligned(16))) char lds[];  // [2 buf][K tile | V tile]
   const int tid = threadIdx.x;
@@ -76,15 +80,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
   const int hk = h / kv_group;
   const int L = seq_len[b];                  // keys
   const int Lq = q_len ? q_len[b] : L;       // query rows (== L except for the decode mapping)
-  if (qb * QB >= Lq) return;
-  const bool active = (qb * QB + w * 32) < Lq;  // wave-uniform: waves without rows only stage tiles
+  if (qb * qrows >= Lq) return;
+  const bool active = w * 32 < qrows && (qb * qrows + w * 32) < Lq;  // wave-uniform: waves without rows only stage tiles
   const long qs = q_start[b], ks0 = k_start[b];
   const long os = o_start ? (long)o_start[b] : qs;
 
   // causal: query row i sits at absolute position coff + i (coff = L - Lq > 0 when a shared prefix's keys
   // precede the rows handled here) and sees keys <= coff + i
   const int coff = L - Lq;
-  const int kmax = CAUSAL ? min(L, qb * QB + QB + coff) : L;
+  const int kmax = CAUSAL ? min(L, qb * qrows + qrows + coff) : L;
   const int ntiles = (kmax + KB - 1) / KB;
 
   // ---- Q fragments (B operand): lane = query column fr, 8 consecutive d per k-step ----
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
   int qrow[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    qrow[qt] = qb * QB + w * 32 + qt * 16 + fr;
+    qrow[qt] = qb * qrows + w * 32 + qt * 16 + fr;
     const bf16_t* qp = Q + (qs + min(qrow[qt], Lq - 1)) * q_ts + (long)h * q_hs;
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     // causal: a tile whose first key lies beyond the LAST row of this wave is masked for all 32 rows - it would add exp2(-inf) = 0
     // to every sum and leave the running maximum alone, so skipping it changes no bit (the wave still stages and meets the
     // barriers).  S = 286 prompts in 128-row blocks: 29 instead of 37 wave-tiles per prompt and head.
-    if (active && (!CAUSAL || t * KB <= qb * QB + w * 32 + 31 + coff)) {
+    if (active && (!CAUSAL || t * KB <= qb * qrows + w * 32 + 31 + coff)) {
 
     // ---- S^T = K . Q^T ----
     f32x4 s[4][2];
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     // ---- online softmax (lane = query column; keys 16kt + 4g + r) ----
     // ragged / causal masking is needed on the last tiles only: keep it a real (wave-uniform) branch -- written
     // as selects it costs ~70 VALU per tile on every tile, and the loop is VALU-bound
-    const bool edge = (t * KB + KB > L) || (CAUSAL && (t * KB + KB - 1 > qb * QB + w * 32 + coff));
+    const bool edge = (t * KB + KB > L) || (CAUSAL && (t * KB + KB - 1 > qb * qrows + w * 32 + coff));
     if (edge) {
       asm volatile("" ::: "memory");  // keeps the compiler from if-converting the block into selects
 #pragma unroll
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / lsum;
-    if (qrow[qt] < Lq) {
+    if (active && qrow[qt] < Lq) {   // (a wave beyond `qrows` holds rows of the NEXT block: it must not write them)
       bf16_t* op = O + (os + qrow[qt]) * o_ts + (long)h * o_hs + g * 4;
 #pragma unroll
       for (int d = 0; d < C::DT; ++d) {
@@ -333,6 +337,8 @@ int launch(const void* Q, long q_ts, long q_hs, const void* K, long k_ts, long k
            int kv_group, int max_len, float scale, hipStream_t st) {
   using C = Cfg<HD>;
   const int nqb = (max_len + QB - 1) / QB;
+  // causal: even split of the longest sequence's rows over its nqb blocks, in whole 32-row wave tiles
+  const int qrows = CAUSAL ? min(QB, ((max_len + nqb - 1) / nqb + 31) / 32 * 32) : QB;
   const int n_pairs = n_seq * n_heads;
   const int lds_bytes = 4 * C::TILE;
   static bool attr_set = false;
@@ -350,7 +356,7 @@ int launch(const void* Q, long q_ts, long q_hs, const void* K, long k_ts, long k
   hipLaunchKernelGGL((attn_fwd_kernel<HD, CAUSAL>), dim3(n_pairs * nqb), dim3(256), lds_bytes, st,
                      (const bf16_t*)Q, q_ts, q_hs, (const bf16_t*)K, k_ts, k_hs, (const bf16_t*)V,
                      v_ts, v_hs, (bf16_t*)O, o_ts, o_hs, q_start, o_start, k_start, seq_len, q_len, n_heads,
-                     kv_group, nqb, n_pairs, scale * 1.4426950408889634f, g_attn_dbg);
+                     kv_group, nqb, n_pairs, scale * 1.4426950408889634f, g_attn_dbg, qrows);
   owc_gemm_profile_end(prof, st);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
@@ -379,6 +385,8 @@ int launch(const void* Q, long q_ts, long q_hs, const void* K, long k_ts, long k
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int DEC_VTILE = KB * 256;  // one V tile: 64 keys x 256 B
 
+template <int NBUF>   // V tiles per wave in LDS: 2 = the next tile is fetched under the current one (128 KiB per block: one block per CU, the
+                      // small-batch form), 1 = 64 KiB per block, two blocks = eight streaming waves per CU (large batches: HBM-bound)
 __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
     const bf16_t* __restrict__ qkv, long ld, const int* __restrict__ pos, const float* __restrict__ cos_t,
     const float* __restrict__ sin_t, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, const int* __restrict__ slot,
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
   for (int d = 0; d < C::DT; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float mrun = -1e30f, lrun = 0.f;
 
-  char* vbuf = lds + w * (2 * DEC_VTILE);
+  char* vbuf = lds + w * (NBUF * DEC_VTILE);
   // V tile t -> this wave's LDS buffer: 16 pieces of 1 KiB (4 keys x 256 B each), rows clamped at the ragged end, the 16-byte
   // chunk order of a row XOR-swizzled with (key & 7) << 1 like the block-staged kernel above
   auto stage_v = [&](int buf, int t) {
@@ -480,10 +488,11 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
   const int vq = fr >> 2, vp = fr & 3;
 
   int buf = 0;
-  if (w < ntiles) stage_v(0, w);
+  if (NBUF == 2 && w < ntiles) stage_v(0, w);
   for (int t = w; t < ntiles; t += 4) {
     load_k(t);
-    if (t + 4 < ntiles) stage_v(buf ^ 1, t + 4);
+    if (NBUF == 1) stage_v(0, t);     // (the previous tile's V reads have retired: their MFMAs were issued)
+    else if (t + 4 < ntiles) stage_v(buf ^ 1, t + 4);
     // ---- S^T = K . Q^T (waits for the K fragments only: the V tiles may still fly)
     f32x4 s[4];
 #pragma unroll
@@ -537,7 +546,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
         pf[sx][4 + r] = f2bf(x[2 * sx + 1][r]);
       }
     // ---- O^T += V^T . P^T : this tile's V pieces have landed (the next tile's 16 may fly)
-    if (t + 4 < ntiles) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if (NBUF == 2 && t + 4 < ntiles) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const char* vt_ = vbuf + buf * DEC_VTILE;
 #pragma unroll
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
         o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[sx], o[d], 0, 0, 0);
       }
     }
-    buf ^= 1;
+    if (NBUF == 2) buf ^= 1;
   }
 
   // ---- merge the four partial results in wave order (LDS reused: every wave is past its last V read after the barrier)
@@ -633,20 +642,28 @@ int owc_launch_attn_decode_fused(const void* qkv, long ld, const int* pos, const
                                  void* vc, const int* slot, const int* write_idx, const int* k_len, void* O, long ldo, int B,
                                  int n_q, int n_kv, int s_max, float scale, hipStream_t st) {
   if (B <= 0 || n_q <= 0 || n_kv <= 0 || (n_q % n_kv) || n_q / n_kv > 16 || (ld & 7) || (ldo & 3)) return OWC_ERR_SHAPE;
-  const int lds_bytes = 4 * 2 * DEC_VTILE;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)attn_decode_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)attn_decode_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * DEC_VTILE) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_decode_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * DEC_VTILE) != hipSuccess)
       return OWC_ERR_HIP;
     attr_set = true;
   }
   const int prof = owc_gemm_profile_begin(0.0, OWC_PROF_ATTN_DECODE, st);
-  hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(B * n_kv), dim3(256), lds_bytes, st, (const bf16_t*)qkv, ld, pos, cos_t, sin_t,
-                     (bf16_t*)kc, (bf16_t*)vc, slot, write_idx, k_len, (bf16_t*)O, ldo, n_q, n_kv, s_max,
-                     scale * 1.4426950408889634f);
+  // more blocks than CUs: the launch is a KV-cache stream - two blocks (eight loading waves) per CU beat the look-ahead buffer.
+  // The two forms differ only in WHEN a V tile is fetched: same arithmetic, same order, same bits.
+  if (B * n_kv > g_decode_nbuf1_min_blocks)
+    hipLaunchKernelGGL(attn_decode_fused_kernel<1>, dim3(B * n_kv), dim3(256), 4 * DEC_VTILE, st, (const bf16_t*)qkv, ld, pos, cos_t,
+                       sin_t, (bf16_t*)kc, (bf16_t*)vc, slot, write_idx, k_len, (bf16_t*)O, ldo, n_q, n_kv, s_max,
+                       scale * 1.4426950408889634f);
+  else
+    hipLaunchKernelGGL(attn_decode_fused_kernel<2>, dim3(B * n_kv), dim3(256), 8 * DEC_VTILE, st, (const bf16_t*)qkv, ld, pos, cos_t,
+                       sin_t, (bf16_t*)kc, (bf16_t*)vc, slot, write_idx, k_len, (bf16_t*)O, ldo, n_q, n_kv, s_max,
+                       scale * 1.4426950408889634f);
   owc_gemm_profile_end(prof, st);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 
+void owc_attn_set_decode_nbuf1(int v) { g_decode_nbuf1_min_blocks = v < 0 ? 256 : v; }
 void owc_attn_class_prefill(int on) { g_attn_class_prefill = on; }
 void owc_attn_set_dbg(int v) { g_attn_dbg = OWC_TK(true) ? v : 0; }

@@ -269,58 +269,32 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
   f32x4 acc[4][1];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // Software-pipelined K loop (round 3).  These launches are one block per CU (or less) with ONE wave per SIMD, so nothing
-  // overlaps unless the wave's own instruction stream does it: with "barrier, DMA issue, 10 ds_reads, 8 MFMAs" in sequence a
-  // K-tile took ~0.30 us (7B down projection at M = 64 ... 256: 88 us for 296 K-tiles whatever M, the ring depth made no
-  // difference - tools/bench_decode_gemms.py) against 0.12 us of matrix-pipe time.  Now the fragments of k-step 1 are read
-  // while the MFMAs of k-step 0 run and the next tile's k-step-0 fragments (and the DMA issue) while those of k-step 1 run; the
-  // slot of tile kt is refilled with tile kt + NS right after the barrier that proves every wave has read it (one tile more
-  // look-ahead than before: NS tiles resident or in flight).  Same ascending accumulation chain per output: bit-identical.
-  // The fragment reads are inline asm with HAND-COUNTED lgkmcnt waits: fragments fetched in one iteration are consumed in the
-  // next, and across the loop back-edge the compiler's own wait insertion falls back to lgkmcnt(0) in front of the first MFMA
-  // group - which would wait for the five reads just issued for the OTHER k-step as well, i.e. no overlap at all.
-  bf16x8 fa0, fa1, fw0[4], fw1[4];
-  auto read_frags = [&](const char* la, int oa, int ow, bf16x8& a, bf16x8 (&wf)[4]) {   // 5 ds_read_b128, in this order
-    const unsigned pa = (unsigned)(size_t)(la + oa), pw = (unsigned)(size_t)(la + ow);
-    asm volatile("ds_read_b128 %0, %1" : "=v"(a) : "v"(pa));
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[0]) : "v"(pw), "n"(TILE64_BYTES));
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[1]) : "v"(pw), "n"(TILE64_BYTES + 2048));
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[2]) : "v"(pw), "n"(TILE64_BYTES + 4096));
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[3]) : "v"(pw), "n"(TILE64_BYTES + 6144));
-  };
-  const char* lds0 = (const char*)(size_t)(unsigned)(size_t)(lptr_t)lds;   // the 32-bit LDS byte offset of the dynamic segment
+  // (Round 3 measured a software-pipelined form of this loop - next k-step's fragments read under the current MFMAs, hand-counted
+  // lgkmcnt, one tile more look-ahead - and an 8-stage ring: both +-0 on every decode shape (7B down projection at M = 64...256:
+  // 88 us for 296 K-tiles whatever M, ring depth or schedule).  The launches are not bound by this loop's instruction stream:
+  // tools/probes/probe_cu_ingest.hip, DESIGN.md section 4.  The simple form stays.)
 #pragma unroll
-  for (int i = 0; i < NS64; ++i) stage(i, i);
-  // tile 0 of this wave has landed (the 4 * (NS64 - 1) newer pieces may fly); the barrier publishes everybody's
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (NS64 - 1)) : "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  read_frags(lds0, offA0, offW0, fa0, fw0);
+  for (int i = 0; i < NS64 - 1; ++i) stage(i, i);
   for (int kt = 0; kt < nk; ++kt) {
-    const char* cur = lds0 + (kt % NS64) * (2 * TILE64_BYTES);
-    const char* nxt = lds0 + ((kt + 1) % NS64) * (2 * TILE64_BYTES);
-    read_frags(cur, offA1, offW1, fa1, fw1);
-    // the five reads of k-step 0 (issued one MFMA group ago) have returned; the five just issued may still fly
-    asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fa0), "+v"(fw0[0]), "+v"(fw0[1]), "+v"(fw0[2]), "+v"(fw0[3])::"memory");
+    // this wave's pieces of stage kt have landed (the 4 * (NS64 - 2) newer ones may fly); the barrier publishes everybody's and
+    // tells that every wave is done reading stage kt - 1, whose slot the next DMA overwrites
+    // (lgkmcnt(0): this wave's own ds_reads of stage kt - 1 have retired too - the MFMAs consumed them long ago, so it costs
+    // nothing, and the WAR guarantee then holds in the source instead of resting on the compiler's placement of its waits)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 * (NS64 - 2)) : "memory");
     __builtin_amdgcn_sched_barrier(0);
+    stage((kt + NS64 - 1) % NS64, kt + NS64 - 1);
+    const char* la = lds + (kt % NS64) * (2 * TILE64_BYTES);
+    const char* lw = la + TILE64_BYTES;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[nt], fa0, acc[nt][0], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    // this wave's pieces of tile kt + 1 have landed (the 4 * (NS64 - 2) newer ones may fly) and its reads of tile kt have
-    // retired (lgkmcnt(0): k-step 1's fragments are in, and it is the WAR guarantee for the slot restaged below); the barrier
-    // publishes tile kt + 1 and proves nobody reads tile kt any more
-    asm volatile("s_waitcnt vmcnt(%5) lgkmcnt(0)\n\ts_barrier"
-                 : "+v"(fa1), "+v"(fw1[0]), "+v"(fw1[1]), "+v"(fw1[2]), "+v"(fw1[3])
-                 : "n"(4 * (NS64 - 2))
-                 : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    stage(kt % NS64, kt + NS64);
-    read_frags(nxt, offA0, offW0, fa0, fw0);   // past the last tile: an over-issued (clamped / zero-page) tile nobody multiplies
-    __builtin_amdgcn_sched_barrier(0);
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 fa = *(const bf16x8*)(la + (ks ? offA1 : offA0));
+      bf16x8 fw[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[nt], fa1, acc[nt][0], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int t = 0; t < 4; ++t) fw[t] = *(const bf16x8*)(lw + (ks ? offW1 : offW0) + t * 16 * 128);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa, acc[nt][0], 0, 0, 0);
+    }
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa0), "+v"(fw0[0]), "+v"(fw0[1]), "+v"(fw0[2]), "+v"(fw0[3])::"memory");   // the last look-ahead reads
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued zero-page pieces, before the block's LDS goes away
   gemm_epilogue<EPI, 1>(acc, m0 + w * 16, n0, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
 }
@@ -860,6 +834,7 @@ bool launch_skinny(const void* A, long lda, const void* W, long ldw, const void*
   if constexpr (EPI == OWC_EPI_NONE || EPI == OWC_EPI_RESIDUAL || EPI == OWC_EPI_SWIGLU) {  // what a decoder step needs
     constexpr int ROWS = EPI == OWC_EPI_SWIGLU ? 32 : 16;
     if (M > 64 || (K & 127) || (N % ROWS) || g_skinny_max_m < M) return false;
+    if (EPI == OWC_EPI_SWIGLU && bias != nullptr) return false;   // the gated vision MLP's biases: the tiled kernels' epilogue adds them
     const dim3 grid(N / ROWS), block(64);
 #define OWC_SK(MT_, D_)                                                                                               \
   hipLaunchKernelGGL((gemm_bf16_skinny_kernel<EPI, MT_, D_>), grid, block, 0, s, (const bf16_t*)A, lda, (const bf16_t*)W, \

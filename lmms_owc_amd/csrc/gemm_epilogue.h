@@ -54,14 +54,35 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
     const int odd = fq & 1;
     const int f = (ncol0 >> 1) + odd * 16 + (fq >> 1) * 8;  // first of this lane's 8 output features
     const int nout = N >> 1;
+    // bias (the gated MLP of the Qwen2.5-VL vision blocks, HF qwen2_5_vl:85-96 with bias=True; the decoders have none): rows of
+    // the weight are [gate 16 | up 16 | ...], so the bias of accumulator tile nt sits at column ncol0 + 16 nt + 4 fq + e
+    float bg[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      if (bias != nullptr) {
+        const bf16x4 b = *(const bf16x4*)(bias + min(ncol0 + nt * 16 + fq * 4, N - 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bg[nt][e] = bf2f(b[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bg[nt][e] = 0.f;
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int m = mrow0 + mt * 16 + fr;
       float o0[4], o1[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        o0[e] = rbf(rbf(act_silu(rbf(acc[0][mt][e]))) * rbf(acc[1][mt][e]));
-        o1[e] = rbf(rbf(act_silu(rbf(acc[2][mt][e]))) * rbf(acc[3][mt][e]));
+        float g0 = acc[0][mt][e], u0 = acc[1][mt][e], g1 = acc[2][mt][e], u1 = acc[3][mt][e];
+        if (bias != nullptr) {   // (no `+ 0.f` on the bias-free path: the decoders' bits stay exactly what they were)
+          g0 += bg[0][e];
+          u0 += bg[1][e];
+          g1 += bg[2][e];
+          u1 += bg[3][e];
+        }
+        o0[e] = rbf(rbf(act_silu(rbf(g0))) * rbf(u0));
+        o1[e] = rbf(rbf(act_silu(rbf(g1))) * rbf(u1));
         swap16(o0[e], o1[e]);
       }
       bf16x8 o;

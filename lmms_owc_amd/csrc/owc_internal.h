@@ -85,7 +85,8 @@ int owc_launch_gemm_bf16_aux(const void* A, long lda, const void* W, long ldw, c
                              const void* R, long ldr, void* C, long ldc, int M, int N, int K, int epi,
                              const void* zeros, hipStream_t s, const owc_gemm_aux* aux);
 void owc_attn_set_dbg(int v);
-void owc_attn_class_prefill(int on);  // profile class of the next non-causal head_dim-128 launches
+void owc_attn_class_prefill(int on);
+void owc_attn_set_decode_nbuf1(int v);  // profile class of the next non-causal head_dim-128 launches
 void owc_llm_set_prune_last(int v);
 void owc_llm_set_decode_fuse(int v);
 int owc_launch_attn_decode_fused(const void* qkv, long ld, const int* pos, const float* cos_t, const float* sin_t, void* kc,
@@ -119,6 +120,12 @@ struct Carver {  // bump allocator over a caller-provided workspace
     return r;
   }
 };
+struct owc_vit_windows {   // Qwen2.5-VL window attention (NULL: Qwen2-VL / CLIP blocks)
+  const int32_t *start, *len;
+  int n, max_len;
+  uint64_t fullatt_mask;
+};
 int owc_vit_layers(owc_ctx* ctx, const owc_vit_layer* layers, int n_layers, void* x, void* h, void* attn,
                    void* qkv, void* mlp, int T, int E, int H, int F, float eps, const int32_t* seq_start,
-                   const int32_t* seq_len, int n_img, int max_len, const owc_gemm_aux* aux, hipStream_t st);
+                   const int32_t* seq_len, int n_img, int max_len, const owc_gemm_aux* aux, hipStream_t st,
+                   const owc_vit_windows* win = nullptr);

@@ -11,13 +11,19 @@
 // the qkv epilogue, HF:442-450) and the CLIP tower of LLaVA (aux == NULL; modeling_clip.py CLIPEncoderLayer).
 int owc_vit_layers(owc_ctx* ctx, const owc_vit_layer* layers, int n_layers, void* x, void* h, void* attn,
                    void* qkv, void* mlp, int T, int E, int H, int F, float eps, const int32_t* seq_start,
-                   const int32_t* seq_len, int n_img, int max_len, const owc_gemm_aux* aux, hipStream_t st) {
+                   const int32_t* seq_len, int n_img, int max_len, const owc_gemm_aux* aux, hipStream_t st,
+                   const owc_vit_windows* win) {
   const int hd = E / H;
   const float scale = 1.0f / sqrtf((float)hd);
+  const bool v25 = win != nullptr;   // Qwen2.5-VL blocks: RMSNorm, gated MLP, window attention
+  auto norm = [&](const void* gamma, const void* beta) -> int {
+    if (v25) return owc_launch_rmsnorm(x, E, gamma, h, E, T, E, eps, nullptr, st);
+    return owc_launch_layernorm(x, E, gamma, beta, h, E, T, E, eps, st);
+  };
   for (int i = 0; i < n_layers; ++i) {
     const owc_vit_layer& L = layers[i];
     // x = x + proj(attn(rope(qkv(norm1(x)))))
-    OWC_TRY(owc_launch_layernorm(x, E, L.ln1_w, L.ln1_b, h, E, T, E, eps, st));
+    OWC_TRY(norm(L.ln1_w, L.ln1_b));
     if (aux) {  // q/k rows of qkv_w are pair-interleaved, rotation in the epilogue
       OWC_TRY(owc_launch_gemm_bf16_aux(h, E, L.qkv_w, E, L.qkv_b, nullptr, 0, qkv, 3 * E, T, 3 * E, E,
                                        OWC_EPI_VROPE, ctx->zeros, st, aux));
@@ -26,15 +32,24 @@ int owc_vit_layers(owc_ctx* ctx, const owc_vit_layer* layers, int n_layers, void
                                    OWC_EPI_NONE, ctx->zeros, st));
     }
     const bf16_t* q = (const bf16_t*)qkv;
-    OWC_TRY(owc_launch_attention(q, 3 * E, hd, q + E, 3 * E, hd, q + 2 * E, 3 * E, hd, attn, E, hd,
-                                 seq_start, nullptr, seq_start, seq_len, nullptr, n_img, H, 1, hd,
-                                 max_len, 0, scale, st));
+    if (v25 && !((win->fullatt_mask >> i) & 1)) {   // HF qwen2_5_vl:448-454: a window layer attends inside each window only
+      OWC_TRY(owc_launch_attention(q, 3 * E, hd, q + E, 3 * E, hd, q + 2 * E, 3 * E, hd, attn, E, hd,
+                                   win->start, nullptr, win->start, win->len, nullptr, win->n, H, 1, hd,
+                                   win->max_len, 0, scale, st));
+    } else {
+      OWC_TRY(owc_launch_attention(q, 3 * E, hd, q + E, 3 * E, hd, q + 2 * E, 3 * E, hd, attn, E, hd,
+                                   seq_start, nullptr, seq_start, seq_len, nullptr, n_img, H, 1, hd,
+                                   max_len, 0, scale, st));
+    }
     OWC_TRY(owc_launch_gemm_bf16(attn, E, L.proj_w, E, L.proj_b, x, E, x, E, T, E, E, OWC_EPI_RESIDUAL,
                                  ctx->zeros, st));
-    // x = x + fc2(quick_gelu(fc1(norm2(x))))
-    OWC_TRY(owc_launch_layernorm(x, E, L.ln2_w, L.ln2_b, h, E, T, E, eps, st));
-    OWC_TRY(owc_launch_gemm_bf16(h, E, L.fc1_w, E, L.fc1_b, nullptr, 0, mlp, F, T, F, E,
-                                 OWC_EPI_QUICK_GELU, ctx->zeros, st));
+    // x = x + fc2(quick_gelu(fc1(norm2(x))))      |  Qwen2.5: x + down(silu(gate(norm2(x))) * up(norm2(x)))
+    OWC_TRY(norm(L.ln2_w, L.ln2_b));
+    if (v25)
+      OWC_TRY(owc_launch_gemm_bf16(h, E, L.fc1_w, E, L.fc1_b, nullptr, 0, mlp, F, T, 2 * F, E, OWC_EPI_SWIGLU, ctx->zeros, st));
+    else
+      OWC_TRY(owc_launch_gemm_bf16(h, E, L.fc1_w, E, L.fc1_b, nullptr, 0, mlp, F, T, F, E,
+                                   OWC_EPI_QUICK_GELU, ctx->zeros, st));
     OWC_TRY(owc_launch_gemm_bf16(mlp, F, L.fc2_w, F, L.fc2_b, x, E, x, E, T, E, F, OWC_EPI_RESIDUAL,
                                  ctx->zeros, st));
   }
@@ -77,7 +92,7 @@ int owc_vit_forward(owc_ctx* ctx, const owc_vit_weights* w, const void* pixel_va
   OWC_TRY(owc_launch_gemm_bf16(pixel_values, ld_pix, w->patch_w, w->patch_k, nullptr, nullptr, 0, x, E,
                                T, E, w->patch_k, OWC_EPI_NONE, ctx->zeros, st));
   OWC_TRY(owc_vit_layers(ctx, w->layers, w->depth, x, h, attn, qkv, mlp, T, E, H, F, w->ln_eps, seq_start,
-                         seq_len, n_img, max_len, &aux, st));
+                         seq_len, n_img, max_len, &aux, st, nullptr));
   // PatchMerger (HF:288-291): ln_q, view [T/4, 4E], Linear+GELU, Linear
   const int M = T / w->merge_unit, E4 = E * w->merge_unit;
   OWC_TRY(owc_launch_layernorm(x, E, w->merger_ln_w, w->merger_ln_b, h, E, T, E, w->ln_eps, st));
@@ -85,6 +100,48 @@ int owc_vit_forward(owc_ctx* ctx, const owc_vit_weights* w, const void* pixel_va
                                E4, OWC_EPI_GELU_ERF, ctx->zeros, st));
   OWC_TRY(owc_launch_gemm_bf16(mlp, E4, w->merger_fc2_w, E4, w->merger_fc2_b, nullptr, 0, out,
                                w->out_dim, M, w->out_dim, E4, OWC_EPI_NONE, ctx->zeros, st));
+  return OWC_OK;
+}
+
+int owc_vit25_forward(owc_ctx* ctx, const owc_vit_weights* w, const void* pixel_values, int64_t ld_pix,
+                      const int32_t* pos_hw, const int32_t* tok_index, const int32_t* out_index, const int32_t* seq_start,
+                      const int32_t* seq_len, int n_img, int max_len, const int32_t* win_start, const int32_t* win_len, int n_win,
+                      int max_win_len, int T, int max_pos_hw, void* out, void* workspace, size_t ws_bytes, void* stream) {
+  if (!ctx || !w || !pixel_values || !pos_hw || !tok_index || !out_index || !seq_start || !seq_len || !win_start || !win_len ||
+      !out || !workspace)
+    return OWC_ERR_ARG;
+  if (w->variant != 1) OWC_FAIL(ctx, OWC_ERR_ARG, "owc_vit25_forward: weights are not the Qwen2.5-VL variant");
+  if (T <= 0 || n_img <= 0 || n_win <= 0 || (T % w->merge_unit) != 0) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_vit25_forward: bad T");
+  if ((w->mlp_hidden % 128) != 0) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_vit25_forward: mlp_hidden must be padded to a multiple of 128");
+  if (max_pos_hw <= 0 || max_pos_hw > w->rope_positions)
+    OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_vit25_forward: a grid side exceeds the vision rotary table (rope_positions)");
+  if (ws_bytes < owc_vit_workspace_bytes(w, T)) OWC_FAIL(ctx, OWC_ERR_WORKSPACE, "owc_vit25_forward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int E = w->embed_dim, H = w->num_heads, hd = E / H, F = w->mlp_hidden;
+  Carver cv(workspace, ws_bytes);
+  void* x = cv.take((size_t)T * E * 2);
+  void* h = cv.take((size_t)T * E * 2);
+  void* attn = cv.take((size_t)T * E * 2);
+  void* qkv = cv.take((size_t)T * E * 3 * 2);
+  void* mlp = cv.take((size_t)T * F * 2);
+  if (F < E || w->out_dim > 4 * E) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_vit25_forward: needs mlp_hidden >= embed_dim and out_dim <= 4 embed_dim (buffers are reused)");
+  const owc_gemm_aux aux = {pos_hw, w->rope_cos, w->rope_sin, 2 * E, hd};
+  const owc_vit_windows win = {win_start, win_len, n_win, max_win_len, w->fullatt_mask};
+
+  // patch embed in the ORIGINAL order (into h), then the window re-order (HF qwen2_5_vl:437-440)
+  OWC_TRY(owc_launch_gemm_bf16(pixel_values, ld_pix, w->patch_w, w->patch_k, nullptr, nullptr, 0, h, E, T, E, w->patch_k,
+                               OWC_EPI_NONE, ctx->zeros, st));
+  OWC_TRY(owc_launch_gather_rows(h, E, tok_index, x, E, T, E, st));
+  OWC_TRY(owc_vit_layers(ctx, w->layers, w->depth, x, h, attn, qkv, mlp, T, E, H, F, w->ln_eps, seq_start, seq_len, n_img,
+                         max_len, &aux, st, &win));
+  // Qwen2_5_VLPatchMerger (HF qwen2_5_vl:137-150): RMSNorm, view [T/4, 4E], Linear + GELU, Linear; rows back in the original order
+  const int M = T / w->merge_unit, E4 = E * w->merge_unit;
+  OWC_TRY(owc_launch_rmsnorm(x, E, w->merger_ln_w, h, E, T, E, w->ln_eps, nullptr, st));
+  OWC_TRY(owc_launch_gemm_bf16(h, E4, w->merger_fc1_w, E4, w->merger_fc1_b, nullptr, 0, mlp, E4, M, E4, E4, OWC_EPI_GELU_ERF,
+                               ctx->zeros, st));
+  OWC_TRY(owc_launch_gemm_bf16(mlp, E4, w->merger_fc2_w, E4, w->merger_fc2_b, nullptr, 0, x, w->out_dim, M, w->out_dim, E4,
+                               OWC_EPI_NONE, ctx->zeros, st));
+  OWC_TRY(owc_launch_gather_rows(x, w->out_dim, out_index, out, w->out_dim, M, w->out_dim, st));
   return OWC_OK;
 }
 

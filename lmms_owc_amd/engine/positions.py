@@ -33,6 +33,40 @@ def vision_pos_hw(grid_thw, merge: int = 2) -> np.ndarray:
 
 
 @lru_cache(maxsize=256)
+def _window_perm(t: int, h: int, w: int, merge: int, ws: int):
+    """One image of Qwen2.5-VL window attention (transformers/vision_utils.get_vision_window_index): the order in which the
+    merged 2x2 token groups are visited so that the groups of one window (ws x ws groups) are contiguous, and the number of
+    groups per window (border windows are ragged; the rule pads a full extra - empty - window when a side is a multiple of
+    `ws`, those are dropped).  Returns (group order int64 [t*gh*gw], groups per non-empty window)."""
+    gh, gw = h // merge, w // merge
+    pad_h, pad_w = ws - gh % ws, ws - gw % ws
+    nh, nw = (gh + pad_h) // ws, (gw + pad_w) // ws
+    padded = np.full((t, gh + pad_h, gw + pad_w), -1, np.int64)
+    padded[:, :gh, :gw] = np.arange(t * gh * gw).reshape(t, gh, gw)
+    padded = padded.reshape(t, nh, ws, nw, ws).transpose(0, 1, 3, 2, 4).reshape(t * nh * nw, ws * ws)
+    counts = (padded >= 0).sum(1)
+    return padded[padded >= 0], counts[counts > 0]
+
+
+def vision_windows(grid_thw, merge: int = 2, window_size: int = 112, patch_size: int = 14):
+    """Window attention bookkeeping of the Qwen2.5-VL vision tower (HF modeling_qwen2_5_vl.py:423-445, :463-465), in PATCH rows:
+    tok_index [T] (source row of every window-ordered row), out_index [T/merge^2] (window-ordered merged row of every output
+    row = argsort(window_index)), win_start / win_len (patch rows per window, in window order)."""
+    ws, unit = window_size // merge // patch_size, merge * merge
+    order, lens, base = [], [], 0
+    for t, h, w in grid_thw:
+        o, c = _window_perm(int(t), int(h), int(w), merge, ws)
+        order.append(o + base)
+        lens.append(c * unit)
+        base += int(t) * (int(h) // merge) * (int(w) // merge)
+    window_index = np.concatenate(order)
+    win_len = np.concatenate(lens).astype(np.int32)
+    win_start = (np.cumsum(win_len) - win_len).astype(np.int32)
+    tok_index = (window_index[:, None] * unit + np.arange(unit)[None, :]).reshape(-1).astype(np.int32)
+    return tok_index, np.argsort(window_index).astype(np.int32), win_start, win_len
+
+
+@lru_cache(maxsize=256)
 def _image_block(t: int, gh: int, gw: int) -> np.ndarray:
     tt = np.arange(t, dtype=np.int32).repeat(gh * gw)
     hh = np.tile(np.arange(gh, dtype=np.int32).repeat(gw), t)

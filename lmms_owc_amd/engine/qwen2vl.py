@@ -49,6 +49,11 @@ class Qwen2VLDims:
     max_grid: int = 1024           # vision rope table length (patches per side): covers max_pixels = 1024 * 28 * 28 at the
                                    # processor's 200:1 aspect limit (sqrt(802816 * 200) / 14 = 905); checked per launch
     decoder_dtype: str = "bf16"    # "fp8": decoder projections as e4m3fn weights + per-token e4m3fn activations (config #5)
+    # vision tower variant: 0 = Qwen2-VL (LayerNorm, fc1 -> quick_gelu -> fc2), 1 = Qwen2.5-VL (RMSNorm, gated SiLU MLP with
+    # biases - `v_mlp` is its intermediate size, 3420 -, window attention except in the `v_fullatt` blocks)
+    v_variant: int = 0
+    v_window: int = 112
+    v_fullatt: tuple = ()
 
 
 DIMS = {
@@ -57,6 +62,12 @@ DIMS = {
                                tie_embeddings=True),
     "qwen2-vl-7b": Qwen2VLDims(),
     "qwen2-vl-72b": Qwen2VLDims(n_layers=80, d_model=8192, n_q_heads=64, n_kv_heads=8, d_ff=29568, vocab=152064),
+    # Qwen2.5-VL (the reference's registry names qwen2.5-vl-7b / -3b, src/models/_qwen2_vl.py:635-648; public config.json values)
+    "qwen2.5-vl-7b": Qwen2VLDims(v_variant=1, v_mlp=3420, v_fullatt=(7, 15, 23, 31)),
+    "qwen2.5-vl-3b": Qwen2VLDims(v_variant=1, v_mlp=3420, v_fullatt=(7, 15, 23, 31), n_layers=36, d_model=2048, n_q_heads=16, n_kv_heads=2,
+                                 d_ff=11008, vocab=151936, tie_embeddings=True),
+    "tiny25": Qwen2VLDims(v_variant=1, v_depth=3, v_embed=160, v_heads=2, v_mlp=420, v_fullatt=(1,), n_layers=2, d_model=256, n_q_heads=2,
+                          n_kv_heads=1, d_ff=512, vocab=512, tie_embeddings=False, max_positions=2048, max_grid=128),
     # structure-preserving miniature for tests / smoke runs (GQA, head_dim 128, vision head_dim 80)
     "tiny": Qwen2VLDims(v_depth=2, v_embed=160, v_heads=2, v_mlp=640, n_layers=2, d_model=256, n_q_heads=2, n_kv_heads=1,
                         d_ff=512, vocab=512, tie_embeddings=False, max_positions=2048, max_grid=128),
@@ -71,6 +82,13 @@ def vision_qkv_row_permutation(embed: int, heads: int) -> torch.Tensor:
     head = torch.stack([j, j + hd // 2], dim=1).reshape(-1)            # [0, hd/2, 1, hd/2+1, ...]
     qk = (torch.arange(2 * heads)[:, None] * hd + head[None, :]).reshape(-1)
     return torch.cat([qk, torch.arange(2 * embed, 3 * embed)])
+
+
+def pad_rows(t: torch.Tensor, rows: int) -> torch.Tensor:
+    """Zero rows appended up to `rows` (first dim)."""
+    if t.shape[0] == rows:
+        return t
+    return torch.cat([t, torch.zeros((rows - t.shape[0], *t.shape[1:]), dtype=t.dtype, device=t.device)], 0)
 
 
 def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
@@ -123,10 +141,22 @@ class Qwen2VLWeights:
         # ---- vision
         vl = (_lib.VitLayer * d.v_depth)()
         perm = vision_qkv_row_permutation(d.v_embed, d.v_heads).to(self.device)
+        v25 = d.v_variant == 1
+        f_pad = (d.v_mlp + 127) // 128 * 128 if v25 else d.v_mlp   # 3420 -> 3456: zero gate / up rows meet zero down columns
         for i in range(d.v_depth):
             p = f"{V}blocks.{i}."
             vl[i].qkv_w = self._k(get(p + "attn.qkv.weight").index_select(0, perm).contiguous())
             vl[i].qkv_b = self._k(get(p + "attn.qkv.bias").index_select(0, perm).contiguous())
+            if v25:   # RMSNorm (no bias), gated MLP with biases: gate / up rows interleaved for the SwiGLU epilogue
+                for f, n in (("ln1_w", "norm1.weight"), ("proj_w", "attn.proj.weight"), ("proj_b", "attn.proj.bias"),
+                             ("ln2_w", "norm2.weight"), ("fc2_b", "mlp.down_proj.bias")):
+                    setattr(vl[i], f, self._k(get(p + n)))
+                vl[i].fc1_w = self._k(interleave_gate_up(pad_rows(get(p + "mlp.gate_proj.weight"), f_pad),
+                                                         pad_rows(get(p + "mlp.up_proj.weight"), f_pad)))
+                vl[i].fc1_b = self._k(interleave_gate_up(pad_rows(get(p + "mlp.gate_proj.bias")[:, None], f_pad),
+                                                         pad_rows(get(p + "mlp.up_proj.bias")[:, None], f_pad)).reshape(-1).contiguous())
+                vl[i].fc2_w = self._k(pad_rows(get(p + "mlp.down_proj.weight").t().contiguous(), f_pad).t().contiguous())
+                continue
             for f, n in (("ln1_w", "norm1.weight"), ("ln1_b", "norm1.bias"),
                          ("proj_w", "attn.proj.weight"), ("proj_b", "attn.proj.bias"),
                          ("ln2_w", "norm2.weight"), ("ln2_b", "norm2.bias"), ("fc1_w", "mlp.fc1.weight"),
@@ -134,13 +164,16 @@ class Qwen2VLWeights:
                 setattr(vl[i], f, self._k(get(p + n)))
         self._vit_layers = vl
         v = self.vit
-        v.depth, v.embed_dim, v.num_heads, v.mlp_hidden = d.v_depth, d.v_embed, d.v_heads, d.v_mlp
+        v.depth, v.embed_dim, v.num_heads, v.mlp_hidden = d.v_depth, d.v_embed, d.v_heads, f_pad
         v.patch_k, v.out_dim, v.merge_unit, v.ln_eps = d.patch_k, d.d_model, d.merge ** 2, 1e-6
         v.patch_w = self._k(get(V + "patch_embed.proj.weight").reshape(d.v_embed, d.patch_k).contiguous())
         v.layers = C.cast(vl, C.POINTER(_lib.VitLayer))
+        v.variant, v.fullatt_mask = d.v_variant, sum(1 << int(i) for i in d.v_fullatt)
         for f, n in (("merger_ln_w", "merger.ln_q.weight"), ("merger_ln_b", "merger.ln_q.bias"),
                      ("merger_fc1_w", "merger.mlp.0.weight"), ("merger_fc1_b", "merger.mlp.0.bias"),
                      ("merger_fc2_w", "merger.mlp.2.weight"), ("merger_fc2_b", "merger.mlp.2.bias")):
+            if v25 and f == "merger_ln_b":
+                continue   # RMSNorm
             setattr(v, f, self._k(get(V + n)))
         vc, vs = ops.rope_table(d.max_grid, hd_v // 4, hd_v // 2, 10000.0, False, self.device)
         v.rope_cos, v.rope_sin, v.rope_positions = self._k(vc), self._k(vs), d.max_grid
@@ -226,12 +259,16 @@ def hf_param_names(d: Qwen2VLDims) -> list[str]:
     """Every HF parameter name of the architecture (transformers 5.x naming), i.e. the keys `random_param` is defined on."""
     V, T = "model.visual.", "model.language_model."
     names = [V + "patch_embed.proj.weight"]
+    block = ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight",
+             "attn.proj.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
+    if d.v_variant == 1:
+        block = ("norm1.weight", "norm2.weight", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+                 "mlp.gate_proj.weight", "mlp.gate_proj.bias", "mlp.up_proj.weight", "mlp.up_proj.bias", "mlp.down_proj.weight",
+                 "mlp.down_proj.bias")
     for i in range(d.v_depth):
-        names += [f"{V}blocks.{i}.{n}" for n in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "attn.qkv.weight",
-                                                 "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "mlp.fc1.weight",
-                                                 "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")]
+        names += [f"{V}blocks.{i}.{n}" for n in block]
     names += [V + n for n in ("merger.ln_q.weight", "merger.ln_q.bias", "merger.mlp.0.weight", "merger.mlp.0.bias",
-                              "merger.mlp.2.weight", "merger.mlp.2.bias")]
+                              "merger.mlp.2.weight", "merger.mlp.2.bias") if not (d.v_variant == 1 and n == "merger.ln_q.bias")]
     names.append(T + "embed_tokens.weight")
     for i in range(d.n_layers):
         names += [f"{T}layers.{i}.{n}" for n in ("self_attn.q_proj.weight", "self_attn.q_proj.bias", "self_attn.k_proj.weight",
@@ -269,7 +306,11 @@ def _param_shape(d: Qwen2VLDims, name: str) -> tuple:
     if name in table:
         return table[name]
     if "visual.blocks." in name:
-        return table[name.split(".", 4)[-1]]
+        tail_v = name.split(".", 4)[-1]
+        if tail_v.startswith("mlp.") and "proj" in tail_v:   # the gated vision MLP of Qwen2.5-VL
+            return {"mlp.gate_proj.weight": (F, E), "mlp.gate_proj.bias": (F,), "mlp.up_proj.weight": (F, E), "mlp.up_proj.bias": (F,),
+                    "mlp.down_proj.weight": (E, F), "mlp.down_proj.bias": (E,)}[tail_v]
+        return table[tail_v]
     if "language_model.layers." in name:
         return table[name.split(".", 4)[-1]]
     raise KeyError(name)
@@ -333,11 +374,24 @@ class Qwen2VLEngine:
         if max_side > self.d.max_grid:   # the rotary table is indexed by patch coordinates (smart_resize allows aspect 200:1)
             raise ValueError(f"an image grid side of {max_side} patches exceeds the vision rotary table "
                              f"(Qwen2VLDims.max_grid = {self.d.max_grid})")
-        pos_hw = self._i32(positions.vision_pos_hw(grid, self.d.merge))
+        hw = positions.vision_pos_hw(grid, self.d.merge)
         starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
         seq_start, seq_len = self._i32(starts), self._i32(lens)
         nbytes = self._lib.owc_vit_workspace_bytes(C.byref(self.w.vit), T)
         ws = self._workspace(nbytes)
+        if self.d.v_variant == 1:   # Qwen2.5-VL: window order (an image's rows stay contiguous), windows of <= 64 patches
+            tok_index, out_index, win_start, win_len = positions.vision_windows(grid, self.d.merge, self.d.v_window, 14)
+            # (named tensors, not temporaries: a temporary is released to torch's caching allocator as soon as its data_ptr() has
+            # been taken, and the next upload would land in the same bytes)
+            t_hw, t_tok, t_out = self._i32(hw[tok_index]), self._i32(tok_index), self._i32(out_index)
+            t_ws, t_wl = self._i32(win_start), self._i32(win_len)
+            rc = self._lib.owc_vit25_forward(self._ctx, C.byref(self.w.vit), pix.data_ptr(), pix.stride(0), t_hw.data_ptr(),
+                                             t_tok.data_ptr(), t_out.data_ptr(), seq_start.data_ptr(), seq_len.data_ptr(), len(grid),
+                                             max(lens), t_ws.data_ptr(), t_wl.data_ptr(), len(win_len), int(win_len.max()), T,
+                                             max_side, out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, self.dev_index)
+            return
+        pos_hw = self._i32(hw)
         rc = self._lib.owc_vit_forward(self._ctx, C.byref(self.w.vit), pix.data_ptr(), pix.stride(0), pos_hw.data_ptr(),
                                        seq_start.data_ptr(), seq_len.data_ptr(), len(grid), T, max(lens), max_side, out.data_ptr(),
                                        ws.data_ptr(), ws.numel(), _lib.stream_ptr())

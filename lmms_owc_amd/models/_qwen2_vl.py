@@ -465,8 +465,16 @@ def dims_from_hf_config(cfg: dict) -> Qwen2VLDims:
     t = cfg.get("text_config", cfg)
     v = cfg["vision_config"]
     rope = t.get("rope_parameters") or t.get("rope_scaling") or {}
+    v25 = {}
+    if cfg.get("model_type") == "qwen2_5_vl" or "fullatt_block_indexes" in v:   # Qwen2.5-VL (reference :106-115)
+        v = {**v, "embed_dim": v["hidden_size"], "mlp_ratio": 0}
+        v25 = dict(v_variant=1, v_window=v.get("window_size", 112), v_fullatt=tuple(v.get("fullatt_block_indexes", (7, 15, 23, 31))))
+        if v.get("hidden_act", "silu") != "silu":
+            raise ValueError("the Qwen2.5-VL vision MLP is implemented for hidden_act = silu")
     return Qwen2VLDims(
-        v_depth=v["depth"], v_embed=v["embed_dim"], v_heads=v["num_heads"], v_mlp=int(v["embed_dim"] * v.get("mlp_ratio", 4)),
+        **v25,
+        v_depth=v["depth"], v_embed=v["embed_dim"], v_heads=v["num_heads"],
+        v_mlp=v["intermediate_size"] if v25 else int(v["embed_dim"] * v.get("mlp_ratio", 4)),
         patch_k=v.get("in_channels", v.get("in_chans", 3)) * v.get("temporal_patch_size", 2) * v.get("patch_size", 14) ** 2,
         merge=v.get("spatial_merge_size", 2), n_layers=t["num_hidden_layers"], d_model=t["hidden_size"],
         n_q_heads=t["num_attention_heads"], n_kv_heads=t["num_key_value_heads"],
@@ -506,6 +514,16 @@ def qwen2_vl_7b(**model_kwargs) -> Qwen2VL:
 @register_model("qwen2-vl-2b")
 def qwen2_vl_2b(**model_kwargs) -> Qwen2VL:
     return Qwen2VL(model_kwargs.pop("model_name_or_path", "Qwen/Qwen2-VL-2B-Instruct"), **model_kwargs)
+
+
+@register_model("qwen2.5-vl-7b")
+def qwen25_vl_7b(**model_kwargs) -> Qwen2VL:
+    return Qwen2VL(model_kwargs.pop("model_name_or_path", "Qwen/Qwen2.5-VL-7B-Instruct"), **model_kwargs)
+
+
+@register_model("qwen2.5-vl-3b")
+def qwen25_vl_3b(**model_kwargs) -> Qwen2VL:
+    return Qwen2VL(model_kwargs.pop("model_name_or_path", "Qwen/Qwen2.5-VL-3B-Instruct"), **model_kwargs)
 
 
 @register_model("qwen2-vl-72b")

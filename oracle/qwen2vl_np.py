@@ -249,7 +249,7 @@ def greedy_argmax(logits: np.ndarray) -> np.ndarray:
 
 def generate(w: dict, cfg: Cfg, input_ids: np.ndarray, pixel_values: np.ndarray | None, grid_thw, max_new_tokens: int,
              *, bf16=False, eos_token_id: int | None = None, pad_token_id: int = 0, return_logits=False, fp8: dict | None = None,
-             forced_tokens=None):
+             forced_tokens=None, vit=None):
     """Greedy generation for ONE prompt (reference batch size is 1, src/models/_base.py:103-104):
     HF:1144-1205 (embed + image scatter + rope index) then the GenerationMixin greedy loop.
     `forced_tokens` (teacher forcing, parity tests): the token fed after step j is forced_tokens[j] instead of the
@@ -258,7 +258,7 @@ def generate(w: dict, cfg: Cfg, input_ids: np.ndarray, pixel_values: np.ndarray 
     ids = np.asarray(input_ids).astype(np.int64)
     x = maybe_bf16(w[T + "embed_tokens.weight"][ids], bf16)
     if pixel_values is not None:
-        img = vit_forward(w, cfg, pixel_values, grid_thw, bf16=bf16)
+        img = (vit or vit_forward)(w, cfg, pixel_values, grid_thw, bf16=bf16)   # `vit`: oracle/qwen25vl_np.py plugs its tower in here
         x[ids == cfg.image_token_id] = img
         pos3, delta = rope_index(ids, grid_thw, cfg)
     else:

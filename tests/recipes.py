@@ -108,6 +108,36 @@ def qwen2vl_weights(cfg: Cfg, seed: int = 1234) -> dict[str, np.ndarray]:
     return {k: _fill(k, shp, seed) for k, shp in qwen2vl_shapes(cfg).items()}
 
 
+def tiny_cfg25():
+    """Qwen2.5-VL miniature with the real structure: RMSNorm + gated-MLP vision blocks (intermediate 420 is NOT a multiple of 16,
+    like the real 3420), vision head_dim 80, 112-pixel windows, three blocks of which the middle one is a full-attention block."""
+    from oracle.qwen25vl_np import Cfg25, Vision25Cfg
+
+    return Cfg25(vision=Vision25Cfg(depth=3, embed_dim=160, num_heads=2, intermediate_size=420, hidden_size=256,
+                                    window_size=112, fullatt_block_indexes=(1,)),
+                 text=TextCfg(hidden_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+                              intermediate_size=512, vocab_size=512, tie_word_embeddings=False), image_token_id=500)
+
+
+def qwen25vl_shapes(cfg) -> dict[str, tuple]:
+    v = cfg.vision
+    E, F = v.embed_dim, v.intermediate_size
+    s = {k: shp for k, shp in qwen2vl_shapes(Cfg(vision=VisionCfg(depth=0, embed_dim=E, num_heads=v.num_heads, hidden_size=v.hidden_size),
+                                                 text=cfg.text, image_token_id=cfg.image_token_id)).items()
+         if "merger.ln_q.bias" not in k}
+    for i in range(v.depth):
+        p = f"model.visual.blocks.{i}."
+        s.update({p + "norm1.weight": (E,), p + "norm2.weight": (E,), p + "attn.qkv.weight": (3 * E, E), p + "attn.qkv.bias": (3 * E,),
+                  p + "attn.proj.weight": (E, E), p + "attn.proj.bias": (E,),
+                  p + "mlp.gate_proj.weight": (F, E), p + "mlp.gate_proj.bias": (F,), p + "mlp.up_proj.weight": (F, E),
+                  p + "mlp.up_proj.bias": (F,), p + "mlp.down_proj.weight": (E, F), p + "mlp.down_proj.bias": (E,)})
+    return s
+
+
+def qwen25vl_weights(cfg, seed: int = 1234) -> dict[str, np.ndarray]:
+    return {k: _fill(k, shp, seed) for k, shp in qwen25vl_shapes(cfg).items()}
+
+
 def pixel_values(grid_thw, seed: int = 7) -> np.ndarray:
     """Synthetic normalised patches [sum(t*h*w), 1176], bf16-representable."""
     n = int(sum(t * h * w for t, h, w in grid_thw))

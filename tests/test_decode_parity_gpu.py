@@ -71,6 +71,46 @@ def test_qwen_every_step_vs_oracle_and_hf(qwen_tiny, gpu, case):
     check_within_hf_bf16_noise(logits, g[f"{case}_bf16_logits"], g[f"{case}_f32_logits"], f"qwen-{case}")
 
 
+# ---------------------------------------------------------------- Qwen2.5-VL tiny (window attention / RMSNorm / gated-MLP vision tower)
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_qwen25_every_step_vs_oracle_and_hf(gpu, case):
+    """The reference's `Qwen2_5_VLForConditionalGeneration` branch (/root/reference/src/models/_qwen2_vl.py:106-115, registry names
+    qwen2.5-vl-7b / -3b): vision tower output and EVERY decode step against oracle/qwen25vl_np.py and HF's bf16 / fp32 goldens
+    (grids with ragged border windows, a window-multiple side, three images in one prompt)."""
+    from lmms_owc_amd.engine.qwen2vl import DIMS, Qwen2VLDims, Qwen2VLEngine, Qwen2VLWeights
+    from oracle import qwen25vl_np as Q25
+
+    cfg = recipes.tiny_cfg25()
+    w = recipes.qwen25vl_weights(cfg, 1234)
+    dims = Qwen2VLDims(**{**DIMS["tiny25"].__dict__, "image_token_id": 500, "max_positions": 512, "max_grid": 64})
+    eng = Qwen2VLEngine(Qwen2VLWeights.from_state_dict(dims, w, gpu), vit_chunk_tokens=200, prefill_chunk_tokens=64)
+    g = np.load(GOLD / "qwen25vl_tiny.npz")
+    grid = [tuple(r) for r in g[f"{case}_grid"].tolist()]
+    pix = recipes.pixel_values(grid, 7)
+    ids, ref_tok = g[f"{case}_ids"], g[f"{case}_f32_tokens"]
+    emb = eng.encode_images(torch.from_numpy(pix).to(BF16).to(gpu), grid)
+    from tests.util import assert_rel_close
+
+    assert_rel_close(to_np(emb), Q25.vit_forward(w, cfg, pix, grid, bf16=True), ORACLE_BOUND, f"qwen2.5-{case} vision tower vs oracle")
+    assert_rel_close(to_np(emb), g[f"{case}_bf16_vit"], HF_BOUND, f"qwen2.5-{case} vision tower vs hf-bf16")
+    assert_rel_close(to_np(emb), g[f"{case}_f32_vit"], HF_BOUND, f"qwen2.5-{case} vision tower vs hf-f32")
+    if grid != [grid[0]]:   # an image alone == inside the chunked, window-reordered launch
+        n0 = grid[0][1] * grid[0][2]
+        solo = eng.encode_images(torch.from_numpy(pix[:n0]).to(BF16).to(gpu), grid[:1])
+        assert torch.equal(solo, emb[: n0 // 4])
+    if not np.array_equal(ref_tok, g[f"{case}_bf16_tokens"]):
+        pytest.skip("HF's bf16 and fp32 runs took different continuations: no single sequence to force")
+    T = len(ref_tok)
+    toks, logits = eng.generate([ids], emb, [grid], T, forced_tokens=ref_tok[None], return_step_logits=True)
+    toks, logits = to_np(toks)[0].astype(int), to_np(logits)[:, 0]
+    _, o_logits = Q25.generate(w, cfg, ids, pix, grid, T, bf16=True, return_logits=True, forced_tokens=ref_tok)
+    n = check_forced_steps(logits, toks, o_logits, None, ORACLE_BOUND, f"qwen2.5-{case} oracle")
+    n += check_forced_steps(logits, toks, g[f"{case}_bf16_logits"], ref_tok, HF_BOUND, f"qwen2.5-{case} hf-bf16")
+    n += check_forced_steps(logits, toks, g[f"{case}_f32_logits"], ref_tok, HF_BOUND, f"qwen2.5-{case} hf-f32")
+    assert n >= 3 * 3
+    check_within_hf_bf16_noise(logits, g[f"{case}_bf16_logits"], g[f"{case}_f32_logits"], f"qwen2.5-{case}")
+
+
 def test_qwen_fp8_every_step_vs_fp8_oracle(qwen_tiny, gpu):
     """fp8 decoder (config #5): own bound, stated in tests/test_fp8_model_gpu.py (an e4m3 code flip is a 6 % step)."""
     from oracle import fp8_np as F
@@ -161,7 +201,7 @@ _W_CACHE: dict = {}   # one entry: the numpy weights of the most recent width (t
 
 OUTLIER_ROWS, OUTLIER_SCALE, OUTLIER_SEED = 16, 4.0, 97
 OUTLIER_BOUND = 0.03          # the scaled rows' own logit bound (see tests/util.check_forced_steps); decisive margin = 2 x this
-FP8_BOUND, FP8_OUTLIER_BOUND = 0.10, 0.12
+FP8_BOUND, FP8_OUTLIER_BOUND = 0.10, 0.13   # observed on MI355X: ordinary columns 6.3-8.0 %, scaled rows 9.1-11.7 %
 
 
 def outlier_rows() -> np.ndarray:
@@ -247,7 +287,7 @@ def _slice_refs(name, B, T, decoder_dtype="bf16"):
 def _run_slice(name, gpu, B, T, decoder_dtype="bf16", frac=ORACLE_BOUND, special_frac=OUTLIER_BOUND, mean_frac=None, min_decisive=3,
                min_total=None):
     """Every checked sequence must offer - and pass - at least `min_decisive` token comparisons with a decisive margin (top-2
-    margin of the ORACLE's logits > 2 x the scaled rows' bound = 6 %; fp8: 24 %), the three sequences together at least
+    margin of the ORACLE's logits > 2 x the scaled rows' bound = 6 %; fp8: 26 %), the three sequences together at least
     `min_total` (default: 10 of 18).  What the oracle offers is known before a GPU runs: `python tools/slice_margins.py`
     (bf16: 3-8 decisive steps per sequence, 11-21 per case; fp8: 1-4 per sequence, 5-8 per case)."""
     _, _, eng = _slice(name, gpu, decoder_dtype)

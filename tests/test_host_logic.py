@@ -77,6 +77,40 @@ def test_cabi_exports_every_declared_symbol():
     assert _lib.load().owc_abi_version() == _lib.ABI_VERSION
 
 
+def test_qwen25_window_bookkeeping_matches_hf_and_registry_names():
+    """Host integers of the Qwen2.5-VL vision tower (engine/positions.vision_windows) against what HF's
+    get_vision_window_index produced at real geometry (tests/golden/qwen25vl_tiny.json), and the reference's registry names
+    (/root/reference/src/models/_qwen2_vl.py:635-648) are registered with the Qwen2.5 dimensions."""
+    import zlib
+
+    import numpy as np
+
+    from lmms_owc_amd.engine import positions
+    from lmms_owc_amd.engine.qwen2vl import DIMS
+    from lmms_owc_amd.models import _api
+
+    meta = json.loads((ROOT / "tests" / "golden" / "qwen25vl_tiny.json").read_text())
+    for name, geo in meta["window_geometry"].items():
+        tok, outi, ws, wl = positions.vision_windows([tuple(g) for g in geo["grid"]])
+        widx = tok.reshape(-1, 4)[:, 0] // 4
+        assert np.array_equal(tok.reshape(-1, 4), widx[:, None] * 4 + np.arange(4)), name     # 2x2 groups travel together
+        assert zlib.crc32(widx.astype(np.int64).tobytes()) == geo["window_index_crc"], name
+        assert np.concatenate([[0], np.cumsum(wl)]).tolist() == geo["cu_window_seqlens"] and wl.max() <= 64, name
+        assert np.array_equal(ws, np.cumsum(wl) - wl) and np.array_equal(outi, np.argsort(widx)), name
+    for key in ("qwen2.5-vl-7b", "qwen2.5-vl-3b"):
+        assert _api.get_model_builder(key) is not None
+        d = DIMS[key]
+        assert d.v_variant == 1 and d.v_mlp == 3420 and d.v_fullatt == (7, 15, 23, 31) and d.v_embed == 1280
+    assert (DIMS["qwen2.5-vl-3b"].d_model, DIMS["qwen2.5-vl-3b"].n_layers, DIMS["qwen2.5-vl-3b"].tie_embeddings) == (2048, 36, True)
+    from lmms_owc_amd.models import _qwen2_vl as mw
+
+    d = mw.dims_from_hf_config({"model_type": "qwen2_5_vl", "text_config": {"num_hidden_layers": 28, "hidden_size": 3584,
+                                "num_attention_heads": 28, "num_key_value_heads": 4, "intermediate_size": 18944, "vocab_size": 152064},
+                                "vision_config": {"depth": 32, "hidden_size": 1280, "num_heads": 16, "intermediate_size": 3420,
+                                                  "out_hidden_size": 3584, "window_size": 112, "fullatt_block_indexes": [7, 15, 23, 31]}})
+    assert (d.v_variant, d.v_embed, d.v_mlp, d.v_fullatt, d.d_model) == (1, 1280, 3420, (7, 15, 23, 31), 3584)
+
+
 def test_product_library_has_no_timing_knobs_and_reads_no_environment():
     """The timing-only experiment knobs (parts of a kernel switched off: garbage results) are compiled out of libowc_hip.so -
     `owc_tuning_set` does not know their names - and the library reads no environment variable (csrc/ has no getenv): an

@@ -208,6 +208,17 @@ def test_decode_attention_fused_equals_the_two_kernel_path(gpu, Hq, Hkv):
         want = _attn_ref(qn[i][:, None, :], kk, vv, False)[:, 0]
         got = b[i].reshape(Hq, hd)
         assert np.abs(got - want).max() <= 0.02 * np.abs(want).max() + 1e-3, (i, klen[i])
+    # the large-batch form (one V buffer per wave, two blocks per CU) fetches the same tiles at other times: same bits
+    from lmms_owc_amd import _lib
+
+    lib = _lib.load()
+    try:
+        assert lib.owc_tuning_set(b"decode_attn_nbuf1", 0) == 0
+        out_c = ops.decode_attention(qkv, i32(pos, gpu), cos, sin, kc0.clone(), vc0.clone(), i32(slot, gpu), i32(widx, gpu),
+                                     i32(klen, gpu), Hq, Hkv, s_max, hd ** -0.5)
+    finally:
+        lib.owc_tuning_set(b"decode_attn_nbuf1", -1)
+    assert torch.equal(out_c, out_b)
     # a sequence's result does not depend on its neighbours: the last sequence alone, bit for bit
     one = ops.decode_attention(qkv[B - 1:], i32(pos[B - 1:], gpu), cos, sin, kc0.clone(), vc0.clone(), i32(slot[B - 1:], gpu),
                                i32(widx[B - 1:], gpu), i32(klen[B - 1:], gpu), Hq, Hkv, s_max, hd ** -0.5)

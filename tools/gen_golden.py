@@ -97,6 +97,73 @@ def gen_qwen():
     print("qwen golden:", {k: v.shape for k, v in out.items()})
 
 
+def hf_qwen25(cfg, weights, dtype):
+    from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
+
+    v, t = cfg.vision, cfg.text
+    hcfg = Qwen2_5_VLConfig(
+        text_config=dict(hidden_size=t.hidden_size, num_hidden_layers=t.num_hidden_layers,
+                         num_attention_heads=t.num_attention_heads, num_key_value_heads=t.num_key_value_heads,
+                         intermediate_size=t.intermediate_size, vocab_size=t.vocab_size, rms_norm_eps=t.rms_norm_eps,
+                         max_position_embeddings=4096, tie_word_embeddings=t.tie_word_embeddings,
+                         rope_parameters=dict(rope_type="default", rope_theta=t.rope_theta, mrope_section=list(t.mrope_section))),
+        vision_config=dict(depth=v.depth, hidden_size=v.embed_dim, num_heads=v.num_heads, out_hidden_size=v.hidden_size,
+                           intermediate_size=v.intermediate_size, patch_size=v.patch_size, spatial_merge_size=v.spatial_merge_size,
+                           temporal_patch_size=v.temporal_patch_size, window_size=v.window_size,
+                           fullatt_block_indexes=list(v.fullatt_block_indexes), hidden_act="silu"),
+        image_token_id=cfg.image_token_id, video_token_id=cfg.image_token_id + 1,
+        vision_start_token_id=cfg.image_token_id + 2, vision_end_token_id=cfg.image_token_id + 3,
+        tie_word_embeddings=t.tie_word_embeddings)
+    hcfg._attn_implementation = "eager"
+    m = Qwen2_5_VLForConditionalGeneration(hcfg)
+    sd = {k: torch.from_numpy(a.copy()) for k, a in weights.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("lm_head" in k or "inv_freq" in k for k in missing), (missing, unexpected)
+    return m.to(dtype).eval()
+
+
+def gen_qwen25():
+    """Qwen2.5-VL (the reference's `Qwen2_5_VLForConditionalGeneration` branch, src/models/_qwen2_vl.py:106-115): vision tower with
+    window attention (grids that leave ragged border windows, a window-multiple side, several images), per-step logits, tokens."""
+    cfg = recipes.tiny_cfg25()
+    w = recipes.qwen25vl_weights(cfg, 1234)
+    out = {}
+    cases = {"a": [(1, 12, 20)], "b": [(1, 6, 4), (1, 16, 8), (1, 10, 18)]}   # 112 px = 8 patches = 4 merged groups per window side
+    for name, grid in cases.items():
+        pix = recipes.pixel_values(grid, seed=7)
+        ids = recipes.prompt_ids(cfg, grid, seed=11)
+        for dtype, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+            m = hf_qwen25(cfg, w, dtype)
+            g = torch.tensor(grid)
+            inp = torch.from_numpy(ids)[None]
+            mm = (inp == cfg.image_token_id).int()
+            with torch.no_grad():
+                vis = m.model.visual(torch.from_numpy(pix).to(dtype), grid_thw=g).pooler_output
+                gen = m.generate(input_ids=inp, attention_mask=torch.ones_like(inp), pixel_values=torch.from_numpy(pix).to(dtype),
+                                 image_grid_thw=g, mm_token_type_ids=mm, do_sample=False, num_beams=1, max_new_tokens=8,
+                                 use_cache=True, eos_token_id=None, pad_token_id=0, output_logits=True,
+                                 return_dict_in_generate=True)
+                pos, delta = m.model.get_rope_index(inp, mm_token_type_ids=mm, image_grid_thw=g)
+            out[f"{name}_{tag}_vit"] = torch.cat(list(vis), 0).float().numpy() if isinstance(vis, (list, tuple)) else vis.float().numpy()
+            out[f"{name}_{tag}_tokens"] = gen.sequences[0, inp.shape[1]:].numpy()
+            out[f"{name}_{tag}_logits"] = torch.stack([l[0] for l in gen.logits]).float().numpy()
+            out[f"{name}_pos3"] = pos[:, 0].numpy()
+            out[f"{name}_delta"] = np.array(int(delta[0, 0]))
+        out[f"{name}_grid"] = np.array(grid)
+        out[f"{name}_ids"] = ids
+    # the integer window bookkeeping at real geometry (448 x 448 and ragged sizes): window_index + cu_window_seqlens from HF
+    from transformers import vision_utils as vu
+
+    geo = {}
+    for gname, grid in {"448": [[1, 32, 32]], "ragged": [[1, 36, 36], [1, 26, 48], [1, 2, 2], [1, 64, 64], [1, 14, 70]]}.items():
+        wi, cu = vu.get_vision_window_index(torch.tensor(grid), spatial_merge_size=2, window_size=112, patch_size=14)
+        geo[gname] = {"grid": grid, "window_index_crc": int(zlib.crc32(wi.numpy().astype(np.int64).tobytes())), "n": int(wi.numel()),
+                      "cu_window_seqlens": cu.tolist()}
+    np.savez_compressed(GOLD / "qwen25vl_tiny.npz", **out)
+    (GOLD / "qwen25vl_tiny.json").write_text(json.dumps({"versions": versions(), "weights_seed": 1234, "cases": cases, "window_geometry": geo}, indent=1))
+    print("qwen2.5 golden:", {k: v.shape for k, v in out.items()})
+
+
 def Cfg448():
     """get_rope_index on a 286-token prompt holding one 32x32-patch image (16x16 merged tokens)."""
     from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
@@ -556,6 +623,8 @@ if __name__ == "__main__":
         gen_llava_next()
     if "qwen" in which:
         gen_qwen()
+    if "qwen25" in which:
+        gen_qwen25()
     if "scorer" in which:
         gen_scorer()
     if "scorer_ragged" in which:

@@ -40,6 +40,77 @@ __global__ __launch_bounds__(1024) void k(const char* __restrict__ buf, size_t s
   if (acc[0] == 0x12345678u && acc[1] == 1u) out[0] = acc[2];
 }
 
+// mode 2: the access pattern of a K-contiguous GEMM operand: one wave-instruction covers 1024 / SEG rows x SEG contiguous bytes
+// (row stride `stride` bytes), consecutive instructions of a wave move along the rows (k direction), 8 instructions in flight.
+template <int SEG>
+__global__ __launch_bounds__(1024) void ks(const char* __restrict__ buf, size_t stride, int rows_total, int iters, unsigned* out) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int RPI = 1024 / SEG;                 // rows per instruction
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int nw = blockDim.x >> 6;
+  const int gw = blockIdx.x * nw + w, ngw = gridDim.x * nw;
+  const int steps = (int)(stride / SEG);
+  for (int it = 0; it < iters; ++it)
+    for (int r0 = gw * RPI; r0 + RPI <= rows_total; r0 += ngw * RPI) {
+      const char* p = buf + (size_t)(r0 + l / (SEG / 16)) * stride + (l % (SEG / 16)) * 16;
+      for (int s = 0; s + 8 <= steps; s += 8) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+          __builtin_amdgcn_global_load_lds((gptr_t)(p + (size_t)(s + d) * SEG), (lptr_t)(lds + (w * 8 + d) * 1024), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+  if (out == nullptr) lds[0] = 1;
+}
+
+// mode 3: STORES.  Every wave writes its own contiguous slice with 16-byte stores (1 KiB per wave-instruction), `burst` instructions
+// back to back, then (optionally) a wait: what can one CU push out, alone and with all 256 CUs writing at once?  (The 256x256 GEMM's
+// epilogue writes 128 KiB per CU in ~6 us = 20 GB/s per CU with every CU in its epilogue at the same time.)
+__global__ __launch_bounds__(1024) void kst(char* __restrict__ buf, size_t slice, int iters, int burst) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int nw = blockDim.x >> 6;
+  char* p = buf + ((size_t)blockIdx.x * nw + w) * slice + l * 16;
+  const u32x4 v = {1u, 2u, 3u, (unsigned)l};
+  const size_t steps = slice / 1024;
+  for (int it = 0; it < iters; ++it)
+    for (size_t s = 0; s + burst <= steps; s += burst) {
+      for (int d = 0; d < burst; ++d) *(u32x4*)(p + (s + d) * 1024) = v;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+void run_store(char* buf, size_t total, int blocks, int waves, int burst) {
+  const size_t slice = (total / ((size_t)blocks * waves)) / (1024 * burst) * (1024 * burst);
+  if (slice == 0) return;
+  const int iters = (int)(((size_t)4 << 30) / (slice * (size_t)blocks * waves)) + 1;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(kst, dim3(blocks), dim3(64 * waves), 0, 0, buf, slice, 1, burst);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(kst, dim3(blocks), dim3(64 * waves), 0, 0, buf, slice, iters, burst);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double bytes = (double)slice * blocks * waves * iters;
+  printf("store burst %2d  blocks %3d x %2d waves  slice %9zu B: %7.1f GB/s per CU  %6.2f TB/s\n", burst, blocks, waves, slice,
+         bytes / ms / 1e6 / blocks, bytes / ms / 1e9);
+}
+
+template <int SEG>
+void run_strided(const char* buf, size_t total, size_t stride, int blocks, int waves, unsigned* out) {
+  const int rows = (int)(total / stride);
+  const int iters = (int)(((size_t)4 << 30) / total) + 1;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int ldsb = waves * 8 * 1024;
+  hipFuncSetAttribute((const void*)ks<SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+  hipLaunchKernelGGL((ks<SEG>), dim3(blocks), dim3(64 * waves), ldsb, 0, buf, stride, rows, 1, out);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((ks<SEG>), dim3(blocks), dim3(64 * waves), ldsb, 0, buf, stride, rows, iters, out);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double bytes = (double)rows * stride * iters;
+  printf("strided seg %4d B  row stride %6zu B  blocks %3d x %2d waves: %7.1f GB/s per CU  %6.2f TB/s\n", SEG, stride, blocks, waves,
+         bytes / ms / 1e6 / blocks, bytes / ms / 1e9);
+}
+
 template <int MODE, int DEPTH>
 void run(const char* buf, size_t total, int blocks, int waves, unsigned* out, const char* tag) {
   const size_t slice = (total / ((size_t)blocks * waves)) / (1024 * DEPTH) * (1024 * DEPTH);
@@ -60,6 +131,28 @@ void run(const char* buf, size_t total, int blocks, int waves, unsigned* out, co
 
 int main(int argc, char** argv) {
   unsigned* out; hipMalloc(&out, 16);
+  if (argc > 1 && argv[1][0] == 'w') {   // `probe_ingest write`: store throughput (128 KiB per CU per round = the GEMM's C tile, and a stream)
+    char* buf; const size_t total = (size_t)2 << 30;
+    if (hipMalloc(&buf, total) != hipSuccess) return 1;
+    for (int blocks : {8, 256})
+      for (int waves : {4, 8})
+        for (int burst : {4, 16}) run_store(buf, total, blocks, waves, burst);
+    return 0;
+  }
+  if (argc > 1) {   // strided part only: `probe_ingest strided`
+    char* buf; const size_t total = (size_t)2 << 30;
+    if (hipMalloc(&buf, total) != hipSuccess) return 1;
+    hipMemset(buf, 1, total);
+    for (size_t stride : {(size_t)37888, (size_t)7168, (size_t)2560})
+      for (int blocks : {112, 256})
+        for (int waves : {4, 8}) {
+          run_strided<64>(buf, total, stride, blocks, waves, out);
+          run_strided<128>(buf, total, stride, blocks, waves, out);
+          run_strided<256>(buf, total, stride, blocks, waves, out);
+          run_strided<512>(buf, total, stride, blocks, waves, out);
+        }
+    return 0;
+  }
   for (size_t mb : {24ul, 192ul, 4096ul}) {
     char* buf; if (hipMalloc(&buf, mb << 20) != hipSuccess) return 1;
     hipMemset(buf, 1, mb << 20);
