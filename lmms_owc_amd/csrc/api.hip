@@ -48,6 +48,7 @@ int owc_tuning_set(const char* name, int value) {
 #endif
   else if (!strcmp(name, "gemm_skinny_deep")) owc_gemm_set_skinny_deep(value);
   else if (!strcmp(name, "decode_fuse")) owc_llm_set_decode_fuse(value);
+  else if (!strcmp(name, "decode_norm_fuse")) owc_gemm_set_norm_fuse_max_m(value);   // max rows (<= 4) for the RMSNorm-fused skinny GEMM; 0 = off
   else if (!strcmp(name, "decode_attn_nbuf1")) owc_attn_set_decode_nbuf1(value);   // block count above which the fused decode attention single-buffers V
   else if (!strcmp(name, "prefill_prune_last")) owc_llm_set_prune_last(value);
   else if (!strcmp(name, "bert_bf16x3")) owc_bert_set_x3(value);

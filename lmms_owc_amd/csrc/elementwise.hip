@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ X,
       for (int e = 0; e < 8; ++e) {
         const float v = bf2f(c[i][e]);
         sum += v;
-        sq += v * v;
+        sq = __builtin_fmaf(v, v, sq);   // pinned: the same fma chain as owc_rms_rstd (owc_common.h)
       }
     }
   }
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ X,
   const float inv_d = 1.0f / (float)d;
   float mean = 0.f, rstd;
   if (RMS) {
-    rstd = rsqrtf(sq * inv_d + eps);
+    rstd = rsqrtf(__builtin_fmaf(sq, inv_d, eps));
   } else {
     mean = sum * inv_d;
     float var = 0.f;

@@ -49,6 +49,7 @@ int g_skinny_max_m = 32;   // M at and below which the weight-streaming skinny k
 int g_mid_max_tiles = 256;  // fewer 128x128 tiles than this -> 64x64 tiles (0 disables: A-B knob "gemm_mid_max_tiles")
 int g_big_min_tiles = 144;  // fewer 256x256 tiles than this -> use the 128x128 kernel (measured: 160-162 tiles 256x256 +24...40 %, 126 tiles -3...8 %; knob "gemm_big_min_tiles")
 int g_skinny_deep = 1;    // the skinny kernel's 9-deep ring for long-K launches of at most one wave per CU (knob "gemm_skinny_deep")
+int g_norm_fuse_max_m = 4; // rows up to which the decoder's RMSNorm is fused into the qkv / gate-up skinny GEMM (knob "decode_norm_fuse", 0 = off; <= 4: 28 KB of LDS per wave at K = 3584)
 int g_pingpong = 1;       // 256x256 launches with K % 128 == 0 use the ping-pong kernel (A-B knob "gemm_pingpong", 0 = lock-step kernel)
 int g_big_min_m = 256;   // M at and above which the 256x256 kernels may run (knob "gemm_big_min_m"; round 1: 1024)
 
@@ -828,6 +829,103 @@ __global__ __launch_bounds__(64) void gemm_bf16_skinny_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Skinny-M GEMM that RMS-normalises its own activations (round 3; M <= 4: greedy decode at the reference's batch size).
+// At batch 1 a decoder layer was eight launches and the two RMSNorms - ONE row of 7 KB each - cost 6.9 us apiece (a launch
+// cannot be shorter than that on this GPU): 9 % of the step.  Here every wave (= block) of the qkv / gate-up projection first
+// issues its W ring, then - while those loads fly - normalises the M raw residual rows itself, with the arithmetic of
+// norm_kernel bit for bit (owc_rms_rstd / owc_rms_apply), into LDS (M x K bf16, rows padded by 16 B against bank conflicts), and
+// takes its activation fragments from there: the activations no longer ride the register ring, so the same registers hold a
+// deeper W ring.  The work is redundant across the N / 16 waves but M <= 4 rows cost ~0.5 us each, under the W latency.
+// Results are those of rmsnorm followed by gemm_bf16_skinny_kernel: bit-identical (tested), so batch invariance holds
+// across the M = 4 / 5 switch to the separate kernels.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int DEPTH>
+__global__ __launch_bounds__(64) void gemm_bf16_skinny_norm_kernel(
+    const bf16_t* __restrict__ X, long ldx, const bf16_t* __restrict__ gamma, float eps, const bf16_t* __restrict__ W, long ldw,
+    const bf16_t* __restrict__ bias, bf16_t* C, long ldc, int M, int N, int K) {
+  constexpr int NT = EPI == OWC_EPI_SWIGLU ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // [M][K * 2 + 16] normalised activations
+  const int l = threadIdx.x;
+  const int fr = l & 15, fq = l >> 4;
+  const int n0 = blockIdx.x * (16 * NT);
+  const int nss = K >> 7;
+  const int pitch = K * 2 + 16;
+
+  const bf16_t* wrow[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) wrow[nt] = W + (long)(n0 + nt * 16 + fr) * ldw + fq * 8;
+  bf16x8 ring[DEPTH][NT][4];
+  auto load_w = [&](int i, int ss) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) ring[i][nt][ks] = *(const bf16x8*)(wrow[nt] + ss * 128 + ks * 32);
+  };
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i) load_w(i, min(i, nss - 1));
+
+  // ---- normalise the M rows into LDS while the ring fills
+  const int nch = K >> 3;
+  for (int m = 0; m < M; ++m) {
+    const bf16_t* x = X + (long)m * ldx;
+    const float rstd = owc_rms_rstd(x, K, eps, l);
+    for (int ch = l; ch < nch; ch += 64) {
+      const bf16x8 c = *(const bf16x8*)(x + ch * 8), g = *(const bf16x8*)(gamma + ch * 8);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = owc_rms_apply(c[e], g[e], rstd);
+      *(bf16x8*)(lds + m * pitch + ch * 16) = o;
+    }
+  }
+  const char* arow = lds + min(fr, M - 1) * pitch + fq * 16;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](int i, int ss) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 xa = *(const bf16x8*)(arow + ss * 256 + ks * 64);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[i][nt][ks], xa, acc[nt], 0, 0, 0);
+    }
+  };
+  int ss = 0;
+  for (; ss + DEPTH <= nss; ss += DEPTH) {
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) {
+      compute(i, ss + i);
+      load_w(i, min(ss + i + DEPTH, nss - 1));
+    }
+  }
+  const int rem = nss - ss;
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i)
+    if (i < rem) compute(i, ss + i);
+  // epilogue: identical to gemm_bf16_skinny_kernel's (lane holds row fr, columns n0 + 16 nt + 4 fq .. +3)
+  const int m = fr;
+  if constexpr (EPI == OWC_EPI_SWIGLU) {
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f2bf(rbf(act_silu(rbf(acc[0][e]))) * rbf(acc[1][e]));
+    if (m < M) *(bf16x4*)(C + (long)m * ldc + (n0 >> 1) + fq * 4) = o;
+  } else {
+    const int n = n0 + fq * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) {
+      const bf16x4 b = *(const bf16x4*)(bias + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = bf2f(b[e]);
+    }
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[0][e] + bv[e]);
+    if (m < M) *(bf16x4*)(C + (long)m * ldc + n) = o;
+  }
+}
+
 template <int EPI>
 bool launch_skinny(const void* A, long lda, const void* W, long ldw, const void* bias, const void* R, long ldr, void* C,
                    long ldc, int M, int N, int K, hipStream_t s) {
@@ -959,6 +1057,36 @@ int owc_launch_gemm_bf16_aux(const void* A, long lda, const void* W, long ldw, c
     default: return OWC_ERR_ARG;
   }
 }
+
+// rmsnorm(X) . W^T (+bias | SwiGLU) for M <= OWC_NORM_FUSE_MAX_M rows in one launch; OWC_ERR_SHAPE when the shape is outside what the fused
+// kernel takes (the caller then runs the two separate kernels: same bits).
+int owc_launch_gemm_bf16_rmsnorm(const void* X, long ldx, const void* gamma, float eps, const void* W, long ldw, const void* bias,
+                                 void* C, long ldc, int M, int N, int K, int epi, hipStream_t s) {
+  if (M <= 0 || M > g_norm_fuse_max_m || (K & 127) || K > 8192 || (ldx & 7) || (ldw & 7) || g_skinny_max_m < M) return OWC_ERR_SHAPE;
+  const bool swiglu = epi == OWC_EPI_SWIGLU && (N & 31) == 0 && (ldc & 3) == 0;
+  if (!swiglu && !(epi == OWC_EPI_NONE && (N & 15) == 0 && (ldc & 3) == 0)) return OWC_ERR_SHAPE;
+  const int lds_bytes = M * (K * 2 + 16);
+  static bool attr_set = false;
+  if (!attr_set) {   // 4 rows of K = 8192 (the 72B decoder) are 65.6 KB: above the default dynamic-LDS limit
+    if (hipFuncSetAttribute((const void*)gemm_bf16_skinny_norm_kernel<OWC_EPI_SWIGLU, 5>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            4 * (8192 * 2 + 16)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_bf16_skinny_norm_kernel<OWC_EPI_NONE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            4 * (8192 * 2 + 16)) != hipSuccess)
+      return OWC_ERR_HIP;
+    attr_set = true;
+  }
+  const int prof = owc_gemm_profile_begin(2.0 * (double)M * (double)N * (double)K, 0, s);
+  if (swiglu) {
+    hipLaunchKernelGGL((gemm_bf16_skinny_norm_kernel<OWC_EPI_SWIGLU, 5>), dim3(N / 32), dim3(64), lds_bytes, s, (const bf16_t*)X, ldx,
+                       (const bf16_t*)gamma, eps, (const bf16_t*)W, ldw, (const bf16_t*)bias, (bf16_t*)C, ldc, M, N, K);
+  } else {
+    hipLaunchKernelGGL((gemm_bf16_skinny_norm_kernel<OWC_EPI_NONE, 8>), dim3(N / 16), dim3(64), lds_bytes, s, (const bf16_t*)X, ldx,
+                       (const bf16_t*)gamma, eps, (const bf16_t*)W, ldw, (const bf16_t*)bias, (bf16_t*)C, ldc, M, N, K);
+  }
+  owc_gemm_profile_end(prof, s);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+void owc_gemm_set_norm_fuse_max_m(int v) { g_norm_fuse_max_m = v < 0 ? 4 : (v > 4 ? 4 : v); }
 
 int owc_launch_gemm_bf16(const void* A, long lda, const void* W, long ldw, const void* bias,
                          const void* R, long ldr, void* C, long ldc, int M, int N, int K, int epi,

@@ -49,6 +49,27 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// RMSNorm statistics of one row held by ONE WAVE, the arithmetic every kernel that normalises a row must share bit for bit
+// (norm_kernel in elementwise.hip; the decode GEMM that normalises its own activations, gemm_bf16.hip): lane l accumulates the
+// 8-element chunks l, l + 64, ... in ascending order with ONE fma per element (pinned: never a separate multiply and add), then the
+// xor-butterfly of wave_sum; rstd = rsq(fma(sq, 1/d, eps)).
+__device__ __forceinline__ float owc_rms_rstd(const bf16_t* __restrict__ x, int d, float eps, int l) {
+  const int nch = d >> 3;
+  float sq = 0.f;
+  for (int ch = l; ch < nch; ch += 64) {
+    const bf16x8 c = *(const bf16x8*)(x + ch * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = bf2f(c[e]);
+      sq = __builtin_fmaf(v, v, sq);
+    }
+  }
+  sq = wave_sum(sq);
+  return rsqrtf(__builtin_fmaf(sq, 1.0f / (float)d, eps));
+}
+// y = bf16(w * bf16(x * rstd))  (Qwen2RMSNorm: the normalised value is cast to the input dtype before the weight multiply)
+__device__ __forceinline__ bf16_t owc_rms_apply(bf16_t x, bf16_t w, float rstd) { return f2bf(bf2f(w) * rbf(bf2f(x) * rstd)); }
+
 // Epilogue selectors shared by the GEMM kernels and the C ABI (include/owc.h).
 enum {
   OWC_EPI_NONE = 0,        // C = bf16(acc + bias)

@@ -203,9 +203,12 @@ static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache
     bf16_t* kc = (bf16_t*)cache->k + (size_t)i * layer_elems;
     bf16_t* vc = (bf16_t*)cache->v + (size_t)i * layer_elems;
     const bool tail = last_index && g_prune_last && i == w->n_layers - 1;  // last prefill layer: only the n_out last-token rows go on
-    // self-attention block (HF:601-614)
-    OWC_TRY(norm(T, x, L.ln1_w));
-    OWC_TRY(linear(T, fp8 ? nullptr : h, d, L.qkv_w, L.qkv_s, L.qkv_b, nullptr, qkv, NQKV, NQKV, d, OWC_EPI_NONE));
+    // self-attention block (HF:601-614); a handful of rows (decode at the reference's batch size): the projection normalises its own
+    // activations (gemm_bf16_skinny_norm_kernel) - same bits as the two launches, one launch less
+    if (fp8 || owc_launch_gemm_bf16_rmsnorm(x, d, L.ln1_w, w->rms_eps, L.qkv_w, d, L.qkv_b, qkv, NQKV, T, NQKV, d, OWC_EPI_NONE, st) != OWC_OK) {
+      OWC_TRY(norm(T, x, L.ln1_w));
+      OWC_TRY(linear(T, fp8 ? nullptr : h, d, L.qkv_w, L.qkv_s, L.qkv_b, nullptr, qkv, NQKV, NQKV, d, OWC_EPI_NONE));
+    }
     const bool fused_decode = decode && g_decode_fuse && hd == 128 && G <= 16;
     if (!fused_decode)
       OWC_TRY(owc_launch_mrope_kv(qkv, NQKV, pos3, pos_stride, w->rope_cos, w->rope_sin, kc, vc, tok_slot,
@@ -241,8 +244,10 @@ static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache
     }
     OWC_TRY(linear(M, attn, (long)Hq * hd, L.o_w, L.o_s, nullptr, xr, xr, d, d, Hq * hd, OWC_EPI_RESIDUAL));
     // MLP block (HF:617-620, :464-466)
-    OWC_TRY(norm(M, xr, L.ln2_w));
-    OWC_TRY(linear(M, fp8 ? nullptr : h, d, L.gateup_w, L.gateup_s, nullptr, nullptr, mlp, F, 2 * F, d, OWC_EPI_SWIGLU));
+    if (fp8 || owc_launch_gemm_bf16_rmsnorm(xr, d, L.ln2_w, w->rms_eps, L.gateup_w, d, nullptr, mlp, F, M, 2 * F, d, OWC_EPI_SWIGLU, st) != OWC_OK) {
+      OWC_TRY(norm(M, xr, L.ln2_w));
+      OWC_TRY(linear(M, fp8 ? nullptr : h, d, L.gateup_w, L.gateup_s, nullptr, nullptr, mlp, F, 2 * F, d, OWC_EPI_SWIGLU));
+    }
     OWC_TRY(linear(M, mlp, F, L.down_w, L.down_s, nullptr, xr, xr, d, d, F, OWC_EPI_RESIDUAL));
   }
   return OWC_OK;

@@ -289,7 +289,7 @@ def _run_slice(name, gpu, B, T, decoder_dtype="bf16", frac=ORACLE_BOUND, special
     """Every checked sequence must offer - and pass - at least `min_decisive` token comparisons with a decisive margin (top-2
     margin of the ORACLE's logits > 2 x the scaled rows' bound = 6 %; fp8: 26 %), the three sequences together at least
     `min_total` (default: 10 of 18).  What the oracle offers is known before a GPU runs: `python tools/slice_margins.py`
-    (bf16: 3-8 decisive steps per sequence, 11-21 per case; fp8: 1-4 per sequence, 5-8 per case)."""
+    (bf16: 3-8 decisive steps per sequence, 11-21 per case; fp8: 1-4 per sequence, 4-8 per case)."""
     _, _, eng = _slice(name, gpu, decoder_dtype)
     cfg, grid, pixs, prompts, pick, check, forced, refs = _slice_refs(name, B, T, decoder_dtype)
     emb = eng.encode_images(torch.from_numpy(np.concatenate(pixs)).to(BF16).to(gpu), grid * 3)   # 3 images x 4 rows
@@ -324,4 +324,4 @@ def test_config_width_decode_steps(gpu, name, B):
 def test_72b_width_fp8_decode_steps(gpu, B):
     """Config #5's fp8 decoder at 72B widths (K = 8192 / 29568 per-token scales): fp8 engine vs the numpy fp8 decoder."""
     _run_slice("72b", gpu, B, 6, decoder_dtype="fp8", frac=FP8_BOUND, special_frac=FP8_OUTLIER_BOUND, mean_frac=0.02, min_decisive=1,
-               min_total=5)
+               min_total=4)   # a 26 % margin is rare: the oracle offers 1 + 2 + 1 (B = 130) and 4 + 2 + 2 (B = 8) such steps

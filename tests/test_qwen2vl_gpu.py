@@ -181,3 +181,27 @@ def test_graph_replayed_decode_equals_eager(setup, gpu):
     a2 = eager.generate(prompts, None, [[] for _ in prompts], 12, eos_token_id=eos, pad_token_id=0, stop_check_every=2)
     b2 = graph.generate(prompts, None, [[] for _ in prompts], 12, eos_token_id=eos, pad_token_id=0, stop_check_every=2)
     assert torch.equal(a2, b2) and int((a2[0, 4:] != 0).sum()) == 0
+
+
+def test_rmsnorm_fused_into_the_skinny_gemm_is_bit_identical(setup, gpu):
+    """Decode at 1-4 sequences: the qkv / gate-up projections normalise their own activations (gemm_bf16_skinny_norm_kernel, one
+    launch less per RMSNorm).  Same bits as rmsnorm + GEMM - for every step's logits with the knob on and off, and therefore across
+    the 4 -> 5 row switch back to the separate kernels (a sequence alone == inside a batch of 6)."""
+    from lmms_owc_amd import _lib
+
+    cfg, w, eng, g = setup
+    r = np.random.default_rng(21)
+    prompts = [r.integers(1, 490, 11 + 2 * i).astype(np.int64) for i in range(6)]
+    lib = _lib.load()
+    for B in (1, 3, 4):
+        try:
+            assert lib.owc_tuning_set(b"decode_norm_fuse", 0) == 0
+            ta, la = eng.generate(prompts[:B], None, [[] for _ in range(B)], 6, return_step_logits=True)
+            assert lib.owc_tuning_set(b"decode_norm_fuse", 4) == 0
+            tb, lb = eng.generate(prompts[:B], None, [[] for _ in range(B)], 6, return_step_logits=True)
+        finally:
+            lib.owc_tuning_set(b"decode_norm_fuse", -1)
+        assert torch.equal(la, lb) and torch.equal(ta, tb), B
+    big = eng.generate(prompts, None, [[] for _ in prompts], 6)                    # 6 rows: the separate kernels
+    for i in (0, 5):
+        assert torch.equal(eng.generate([prompts[i]], None, [[]], 6)[0], big[i]), i   # 1 row: the fused kernel

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(1024) void ks(const char* __restrict__ buf, size_t 
 // mode 3: STORES.  Every wave writes its own contiguous slice with 16-byte stores (1 KiB per wave-instruction), `burst` instructions
 // back to back, then (optionally) a wait: what can one CU push out, alone and with all 256 CUs writing at once?  (The 256x256 GEMM's
 // epilogue writes 128 KiB per CU in ~6 us = 20 GB/s per CU with every CU in its epilogue at the same time.)
-__global__ __launch_bounds__(1024) void kst(char* __restrict__ buf, size_t slice, int iters, int burst) {
+__global__ __launch_bounds__(1024) void kst(char* __restrict__ buf, size_t slice, int iters, int burst, int xcd_mask) {
+  if (!((xcd_mask >> (blockIdx.x & 7)) & 1)) return;   // blocks are dealt to the 8 XCDs round-robin: only the XCDs of the mask write
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int nw = blockDim.x >> 6;
   char* p = buf + ((size_t)blockIdx.x * nw + w) * slice + l * 16;
@@ -79,19 +80,20 @@ __global__ __launch_bounds__(1024) void kst(char* __restrict__ buf, size_t slice
     }
 }
 
-void run_store(char* buf, size_t total, int blocks, int waves, int burst) {
+void run_store(char* buf, size_t total, int blocks, int waves, int burst, int xcd_mask = 0xff) {
   const size_t slice = (total / ((size_t)blocks * waves)) / (1024 * burst) * (1024 * burst);
   if (slice == 0) return;
   const int iters = (int)(((size_t)4 << 30) / (slice * (size_t)blocks * waves)) + 1;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL(kst, dim3(blocks), dim3(64 * waves), 0, 0, buf, slice, 1, burst);
+  hipLaunchKernelGGL(kst, dim3(blocks), dim3(64 * waves), 0, 0, buf, slice, 1, burst, xcd_mask);
   hipEventRecord(e0);
-  hipLaunchKernelGGL(kst, dim3(blocks), dim3(64 * waves), 0, 0, buf, slice, iters, burst);
+  hipLaunchKernelGGL(kst, dim3(blocks), dim3(64 * waves), 0, 0, buf, slice, iters, burst, xcd_mask);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  const double bytes = (double)slice * blocks * waves * iters;
-  printf("store burst %2d  blocks %3d x %2d waves  slice %9zu B: %7.1f GB/s per CU  %6.2f TB/s\n", burst, blocks, waves, slice,
-         bytes / ms / 1e6 / blocks, bytes / ms / 1e9);
+  const int active = blocks * __builtin_popcount(xcd_mask & 0xff) / 8;
+  const double bytes = (double)slice * active * waves * iters;
+  printf("store burst %2d  blocks %3d (XCD mask %02x: %3d active) x %2d waves: %7.1f GB/s per active CU  %6.2f TB/s\n", burst, blocks,
+         xcd_mask & 0xff, active, waves, bytes / ms / 1e6 / active, bytes / ms / 1e9);
 }
 
 template <int SEG>
@@ -137,6 +139,8 @@ int main(int argc, char** argv) {
     for (int blocks : {8, 256})
       for (int waves : {4, 8})
         for (int burst : {4, 16}) run_store(buf, total, blocks, waves, burst);
+    // is the 5.8 TB/s of all 256 CUs a chip limit (HBM) or eight per-XCD limits?  all 32 CUs of ONE / TWO / FOUR XCDs writing
+    for (int mask : {0x01, 0x03, 0x0f, 0xff}) run_store(buf, total, 256, 8, 16, mask);
     return 0;
   }
   if (argc > 1) {   // strided part only: `probe_ingest strided`
