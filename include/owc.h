@@ -58,11 +58,14 @@ const char* owc_last_error(const owc_ctx* ctx);
 /* A-B / tuning knobs (process-wide; the library reads NO environment variable - every switch goes through this call):
  * "gemm_big_min_m", "gemm_big_min_tiles" (fewest 256x256 tiles for which the 256x256 kernels run; negative = default 144),
  * "gemm_skinny_max_m" (0 disables the weight-streaming small-M kernel, a negative value restores the defaults),
- * "gemm_mid_max_tiles" (0 disables the 64x64-tile kernel), "gemm_pingpong" (0: the lock-step 256x256 kernels, 1 = default: bf16
- * ping-pong kernel, 2: the fp8 ping-pong kernel too), "prefill_prune_last" (0: owc_llm_prefill runs the last layer's attention /
+ * "gemm_mid_max_tiles" (0 disables the 64x64-tile kernel), "gemm_pingpong" (0: the lock-step 256x256 kernels, 1: bf16
+ * ping-pong only, 2 / negative = default: the bf16 and the fp8 ping-pong kernels), "prefill_prune_last" (0: owc_llm_prefill runs the last layer's attention /
  * o-proj / MLP on every row instead of the last-token rows only -- same logits bit for bit, tested), "bert_bf16x3" (0:
- * owc_bert_embed runs its linears on the exact f32-input MFMA instead of the three-piece bf16 split), "decode_fuse" (0: the
- * decode step runs the separate RMSNorm / M-RoPE + KV-write kernels instead of the fused ones -- same bits, tested).
+ * owc_bert_embed runs its linears on the exact f32-input MFMA instead of the three-piece bf16 split), "decode_fuse" (0: a
+ * decode step runs mrope_kv + the generic attention kernel instead of owc_decode_attention), "decode_attn_nbuf1" (block count above
+ * which the fused decode attention single-buffers V), "decode_norm_fuse" (rows up to which the decoder's RMSNorm is fused into the
+ * qkv / gate-up skinny GEMM: 0 off, default 2, at most 4 -- same bits, tested), "gemm_skinny_deep" (0: no 9-deep ring for the long-K
+ * skinny launches).
  * Every knob above selects between kernels that return the SAME results.  The timing-only experiment knobs "gemm_dbg" /
  * "attn_dbg" (parts of a kernel switched off to price them; outputs are garbage) exist only in libowc_hip_timing.so, which
  * `python -m lmms_owc_amd.build --timing` builds with -DOWC_TIMING_KNOBS for tools/; the product library does not know them.

@@ -38,9 +38,9 @@ int owc_tuning_set(const char* name, int value) {
   }
   else if (!strcmp(name, "gemm_big_min_m")) owc_gemm_set_big_min_m(value);
   else if (!strcmp(name, "gemm_big_min_tiles")) owc_gemm_set_big_min_tiles(value);
-  else if (!strcmp(name, "gemm_pingpong")) {  // 0: lock-step kernels, 1 (default): bf16 ping-pong, 2: the fp8 ping-pong kernel as well
+  else if (!strcmp(name, "gemm_pingpong")) {  // 0: lock-step kernels, 1: bf16 ping-pong only, 2 or negative (default): bf16 and fp8 ping-pong
     owc_gemm_set_pingpong(value != 0);
-    owc_gemm_fp8_set_pingpong(value >= 2);
+    owc_gemm_fp8_set_pingpong(value >= 2 || value < 0);
   }
 #ifdef OWC_TIMING_KNOBS   // timing-only experiments: the product library does not know these names (OWC_ERR_ARG)
   else if (!strcmp(name, "gemm_dbg")) owc_gemm_set_dbg(value);

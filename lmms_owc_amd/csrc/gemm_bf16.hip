@@ -49,7 +49,9 @@ int g_skinny_max_m = 32;   // M at and below which the weight-streaming skinny k
 int g_mid_max_tiles = 256;  // fewer 128x128 tiles than this -> 64x64 tiles (0 disables: A-B knob "gemm_mid_max_tiles")
 int g_big_min_tiles = 144;  // fewer 256x256 tiles than this -> use the 128x128 kernel (measured: 160-162 tiles 256x256 +24...40 %, 126 tiles -3...8 %; knob "gemm_big_min_tiles")
 int g_skinny_deep = 1;    // the skinny kernel's 9-deep ring for long-K launches of at most one wave per CU (knob "gemm_skinny_deep")
-int g_norm_fuse_max_m = 4; // rows up to which the decoder's RMSNorm is fused into the qkv / gate-up skinny GEMM (knob "decode_norm_fuse", 0 = off; <= 4: 28 KB of LDS per wave at K = 3584)
+int g_norm_fuse_max_m = 2; // rows up to which the decoder's RMSNorm is fused into the qkv / gate-up skinny GEMM (knob "decode_norm_fuse", 0 = off, at most 4).
+                           // Measured, 7B decode step in ms, separate / fused: 1 row 3.78 / 3.44, 2 rows 3.78 / 3.65, 4 rows 3.88 / 4.11 - every wave
+                           // normalises every row itself, so beyond 2 rows the redundant work outweighs the launch it saves
 int g_pingpong = 1;       // 256x256 launches with K % 128 == 0 use the ping-pong kernel (A-B knob "gemm_pingpong", 0 = lock-step kernel)
 int g_big_min_m = 256;   // M at and above which the 256x256 kernels may run (knob "gemm_big_min_m"; round 1: 1024)
 
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(64) void gemm_bf16_skinny_kernel(
 
 
 // ------------------------------------------------------------------------------------------------
-// Skinny-M GEMM that RMS-normalises its own activations (round 3; M <= 4: greedy decode at the reference's batch size).
+// Skinny-M GEMM that RMS-normalises its own activations (round 3; M <= 2 by default, at most 4: greedy decode at the reference's batch size).
 // At batch 1 a decoder layer was eight launches and the two RMSNorms - ONE row of 7 KB each - cost 6.9 us apiece (a launch
 // cannot be shorter than that on this GPU): 9 % of the step.  Here every wave (= block) of the qkv / gate-up projection first
 // issues its W ring, then - while those loads fly - normalises the M raw residual rows itself, with the arithmetic of
@@ -839,7 +841,7 @@ __global__ __launch_bounds__(64) void gemm_bf16_skinny_kernel(
 // takes its activation fragments from there: the activations no longer ride the register ring, so the same registers hold a
 // deeper W ring.  The work is redundant across the N / 16 waves but M <= 4 rows cost ~0.5 us each, under the W latency.
 // Results are those of rmsnorm followed by gemm_bf16_skinny_kernel: bit-identical (tested), so batch invariance holds
-// across the M = 4 / 5 switch to the separate kernels.
+// across the switch to the separate kernels.
 // ------------------------------------------------------------------------------------------------
 template <int EPI, int DEPTH>
 __global__ __launch_bounds__(64) void gemm_bf16_skinny_norm_kernel(
@@ -1086,7 +1088,7 @@ int owc_launch_gemm_bf16_rmsnorm(const void* X, long ldx, const void* gamma, flo
   owc_gemm_profile_end(prof, s);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
-void owc_gemm_set_norm_fuse_max_m(int v) { g_norm_fuse_max_m = v < 0 ? 4 : (v > 4 ? 4 : v); }
+void owc_gemm_set_norm_fuse_max_m(int v) { g_norm_fuse_max_m = v < 0 ? 2 : (v > 4 ? 4 : v); }
 
 int owc_launch_gemm_bf16(const void* A, long lda, const void* W, long ldw, const void* bias,
                          const void* R, long ldr, void* C, long ldc, int M, int N, int K, int epi,

@@ -22,7 +22,9 @@ constexpr int BT = 256, BKB = 128;                 // tile edge, K-tile in BYTES
 constexpr int OP_BYTES = BT * BKB;                 // 32 KiB per operand per stage
 constexpr int STAGE_BYTES = 2 * OP_BYTES;
 constexpr int GROUP_M2 = 4;
-int g_fp8_pingpong = 0;       // follows the "gemm_pingpong" knob when set explicitly; OFF by default: measured slower than the lock-step fp8 kernel (1.74 vs 2.44 PF on 7b.gateup - the 12-read phase and the tail spills), kept for A-B
+int g_fp8_pingpong = 1;       // "gemm_pingpong" knob: 2 / default = on, 0 or 1 = the lock-step fp8 kernel.  Round 2 had it off (1.74 vs 2.44 PF on 7b.gateup);
+                              // round 3 found why - LLVM sank the last K-tile's MFMAs into the epilogue's store blocks (scratch) - and gave it the
+                              // bf16 kernel's two-set W layout: 7b.down 2573 -> 3001, 72b.gateup 2658 -> 3008, sq8192 2736 -> 3059 TFLOP/s
 int g_fp8_skinny_max_m = 64;  // follows the "gemm_skinny_max_m" knob
 int g_fp8_mid_max_tiles = 128;  // fewer 256x256 tiles than this -> 64x64 tiles (follows "gemm_mid_max_tiles": 0 disables)
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;
@@ -323,17 +325,21 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256pp_kernel(
       aoff[h][j] = (unsigned)((long)min(row, M - 1 - m0) * lda + c * 16);
       woff[h][j] = (unsigned)((long)min(row, N - 1 - n0) * ldw + c * 16);
     }
+  // scalar K-tile base + 32-bit lane offsets, pinned (as in gemm_bf16_nt_256pp_kernel): without it the compiler keeps a 64-bit
+  // per-lane pointer per piece alive across the loop - this kernel then needs 256 VGPRs + 470-680 bytes of scratch per lane
   auto issue_a = [&](int kt, int h) {
     char* dst = lds + (kt & 1) * STAGE_BYTES + (128 * h + 16 * w) * 128;
-    const long kb = (long)kt * BKB;
-    glds16(abase + kb + aoff[h][0], dst);
-    glds16(abase + kb + aoff[h][1], dst + 1024);
+    const char* ab = abase + (long)kt * BKB;
+    asm volatile("" : "+s"(ab), "+v"(aoff[h][0]), "+v"(aoff[h][1]));
+    glds16(ab + aoff[h][0], dst);
+    glds16(ab + aoff[h][1], dst + 1024);
   };
   auto issue_w = [&](int kt, int h) {
     char* dst = lds + (kt & 1) * STAGE_BYTES + OP_BYTES + (128 * h + 16 * w) * 128;
-    const long kb = (long)kt * BKB;
-    glds16(wbase + kb + woff[h][0], dst);
-    glds16(wbase + kb + woff[h][1], dst + 1024);
+    const char* wb = wbase + (long)kt * BKB;
+    asm volatile("" : "+s"(wb), "+v"(woff[h][0]), "+v"(woff[h][1]));
+    glds16(wb + woff[h][0], dst);
+    glds16(wb + woff[h][1], dst + 1024);
   };
   const int wr = w >> 2, wc = w & 3;
   const int fr = l & 15, fq = l >> 4;
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256pp_kernel(
   const int chlo = (fq ^ swz) << 4, chhi = ((4 + fq) ^ swz) << 4;   // the operand byte pairing of gemm_fp8_nt_256_kernel
 
   f32x4 acc[4][8];  // [nt][mt]
-  i32x8 fa[4], wy[2], wx[2];   // (a third W set as in the bf16 kernel spills here: the column-half-0 set is re-read in p0 instead)
+  i32x8 fa[4], wy[2], wx0[2], wx1[2];   // A m-half, W column half 1, and TWO sets of W column half 0 (this K-tile's / the next one's)
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   auto rd = [&](i32x8& dst, const char* p) {
     const i32x4 lo = *(const i32x4*)(p + chlo), hi = *(const i32x4*)(p + chhi);
@@ -376,15 +382,17 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256pp_kernel(
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto ktile = [&](auto mode_c, int u) {
+  // the schedule of gemm_bf16_nt_256pp_kernel phase for phase: p0 reads A (8 ds_read_b128), p1 W half 1 (4), p2 A (8), p3 the NEXT
+  // tile's W half 0 into the other register set (4)
+  auto ktile = [&](auto mode_c, int u, i32x8 (&wcur)[2], i32x8 (&wnxt)[2]) {
     constexpr int MODE = decltype(mode_c)::value;   // 0 steady, 1 second to last, 2 last K-tile
     const char* cur = lds + (u & 1) * STAGE_BYTES;
-    read_w(wx, cur, 0);
+    const char* nxt = lds + ((u + 1) & 1) * STAGE_BYTES;
     read_a(cur, 0);
-    if constexpr (MODE <= 1) issue_a(u + 1, 1);
     OWC_PP_SYNC_L(-1);
-    quadrant(wx, 0, 0);
+    quadrant(wcur, 0, 0);
     read_w(wy, cur, 1);
+    if constexpr (MODE <= 1) issue_a(u + 1, 1);
     OWC_PP_SYNC_L(-1);
     quadrant(wy, 0, 1);
     read_a(cur, 1);
@@ -397,6 +405,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256pp_kernel(
       OWC_PP_SYNC_L(-1);
     }
     quadrant(wy, 1, 1);
+    if constexpr (MODE <= 1) read_w(wnxt, nxt, 0);
     if constexpr (MODE == 0) {
       issue_w(u + 2, 1);
       issue_a(u + 2, 0);
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256pp_kernel(
     } else {
       OWC_PP_SYNC_L(-1);
     }
-    quadrant(wx, 1, 0);
+    quadrant(wcur, 1, 0);
   };
   issue_a(0, 0);
   issue_a(0, 1);
@@ -421,6 +430,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256pp_kernel(
     for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
+  read_w(wx0, lds, 0);
   if (wr) {
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -428,15 +438,28 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256pp_kernel(
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
-  int u = 0;
-  for (; u + 2 < nk; ++u) ktile(I0{}, u);
-  ktile(I1{}, u);
-  ktile(I2{}, u + 1);
+  int u = 0;   // K-tiles in pairs (the two W half-0 sets alternate): an EVEN number of K-tiles, checked by the launcher.  (A second
+               // peeled tail for odd counts makes the register allocator park the accumulators in scratch: 660-710 bytes per lane.
+               // The one odd case on the path, the 72B down projection's K = 29568 = 231 tiles, is zero-padded to 232 at load time.)
+  for (; u + 2 < nk; u += 2) {
+    ktile(I0{}, u, wx0, wx1);
+    ktile(I0{}, u + 1, wx1, wx0);
+  }
+  ktile(I1{}, u, wx0, wx1);
+  ktile(I2{}, u + 1, wx1, wx0);
   if (!wr) {
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   }
 #undef OWC_PP_SYNC_L
+  // Pin the accumulators HERE.  MFMAs have no side effects the barriers order, so LLVM's sinking pass moved the 32 MFMAs of the
+  // last K-tile down into the 16 conditional store blocks of the epilogue (two MFMAs per block, their operands parked in scratch:
+  // 470-680 bytes per lane, and the last two of K / 128 K-tiles ran at a fraction of the loop's speed) - the reason this kernel
+  // lost to the lock-step one in round 2.  With the values demanded at this point the tail stays a K-tile.
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(acc[i][j]));
   {
     f32x4 swv[4];
 #pragma unroll
@@ -694,7 +717,7 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
     owc_gemm_profile_end(prof, s);
     return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
   }
-  if (g_fp8_pingpong && K >= 2 * BKB)
+  if (g_fp8_pingpong && K >= 2 * BKB && (K % (2 * BKB)) == 0)
     hipLaunchKernelGGL(gemm_fp8_nt_256pp_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), LDS_BYTES, s,
                        (const uint8_t*)A, lda, sa, (const uint8_t*)W, ldw, sw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C,
                        ldc, M, N, K, tiles_m, tiles_n, aux);

@@ -188,13 +188,19 @@ class Qwen2VLWeights:
         if getattr(d, "decoder_dtype", "bf16") not in ("bf16", "fp8"):
             raise ValueError("decoder_dtype must be 'bf16' or 'fp8'")
         ll = (_lib.LlmLayer * d.n_layers)()
+        # fp8: the 256x256 ping-pong kernel walks K-tiles of 128 in pairs, so the down projection's K = d_ff is zero-padded to a
+        # multiple of 256 (72B: 29568 = 231 tiles -> 29696): zero gate / up rows give silu(0) * 0 = 0, which quantises to code 0 and
+        # meets zero columns of down_proj - the same values, exactly
+        ff = (d.d_ff + 255) // 256 * 256 if fp8 else d.d_ff
         for i in range(d.n_layers):
             p = f"{T}layers.{i}."
             qkv_w = torch.cat([get(p + "self_attn.q_proj.weight"), get(p + "self_attn.k_proj.weight"),
                                get(p + "self_attn.v_proj.weight")], 0).contiguous()
-            gu = interleave_gate_up(get(p + "mlp.gate_proj.weight"), get(p + "mlp.up_proj.weight"))
+            gu = interleave_gate_up(pad_rows(get(p + "mlp.gate_proj.weight"), ff), pad_rows(get(p + "mlp.up_proj.weight"), ff))
             ll[i].ln1_w = self._k(get(p + "input_layernorm.weight"))
             o_w, down_w = get(p + "self_attn.o_proj.weight"), get(p + "mlp.down_proj.weight")
+            if ff != d.d_ff:
+                down_w = pad_rows(down_w.t().contiguous(), ff).t().contiguous()
             if fp8:  # per-output-channel e4m3fn codes + float scales; the bf16 tensors are dropped right away
                 (qkv_w, ll[i].qkv_s), (o_w, ll[i].o_s) = self._q8(qkv_w), self._q8(o_w)
                 (gu, ll[i].gateup_s), (down_w, ll[i].down_s) = self._q8(gu), self._q8(down_w)
@@ -209,7 +215,7 @@ class Qwen2VLWeights:
         self._llm_layers = ll
         m = self.llm
         m.n_layers, m.d_model, m.n_q_heads, m.n_kv_heads = d.n_layers, d.d_model, d.n_q_heads, d.n_kv_heads
-        m.head_dim, m.d_ff, m.vocab = d.head_dim, d.d_ff, d.vocab
+        m.head_dim, m.d_ff, m.vocab = d.head_dim, ff, d.vocab
         m.mrope_sec0, m.mrope_sec1, m.rms_eps = d.mrope_section[0], d.mrope_section[1], d.rms_eps
         self.embed = get(T + "embed_tokens.weight")
         m.embed = self._k(self.embed)

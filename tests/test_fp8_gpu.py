@@ -178,3 +178,40 @@ def test_gemm_fp8_mid_kernel_race_screen(gpu, m, n, k, epi):
     finally:
         lib.owc_tuning_set(b"gemm_mid_max_tiles", 256)
         lib.owc_tuning_set(b"gemm_skinny_max_m", -1)
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(2048, 4096, 512, "bias"), (1024, 2048, 8192, "res"), (1000, 1536, 1024, "res"), (1024, 2048, 3584, "swiglu"),
+                                       (512, 1024, 256, "bias"), (700, 1096, 768, "bias")])
+def test_gemm_fp8_pingpong_bit_identical_race_screen(gpu, m, n, k, epi):
+    """gemm_fp8_nt_256pp_kernel (two waves per SIMD alternate MFMA / load roles, counted vmcnt, two W half-0 register sets
+    alternating per K-tile, peeled two-tile tail) against the lock-step 256x256 fp8 kernel: 2 ... 64 K-tiles (the minimum: only the
+    peeled tail runs), ragged M / N, every epilogue, 12 launches each - the same bits every time.  An odd K-tile count (768 = 6 tiles
+    is even; 29568 = 231 is not) stays on the lock-step kernel by dispatch."""
+    from lmms_owc_amd import _lib, ops
+    from lmms_owc_amd.engine.qwen2vl import interleave_gate_up
+
+    lib = _lib.load()
+    x = bf16_randn((m, k), 280 + m, 1.0, gpu)
+    w = bf16_randn((n, k), 281, 0.05, gpu)
+    xq, xs = ops.quantize_rows_fp8(x)
+    wq, ws = ops.quantize_rows_fp8(w)
+    bias = bf16_randn((n,), 5, 0.5, gpu) if epi == "bias" else None
+    r = bf16_randn((m, n), 9, 1.0, gpu) if epi == "res" else None
+    if epi == "swiglu":
+        f = n // 2
+        wq = interleave_gate_up(wq[:f].view(torch.int8), wq[f:].view(torch.int8)).view(torch.uint8)
+        ws = interleave_gate_up(ws[:f, None], ws[f:, None])[:, 0].contiguous()
+    e = {"bias": _lib.EPI_NONE, "res": _lib.EPI_RESIDUAL, "swiglu": _lib.EPI_SWIGLU}[epi]
+    try:
+        lib.owc_tuning_set(b"gemm_skinny_max_m", 0)
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 0)          # always the 256x256 kernels
+        assert lib.owc_tuning_set(b"gemm_pingpong", 1) == 0    # bf16 ping-pong, fp8 lock-step
+        want = ops.gemm_fp8(xq, xs, wq, ws, bias, epilogue=e, residual=r)
+        assert lib.owc_tuning_set(b"gemm_pingpong", 2) == 0    # fp8 ping-pong as well
+        for i in range(12):
+            got = ops.gemm_fp8(xq, xs, wq, ws, bias, epilogue=e, residual=r)
+            assert torch.equal(got, want), (i, int((got != want).sum()))
+    finally:
+        lib.owc_tuning_set(b"gemm_pingpong", -1)
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 256)
+        lib.owc_tuning_set(b"gemm_skinny_max_m", -1)

@@ -184,9 +184,10 @@ def test_graph_replayed_decode_equals_eager(setup, gpu):
 
 
 def test_rmsnorm_fused_into_the_skinny_gemm_is_bit_identical(setup, gpu):
-    """Decode at 1-4 sequences: the qkv / gate-up projections normalise their own activations (gemm_bf16_skinny_norm_kernel, one
-    launch less per RMSNorm).  Same bits as rmsnorm + GEMM - for every step's logits with the knob on and off, and therefore across
-    the 4 -> 5 row switch back to the separate kernels (a sequence alone == inside a batch of 6)."""
+    """Decode at 1-2 sequences (the kernel takes up to 4: the knob's maximum is exercised here): the qkv / gate-up projections
+    normalise their own activations (gemm_bf16_skinny_norm_kernel, one launch less per RMSNorm).  Same bits as rmsnorm + GEMM - for
+    every step's logits with the knob on and off, and therefore across the switch back to the separate kernels (a sequence alone
+    == inside a batch of 6)."""
     from lmms_owc_amd import _lib
 
     cfg, w, eng, g = setup
