@@ -48,6 +48,7 @@ int g_skinny_max_m = 32;   // M at and below which the weight-streaming skinny k
                            // measured on the 7B decode step, ms: M = 33 6.4 skinny / 6.9 64x64 tiles, 40 7.0 / 6.7, 48 7.5 / 6.9, 64 9.8 / 6.6
 int g_mid_max_tiles = 256;  // fewer 128x128 tiles than this -> 64x64 tiles (0 disables: A-B knob "gemm_mid_max_tiles")
 int g_big_min_tiles = 144;  // fewer 256x256 tiles than this -> use the 128x128 kernel (measured: 160-162 tiles 256x256 +24...40 %, 126 tiles -3...8 %; knob "gemm_big_min_tiles")
+int g_small_tiles = 1;    // 64x64-tile kernel: also 32x64 / 64x32 / 32x32 tiles where they shorten the launch (knob "gemm_small_tiles": 0 off, 2 + shape forces one)
 int g_skinny_deep = 1;    // the skinny kernel's 9-deep ring for long-K launches of at most one wave per CU (knob "gemm_skinny_deep")
 int g_norm_fuse_max_m = 2; // rows up to which the decoder's RMSNorm is fused into the qkv / gate-up skinny GEMM (knob "decode_norm_fuse", 0 = off, at most 4).
                            // Measured, 7B decode step in ms, separate / fused: 1 row 3.78 / 3.44, 2 rows 3.78 / 3.65, 4 rows 3.88 / 4.11 - every wave
@@ -197,12 +198,22 @@ constexpr int TILE64_BYTES = B64 * BK * 2;  // 8 KiB per operand tile
 // stages (A + W tile each): 4 (64 KiB, two blocks per CU) unless the launch has more blocks than 2 per CU and at most 3 per CU, where
 // 3 stages (48 KiB) keep it to one round (the 7B gate/up projection at M <= 64 is 592 blocks)
 
-template <int EPI, int NS64, bool KTAIL>
+// Tile shape TM x TN in {64, 32} x {64, 32} (round 3).  What bounds these launches is neither this loop nor its bytes in flight but the
+// per-CU ingest: with HBM misses in the mix a CU pulls ~56-60 GB/s whatever the ring depth (L2-hit re-reads of A queue behind the
+// misses: tools/probes/probe_cu_ingest.hip `gemm` reproduces this kernel's 0.29 us per K-tile with the LDS-DMA alone), so the time is
+// (TM + TN) * K * 2 bytes per block / 58 GB/s - and the right tile is the one with the smallest TM + TN that still fits the launch in
+// one round of 256 CUs (launch(): 64x64 for M = 256, 32x64 for M = 128, 32x32 for M = 64 on the N = 3584 projections).  TM / 16 waves
+// own one 16-row m tile x all TN columns; with TM = 32 waves 2-3 only stage.  Same accumulation chain: bit-identical.
+template <int EPI, int NS64, bool KTAIL, int TM = 64, int TN = 64>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
     const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
     const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv,
     long ldc, int M, int N, int K, const void* __restrict__ zeros, int tiles_m, int tiles_n, owc_gemm_aux aux) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];  // [stage][A|W][64 rows][128 B]
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // [stage][A: TM rows | W: TN rows][128 B]
+  constexpr int STAGE = (TM + TN) * 128;      // bytes per stage
+  constexpr int NPA = TM / 8, NPT = (TM + TN) / 8, NPW = NPT / 4;   // 1-KiB DMA pieces: of A, in all, per wave (2, 3 or 4)
+  constexpr int NTW = TN / 16;                // n tiles of an active wave (4 or 2)
+  static_assert(EPI != OWC_EPI_SWIGLU || TN == 64, "the SwiGLU epilogue pairs two gate/up tile pairs");
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
@@ -215,41 +226,35 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
   const int group = lid / width;
   const int first_m = group * GROUP_M;
   const int gsize = min(tiles_m - first_m, GROUP_M);
-  const int m0 = (first_m + (lid % width) % gsize) * B64, n0 = ((lid % width) / gsize) * B64;
+  const int m0 = (first_m + (lid % width) % gsize) * TM, n0 = ((lid % width) / gsize) * TN;
 
-  // staging: wave w moves rows [16w, 16w+16) of both tiles, 2 pieces of 8 rows
-  const char* asrc[2];
-  const char* wsrc[2];
-  int kchunk[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = 16 * w + 8 * j + (l >> 3);
-    const int c = (l & 7) ^ ((row >> 1) & 7);
-    kchunk[j] = c * 8;
-    asrc[j] = (const char*)(A + (long)min(m0 + row, M - 1) * lda + c * 8);
-    wsrc[j] = (const char*)(W + (long)min(n0 + row, N - 1) * ldw + c * 8);
-  }
-  const int nk = (K + BK - 1) / BK;
-  // always 4 LDS-DMA instructions per wave and stage, also past the end of K (zero page: an L2 hit nobody reads), so that the
-  // counted waits below hold on every iteration
+  // staging: piece p = w + 4 i (i < NPW) of a stage; pieces [0, NPA) are 8-row slabs of the A tile, the rest of the W tile.  Whether
+  // piece i of a wave is an A or a W slab is the same for all four waves (NPA is a multiple of 4): a compile-time fact.
+  const char* src[NPW];
+  int kchunk[NPW];
   const char* abase = (const char*)(A + (long)m0 * lda);
   const char* wbase = (const char*)(W + (long)n0 * ldw);
-  unsigned aoff[2], woff[2];
+  unsigned off[NPW];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    aoff[j] = (unsigned)(asrc[j] - abase);
-    woff[j] = (unsigned)(wsrc[j] - wbase);
+  for (int i = 0; i < NPW; ++i) {
+    const bool is_a = 4 * i < NPA;
+    const int row = 8 * (w + 4 * i - (is_a ? 0 : NPA)) + (l >> 3);   // row inside its tile
+    const int c = (l & 7) ^ ((row >> 1) & 7);
+    kchunk[i] = c * 8;
+    src[i] = is_a ? (const char*)(A + (long)min(m0 + row, M - 1) * lda + c * 8) : (const char*)(W + (long)min(n0 + row, N - 1) * ldw + c * 8);
+    off[i] = (unsigned)(src[i] - (is_a ? abase : wbase));
   }
+  const int nk = (K + BK - 1) / BK;
+  // always NPW LDS-DMA instructions per wave and stage, also past the end of K (zero page: an L2 hit nobody reads), so that the
+  // counted waits below hold on every iteration
   auto stage = [&](int buf, int kt) {
-    char* la = lds + buf * (2 * TILE64_BYTES) + w * 2048;
-    char* lw = la + TILE64_BYTES;
+    char* dst = lds + buf * STAGE + w * 1024;
     const int k0 = kt * BK;
     if constexpr (KTAIL) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const bool ok = (k0 + kchunk[j]) < K;
-        glds16(ok ? (const void*)(asrc[j] + (long)k0 * 2) : zeros, la + j * 1024);
-        glds16(ok ? (const void*)(wsrc[j] + (long)k0 * 2) : zeros, lw + j * 1024);
+      for (int i = 0; i < NPW; ++i) {
+        const bool ok = (k0 + kchunk[i]) < K;
+        glds16(ok ? (const void*)(src[i] + (long)k0 * 2) : zeros, dst + i * 4096);
       }
     } else {   // K % 64 == 0; the pieces issued past the end of K (the ring's over-issue) re-read the last K-tile: nobody reads them
       const long kk = (long)min(k0, K - BK) * 2;
@@ -257,49 +262,48 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
       const char* wb = wbase + kk;
       asm volatile("" : "+s"(ab), "+s"(wb));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        asm volatile("" : "+v"(aoff[j]), "+v"(woff[j]));
-        glds16(ab + aoff[j], la + j * 1024);
-        glds16(wb + woff[j], lw + j * 1024);
+      for (int i = 0; i < NPW; ++i) {
+        asm volatile("" : "+v"(off[i]));
+        glds16((4 * i < NPA ? ab : wb) + off[i], dst + i * 4096);
       }
     }
   };
   const int fr = l & 15, fq = l >> 4;
   const int swz = (fr >> 1) & 7;
+  const bool active = w < TM / 16;   // wave w: m tile w (waves 2-3 of a 32-row tile only stage)
   const int offA0 = (w * 16 + fr) * 128 + (((0 + fq) ^ swz) << 4), offA1 = (w * 16 + fr) * 128 + (((4 + fq) ^ swz) << 4);
-  const int offW0 = fr * 128 + (((0 + fq) ^ swz) << 4), offW1 = fr * 128 + (((4 + fq) ^ swz) << 4);
+  const int offW0 = TM * 128 + fr * 128 + (((0 + fq) ^ swz) << 4), offW1 = TM * 128 + fr * 128 + (((4 + fq) ^ swz) << 4);
 
   f32x4 acc[4][1];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // (Round 3 measured a software-pipelined form of this loop - next k-step's fragments read under the current MFMAs, hand-counted
-  // lgkmcnt, one tile more look-ahead - and an 8-stage ring: both +-0 on every decode shape (7B down projection at M = 64...256:
-  // 88 us for 296 K-tiles whatever M, ring depth or schedule).  The launches are not bound by this loop's instruction stream:
-  // tools/probes/probe_cu_ingest.hip, DESIGN.md section 4.  The simple form stays.)
+  // lgkmcnt, one tile more look-ahead - and an 8-stage ring: both +-0 on every decode shape.  The simple form stays.)
 #pragma unroll
   for (int i = 0; i < NS64 - 1; ++i) stage(i, i);
   for (int kt = 0; kt < nk; ++kt) {
-    // this wave's pieces of stage kt have landed (the 4 * (NS64 - 2) newer ones may fly); the barrier publishes everybody's and
+    // this wave's pieces of stage kt have landed (the NPW * (NS64 - 2) newer ones may fly); the barrier publishes everybody's and
     // tells that every wave is done reading stage kt - 1, whose slot the next DMA overwrites
     // (lgkmcnt(0): this wave's own ds_reads of stage kt - 1 have retired too - the MFMAs consumed them long ago, so it costs
     // nothing, and the WAR guarantee then holds in the source instead of resting on the compiler's placement of its waits)
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 * (NS64 - 2)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPW * (NS64 - 2)) : "memory");
     __builtin_amdgcn_sched_barrier(0);
     stage((kt + NS64 - 1) % NS64, kt + NS64 - 1);
-    const char* la = lds + (kt % NS64) * (2 * TILE64_BYTES);
-    const char* lw = la + TILE64_BYTES;
+    if (active) {
+      const char* la = lds + (kt % NS64) * STAGE;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 fa = *(const bf16x8*)(la + (ks ? offA1 : offA0));
-      bf16x8 fw[4];
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 fa = *(const bf16x8*)(la + (ks ? offA1 : offA0));
+        bf16x8 fw[NTW];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) fw[t] = *(const bf16x8*)(lw + (ks ? offW1 : offW0) + t * 16 * 128);
+        for (int t = 0; t < NTW; ++t) fw[t] = *(const bf16x8*)(la + (ks ? offW1 : offW0) + t * 16 * 128);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa, acc[nt][0], 0, 0, 0);
+        for (int nt = 0; nt < NTW; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa, acc[nt][0], 0, 0, 0);
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued zero-page pieces, before the block's LDS goes away
-  gemm_epilogue<EPI, 1>(acc, m0 + w * 16, n0, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
+  if (active) gemm_epilogue<EPI, 1, false, NTW / 2>(acc, m0 + w * 16, n0, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1006,13 +1010,49 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
                        (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, g_gemm_dbg, aux);
   else if (g_mid_max_tiles > 0 && tiles_m * tiles_n < g_mid_max_tiles) {  // too few 128x128 tiles for 256 CUs: 64x64 tiles
     const int tm64 = (M + B64 - 1) / B64, tn64 = (N + B64 - 1) / B64;
-#define OWC_L64(NS_, KT_)                                                                                                  \
-  hipLaunchKernelGGL((gemm_bf16_nt_64_kernel<EPI, NS_, KT_>), dim3(tm64 * tn64), dim3(256), NS_ * 2 * TILE64_BYTES, s,        \
-                     (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C, ldc, M, N,   \
-                     K, zeros, tm64, tn64, aux)
+#define OWC_L64(NS_, KT_, TM_, TN_)                                                                                        \
+  do {                                                                                                                     \
+    constexpr int lds_ = NS_ * (TM_ + TN_) * 128;                                                                          \
+    static bool set_ = false;                                                                                              \
+    if (!set_ && lds_ > 65536) {                                                                                           \
+      if (hipFuncSetAttribute((const void*)gemm_bf16_nt_64_kernel<EPI, NS_, KT_, TM_, TN_>,                                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) return OWC_ERR_HIP;         \
+      set_ = true;                                                                                                         \
+    }                                                                                                                      \
+    const int tm_ = (M + TM_ - 1) / TM_, tn_ = (N + TN_ - 1) / TN_;                                                        \
+    hipLaunchKernelGGL((gemm_bf16_nt_64_kernel<EPI, NS_, KT_, TM_, TN_>), dim3(tm_ * tn_), dim3(256), lds_, s,             \
+                       (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C, ldc,   \
+                       M, N, K, zeros, tm_, tn_, aux);                                                                     \
+  } while (0)
     const bool ktail = (K % BK) != 0;
-    if (tm64 * tn64 > 512 && tm64 * tn64 <= 768) { if (ktail) OWC_L64(3, true); else OWC_L64(3, false); }
-    else { if (ktail) OWC_L64(4, true); else OWC_L64(4, false); }
+    // Tile shape: the launch lasts ceil(blocks / 256 CUs) x (TM + TN) x K x 2 bytes at the ~58 GB/s one CU ingests (see the kernel's
+    // header), so take the shape with the smallest such product; ties go to the larger tile (fewer L2 re-reads).  Only the
+    // epilogues the decode projections use are instantiated for the small shapes (SwiGLU pairs 64 columns: TM only).
+    int shape = 0;   // 0: 64x64, 1: 32x64, 2: 64x32, 3: 32x32
+    if constexpr (EPI == OWC_EPI_NONE || EPI == OWC_EPI_RESIDUAL || EPI == OWC_EPI_SWIGLU) {
+      if (!ktail && g_small_tiles) {
+        auto cost = [&](int tm, int tn) { return (long)(((long)((M + tm - 1) / tm) * ((N + tn - 1) / tn) + 255) / 256) * (tm + tn); };
+        long best = cost(64, 64);
+        if (cost(32, 64) < best) { best = cost(32, 64); shape = 1; }
+        if constexpr (EPI != OWC_EPI_SWIGLU) {
+          if (cost(64, 32) < best) { best = cost(64, 32); shape = 2; }
+          if (cost(32, 32) < best) { best = cost(32, 32); shape = 3; }
+        }
+        if (g_small_tiles > 1) shape = (g_small_tiles - 2) & 3;   // timing builds: force a shape
+        if (EPI == OWC_EPI_SWIGLU && shape > 1) shape = 0;
+      }
+    }
+    if (shape == 0) {
+      if (tm64 * tn64 > 512 && tm64 * tn64 <= 768) { if (ktail) OWC_L64(3, true, 64, 64); else OWC_L64(3, false, 64, 64); }
+      else { if (ktail) OWC_L64(4, true, 64, 64); else OWC_L64(4, false, 64, 64); }
+    }
+    if constexpr (EPI == OWC_EPI_NONE || EPI == OWC_EPI_RESIDUAL || EPI == OWC_EPI_SWIGLU) {
+      if (shape == 1) OWC_L64(6, false, 32, 64);
+      if constexpr (EPI != OWC_EPI_SWIGLU) {
+        if (shape == 2) OWC_L64(6, false, 64, 32);
+        if (shape == 3) OWC_L64(8, false, 32, 32);
+      }
+    }
 #undef OWC_L64
   } else
   {
@@ -1161,3 +1201,4 @@ void owc_gemm_set_big_min_tiles(int v) { g_big_min_tiles = v < 0 ? 144 : v; }
 void owc_gemm_set_skinny_max_m(int v) { g_skinny_max_m = v < 0 ? 32 : v; }  // negative: back to the default
 void owc_gemm_set_pingpong(int v) { g_pingpong = v; }
 void owc_gemm_set_skinny_deep(int v) { g_skinny_deep = v; }
+void owc_gemm_set_small_tiles(int v) { g_small_tiles = v < 0 ? 1 : v; }

@@ -27,7 +27,8 @@ __device__ __forceinline__ void swap16(float& x, float& y) {
 // tile (row pitch `cpitch` bytes, 16-byte chunks XOR-swizzled by row & 7, block-local origin (lrow0, lcol0)) and
 // store_ctile() writes them out as whole rows.  Why: a lane group of the MFMA layout only covers 64 contiguous bytes of
 // a row, and half-line writes measurably slow the whole kernel (ablation: full-line pattern +2..8 %).
-template <int EPI, int MT, bool FULL = false>
+// NTP: pairs of 16-column tiles the wave holds in acc[0 .. 2 NTP) (2 = a 64-column wave tile, 1 = a 32-column one)
+template <int EPI, int MT, bool FULL = false, int NTP = 2>
 __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mrow0, int ncol0, int fr, int fq,
                                               const bf16_t* __restrict__ bias, const bf16_t* R, long ldr,
                                               void* Cv, long ldc, int M, int N, const owc_gemm_aux& aux,
@@ -38,7 +39,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
     for (int mt = 0; mt < MT; ++mt) {
       const int m = mrow0 + mt * 16 + fr;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
+      for (int nt = 0; nt < 2 * NTP; ++nt) {
         const int n = ncol0 + nt * 16 + fq * 4;
         f32x4 v = acc[nt][mt];
         if (bias != nullptr && n < N) {
@@ -102,7 +103,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
     bf16_t* C = (bf16_t*)Cv;
     const int odd = fq & 1;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NTP; ++p) {
       const int n = ncol0 + (2 * p + odd) * 16 + (fq >> 1) * 8;  // first of this lane's 8 columns
       const int nc = min(n, N - 8);
       float bv[8];

@@ -81,6 +81,7 @@ void owc_gemm_set_norm_fuse_max_m(int v);
 int owc_launch_gemm_bf16_rmsnorm(const void* X, long ldx, const void* gamma, float eps, const void* W, long ldw, const void* bias,
                                  void* C, long ldc, int M, int N, int K, int epi, hipStream_t s);
 void owc_gemm_set_skinny_deep(int v);
+void owc_gemm_set_small_tiles(int v);
 void owc_gemm_fp8_set_pingpong(int v);
 void owc_gemm_fp8_set_skinny_max_m(int v);
 void owc_gemm_fp8_set_mid_max_tiles(int v);

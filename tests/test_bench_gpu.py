@@ -37,3 +37,10 @@ def test_two_ranks_share_one_gpu(gpu):
     assert out["batch_invariance_check"].startswith("ok")
     assert out["roofline"]["launches"] > 0 and 0 < out["roofline"]["frac"] < 1     # rank 0's launches only
     assert out["label_cosine_per_sec"] > 0 and out["images_per_s_from_host_uint8"] > 0
+    # round 3: three attention objects (decode priced in bytes against HBM), the HBM-regime decode leg on rank 0
+    att = out["roofline_attention"]
+    assert set(att) == {"vision", "prefill", "decode"} and att["decode"]["bound"] == "hbm" and att["decode"]["unit"] == "GB/s"
+    assert all(a["launches"] > 0 and 0 < a["frac"] < 1 for a in att.values())
+    dec = out["roofline_decode"]
+    assert dec["bound"] == "hbm" and dec["batch"] == 1 and [r["batch"] for r in dec["by_batch"]] == [1, 32, 128]
+    assert all(0 < r["frac"] < 1 and r["ms_per_step"] > 0 for r in dec["by_batch"])
