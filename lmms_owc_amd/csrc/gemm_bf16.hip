@@ -48,13 +48,13 @@ int g_skinny_max_m = 32;   // M at and below which the weight-streaming skinny k
                            // measured on the 7B decode step, ms: M = 33 6.4 skinny / 6.9 64x64 tiles, 40 7.0 / 6.7, 48 7.5 / 6.9, 64 9.8 / 6.6
 int g_mid_max_tiles = 256;  // fewer 128x128 tiles than this -> 64x64 tiles (0 disables: A-B knob "gemm_mid_max_tiles")
 int g_big_min_tiles = 144;  // fewer 256x256 tiles than this -> use the 128x128 kernel (measured: 160-162 tiles 256x256 +24...40 %, 126 tiles -3...8 %; knob "gemm_big_min_tiles")
-int g_small_tiles = 1;    // 64x64-tile kernel: also 32x64 / 64x32 / 32x32 tiles where they shorten the launch (knob "gemm_small_tiles": 0 off, 2 + shape forces one)
+int g_small_tiles = 1;    // 64x64-tile kernel: also 32x64 / 64x32 / 32x32 tiles where they shorten the launch (knob "gemm_small_tiles": 0 off, 2 / 3 / 4 force 64x64 / 64x32 / 32x32)
 int g_skinny_deep = 1;    // the skinny kernel's 9-deep ring for long-K launches of at most one wave per CU (knob "gemm_skinny_deep")
 int g_norm_fuse_max_m = 2; // rows up to which the decoder's RMSNorm is fused into the qkv / gate-up skinny GEMM (knob "decode_norm_fuse", 0 = off, at most 4).
                            // Measured, 7B decode step in ms, separate / fused: 1 row 3.78 / 3.44, 2 rows 3.78 / 3.65, 4 rows 3.88 / 4.11 - every wave
                            // normalises every row itself, so beyond 2 rows the redundant work outweighs the launch it saves
 int g_pingpong = 1;       // 256x256 launches with K % 128 == 0 use the ping-pong kernel (A-B knob "gemm_pingpong", 0 = lock-step kernel)
-int g_big_min_m = 256;   // M at and above which the 256x256 kernels may run (knob "gemm_big_min_m"; round 1: 1024)
+int g_big_min_m = 129;   // M at and above which the 256x256 kernels may run (knob "gemm_big_min_m"; round 1: 1024)
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
@@ -201,9 +201,10 @@ constexpr int TILE64_BYTES = B64 * BK * 2;  // 8 KiB per operand tile
 // Tile shape TM x TN in {64, 32} x {64, 32} (round 3).  What bounds these launches is neither this loop nor its bytes in flight but the
 // per-CU ingest: with HBM misses in the mix a CU pulls ~56-60 GB/s whatever the ring depth (L2-hit re-reads of A queue behind the
 // misses: tools/probes/probe_cu_ingest.hip `gemm` reproduces this kernel's 0.29 us per K-tile with the LDS-DMA alone), so the time is
-// (TM + TN) * K * 2 bytes per block / 58 GB/s - and the right tile is the one with the smallest TM + TN that still fits the launch in
-// one round of 256 CUs (launch(): 64x64 for M = 256, 32x64 for M = 128, 32x32 for M = 64 on the N = 3584 projections).  TM / 16 waves
-// own one 16-row m tile x all TN columns; with TM = 32 waves 2-3 only stage.  Same accumulation chain: bit-identical.
+// the block's bytes over that rate, the W (miss) bytes weighing ~10x the A (L2-hit) bytes - and the right tile for a launch that
+// cannot fill 256 CUs with 64x64 tiles is a narrower one (launch(): 32x32 for M <= 64, 64x32 for M <= 256 on the N = 3584
+// projections: the 7B down projection 122 -> 72 / 84 / 115 us at M = 64 / 128 / 256).  TM / 16 waves own one 16-row m tile x all TN
+// columns; with TM = 32 waves 2-3 only stage.  Same accumulation chain: bit-identical.
 template <int EPI, int NS64, bool KTAIL, int TM = 64, int TN = 64>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
     const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
@@ -966,10 +967,12 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
            long ldr, void* C, long ldc, int M, int N, int K, const void* zeros, hipStream_t s,
            const owc_gemm_aux& aux) {
   // 256x256 tiles need enough of them to fill the 256 CUs (one block per CU); otherwise 128x128 (2 per CU)
-  // ... and, below 1024 rows, only when padding M to 256 wastes at most an eighth of the tile rows (measured on the 7B gate/up
-  // projection: M = 256 / 512 / 768 135 -> 81 / 198 -> 155 / 255 -> 163 us against the 128x128 kernel, M = 384 138 -> 149 us)
-  const int pad256 = (M + BT - 1) / BT * BT - M;
-  const bool big = M >= g_big_min_m && (M >= 1024 || pad256 * 8 <= M) && N >= BT && (K % BK) == 0 &&
+  // ... and, below 1024 rows, not when M is three 128-row tiles (the second 256-row tile half empty).  Measured on the 7B gate/up
+  // projection, 256x256 against 128x128 tiles: M = 192 / 256 / 512 / 768 86 <- 120 / 81 <- 135 / 155 <- 198 / 163 <- 255 us, but
+  // M = 384 149 <- 138 us.  (Round 2's rule - padding to 256 wastes at most an eighth of the rows - left M = 129..223 and
+  // 385..455 on the 128x128 kernel: the B = 192 decode step was slower than the B = 256 one.)
+  const int mt128 = (M + BM - 1) / BM;
+  const bool big = M >= g_big_min_m && (M >= 1024 || mt128 != 3) && N >= BT && (K % BK) == 0 &&
                    (long)((M + BT - 1) / BT) * ((N + BT - 1) / BT) >= g_big_min_tiles;
   const int tiles_m = big ? (M + BT - 1) / BT : (M + BM - 1) / BM;
   const int tiles_n = big ? (N + BT - 1) / BT : (N + BN - 1) / BN;
@@ -1025,33 +1028,28 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
                        M, N, K, zeros, tm_, tn_, aux);                                                                     \
   } while (0)
     const bool ktail = (K % BK) != 0;
-    // Tile shape: the launch lasts ceil(blocks / 256 CUs) x (TM + TN) x K x 2 bytes at the ~58 GB/s one CU ingests (see the kernel's
-    // header), so take the shape with the smallest such product; ties go to the larger tile (fewer L2 re-reads).  Only the
-    // epilogues the decode projections use are instantiated for the small shapes (SwiGLU pairs 64 columns: TM only).
-    int shape = 0;   // 0: 64x64, 1: 32x64, 2: 64x32, 3: 32x32
-    if constexpr (EPI == OWC_EPI_NONE || EPI == OWC_EPI_RESIDUAL || EPI == OWC_EPI_SWIGLU) {
+    // Tile shape (measured, profiles/r03_gemm_small_tiles_ab.txt): a launch that leaves CUs idle is bound by what ONE CU pulls from HBM
+    // (~40-55 GB/s of misses, see the kernel's header), so its time goes with the W bytes per block - halving TN nearly halves it,
+    // halving TM (L2 hits) barely matters on its own but doubles the blocks.  Hence: 64x64 once it fills the chip; else 32x32 when
+    // that still fits one round of 256 CUs; else 64x32 up to two rounds.  (32x64 measured -3 %: not instantiated; SwiGLU pairs 64
+    // columns and its shapes have many n tiles anyway.)
+    int shape = 0;   // 0: 64x64, 1: 64x32, 2: 32x32
+    if constexpr (EPI == OWC_EPI_NONE || EPI == OWC_EPI_RESIDUAL) {
       if (!ktail && g_small_tiles) {
-        auto cost = [&](int tm, int tn) { return (long)(((long)((M + tm - 1) / tm) * ((N + tn - 1) / tn) + 255) / 256) * (tm + tn); };
-        long best = cost(64, 64);
-        if (cost(32, 64) < best) { best = cost(32, 64); shape = 1; }
-        if constexpr (EPI != OWC_EPI_SWIGLU) {
-          if (cost(64, 32) < best) { best = cost(64, 32); shape = 2; }
-          if (cost(32, 32) < best) { best = cost(32, 32); shape = 3; }
-        }
-        if (g_small_tiles > 1) shape = (g_small_tiles - 2) & 3;   // timing builds: force a shape
-        if (EPI == OWC_EPI_SWIGLU && shape > 1) shape = 0;
+        auto blocks = [&](int tm, int tn) { return (long)((M + tm - 1) / tm) * ((N + tn - 1) / tn); };
+        if (blocks(64, 64) > 256) shape = 0;
+        else if (blocks(32, 32) <= 256) shape = 2;
+        else if (blocks(64, 32) <= 512) shape = 1;
+        if (g_small_tiles > 1) shape = (g_small_tiles - 2) % 3;   // A-B: force a shape
       }
     }
     if (shape == 0) {
       if (tm64 * tn64 > 512 && tm64 * tn64 <= 768) { if (ktail) OWC_L64(3, true, 64, 64); else OWC_L64(3, false, 64, 64); }
       else { if (ktail) OWC_L64(4, true, 64, 64); else OWC_L64(4, false, 64, 64); }
     }
-    if constexpr (EPI == OWC_EPI_NONE || EPI == OWC_EPI_RESIDUAL || EPI == OWC_EPI_SWIGLU) {
-      if (shape == 1) OWC_L64(6, false, 32, 64);
-      if constexpr (EPI != OWC_EPI_SWIGLU) {
-        if (shape == 2) OWC_L64(6, false, 64, 32);
-        if (shape == 3) OWC_L64(8, false, 32, 32);
-      }
+    if constexpr (EPI == OWC_EPI_NONE || EPI == OWC_EPI_RESIDUAL) {
+      if (shape == 1) OWC_L64(6, false, 64, 32);
+      if (shape == 2) OWC_L64(8, false, 32, 32);
     }
 #undef OWC_L64
   } else

@@ -234,6 +234,43 @@ def test_gemm_mid_kernel_race_screen(gpu, m, n, k, epi):
         lib.owc_tuning_set(b"gemm_skinny_max_m", SKINNY_MAX_M)
 
 
+@pytest.mark.parametrize("m,n,k,epi", [(64, 3584, 18944, "residual"), (128, 3584, 3584, "residual"), (100, 4608, 3584, "none"),
+                                       (40, 1096, 128, "none"), (130, 520, 64, "residual"), (96, 4736, 3584, "swiglu"),
+                                       (33, 264, 1024, "none")])
+def test_gemm_small_tile_shapes_race_screen(gpu, m, n, k, epi):
+    """The 64x64 ring kernel's 64x32 / 32x32 tile shapes (deeper rings, two of the four waves only staging when TM = 32),
+    each FORCED on shapes with ragged M / N, one and two K-tiles (fewer than ring stages) and the 7B decode projections, against the
+    64x64 shape and the 128x128 kernel, 10 times each: bit-identical (one ascending K chain per output whatever the tile)."""
+    from lmms_owc_amd import _lib, ops
+
+    lib = _lib.load()
+    a = bf16_randn((m, k), 90 + (m % 97), device=gpu)
+    w = bf16_randn((n, k), 91, 0.05, device=gpu)
+    b = bf16_randn((n,), 92, device=gpu)
+    r = bf16_randn((m, n), 93, device=gpu)
+    E = {"none": _lib.EPI_NONE, "residual": _lib.EPI_RESIDUAL, "swiglu": _lib.EPI_SWIGLU}[epi]
+
+    def run():
+        if epi == "swiglu":
+            return ops.gemm_bf16(a, w, None, epilogue=E)
+        return ops.gemm_bf16(a, w, b, epilogue=E, residual=r if epi == "residual" else None)
+
+    lib.owc_tuning_set(b"gemm_skinny_max_m", 0)
+    try:
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 0)
+        want = run()
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 1 << 30)
+        for shape in (2, 3, 4, 1):   # forced 64x64, 64x32, 32x32 (SwiGLU always runs 64x64), then the default
+            assert lib.owc_tuning_set(b"gemm_small_tiles", shape) == 0
+            for i in range(10):
+                got = run()
+                assert torch.equal(got, want), (shape, i, (got != want).sum().item())
+    finally:
+        lib.owc_tuning_set(b"gemm_small_tiles", 1)
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 256)
+        lib.owc_tuning_set(b"gemm_skinny_max_m", SKINNY_MAX_M)
+
+
 @pytest.mark.parametrize("m,n,k,epi", [(4096, 4096, 4096, "none"), (2048, 37888, 3584, "swiglu"), (32768, 1280, 1280, "residual"),
                                        (1100, 13000, 384, "none"), (65536, 1280, 256, "quick_gelu"), (3000, 5120, 5120, "f32")])
 def test_pingpong_kernel_bit_identical_to_lockstep_race_screen(gpu, m, n, k, epi):
