@@ -853,7 +853,7 @@ __global__ __launch_bounds__(64) void gemm_bf16_skinny_norm_kernel(
     const bf16_t* __restrict__ X, long ldx, const bf16_t* __restrict__ gamma, float eps, const bf16_t* __restrict__ W, long ldw,
     const bf16_t* __restrict__ bias, bf16_t* C, long ldc, int M, int N, int K) {
   constexpr int NT = EPI == OWC_EPI_SWIGLU ? 2 : 1;
-  extern __shared__ __attribute__((aligned(16))) char lds[];   // [M][K * 2 + 16] normalised activations
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // [M][K * 2 + 16] activations (raw, then normalised in place) | [K * 2] gamma
   const int l = threadIdx.x;
   const int fr = l & 15, fq = l >> 4;
   const int n0 = blockIdx.x * (16 * NT);
@@ -870,20 +870,58 @@ __global__ __launch_bounds__(64) void gemm_bf16_skinny_norm_kernel(
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) ring[i][nt][ks] = *(const bf16x8*)(wrow[nt] + ss * 128 + ks * 32);
   };
+  // The raw rows and gamma go into LDS (1-KiB LDS-DMA pieces) BEFORE the ring is issued: loads return in order, so issued behind the
+  // ring they - and with them the norm phase and the first MFMA - waited for DEPTH super-steps of HBM latency (round 3: qkv at
+  // M = 1 15.2 us; the same bytes without any arithmetic 9.7 us).  Needs K % 512 == 0 (whole pieces); otherwise the old order.
+  const int nch = K >> 3;
+  const bool pre = (nch & 63) == 0;
+  char* gl = lds + M * pitch;   // gamma, staged (pre only)
+  if (pre) {
+    for (int j = 0; j < (nch >> 6); ++j) {
+      glds16(gamma + (j * 64 + l) * 8, gl + j * 1024);
+      for (int m = 0; m < M; ++m) glds16(X + (long)m * ldx + (j * 64 + l) * 8, lds + m * pitch + j * 1024);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < DEPTH; ++i) load_w(i, min(i, nss - 1));
+  __builtin_amdgcn_sched_barrier(0);
 
-  // ---- normalise the M rows into LDS while the ring fills
-  const int nch = K >> 3;
-  for (int m = 0; m < M; ++m) {
-    const bf16_t* x = X + (long)m * ldx;
-    const float rstd = owc_rms_rstd(x, K, eps, l);
-    for (int ch = l; ch < nch; ch += 64) {
-      const bf16x8 c = *(const bf16x8*)(x + ch * 8), g = *(const bf16x8*)(gamma + ch * 8);
-      bf16x8 o;
+  // ---- normalise the M rows in LDS while the ring fills (the arithmetic of owc_rms_rstd / owc_rms_apply, bit for bit)
+  if (pre) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH * NT * 4) : "memory");   // the staged rows have landed; the ring may fly
+    for (int m = 0; m < M; ++m) {
+      char* xrow = lds + m * pitch;
+      float sq = 0.f;
+      for (int ch = l; ch < nch; ch += 64) {
+        const bf16x8 c = *(const bf16x8*)(xrow + ch * 16);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = owc_rms_apply(c[e], g[e], rstd);
-      *(bf16x8*)(lds + m * pitch + ch * 16) = o;
+        for (int e = 0; e < 8; ++e) {
+          const float v = bf2f(c[e]);
+          sq = __builtin_fmaf(v, v, sq);
+        }
+      }
+      sq = wave_sum(sq);
+      const float rstd = rsqrtf(__builtin_fmaf(sq, 1.0f / (float)K, eps));
+      for (int ch = l; ch < nch; ch += 64) {   // in place: a lane rewrites the chunks it read
+        const bf16x8 c = *(const bf16x8*)(xrow + ch * 16), g = *(const bf16x8*)(gl + ch * 16);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = owc_rms_apply(c[e], g[e], rstd);
+        *(bf16x8*)(xrow + ch * 16) = o;
+      }
+    }
+  } else {
+    for (int m = 0; m < M; ++m) {
+      const bf16_t* x = X + (long)m * ldx;
+      const float rstd = owc_rms_rstd(x, K, eps, l);
+      for (int ch = l; ch < nch; ch += 64) {
+        const bf16x8 c = *(const bf16x8*)(x + ch * 8), g = *(const bf16x8*)(gamma + ch * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = owc_rms_apply(c[e], g[e], rstd);
+        *(bf16x8*)(lds + m * pitch + ch * 16) = o;
+      }
     }
   }
   const char* arow = lds + min(fr, M - 1) * pitch + fq * 16;
@@ -1105,13 +1143,13 @@ int owc_launch_gemm_bf16_rmsnorm(const void* X, long ldx, const void* gamma, flo
   if (M <= 0 || M > g_norm_fuse_max_m || (K & 127) || K > 8192 || (ldx & 7) || (ldw & 7) || g_skinny_max_m < M) return OWC_ERR_SHAPE;
   const bool swiglu = epi == OWC_EPI_SWIGLU && (N & 31) == 0 && (ldc & 3) == 0;
   if (!swiglu && !(epi == OWC_EPI_NONE && (N & 15) == 0 && (ldc & 3) == 0)) return OWC_ERR_SHAPE;
-  const int lds_bytes = M * (K * 2 + 16);
+  const int lds_bytes = M * (K * 2 + 16) + K * 2;   // the rows (normalised in place) + gamma
   static bool attr_set = false;
   if (!attr_set) {   // 4 rows of K = 8192 (the 72B decoder) are 65.6 KB: above the default dynamic-LDS limit
     if (hipFuncSetAttribute((const void*)gemm_bf16_skinny_norm_kernel<OWC_EPI_SWIGLU, 5>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            4 * (8192 * 2 + 16)) != hipSuccess ||
+                            4 * (8192 * 2 + 16) + 8192 * 2) != hipSuccess ||
         hipFuncSetAttribute((const void*)gemm_bf16_skinny_norm_kernel<OWC_EPI_NONE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            4 * (8192 * 2 + 16)) != hipSuccess)
+                            4 * (8192 * 2 + 16) + 8192 * 2) != hipSuccess)
       return OWC_ERR_HIP;
     attr_set = true;
   }
