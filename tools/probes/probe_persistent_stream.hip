@@ -67,13 +67,18 @@ __global__ void chase_kernel(const unsigned* ring, unsigned* act, unsigned* out)
 // FENCED: release / acquire at agent scope (the compiler adds the L2 write-back + invalidate a coarse-grained buffer needs to be
 // seen by another XCD).  !FENCED: relaxed counter; the data that crosses the barrier is itself moved with agent-scope
 // (cache-bypassing) loads / stores and the stores are waited for before the counter moves.
+// (relaxed flavour, two levels: the 32 blocks of an XCD - block b runs on XCD b % 8 - count on their own line, the last of them
+// counts on the global line all blocks poll: 32 + 8 serialised atomics instead of 256.)
 template <bool FENCED>
 __device__ __forceinline__ bool grid_barrier(unsigned* cnt, unsigned target, unsigned* fail) {
-  if (!FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (prefetch DMAs too: the probe's worst case)
   __syncthreads();
   if (threadIdx.x == 0) {
     if (FENCED) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    else __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else {
+      const unsigned per = gridDim.x / 8;
+      const unsigned old = __hip_atomic_fetch_add(cnt + 32 * (1 + (blockIdx.x & 7)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((old + 1) % per == 0) __hip_atomic_fetch_add(cnt, per, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     long spins = 0;
     while ((FENCED ? __hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
                    : __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
@@ -96,53 +101,50 @@ __global__ __launch_bounds__(256) void step_kernel(const char* __restrict__ wbas
   u32x4 acc = {0, 0, 0, 0};
   const int nph = plan.layers * NPH;
   unsigned bar = 0;
-  // the pieces of all phases form ONE sequence per wave; `iss` (phase, piece) runs up to RING pieces ahead of `con`
-  int iph = 0, ipc = 0;     // next piece to issue
-  int inflight = 0;
-  auto piece_ptr = [&](int ph, int pc) {
+  auto base_of = [&](int ph) {
     const int L = ph / NPH, q = ph % NPH;
-    return wbase + (size_t)L * plan.layer_bytes + plan.off[q] + (size_t)gw * plan.per_wave[q] + (size_t)pc * 1024 + l * 16;
+    return wbase + (size_t)L * plan.layer_bytes + plan.off[q] + (size_t)gw * plan.per_wave[q] + l * 16;
   };
-  int slot_i = 0, slot_c = 0;
-  auto issue_upto = [&](int limit_ph) {   // issue while the ring has room and the next piece belongs to a phase <= limit_ph
-    while (inflight < RING && iph < nph && iph <= limit_ph) {
-      const int np = (int)(plan.per_wave[iph % NPH] >> 10);
-      if (ipc >= np) { ++iph; ipc = 0; continue; }
-      __builtin_amdgcn_global_load_lds((gptr_t)piece_ptr(iph, ipc), (lptr_t)(slot0 + slot_i * 1024), 16, 0, 0);
-      slot_i = (slot_i + 1) % RING;
-      ++ipc;
-      ++inflight;
-    }
-  };
+  // a wave's ring: RING slots; `primed` pieces of the CURRENT phase are already in flight when the phase starts (AHEAD)
+  int primed = 0, sb = 0;   // sb: ring slot of the current phase's piece 0
   for (int ph = 0; ph < nph; ++ph) {
     const int q = ph % NPH;
+    const int np = (int)(plan.per_wave[q] >> 10);
     if (ph > 0) {
-      if (AHEAD) issue_upto(ph);   // the ring fills with this phase's first pieces BEFORE the grid waits
       grid_barrier<FENCED>(cnt, ++bar * gridDim.x, fail);
       acc[0] ^= __hip_atomic_load(act + ((blockIdx.x * 37 + 11) & 255) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const int np = (int)(plan.per_wave[q] >> 10);
-    if (np == 0) {   // attention: 4 blocks chase, the rest go straight to the barrier (their rings already prefetch)
+    if (np == 0) {   // attention: 4 blocks chase, the rest go straight to the barrier
       if (blockIdx.x < 4 && threadIdx.x == 0) {
         unsigned idx = acc[0] & 1023u;
         chase(ring, idx);
         acc[1] ^= idx;
       }
     } else {
-      for (int pc = 0; pc < np; ++pc) {
-        issue_upto(AHEAD ? ph + 1 : ph);
-        // wait for the oldest piece: `inflight - 1` newer ones may stay in flight.  vmcnt takes an immediate: a small switch.
-        switch (inflight - 1) {
-#define W_(n) case n: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory"); break;
-          W_(0) W_(1) W_(2) W_(3) W_(4) W_(5) W_(6) W_(7) W_(8) W_(9) W_(10) W_(11) W_(12) W_(13) W_(14) W_(15)
-          W_(16) W_(17) W_(18) W_(19) W_(20) W_(21) W_(22) W_(23) W_(24) W_(25) W_(26) W_(27) W_(28) W_(29) W_(30) W_(31)
-#undef W_
-          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const char* p = base_of(ph);
+      for (int i = primed; i < RING && i < np; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(p + (size_t)i * 1024), (lptr_t)(slot0 + ((sb + i) % RING) * 1024), 16, 0, 0);
+      primed = 0;
+      // the next streaming phase (its ring is primed under this phase's tail when AHEAD)
+      int nx = ph + 1;
+      while (nx < nph && plan.per_wave[nx % NPH] == 0) ++nx;
+      const char* pn = nx < nph ? base_of(nx) : p;
+      const int npn = nx < nph ? (int)(plan.per_wave[nx % NPH] >> 10) : 0;
+      for (int i = 0; i < np; ++i) {
+        // RING - 1 newer pieces stay in flight throughout: past the end of this phase they are the next phase's (AHEAD) - or
+        // nothing, and the wait drains
+        if (AHEAD || i + RING <= np) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING - 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        char* slot = slot0 + ((sb + i) % RING) * 1024;
+        acc ^= *(const u32x4*)(slot + l * 16);
+        const int j = i + RING;
+        if (j < np) __builtin_amdgcn_global_load_lds((gptr_t)(p + (size_t)j * 1024), (lptr_t)slot, 16, 0, 0);
+        else if (AHEAD) {   // always issue, so that the counted wait above stays exact (past the very end: a re-read nobody uses)
+          const int jn = min(j - np, max(npn - 1, 0));
+          __builtin_amdgcn_global_load_lds((gptr_t)(pn + (size_t)jn * 1024), (lptr_t)slot, 16, 0, 0);
         }
-        acc ^= *(const u32x4*)(slot0 + slot_c * 1024 + l * 16);
-        slot_c = (slot_c + 1) % RING;
-        --inflight;
       }
+      if (AHEAD) primed = min(RING, npn);
+      sb = (sb + np) % RING;   // next-phase piece k went to slot (sb + np + k) % RING
     }
     if (threadIdx.x == 0) __hip_atomic_store(act + blockIdx.x * 32, acc[1] | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -159,7 +161,7 @@ int main(int argc, char** argv) {
   size_t off = 0;
   for (int q = 0; q < NPH; ++q) {
     plan.off[q] = off;
-    plan.per_wave[q] = (sz[q] / 1024 / 1024) * 1024;   // bytes / 1024 waves, whole KiB
+    plan.per_wave[q] = sz[q] ? ((sz[q] / 1024 / 1024) < 32 ? 32 : (sz[q] / 1024 / 1024)) * 1024 : 0;   // bytes / 1024 waves, whole KiB, at least one ring (the o projection: 24 -> 32 KiB)
     off += plan.per_wave[q] * 1024;
   }
   plan.layer_bytes = off;
@@ -175,7 +177,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(ring, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&act, 256 * 32 * 4));
   CK(hipMemset(act, 0, 256 * 32 * 4));
-  CK(hipMalloc(&cnt, 4));
+  CK(hipMalloc(&cnt, 4 * 32 * 9));
   CK(hipMalloc(&fail, 4));
   CK(hipMalloc(&out, 4));
   CK(hipMemset(fail, 0, 4));
@@ -216,7 +218,7 @@ int main(int argc, char** argv) {
     if (empty && mode == 0) continue;
     float best = 1e30f;
     for (int rep = 0; rep < steps + 1; ++rep) {
-      CK(hipMemset(cnt, 0, 4));
+      CK(hipMemset(cnt, 0, 4 * 32 * 9));
       CK(hipEventRecord(e0));
       if (mode == 0) {
         for (int L = 0; L < plan.layers; ++L)
@@ -237,8 +239,8 @@ int main(int argc, char** argv) {
     unsigned f = 0;
     CK(hipMemcpy(&f, fail, 4, hipMemcpyDeviceToHost));
     const char* names[5] = {"one launch per phase                          ", "resident grid, fenced barrier per phase       ",
-                            "resident grid, fenced barrier, ring runs ahead", "resident grid, relaxed barrier per phase      ",
-                            "resident grid, relaxed barrier, ring runs ahead"};
+                            "resident grid, fenced barrier, ring runs ahead", "resident grid, 2-level relaxed barrier         ",
+                            "resident grid, 2-level relaxed, ring runs ahead"};
     printf("mode %d %s: %.3f ms per step = %.2f TB/s of weights, %.1f us per layer%s\n", mode, names[mode], best, total / best / 1e9,
            best * 1e3 / plan.layers, f ? "  [a barrier TIMED OUT]" : "");
   }
