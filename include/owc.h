@@ -197,6 +197,10 @@ int owc_embed_tokens(owc_ctx* ctx, const int32_t* ids, const int32_t* img_index,
 /* greedy argmax over bf16 logits rows (lowest index on ties). */
 int owc_argmax_bf16(owc_ctx* ctx, const void* logits, int64_t ld, int rows, int vocab,
                     int32_t* out, void* stream);
+/* out[r] = log softmax(logits[r])[target[r]] in fp32 (0 where target[r] < 0): the per-token terms of HF's causal-LM loss,
+ * which LLaVA.loglikelihood averages (reference src/models/_llava_hf.py:243-245, outputs["loss"]). */
+int owc_token_logprob_bf16(owc_ctx* ctx, const void* logits, int64_t ld, const int32_t* target, int rows, int vocab, float* out,
+                           void* stream);
 
 /* uint8 [n,3,H,W] -> pixel_values rows [n * (H/14)*(W/14), 1176] bf16
  * (HF image_processing_qwen2_vl.py:164-246: rescale, normalise, duplicate frame, patchify). */
@@ -327,8 +331,11 @@ size_t owc_llm_workspace_bytes(const owc_llm_weights* w, int T, int n_seq);
  *   prefix is computed ONCE as segment n_seq-1 (tok_slot = -1 on its rows: the K/V rows are written to all slots
  *   [bcast_first_slot, +bcast_n_slots)), the other segments hold only the per-image suffixes.
  *   last_index: int32[n_out] = row of each prompt's last token (n_out = number of real prompts <= n_seq).
- * Writes the KV cache and next_tok[n_out] = argmax of the last position's logits.
- * `logits_out` (optional, [n_out, vocab] bf16) receives those logits. */
+ *   Scoring mode (n_out > n_seq, at most T): last_index names ANY n_out packed rows - the positions whose logits a
+ *   loglikelihood request needs (reference src/models/_llava_hf.py:243-252 reads outputs["logits"] of every position) - and the
+ *   last layer then runs on every row; the workspace must be sized with owc_llm_workspace_bytes(w, T, n_out).
+ * Writes the KV cache and next_tok[n_out] = argmax of those rows' logits.
+ * `logits_out` (optional, [n_out, vocab] bf16) receives the logits. */
 int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* cache,
                     const int32_t* ids, const int32_t* img_index, const void* img_embeds,
                     const int32_t* pos3, const int32_t* tok_slot, const int32_t* tok_idx,

@@ -16,7 +16,7 @@
 
 extern "C" {
 
-int owc_abi_version(void) { return 12; }
+int owc_abi_version(void) { return 13; }
 
 int owc_has_timing_knobs(void) {   // 1 only in libowc_hip_timing.so (tools/); the product library answers 0
 #ifdef OWC_TIMING_KNOBS
@@ -173,6 +173,12 @@ int owc_argmax_bf16(owc_ctx* ctx, const void* logits, int64_t ld, int rows, int 
                     void* stream) {
   if (!ctx || !logits || !out) return OWC_ERR_ARG;
   RET(ctx, "owc_argmax_bf16", owc_launch_argmax(logits, ld, rows, vocab, out, ST(stream)));
+}
+
+int owc_token_logprob_bf16(owc_ctx* ctx, const void* logits, int64_t ld, const int32_t* target, int rows, int vocab, float* out,
+                           void* stream) {
+  if (!ctx || !logits || !target || !out) return OWC_ERR_ARG;
+  RET(ctx, "owc_token_logprob_bf16", owc_launch_token_logprob(logits, ld, target, rows, vocab, out, ST(stream)));
 }
 
 int owc_patchify_u8(owc_ctx* ctx, const uint8_t* images, void* pixel_values, int64_t ld, int n, int H,

@@ -476,6 +476,35 @@ __global__ void seq_iota_kernel(int* __restrict__ start, int* __restrict__ len, 
   }
 }
 
+// log p(target | row) = logit[target] - logsumexp(row) in fp32 over bf16 logits (HF: CrossEntropyLoss on logits.float(), the
+// loss of LLaVA.loglikelihood, reference _llava_hf.py:243-245).  One block per row: max, then sum of exp(x - max) (ascending
+// chunks per thread, fixed tree across threads: deterministic).  target < 0 (an ignored label): 0.
+__global__ __launch_bounds__(256) void token_logprob_kernel(const bf16_t* __restrict__ logits, long ld, const int* __restrict__ target,
+                                                             int V, float* __restrict__ out) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const bf16_t* x = logits + (long)row * ld;
+  const int t = target[row];
+  if (t < 0 || t >= V) {
+    if (threadIdx.x == 0) out[row] = 0.f;
+    return;
+  }
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < V; i += 256) mx = fmaxf(mx, bf2f(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < V; i += 256) sum += __expf(bf2f(x[i]) - mx);
+  sum = wave_sum(sum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) out[row] = bf2f(x[t]) - mx - __logf((red[0] + red[1]) + (red[2] + red[3]));
+}
+
 }  // namespace
 
 int owc_launch_clip_patchify(const uint8_t* img, void* out, long ldo, int kpad, int n_img, int S,
@@ -586,6 +615,12 @@ int owc_launch_embed(const int* ids, const int* img_index, const void* table, co
   const long total = (long)T * (d / 8);
   hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ids,
                      img_index, (const bf16_t*)table, (const bf16_t*)img, (bf16_t*)out, T, d);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_token_logprob(const void* logits, long ld, const int* target, int rows, int V, float* out, hipStream_t st) {
+  if (rows <= 0 || V <= 0) return OWC_ERR_SHAPE;
+  hipLaunchKernelGGL(token_logprob_kernel, dim3(rows), dim3(256), 0, st, (const bf16_t*)logits, ld, target, V, out);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 

@@ -54,6 +54,7 @@ int owc_launch_mrope_kv(void* qkv, long ld, const int* pos3, long pos_stride, co
 int owc_launch_embed(const int* ids, const int* img_index, const void* table, const void* img,
                      void* out, int T, int d, hipStream_t st);
 int owc_launch_argmax(const void* logits, long ld, int rows, int V, int* out, hipStream_t st);
+int owc_launch_token_logprob(const void* logits, long ld, const int* target, int rows, int V, float* out, hipStream_t st);
 int owc_launch_decode_update(int* next_tok, uint8_t* done, int* out_tokens, int out_stride, int step,
                              const int* step_state, int B, int eos0, int eos1, int pad, hipStream_t st);
 int owc_launch_decode_advance(int* pos, int* widx, int* klen, int* step_state, int B, hipStream_t st);

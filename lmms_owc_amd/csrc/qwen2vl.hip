@@ -263,11 +263,13 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
   if (!ctx || !w || !cache || !ids || !pos3 || !tok_slot || !tok_idx || !seq_start || !seq_len ||
       !k_start || !last_index || !next_tok || !workspace)
     return OWC_ERR_ARG;
-  if (n_out <= 0 || n_out > n_seq) OWC_FAIL(ctx, OWC_ERR_ARG, "owc_llm_prefill: 0 < n_out <= n_seq");
+  if (n_out <= 0 || n_out > T) OWC_FAIL(ctx, OWC_ERR_ARG, "owc_llm_prefill: 0 < n_out <= T");
+  const bool scoring = n_out > n_seq;   // logits of arbitrary rows: no pruned last layer (its rows attend like last tokens)
+  const int n_rows = scoring ? n_out : n_seq;
   if (w->head_dim != 128) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_llm_prefill: head_dim must be 128");
   if (w->weight_dtype == OWC_WEIGHTS_FP8 && ((w->d_model % 128) || (w->d_ff % 128)))
     OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_llm_prefill: fp8 weights need d_model and d_ff to be multiples of 128");
-  if (ws_bytes < owc_llm_workspace_bytes(w, T, n_seq)) OWC_FAIL(ctx, OWC_ERR_WORKSPACE, "owc_llm_prefill: workspace too small");
+  if (ws_bytes < owc_llm_workspace_bytes(w, T, n_rows)) OWC_FAIL(ctx, OWC_ERR_WORKSPACE, "owc_llm_prefill: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int d = w->d_model;
   Carver cv(workspace, ws_bytes);
@@ -276,12 +278,12 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
   void* qkv = cv.take((size_t)T * (w->n_q_heads + 2 * w->n_kv_heads) * w->head_dim * 2);
   void* attn = cv.take((size_t)T * w->n_q_heads * w->head_dim * 2);
   void* mlp = cv.take((size_t)T * w->d_ff * 2);
-  void* xl = cv.take((size_t)n_seq * d * 2);
-  void* last = cv.take((size_t)n_seq * d * 2);
-  int32_t* idx3 = (int32_t*)cv.take((size_t)n_seq * 4);
-  cv.take((size_t)n_seq * 4);
-  cv.take((size_t)n_seq * 4);
-  void* logits = cv.take((size_t)n_seq * w->vocab * 2);
+  void* xl = cv.take((size_t)n_rows * d * 2);
+  void* last = cv.take((size_t)n_rows * d * 2);
+  int32_t* idx3 = (int32_t*)cv.take((size_t)n_rows * 4);
+  cv.take((size_t)n_rows * 4);
+  cv.take((size_t)n_rows * 4);
+  void* logits = cv.take((size_t)n_rows * w->vocab * 2);
   if (logits_out) logits = logits_out;
   void* q8 = nullptr;
   float* qs = nullptr;
@@ -294,10 +296,10 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
 
   OWC_TRY(owc_launch_embed(ids, img_index, w->embed, img_embeds, x, T, d, st));
   OWC_TRY(llm_layers(ctx, w, cache, x, h, qkv, attn, mlp, q8, qs, pos3, T, tok_slot, tok_idx, seq_start, nullptr,
-                     k_start, seq_len, q_len, n_seq, T, max_len, false, bcast_first_slot, bcast_n_slots, last_index, n_out, xl,
-                     idx3, st));
+                     k_start, seq_len, q_len, n_seq, T, max_len, false, bcast_first_slot, bcast_n_slots, scoring ? nullptr : last_index,
+                     n_out, xl, idx3, st));
   // final norm on the last token of every prompt only (the rows the last layer left in xl), then lm_head + greedy argmax
-  if (!g_prune_last) OWC_TRY(owc_launch_gather_rows(x, d, last_index, xl, d, n_out, d, st));
+  if (!g_prune_last || scoring) OWC_TRY(owc_launch_gather_rows(x, d, last_index, xl, d, n_out, d, st));
   OWC_TRY(owc_launch_rmsnorm(xl, d, w->final_norm_w, last, d, n_out, d, w->rms_eps, nullptr, st));
   OWC_TRY(owc_launch_gemm_bf16(last, d, w->lm_head_w, d, nullptr, nullptr, 0, logits, w->vocab, n_out,
                                w->vocab, d, OWC_EPI_NONE, ctx->zeros, st));

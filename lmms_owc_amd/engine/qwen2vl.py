@@ -548,6 +548,53 @@ class Qwen2VLEngine:
             return out_tokens, step_logits
         return (out_tokens, first_logits) if return_logits else out_tokens
 
+    def score(self, ids, img_embeds: torch.Tensor | None, grids: list, start: int, *, img_rows=None):
+        """Teacher-forced scoring of ONE token sequence (prompt + continuation) in a single prefill: the logits of the positions
+        start-1 .. S-1.  Returns (logprob float32 [S - start]: log p(ids[i] | ids[:i]) for i = start .. S-1, from the logits of
+        position i-1; argmax int32 [S - start]: argmax of the logits AT positions start .. S-1) - the two things a loglikelihood
+        request is made of (reference src/models/_llava_hf.py:236-252: HF's shifted cross-entropy and the reference's unshifted
+        greedy comparison)."""
+        d = self.d
+        ids = np.asarray(ids, dtype=np.int32)
+        S = len(ids)
+        if not 1 <= start <= S:
+            raise ValueError("score: need 1 <= start <= len(ids)")
+        kc = torch.empty(d.n_layers * d.n_kv_heads * S * d.head_dim, dtype=BF16, device=self.device)
+        vc = torch.empty_like(kc)
+        cache = _lib.KvCache(kc.data_ptr(), vc.data_ptr(), 1, S)
+        if grids:
+            p3, _ = positions.mrope_positions(ids, grids, d.image_token_id, d.merge)
+        else:
+            p3 = np.tile(np.arange(S, dtype=np.int32)[None], (3, 1))
+        if int(p3.max()) + 1 > d.max_positions:
+            raise ValueError("sequence exceeds the rope table (raise Qwen2VLDims.max_positions)")
+        is_img = ids == d.image_token_id
+        iidx = np.full(S, -1, dtype=np.int32)
+        n_img = int(is_img.sum())
+        rows = np.arange(n_img, dtype=np.int32) if img_rows is None else np.asarray(img_rows, dtype=np.int32)
+        if len(rows) != n_img or (n_img and (img_embeds is None or rows.min() < 0 or rows.max() >= img_embeds.shape[0])):
+            raise ValueError("image token count does not match the image feature rows")
+        iidx[is_img] = rows
+        want = np.arange(start - 1, S, dtype=np.int32)            # rows whose logits are needed
+        n_out = len(want)
+        t_ids, t_pos3, t_iidx = self._i32(ids), self._i32(p3), self._i32(iidx)
+        t_slot, t_idx = self._i32(np.zeros(S, np.int32)), self._i32(np.arange(S, dtype=np.int32))
+        t_start, t_len, t_kstart, t_want = self._i32([0]), self._i32([S]), self._i32([0]), self._i32(want)
+        logits = torch.empty((n_out, d.vocab), dtype=BF16, device=self.device)
+        top = torch.empty(n_out, dtype=I32, device=self.device)
+        ws = self._workspace(self._lib.owc_llm_workspace_bytes(C.byref(self.w.llm), S, max(n_out, 1)))
+        rc = self._lib.owc_llm_prefill(
+            self._ctx, C.byref(self.w.llm), C.byref(cache), t_ids.data_ptr(), t_iidx.data_ptr(), _lib.ptr(img_embeds),
+            t_pos3.data_ptr(), t_slot.data_ptr(), t_idx.data_ptr(), t_start.data_ptr(), t_len.data_ptr(), t_len.data_ptr(),
+            t_kstart.data_ptr(), t_want.data_ptr(), 1, n_out, S, S, 0, 1, top.data_ptr(), logits.data_ptr(), ws.data_ptr(),
+            ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, self.dev_index)
+        if n_out == 1:      # one row is the ordinary last-token prefill (n_out == n_seq): nothing to score
+            return np.zeros(0, np.float32), np.zeros(0, np.int32)
+        target = self._i32(np.concatenate([ids[start:], [-1]]).astype(np.int32))
+        lp = ops.token_logprob_bf16(logits, target)
+        return lp[:-1].cpu().numpy(), top[1:].cpu().numpy()
+
     def _common_prefix(self, prompts, b0: int, b1: int) -> int:
         """Length of the leading run of text tokens shared by every prompt of the chunk (system prompt, question
         preamble, <|vision_start|>): identical ids at identical positions give identical hidden states in every

@@ -32,6 +32,10 @@ _VICUNA_SYSTEM = ("A chat between a curious user and an artificial intelligence 
                   "detailed, and polite answers to the user's questions.")
 
 
+def _flatten(nested: list) -> list:
+    return [x for sub in nested for x in sub]
+
+
 def vicuna_prompt(messages: list[dict], eos_token: str = "</s>", add_generation_prompt: bool = True) -> str:
     """Text the reference's fallback chat template (`_llava_hf.py:23`) renders: system preamble before the first
     turn, `USER: ... ` / ` ASSISTANT: ...</s>` turns, and a trailing `ASSISTANT:` generation prompt."""
@@ -132,7 +136,30 @@ class LLaVA(Model):
         return cache[max_new_tokens]
 
     def loglikelihood(self, requests: list) -> list[tuple[float, bool]]:
-        raise NotImplementedError("loglikelihood is outside the accelerated path (SURVEY.md §8f: generation only)")
+        """(loss, greedy-match) per request, with the reference's semantics (src/models/_llava_hf.py:169-258): request args are
+        (context, doc_to_target | str, doc_to_visual, doc_id, task, split); `<image>` tokens are ALWAYS prepended (:204-206);
+        prompt = template(user turn, generation prompt), prompt + continuation = template(user, assistant) without one (:213-227);
+        the labels mask is the length of the prompt tokenised WITHOUT image expansion (:231-232: expanded image positions and the
+        rest of the prompt stay in the loss), loss = HF's mean shifted cross-entropy, and the greedy flag compares the UNSHIFTED
+        argmax with the ids (:246-251).  One prefill per request (owc_llm_prefill's scoring mode), batch size 1 like the reference."""
+        res = []
+        eng, tok = self._model, self._tokenizer
+        for context, doc_to_target, doc_to_visual, doc_id, task, split in [r.args for r in requests]:
+            doc = self.task_dict[task][split][doc_id]
+            continuation = doc_to_target if isinstance(doc_to_target, str) else doc_to_target(doc)
+            visuals = _flatten([doc_to_visual(doc)])
+            context = f"{' '.join([DEFAULT_IMAGE_TOKEN] * len(visuals))}\n{context}"
+            messages = [{"role": "user", "content": context}, {"role": "assistant", "content": continuation}]
+            prompt = self._render_messages(messages[:-1], True)
+            full = self._render_messages(messages, False)
+            feats, rows = self._encode_visuals(visuals)
+            ids = self._expand(tok.encode(full, add_special_tokens=True), [len(r) for r in rows])
+            n_ctx = len(tok.encode(prompt, add_special_tokens=True))
+            if not 1 <= n_ctx < len(ids):
+                raise ValueError("loglikelihood: empty continuation")
+            lp, top = eng.score(ids, feats, [], n_ctx, img_rows=np.concatenate(rows) if rows else np.zeros(0, np.int64))
+            res.append((float(-np.mean(lp, dtype=np.float64)), bool(np.array_equal(top, ids[n_ctx:]))))
+        return res
 
     def generate_until_multi_round(self, requests: list) -> list[tuple]:
         """Multi-round generation (/root/reference/src/models/_llava_hf.py:394-584; the `*_llamav_o1` task configs).  As the
@@ -188,23 +215,27 @@ class LLaVA(Model):
 
     # ------------------------------------------------------------------ prompt building
     def _render(self, context: str) -> str:
+        return self._render_messages([{"role": "user", "content": context}], True)
+
+    def _render_messages(self, messages: list[dict], add_generation_prompt: bool) -> str:
         tok = self._tokenizer
-        messages = [{"role": "user", "content": context}]
         template = self._chat_template if self._chat_template is not None else getattr(tok, "chat_template", None)
         if template is None:
-            return vicuna_prompt(messages, getattr(tok, "eos_token", "</s>") or "</s>")
+            return vicuna_prompt(messages, getattr(tok, "eos_token", "</s>") or "</s>", add_generation_prompt)
         if isinstance(tok, ByteTokenizer):
             from jinja2.sandbox import ImmutableSandboxedEnvironment
 
             env = ImmutableSandboxedEnvironment(trim_blocks=True, lstrip_blocks=True)
-            return env.from_string(template).render(messages=messages, add_generation_prompt=True, eos_token=tok.eos_token)
+            return env.from_string(template).render(messages=messages, add_generation_prompt=add_generation_prompt, eos_token=tok.eos_token)
         tok.chat_template = template
-        return tok.apply_chat_template(messages, tokenize=False, add_generation_prompt=True)
+        return tok.apply_chat_template(messages, tokenize=False, add_generation_prompt=add_generation_prompt)
 
     def _prompt_ids(self, context: str, n_image_tokens: list[int]) -> np.ndarray:
         """Rendered prompt -> ids with every `<image>` placeholder expanded to that image's feature count
         (what LlavaProcessor / LlavaNextProcessor do on the text before tokenising)."""
-        ids = self._tokenizer.encode(self._render(context), add_special_tokens=True)
+        return self._expand(self._tokenizer.encode(self._render(context), add_special_tokens=True), n_image_tokens)
+
+    def _expand(self, ids, n_image_tokens: list[int]) -> np.ndarray:
         out, it = [], iter(n_image_tokens)
         for t in ids:
             if t == self._dims.image_token_id:
@@ -240,10 +271,9 @@ class LLaVA(Model):
     def decode_tokens(self, rows: list) -> list[str]:
         return self._tokenizer.batch_decode([np.asarray(r) for r in rows], skip_special_tokens=True)
 
-    def _generate_chunk(self, contexts, visuals_per_doc, max_new: int, feature_cache: dict | None = None) -> list[np.ndarray]:
-        """One engine pass: single-turn prompts (context + that document's images) -> greedy token rows cut at EOS."""
-        eng, tok = self._model, self._tokenizer
-        flat = [v for vs in visuals_per_doc for v in vs]
+    def _encode_visuals(self, flat: list, feature_cache: dict | None = None):
+        """Images -> (projected CLIP feature rows of all their views, the feature-row list of every image in prompt order)."""
+        eng = self._model
         if feature_cache is None:
             prepared = list(self._pool.map(self._views, flat))  # PIL resampling releases the GIL
         else:
@@ -258,6 +288,12 @@ class LLaVA(Model):
             u8 = _lib.h2d(np.concatenate([p[0] for p in prepared]), self._device)
             feats = eng.encode_views(eng.patchify(u8, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD))
             rows = eng.feature_rows(views_per_image, sizes)
+        return feats, rows
+
+    def _generate_chunk(self, contexts, visuals_per_doc, max_new: int, feature_cache: dict | None = None) -> list[np.ndarray]:
+        """One engine pass: single-turn prompts (context + that document's images) -> greedy token rows cut at EOS."""
+        eng, tok = self._model, self._tokenizer
+        feats, rows = self._encode_visuals([v for vs in visuals_per_doc for v in vs], feature_cache)
         prompts, rows_per_prompt, cur = [], [], 0
         for ctx, visuals in zip(contexts, visuals_per_doc):
             mine = rows[cur:cur + len(visuals)]

@@ -168,6 +168,14 @@ def argmax_bf16(logits):
     return out
 
 
+def token_logprob_bf16(logits, target):
+    """log softmax(logits[r])[target[r]] (fp32; 0 where target[r] < 0) for bf16 logits [rows, vocab], int32 targets [rows]."""
+    out = torch.empty((logits.shape[0],), dtype=torch.float32, device=logits.device)
+    _call("owc_token_logprob_bf16", _dev(logits), logits.data_ptr(), logits.stride(0), target.data_ptr(), logits.shape[0],
+          logits.shape[1], out.data_ptr())
+    return out
+
+
 def patchify_u8(images, mean, std, out=None):
     """uint8 [n,3,H,W] (H, W multiples of 28) -> pixel_values [n*(H/14)*(W/14), 1176] bf16."""
     assert images.dtype == torch.uint8 and images.dim() == 4 and images.is_contiguous()

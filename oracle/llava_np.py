@@ -115,13 +115,9 @@ def pack_anyres(w: dict, cfg: LlavaCfg, feats: np.ndarray, image_size) -> np.nda
     return np.concatenate([feats[0], canvas.reshape(-1, d)], 0)
 
 
-def generate(w: dict, cfg: LlavaCfg, input_ids: np.ndarray, pixel_values: np.ndarray | None, max_new_tokens: int, *,
-             bf16=False, eos_token_id: int | None = None, pad_token_id: int = 0, return_logits=False,
-             image_sizes=None, views_per_image=None, forced_tokens=None):
-    """Greedy generation for ONE prompt whose <image> placeholders are already expanded to one id per feature row.
-    `forced_tokens`: teacher forcing - the token fed after step j is forced_tokens[j]; `out` still holds the argmax.
-    LLaVA-NeXT: pixel_values holds all views of all images, `views_per_image` / `image_sizes` (h, w) split them."""
-    qcfg = Q.Cfg(text=cfg.text, image_token_id=cfg.image_token_id)
+def _embed(w: dict, cfg: LlavaCfg, input_ids, pixel_values, bf16, image_sizes, views_per_image):
+    """inputs_embeds of one prompt: token embeddings with the image-token rows replaced by the projected (LLaVA-NeXT: packed)
+    CLIP features (HF modeling_llava.py LlavaModel.forward)."""
     ids = np.asarray(input_ids).astype(np.int64)
     x = maybe_bf16(w[Q.T + "embed_tokens.weight"][ids], bf16)
     if pixel_values is not None:
@@ -133,6 +129,38 @@ def generate(w: dict, cfg: LlavaCfg, input_ids: np.ndarray, pixel_values: np.nda
                 v0 += nv
             feats = maybe_bf16(np.concatenate(packed, 0), bf16)
         x[ids == cfg.image_token_id] = feats.reshape(-1, feats.shape[-1])
+    return ids, x
+
+
+def loglikelihood(w: dict, cfg: LlavaCfg, input_ids: np.ndarray, pixel_values: np.ndarray | None, n_ctx: int, *, bf16=False,
+                  image_sizes=None, views_per_image=None, return_logits=False):
+    """The reference's LLaVA.loglikelihood arithmetic for ONE request (src/models/_llava_hf.py:229-252): `input_ids` is prompt +
+    continuation with the image placeholders expanded, `n_ctx` the length of the prompt tokenised WITHOUT the expansion - the
+    reference masks labels[:, :n_ctx] only (:232), so expanded image positions and the rest of the prompt stay in the loss.
+    loss = HF's causal-LM loss: mean over i in [n_ctx, S) of -log softmax(logits[i - 1])[ids[i]] on fp32-upcast logits;
+    max_equal = all(argmax(logits[i]) == ids[i] for i in [n_ctx, S)) - the UNSHIFTED comparison the reference makes (:246-251).
+    Returns (loss, max_equal[, logits of positions n_ctx-1 .. S-1])."""
+    qcfg = Q.Cfg(text=cfg.text, image_token_id=cfg.image_token_id)
+    ids, x = _embed(w, cfg, input_ids, pixel_values, bf16, image_sizes, views_per_image)
+    S = len(ids)
+    pos3 = np.tile(np.arange(S)[None], (3, 1))
+    h = Q.llm_forward(w, qcfg, x, pos3, Q.KVCache(cfg.text.num_hidden_layers), bf16=bf16)
+    logits = Q.lm_head(w, qcfg, h[n_ctx - 1:], bf16=bf16).astype(np.float32)      # rows n_ctx-1 .. S-1
+    z = logits[:-1] - logits[:-1].max(-1, keepdims=True)
+    logp = z - np.log(np.exp(z).sum(-1, keepdims=True))
+    loss = float(-logp[np.arange(S - n_ctx), ids[n_ctx:]].mean())
+    max_equal = bool((Q.greedy_argmax(logits[1:]) == ids[n_ctx:]).all())
+    return (loss, max_equal, logits) if return_logits else (loss, max_equal)
+
+
+def generate(w: dict, cfg: LlavaCfg, input_ids: np.ndarray, pixel_values: np.ndarray | None, max_new_tokens: int, *,
+             bf16=False, eos_token_id: int | None = None, pad_token_id: int = 0, return_logits=False,
+             image_sizes=None, views_per_image=None, forced_tokens=None):
+    """Greedy generation for ONE prompt whose <image> placeholders are already expanded to one id per feature row.
+    `forced_tokens`: teacher forcing - the token fed after step j is forced_tokens[j]; `out` still holds the argmax.
+    LLaVA-NeXT: pixel_values holds all views of all images, `views_per_image` / `image_sizes` (h, w) split them."""
+    qcfg = Q.Cfg(text=cfg.text, image_token_id=cfg.image_token_id)
+    ids, x = _embed(w, cfg, input_ids, pixel_values, bf16, image_sizes, views_per_image)
     pos3 = np.tile(np.arange(len(ids))[None], (3, 1))
     cache = Q.KVCache(cfg.text.num_hidden_layers)
     h = Q.llm_forward(w, qcfg, x, pos3, cache, bf16=bf16)

@@ -101,6 +101,36 @@ def test_batched_equals_single(setup, gpu):
     assert t.shape == (1, 3)
 
 
+def test_score_matches_oracle_and_hf_loglikelihood(setup, gpu):
+    """LLaVA.loglikelihood's arithmetic (reference _llava_hf.py:229-252) through owc_llm_prefill's scoring mode (logits of every
+    position from n_ctx - 1 on) + owc_token_logprob_bf16: loss and unshifted greedy tokens against the numpy oracle and the values
+    HF's own model returned (tests/golden/llava_loglik_tiny.npz).  Bounds: the per-token log-probabilities within 2 % of
+    max |logit| of the oracle's (the logit bound: a log-softmax moves by at most twice the logit error), the loss - a mean of 21
+    such terms - within 1 % of HF's bf16 AND fp32 values (HF's own bf16-vs-fp32 gap on this case: 0.03 %)."""
+    cfg, w, eng, _ = setup
+    g = np.load(GOLD / "llava_loglik_tiny.npz")
+    ids, n_ctx, pix = g["ids"], int(g["n_ctx"]), g["pix"]
+    rows = np.concatenate(eng.feature_rows([1]))
+    lp, top = eng.score(ids, _feats(eng, pix, gpu), [], n_ctx, img_rows=rows)
+    assert lp.shape == (len(ids) - n_ctx,) and top.shape == lp.shape
+    o_loss, o_eq, o_logits = L.loglikelihood(w, cfg, ids, pix, n_ctx, bf16=True, return_logits=True)
+    z = o_logits[:-1] - o_logits[:-1].max(-1, keepdims=True)
+    o_lp = (z - np.log(np.exp(z).sum(-1, keepdims=True)))[np.arange(len(lp)), ids[n_ctx:]]
+    assert np.abs(lp - o_lp).max() <= 2 * 0.02 * np.abs(o_logits).max(), np.abs(lp - o_lp).max()
+    loss = float(-lp.mean())
+    print(f"[loglik] HIP loss {loss:.5f}  oracle-bf16 {o_loss:.5f}  HF bf16 {float(g['bf16_loss']):.5f}  HF f32 {float(g['f32_loss']):.5f}")
+    for ref in (o_loss, float(g["bf16_loss"]), float(g["f32_loss"])):
+        assert abs(loss - ref) <= 0.01 * ref, (loss, ref)
+    # greedy tokens at the scored positions: equal to HF's wherever HF's top-2 margin is decisive (> 6 % of max |logit|)
+    ref = g["f32_logits"][1:]
+    sure = np.array([np.sort(r)[-1] - np.sort(r)[-2] > 0.06 * np.abs(r).max() for r in ref])
+    assert sure.sum() >= 1 and np.array_equal(top[sure], g["f32_greedy"][sure]), (top, g["f32_greedy"], sure)
+    assert bool((top == ids[n_ctx:]).all()) == bool(g["f32_max_equal"])
+    # scoring leaves the ordinary path alone: start == len(ids) scores nothing
+    lp0, top0 = eng.score(ids, _feats(eng, pix, gpu), [], len(ids), img_rows=rows)
+    assert lp0.size == 0 and top0.size == 0
+
+
 def test_clip_patchify_u8_matches_numpy(setup, gpu):
     cfg, w, eng, g = setup
     gen = torch.Generator().manual_seed(0)

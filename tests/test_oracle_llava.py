@@ -73,3 +73,30 @@ def test_next_generate_bf16_matches_hf():
                               views_per_image=g["views"].tolist())
     assert toks.tolist() == g["bf16_tokens"].tolist()
     assert np.abs(logits - g["bf16_logits"]).max() <= 0.05 * np.abs(g["bf16_logits"]).max()
+
+
+def test_loglikelihood_matches_hf_with_the_references_label_mask():
+    """The reference's LLaVA.loglikelihood (src/models/_llava_hf.py:229-252) on HF's own model (tools/gen_golden.py
+    gen_llava_loglik): the loss over every position from the UN-expanded prompt length on (image positions included) and the
+    unshifted greedy comparison."""
+    g = np.load(GOLDEN / "llava_loglik_tiny.npz")
+    cfg = recipes.tiny_llava_cfg()
+    w = recipes.llava_weights(cfg, 1234)
+    n_ctx = int(g["n_ctx"])
+    loss, eq, logits = L.loglikelihood(w, cfg, g["ids"], g["pix"], n_ctx, return_logits=True)
+    assert abs(loss - float(g["f32_loss"])) <= 1e-5 and eq == bool(g["f32_max_equal"])
+    np.testing.assert_allclose(logits, g["f32_logits"], rtol=3e-4, atol=3e-4)
+    assert np.argmax(logits[1:], -1).tolist() == g["f32_greedy"].tolist()
+    loss16, eq16 = L.loglikelihood(w, cfg, g["ids"], g["pix"], n_ctx, bf16=True)
+    assert abs(loss16 - float(g["bf16_loss"])) <= 2e-3 * float(g["bf16_loss"]) and eq16 == bool(g["bf16_max_equal"])
+    # the flag's True branch, text only (with an image the scored range holds image-token positions, whose greedy token would have
+    # to be the image token itself): iterate ids[n:] <- argmax(logits[n:]) to a fixed point of the unshifted comparison
+    ids = np.random.default_rng(3).integers(1, 400, 14)
+    for _ in range(12):
+        _, eq, lg = L.loglikelihood(w, cfg, ids, None, 8, return_logits=True)
+        new = np.argmax(lg[1:], -1)
+        if np.array_equal(new, ids[8:]):
+            assert eq is True
+            break
+        assert eq is False
+        ids[8:] = new

@@ -281,6 +281,33 @@ def test_llava_real_checkpoint_loading_path(gpu, tmp_path, nxt):
     direct = lm.tokenizer.batch_decode([toks[: stop[0]] if len(stop) else toks], skip_special_tokens=True)[0]
     assert lm.generate_until([task.instances[0]])[0] == direct
 
+    # LLaVA.loglikelihood (reference _llava_hf.py:169-258) on the same checkpoint: (loss, greedy flag) per request, against the numpy
+    # oracle fed with the ids the reference's recipe yields (always-prepended <image>, Vicuna fallback template, labels masked up
+    # to the UN-expanded prompt length); a str target and a callable target
+    from lmms_owc_amd.models._llava_hf import vicuna_prompt
+    from lmms_owc_amd.tasks import TaskInstance
+    from oracle import llava_np
+
+    name, split = task.task_name, task.instances[0].args[5]
+    reqs = [TaskInstance("loglikelihood", (ctx, " a sea lion", task.instances[0].args[2], 0, name, split), 0),
+            TaskInstance("loglikelihood", (ctx, lambda doc: " " + str(doc["target"]), task.instances[1].args[2], 1, name, split), 1)]
+    got = lm.loglikelihood(reqs)
+    assert len(got) == 2 and all(isinstance(l, float) and isinstance(e, bool) for l, e in got)
+    cont = [" a sea lion", " " + str(task.docs[1]["target"])]
+    for i, (loss, eq) in enumerate(got):
+        msgs = [{"role": "user", "content": f"<image>\n{ctx}"}, {"role": "assistant", "content": cont[i]}]
+        n_ctx = len(lm.tokenizer.encode(vicuna_prompt(msgs[:1], "</s>", True), add_special_tokens=True))
+        v_i, size_i = lm._views(task.docs[i]["visual"])
+        rows_i = eng.feature_rows([v_i.shape[0]], [size_i])[0]
+        ids_i = lm._expand(lm.tokenizer.encode(vicuna_prompt(msgs, "</s>", False), add_special_tokens=True), [len(rows_i)])
+        assert ids_i[0] == 1 and 1 <= n_ctx < len(ids_i) and (ids_i == info["image_token"]).sum() == len(rows_i)
+        pix = (v_i.astype(np.float32) / 255.0 - np.array(imageproc.OPENAI_CLIP_MEAN, np.float32)[None, :, None, None]) \
+            / np.array(imageproc.OPENAI_CLIP_STD, np.float32)[None, :, None, None]
+        kw = {"image_sizes": [size_i], "views_per_image": [v_i.shape[0]]} if nxt else {}
+        o_loss, o_eq = llava_np.loglikelihood(info["weights"], info["cfg"], ids_i, pix, n_ctx, bf16=True, **kw)
+        print(f"[loglik plugin] request {i}: HIP loss {loss:.5f} oracle {o_loss:.5f} flags {eq} {o_eq}")
+        assert abs(loss - o_loss) <= 0.01 * o_loss and eq == o_eq, (i, loss, o_loss, eq, o_eq)
+
 
 class IdTokenizer:
     """A text is a string of space-separated token ids (what tools/gen_golden.py fed the reference's scorer)."""

@@ -565,6 +565,55 @@ PROMPT_CASES = [
 ]
 
 
+def gen_llava_loglik():
+    """The arithmetic of the reference's LLaVA.loglikelihood (/root/reference/src/models/_llava_hf.py:229-252) run on HF's tiny LLaVA:
+    labels = input_ids with the first `n_ctx` positions masked (n_ctx = length of the prompt tokenised WITHOUT image expansion, so
+    image positions stay in the loss), outputs = model(**inputs, labels=labels) -> loss, and the UNSHIFTED comparison
+    argmax(logits)[n_ctx:] == input_ids[n_ctx:]."""
+    from transformers import CLIPVisionConfig, LlamaConfig, LlavaConfig, LlavaForConditionalGeneration
+
+    cfg = recipes.tiny_llava_cfg()
+    w = recipes.llava_weights(cfg, 1234)
+    v, t = cfg.vision, cfg.text
+    hcfg = LlavaConfig(
+        vision_config=CLIPVisionConfig(hidden_size=v.hidden_size, intermediate_size=v.intermediate_size,
+                                       num_hidden_layers=v.num_hidden_layers, num_attention_heads=v.num_attention_heads,
+                                       image_size=v.image_size, patch_size=v.patch_size, hidden_act="quick_gelu",
+                                       layer_norm_eps=v.layer_norm_eps, projection_dim=64),
+        text_config=LlamaConfig(hidden_size=t.hidden_size, intermediate_size=t.intermediate_size, num_hidden_layers=t.num_hidden_layers,
+                                num_attention_heads=t.num_attention_heads, num_key_value_heads=t.num_key_value_heads,
+                                vocab_size=t.vocab_size, rms_norm_eps=t.rms_norm_eps, max_position_embeddings=1024,
+                                rope_theta=t.rope_theta, tie_word_embeddings=False),
+        image_token_id=cfg.image_token_id, vision_feature_layer=cfg.vision_feature_layer,
+        vision_feature_select_strategy="default", projector_hidden_act="gelu", image_seq_length=16)
+    hcfg._attn_implementation = "eager"
+    r = np.random.default_rng(23)
+    pix = recipes.clip_pixels(1, v.image_size)
+    head, tail, cont = r.integers(1, 400, 5), r.integers(1, 400, 9), r.integers(1, 400, 6)
+    ids = np.concatenate([head, np.full(16, cfg.image_token_id), tail, cont]).astype(np.int64)
+    n_ctx = len(head) + 1 + len(tail)          # the un-expanded prompt: one <image> token
+    out = {"ids": ids, "n_ctx": np.array(n_ctx), "pix": pix}
+    for dtype, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        m = LlavaForConditionalGeneration(hcfg)
+        missing, unexpected = m.load_state_dict({k: torch.from_numpy(a.copy()) for k, a in w.items()}, strict=False)
+        assert not unexpected and all("post_layernorm" in k or "position_ids" in k for k in missing), (missing, unexpected)
+        m = m.to(dtype).eval()
+        inp = torch.from_numpy(ids)[None]
+        labels = inp.clone()
+        labels[:, :n_ctx] = -100
+        with torch.inference_mode():
+            o = m(input_ids=inp, attention_mask=torch.ones_like(inp), pixel_values=torch.from_numpy(pix).to(dtype), labels=labels)
+        greedy = o["logits"].argmax(dim=-1)[:, n_ctx:inp.shape[1]]
+        out[f"{tag}_loss"] = np.array(float(o["loss"].item()))
+        out[f"{tag}_greedy"] = greedy[0].numpy()
+        out[f"{tag}_max_equal"] = np.array(bool((greedy == inp[:, n_ctx:]).all()))
+        out[f"{tag}_logits"] = o["logits"][0, n_ctx - 1:].float().numpy()
+    np.savez_compressed(GOLD / "llava_loglik_tiny.npz", **out)
+    (GOLD / "llava_loglik_tiny.json").write_text(json.dumps({"versions": versions(), "weights_seed": 1234,
+                                                             "source": "_llava_hf.py:229-252 on HF LlavaForConditionalGeneration"}, indent=1))
+    print("llava loglik golden:", {k: (v.shape if v.ndim else v.item()) for k, v in out.items()})
+
+
 def gen_llava_prompt():
     """Text the reference's fallback chat template renders (the template string is read from the reference at
     generation time, /root/reference/src/models/_llava_hf.py:23, and rendered the way HF apply_chat_template does)."""
@@ -617,6 +666,8 @@ if __name__ == "__main__":
         gen_ranking()
     if "llava_prompt" in which:
         gen_llava_prompt()
+    if "llava_loglik" in which:
+        gen_llava_loglik()
     if "llava_image" in which:
         gen_llava_image()
     if "llava_next" in which:
