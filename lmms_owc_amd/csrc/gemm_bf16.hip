@@ -49,6 +49,8 @@ int g_skinny_max_m = 32;   // M at and below which the weight-streaming skinny k
 int g_mid_max_tiles = 256;  // fewer 128x128 tiles than this -> 64x64 tiles (0 disables: A-B knob "gemm_mid_max_tiles")
 int g_big_min_tiles = 144;  // fewer 256x256 tiles than this -> use the 128x128 kernel (measured: 160-162 tiles 256x256 +24...40 %, 126 tiles -3...8 %; knob "gemm_big_min_tiles")
 int g_small_tiles = 1;    // 64x64-tile kernel: also 32x64 / 64x32 / 32x32 tiles where they shorten the launch (knob "gemm_small_tiles": 0 off, 2 / 3 / 4 force 64x64 / 64x32 / 32x32)
+int g_tall_tiles = 1;     // 64x160 / 128x160 tiles of the ring kernel for launches of <= 128 rows x many columns (knob "gemm_wide_tiles")
+int g_tall_tiles_max_m = 128;
 int g_skinny_deep = 1;    // the skinny kernel's 9-deep ring for long-K launches of at most one wave per CU (knob "gemm_skinny_deep")
 int g_norm_fuse_max_m = 2; // rows up to which the decoder's RMSNorm is fused into the qkv / gate-up skinny GEMM (knob "decode_norm_fuse", 0 = off, at most 4).
                            // Measured, 7B decode step in ms, separate / fused: 1 row 3.78 / 3.44, 2 rows 3.78 / 3.65, 4 rows 3.88 / 4.11 - every wave
@@ -214,7 +216,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
   constexpr int STAGE = (TM + TN) * 128;      // bytes per stage
   constexpr int NPA = TM / 8, NPT = (TM + TN) / 8, NPW = NPT / 4;   // 1-KiB DMA pieces: of A, in all, per wave (2, 3 or 4)
   constexpr int NTW = TN / 16;                // n tiles of an active wave (4 or 2)
-  static_assert(EPI != OWC_EPI_SWIGLU || TN == 64, "the SwiGLU epilogue pairs two gate/up tile pairs");
+  constexpr int MTW = TM > 64 ? TM / 64 : 1;  // m tiles of a wave: TM = 128 gives every wave 32 rows (two tiles)
+  static_assert(TN % 32 == 0 && (TM + TN) % 32 == 0, "whole tile pairs; the DMA pieces of a stage divide over four waves");
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
@@ -271,13 +274,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
   };
   const int fr = l & 15, fq = l >> 4;
   const int swz = (fr >> 1) & 7;
-  const bool active = w < TM / 16;   // wave w: m tile w (waves 2-3 of a 32-row tile only stage)
-  const int offA0 = (w * 16 + fr) * 128 + (((0 + fq) ^ swz) << 4), offA1 = (w * 16 + fr) * 128 + (((4 + fq) ^ swz) << 4);
+  const bool active = w * 16 * MTW < TM;   // wave w: rows [16 MTW w, +16 MTW) (waves 2-3 of a 32-row tile only stage)
+  const int offA0 = (w * 16 * MTW + fr) * 128 + (((0 + fq) ^ swz) << 4), offA1 = (w * 16 * MTW + fr) * 128 + (((4 + fq) ^ swz) << 4);
   const int offW0 = TM * 128 + fr * 128 + (((0 + fq) ^ swz) << 4), offW1 = TM * 128 + fr * 128 + (((4 + fq) ^ swz) << 4);
 
-  f32x4 acc[4][1];
+  f32x4 acc[NTW < 4 ? 4 : NTW][MTW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < (NTW < 4 ? 4 : NTW); ++i)
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // (Round 3 measured a software-pipelined form of this loop - next k-step's fragments read under the current MFMAs, hand-counted
   // lgkmcnt, one tile more look-ahead - and an 8-stage ring: both +-0 on every decode shape.  The simple form stays.)
 #pragma unroll
@@ -294,17 +299,32 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
       const char* la = lds + (kt % NS64) * STAGE;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 fa = *(const bf16x8*)(la + (ks ? offA1 : offA0));
-        bf16x8 fw[NTW];
+        bf16x8 fa[MTW], fw[NTW];
+#pragma unroll
+        for (int t = 0; t < MTW; ++t) fa[t] = *(const bf16x8*)(la + (ks ? offA1 : offA0) + t * 16 * 128);
 #pragma unroll
         for (int t = 0; t < NTW; ++t) fw[t] = *(const bf16x8*)(la + (ks ? offW1 : offW0) + t * 16 * 128);
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa, acc[nt][0], 0, 0, 0);
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
       }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued zero-page pieces, before the block's LDS goes away
-  if (active) gemm_epilogue<EPI, 1, false, NTW / 2>(acc, m0 + w * 16, n0, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
+  if (active) {
+    if constexpr (NTW <= 4) {
+      gemm_epilogue<EPI, MTW, false, NTW / 2>(*(const f32x4(*)[4][MTW])&acc[0], m0 + w * 16 * MTW, n0, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
+    } else {   // a wide tile: the shared epilogue on groups of four n tiles (two tile pairs), a single pair at the end
+#pragma unroll
+      for (int g = 0; g < NTW / 4; ++g)
+        gemm_epilogue<EPI, MTW, false, 2>(*(const f32x4(*)[4][MTW])&acc[4 * g], m0 + w * 16 * MTW, n0 + 64 * g, fr, fq, bias, R, ldr, Cv, ldc,
+                                          M, N, aux);
+      if constexpr (NTW % 4 != 0)
+        gemm_epilogue<EPI, MTW, false, 1>(*(const f32x4(*)[4][MTW])&acc[NTW - 2], m0 + w * 16 * MTW, n0 + 16 * (NTW - 2), fr, fq, bias, R, ldr,
+                                          Cv, ldc, M, N, aux);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -978,6 +998,9 @@ bool launch_skinny(const void* A, long lda, const void* W, long ldw, const void*
     constexpr int ROWS = EPI == OWC_EPI_SWIGLU ? 32 : 16;
     if (M > 64 || (K & 127) || (N % ROWS) || g_skinny_max_m < M) return false;
     if (EPI == OWC_EPI_SWIGLU && bias != nullptr) return false;   // the gated vision MLP's biases: the tiled kernels' epilogue adds them
+    // more 16-row waves than CUs and more than one m tile each (the 7B qkv projection, N = 4608, at M = 17-32): the ring
+    // kernel's 32x32 tiles are faster (23.7 -> 15.5 us at M = 32; equal at M = 16)
+    if (EPI != OWC_EPI_SWIGLU && M > 16 && N / ROWS > 256 && (K % BK) == 0 && g_small_tiles && K <= 4096) return false;
     const dim3 grid(N / ROWS), block(64);
 #define OWC_SK(MT_, D_)                                                                                               \
   hipLaunchKernelGGL((gemm_bf16_skinny_kernel<EPI, MT_, D_>), grid, block, 0, s, (const bf16_t*)A, lda, (const bf16_t*)W, \
@@ -1032,7 +1055,10 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
     attr_set = true;
   }
   const int prof = owc_gemm_profile_begin(2.0 * (double)M * (double)N * (double)K, 0, s);
-  if (launch_skinny<EPI>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, s)) {
+  // (the wide ring tiles below beat the skinny kernel on their shapes at every M: 48.5 us against 53.9 ... 70.1 us at M = 1 ... 32)
+  const bool wide = g_tall_tiles && (K % BK) == 0 && (EPI == OWC_EPI_NONE || EPI == OWC_EPI_SWIGLU) && M <= 128 &&
+                    (N + 159) / 160 <= 256 && (N + 159) / 160 >= 128;
+  if (!wide && launch_skinny<EPI>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, s)) {
     owc_gemm_profile_end(prof, s);
     return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
   }
@@ -1049,7 +1075,7 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
     hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), 2 * STAGE_BYTES, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
                        (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, g_gemm_dbg, aux);
-  else if (g_mid_max_tiles > 0 && tiles_m * tiles_n < g_mid_max_tiles) {  // too few 128x128 tiles for 256 CUs: 64x64 tiles
+  else if (!wide && g_mid_max_tiles > 0 && tiles_m * tiles_n < g_mid_max_tiles) {  // too few 128x128 tiles for 256 CUs: 64x64 tiles
     const int tm64 = (M + B64 - 1) / B64, tn64 = (N + B64 - 1) / B64;
 #define OWC_L64(NS_, KT_, TM_, TN_)                                                                                        \
   do {                                                                                                                     \
@@ -1090,6 +1116,32 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
       if (shape == 2) OWC_L64(8, false, 32, 32);
     }
 #undef OWC_L64
+  } else if (wide) {
+    // At most 128 rows x tens of thousands of columns (the 7B gate/up projection of a decode step up to batch 128): a weight stream in which
+    // every block ALSO re-reads the whole A (M x K) out of L2, and what a CU can ingest (A + W, ~40-58 GB/s with misses in the
+    // mix) is the bound - so the tile is as WIDE as it can be while the launch still fills the chip in one round: 160 columns
+    // (N = 37888: 237 blocks; per CU 0.9 MB of A + 1.15 MB of W instead of 2.3 x (0.9 + 0.46) with 128x64 / 128x128 tiles),
+    // four 28 / 36-KiB stages.  (Measured first: 128x64 tiles with three stages - more bytes in flight, same bytes per CU - were
+    // 4 % SLOWER than the 128x128 kernel.)
+    constexpr int NS_ = 4, TN_ = 160;
+#define OWC_LWIDE(TM_)                                                                                                      \
+  do {                                                                                                                      \
+    constexpr int lds_ = NS_ * (TM_ + TN_) * 128;                                                                           \
+    static bool set_ = false;                                                                                               \
+    if (!set_) {                                                                                                            \
+      if (hipFuncSetAttribute((const void*)gemm_bf16_nt_64_kernel<EPI, NS_, false, TM_, TN_>,                              \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) return OWC_ERR_HIP;          \
+      set_ = true;                                                                                                          \
+    }                                                                                                                       \
+    const int tm_ = (M + TM_ - 1) / TM_, tn_ = (N + TN_ - 1) / TN_;                                                         \
+    hipLaunchKernelGGL((gemm_bf16_nt_64_kernel<EPI, NS_, false, TM_, TN_>), dim3(tm_ * tn_), dim3(256), lds_, s,            \
+                       (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C, ldc, M, \
+                       N, K, zeros, tm_, tn_, aux);                                                                         \
+  } while (0)
+    if constexpr (EPI == OWC_EPI_NONE || EPI == OWC_EPI_SWIGLU) {
+      if (M <= 32) OWC_LWIDE(32); else if (M <= 64) OWC_LWIDE(64); else OWC_LWIDE(128);
+    }
+#undef OWC_LWIDE
   } else
   {
     if ((K % BK) != 0)
@@ -1237,4 +1289,5 @@ void owc_gemm_set_big_min_tiles(int v) { g_big_min_tiles = v < 0 ? 144 : v; }
 void owc_gemm_set_skinny_max_m(int v) { g_skinny_max_m = v < 0 ? 32 : v; }  // negative: back to the default
 void owc_gemm_set_pingpong(int v) { g_pingpong = v; }
 void owc_gemm_set_skinny_deep(int v) { g_skinny_deep = v; }
+void owc_gemm_set_tall_tiles(int v) { g_tall_tiles = v != 0; g_tall_tiles_max_m = 128; }
 void owc_gemm_set_small_tiles(int v) { g_small_tiles = v < 0 ? 1 : v; }

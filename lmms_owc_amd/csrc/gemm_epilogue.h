@@ -50,6 +50,39 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
         if (FULL || (m < M && n < N)) *(f32x4*)(C + (long)m * ldc + n) = v;
       }
     }
+  } else if constexpr (EPI == OWC_EPI_SWIGLU && NTP == 1) {
+    // one gate / up tile pair (acc[0], acc[1]): a lane owns 4 consecutive features of its row - 8-byte stores, no lane exchange
+    bf16_t* C = (bf16_t*)Cv;
+    const int f = (ncol0 >> 1) + fq * 4;
+    const int nout = N >> 1;
+    float bgv[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bgv[nt][e] = 0.f;
+    if (bias != nullptr) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const bf16x4 b = *(const bf16x4*)(bias + min(ncol0 + nt * 16 + fq * 4, N - 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bgv[nt][e] = bf2f(b[e]);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mrow0 + mt * 16 + fr;
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float g0 = acc[0][mt][e], u0 = acc[1][mt][e];
+        if (bias != nullptr) {
+          g0 += bgv[0][e];
+          u0 += bgv[1][e];
+        }
+        o[e] = f2bf(rbf(rbf(act_silu(rbf(g0))) * rbf(u0)));
+      }
+      if (FULL || (m < M && f < nout)) *(bf16x4*)(C + (long)m * ldc + f) = o;
+    }
   } else if constexpr (EPI == OWC_EPI_SWIGLU) {
     bf16_t* C = (bf16_t*)Cv;
     const int odd = fq & 1;

@@ -271,6 +271,36 @@ def test_gemm_small_tile_shapes_race_screen(gpu, m, n, k, epi):
         lib.owc_tuning_set(b"gemm_skinny_max_m", SKINNY_MAX_M)
 
 
+@pytest.mark.parametrize("m,n,k,epi", [(128, 37888, 3584, "swiglu"), (100, 33000, 1024, "none"), (40, 37888, 128, "swiglu"),
+                                       (64, 40960, 64, "none"), (65, 20512, 3584, "swiglu")])
+def test_gemm_wide_tiles_race_screen(gpu, m, n, k, epi):
+    """At most 128 rows x tens of thousands of columns (gate/up at decode batch 33-128): the ring kernel's 64x160 / 128x160 tiles
+    (ten n tiles per wave: the shared epilogue on two groups of four + a single tile pair; four stages) against the other kernels, 8
+    times: bit-identical; ragged M / N (N not a multiple of 160), one and two K-tiles (fewer than stages)."""
+    from lmms_owc_amd import _lib, ops
+
+    lib = _lib.load()
+    a = bf16_randn((m, k), 95 + (m % 97), device=gpu)
+    w = bf16_randn((n, k), 96, 0.05, device=gpu)
+    b = bf16_randn((n,), 97, device=gpu)
+    E = {"none": _lib.EPI_NONE, "swiglu": _lib.EPI_SWIGLU}[epi]
+
+    def run():
+        return ops.gemm_bf16(a, w, None if epi == "swiglu" else b, epilogue=E)
+
+    lib.owc_tuning_set(b"gemm_skinny_max_m", 0)
+    try:
+        assert lib.owc_tuning_set(b"gemm_wide_tiles", 0) == 0
+        want = run()
+        assert lib.owc_tuning_set(b"gemm_wide_tiles", 1) == 0
+        for i in range(8):
+            got = run()
+            assert torch.equal(got, want), (i, (got != want).sum().item())
+    finally:
+        lib.owc_tuning_set(b"gemm_wide_tiles", 1)
+        lib.owc_tuning_set(b"gemm_skinny_max_m", SKINNY_MAX_M)
+
+
 @pytest.mark.parametrize("m,n,k,epi", [(4096, 4096, 4096, "none"), (2048, 37888, 3584, "swiglu"), (32768, 1280, 1280, "residual"),
                                        (1100, 13000, 384, "none"), (65536, 1280, 256, "quick_gelu"), (3000, 5120, 5120, "f32")])
 def test_pingpong_kernel_bit_identical_to_lockstep_race_screen(gpu, m, n, k, epi):
