@@ -50,7 +50,8 @@ int g_mid_max_tiles = 256;  // fewer 128x128 tiles than this -> 64x64 tiles (0 d
 int g_big_min_tiles = 144;  // fewer 256x256 tiles than this -> use the 128x128 kernel (measured: 160-162 tiles 256x256 +24...40 %, 126 tiles -3...8 %; knob "gemm_big_min_tiles")
 int g_small_tiles = 1;    // 64x64-tile kernel: also 32x64 / 64x32 / 32x32 tiles where they shorten the launch (knob "gemm_small_tiles": 0 off, 2 / 3 / 4 force 64x64 / 64x32 / 32x32)
 int g_tall_tiles = 1;     // 64x160 / 128x160 tiles of the ring kernel for launches of <= 128 rows x many columns (knob "gemm_wide_tiles")
-int g_tall_tiles_max_m = 128;
+int g_k_pairs = 1;        // ring kernel, long K: four (knob value 2: two) K-tiles per stage (knob "gemm_k_pairs"; 0 off)
+int g_k_pairs_min_k = 2048;   // (knob "gemm_k_pairs_min_k")
 int g_skinny_deep = 1;    // the skinny kernel's 9-deep ring for long-K launches of at most one wave per CU (knob "gemm_skinny_deep")
 int g_norm_fuse_max_m = 2; // rows up to which the decoder's RMSNorm is fused into the qkv / gate-up skinny GEMM (knob "decode_norm_fuse", 0 = off, at most 4).
                            // Measured, 7B decode step in ms, separate / fused: 1 row 3.78 / 3.44, 2 rows 3.78 / 3.65, 4 rows 3.88 / 4.11 - every wave
@@ -207,13 +208,15 @@ constexpr int TILE64_BYTES = B64 * BK * 2;  // 8 KiB per operand tile
 // cannot fill 256 CUs with 64x64 tiles is a narrower one (launch(): 32x32 for M <= 64, 64x32 for M <= 256 on the N = 3584
 // projections: the 7B down projection 122 -> 72 / 84 / 115 us at M = 64 / 128 / 256).  TM / 16 waves own one 16-row m tile x all TN
 // columns; with TM = 32 waves 2-3 only stage.  Same accumulation chain: bit-identical.
-template <int EPI, int NS64, bool KTAIL, int TM = 64, int TN = 64>
+template <int EPI, int NS64, bool KTAIL, int TM = 64, int TN = 64, int KPS = 1>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
     const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
     const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv,
     long ldc, int M, int N, int K, const void* __restrict__ zeros, int tiles_m, int tiles_n, owc_gemm_aux aux) {
   extern __shared__ __attribute__((aligned(16))) char lds[];  // [stage][A: TM rows | W: TN rows][128 B]
-  constexpr int STAGE = (TM + TN) * 128;      // bytes per stage
+  constexpr int SUB = (TM + TN) * 128;        // bytes of one K-tile's A and W tiles
+  constexpr int STAGE = KPS * SUB;            // bytes per stage: KPS consecutive K-tiles behind ONE wait + barrier (long-K launches)
+  static_assert(!KTAIL || KPS == 1, "the zero-page tail form stages one K-tile");
   constexpr int NPA = TM / 8, NPT = (TM + TN) / 8, NPW = NPT / 4;   // 1-KiB DMA pieces: of A, in all, per wave (2, 3 or 4)
   constexpr int NTW = TN / 16;                // n tiles of an active wave (4 or 2)
   constexpr int MTW = TM > 64 ? TM / 64 : 1;  // m tiles of a wave: TM = 128 gives every wave 32 rows (two tiles)
@@ -251,24 +254,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
   const int nk = (K + BK - 1) / BK;
   // always NPW LDS-DMA instructions per wave and stage, also past the end of K (zero page: an L2 hit nobody reads), so that the
   // counted waits below hold on every iteration
-  auto stage = [&](int buf, int kt) {
+  auto stage = [&](int buf, int kt) {   // kt: index of the STAGE (KPS K-tiles)
     char* dst = lds + buf * STAGE + w * 1024;
-    const int k0 = kt * BK;
     if constexpr (KTAIL) {
+      const int k0 = kt * BK;
 #pragma unroll
       for (int i = 0; i < NPW; ++i) {
         const bool ok = (k0 + kchunk[i]) < K;
         glds16(ok ? (const void*)(src[i] + (long)k0 * 2) : zeros, dst + i * 4096);
       }
     } else {   // K % 64 == 0; the pieces issued past the end of K (the ring's over-issue) re-read the last K-tile: nobody reads them
-      const long kk = (long)min(k0, K - BK) * 2;
-      const char* ab = abase + kk;
-      const char* wb = wbase + kk;
-      asm volatile("" : "+s"(ab), "+s"(wb));
 #pragma unroll
-      for (int i = 0; i < NPW; ++i) {
-        asm volatile("" : "+v"(off[i]));
-        glds16((4 * i < NPA ? ab : wb) + off[i], dst + i * 4096);
+      for (int u = 0; u < KPS; ++u) {
+        const long kk = (long)min((kt * KPS + u) * BK, K - BK) * 2;
+        const char* ab = abase + kk;
+        const char* wb = wbase + kk;
+        asm volatile("" : "+s"(ab), "+s"(wb));
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+          asm volatile("" : "+v"(off[i]));
+          glds16((4 * i < NPA ? ab : wb) + off[i], dst + u * SUB + i * 4096);
+        }
       }
     }
   };
@@ -285,29 +291,34 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
     for (int j = 0; j < MTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // (Round 3 measured a software-pipelined form of this loop - next k-step's fragments read under the current MFMAs, hand-counted
   // lgkmcnt, one tile more look-ahead - and an 8-stage ring: both +-0 on every decode shape.  The simple form stays.)
+  const int nst = (nk + KPS - 1) / KPS;   // stages
 #pragma unroll
   for (int i = 0; i < NS64 - 1; ++i) stage(i, i);
-  for (int kt = 0; kt < nk; ++kt) {
-    // this wave's pieces of stage kt have landed (the NPW * (NS64 - 2) newer ones may fly); the barrier publishes everybody's and
-    // tells that every wave is done reading stage kt - 1, whose slot the next DMA overwrites
-    // (lgkmcnt(0): this wave's own ds_reads of stage kt - 1 have retired too - the MFMAs consumed them long ago, so it costs
+  for (int st = 0; st < nst; ++st) {
+    // this wave's pieces of stage st have landed (the KPS * NPW * (NS64 - 2) newer ones may fly); the barrier publishes everybody's
+    // and tells that every wave is done reading stage st - 1, whose slot the next DMA overwrites
+    // (lgkmcnt(0): this wave's own ds_reads of stage st - 1 have retired too - the MFMAs consumed them long ago, so it costs
     // nothing, and the WAR guarantee then holds in the source instead of resting on the compiler's placement of its waits)
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPW * (NS64 - 2)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(KPS * NPW * (NS64 - 2)) : "memory");
     __builtin_amdgcn_sched_barrier(0);
-    stage((kt + NS64 - 1) % NS64, kt + NS64 - 1);
+    stage((st + NS64 - 1) % NS64, st + NS64 - 1);
     if (active) {
-      const char* la = lds + (kt % NS64) * STAGE;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 fa[MTW], fw[NTW];
+      for (int u = 0; u < KPS; ++u) {
+        if (KPS > 1 && st * KPS + u >= nk) break;   // an odd number of K-tiles: the last stage is half used
+        const char* la = lds + (st % NS64) * STAGE + u * SUB;
 #pragma unroll
-        for (int t = 0; t < MTW; ++t) fa[t] = *(const bf16x8*)(la + (ks ? offA1 : offA0) + t * 16 * 128);
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 fa[MTW], fw[NTW];
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) fw[t] = *(const bf16x8*)(la + (ks ? offW1 : offW0) + t * 16 * 128);
+          for (int t = 0; t < MTW; ++t) fa[t] = *(const bf16x8*)(la + (ks ? offA1 : offA0) + t * 16 * 128);
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
+          for (int t = 0; t < NTW; ++t) fw[t] = *(const bf16x8*)(la + (ks ? offW1 : offW0) + t * 16 * 128);
 #pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
+          for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
+        }
       }
     }
   }
@@ -1077,17 +1088,18 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
                        (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, g_gemm_dbg, aux);
   else if (!wide && g_mid_max_tiles > 0 && tiles_m * tiles_n < g_mid_max_tiles) {  // too few 128x128 tiles for 256 CUs: 64x64 tiles
     const int tm64 = (M + B64 - 1) / B64, tn64 = (N + B64 - 1) / B64;
-#define OWC_L64(NS_, KT_, TM_, TN_)                                                                                        \
+#define OWC_L64(NS_, KT_, TM_, TN_, ...)                                                                                   \
   do {                                                                                                                     \
-    constexpr int lds_ = NS_ * (TM_ + TN_) * 128;                                                                          \
+    constexpr int kps_ = (0, ##__VA_ARGS__) ? (0, ##__VA_ARGS__) : 1;                                                      \
+    constexpr int lds_ = NS_ * kps_ * (TM_ + TN_) * 128;                                                                   \
     static bool set_ = false;                                                                                              \
     if (!set_ && lds_ > 65536) {                                                                                           \
-      if (hipFuncSetAttribute((const void*)gemm_bf16_nt_64_kernel<EPI, NS_, KT_, TM_, TN_>,                                \
+      if (hipFuncSetAttribute((const void*)gemm_bf16_nt_64_kernel<EPI, NS_, KT_, TM_, TN_, kps_>,                          \
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) return OWC_ERR_HIP;         \
       set_ = true;                                                                                                         \
     }                                                                                                                      \
     const int tm_ = (M + TM_ - 1) / TM_, tn_ = (N + TN_ - 1) / TN_;                                                        \
-    hipLaunchKernelGGL((gemm_bf16_nt_64_kernel<EPI, NS_, KT_, TM_, TN_>), dim3(tm_ * tn_), dim3(256), lds_, s,             \
+    hipLaunchKernelGGL((gemm_bf16_nt_64_kernel<EPI, NS_, KT_, TM_, TN_, kps_>), dim3(tm_ * tn_), dim3(256), lds_, s,       \
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C, ldc,   \
                        M, N, K, zeros, tm_, tn_, aux);                                                                     \
   } while (0)
@@ -1108,12 +1120,26 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
       }
     }
     if (shape == 0) {
-      if (tm64 * tn64 > 512 && tm64 * tn64 <= 768) { if (ktail) OWC_L64(3, true, 64, 64); else OWC_L64(3, false, 64, 64); }
+      if (g_k_pairs && !ktail && K >= g_k_pairs_min_k && tm64 * tn64 <= 512) OWC_L64(2, false, 64, 64, 2);   // (qkv at M = 300-400: 33 -> 29 us)
+      else if (tm64 * tn64 > 512 && tm64 * tn64 <= 768) { if (ktail) OWC_L64(3, true, 64, 64); else OWC_L64(3, false, 64, 64); }
       else { if (ktail) OWC_L64(4, true, 64, 64); else OWC_L64(4, false, 64, 64); }
     }
     if constexpr (EPI == OWC_EPI_NONE || EPI == OWC_EPI_RESIDUAL) {
-      if (shape == 1) OWC_L64(6, false, 64, 32);
-      if (shape == 2) OWC_L64(8, false, 32, 32);
+      // long K, one block per CU: two K-tiles per stage (one wait + barrier per 128 of K)
+      const long nb = shape == 1 ? (long)((M + 63) / 64) * ((N + 31) / 32) : (long)((M + 31) / 32) * ((N + 31) / 32);
+      const bool longk = g_k_pairs && K >= g_k_pairs_min_k;
+      const int kps = (longk && nb <= 256) ? (g_k_pairs == 2 ? 2 : 4) : 1;
+      if (shape == 1) {
+        if (kps == 4) OWC_L64(3, false, 64, 32, 4);
+        else if (kps == 2) OWC_L64(4, false, 64, 32, 2);
+        else if (longk && (long)tm64 * tn64 <= 256) OWC_L64(3, false, 64, 64, 2);   // two rounds of 64x32: one of 64x64 (M = 129-256: 115 -> 89 us)
+        else OWC_L64(6, false, 64, 32);
+      }
+      if (shape == 2) {
+        if (kps == 4) OWC_L64(4, false, 32, 32, 4);
+        else if (kps == 2) OWC_L64(5, false, 32, 32, 2);
+        else OWC_L64(8, false, 32, 32);
+      }
     }
 #undef OWC_L64
   } else if (wide) {
@@ -1139,6 +1165,7 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
                        N, K, zeros, tm_, tn_, aux);                                                                         \
   } while (0)
     if constexpr (EPI == OWC_EPI_NONE || EPI == OWC_EPI_SWIGLU) {
+      // (two K-tiles per stage, measured: +-0 ... -12 % here - these launches run at the HBM rate, not at the per-K-tile cost)
       if (M <= 32) OWC_LWIDE(32); else if (M <= 64) OWC_LWIDE(64); else OWC_LWIDE(128);
     }
 #undef OWC_LWIDE
@@ -1289,5 +1316,7 @@ void owc_gemm_set_big_min_tiles(int v) { g_big_min_tiles = v < 0 ? 144 : v; }
 void owc_gemm_set_skinny_max_m(int v) { g_skinny_max_m = v < 0 ? 32 : v; }  // negative: back to the default
 void owc_gemm_set_pingpong(int v) { g_pingpong = v; }
 void owc_gemm_set_skinny_deep(int v) { g_skinny_deep = v; }
-void owc_gemm_set_tall_tiles(int v) { g_tall_tiles = v != 0; g_tall_tiles_max_m = 128; }
+void owc_gemm_set_k_pairs(int v) { g_k_pairs = v; }
+void owc_gemm_set_k_pairs_min_k(int v) { g_k_pairs_min_k = v < 0 ? 2048 : v; }
+void owc_gemm_set_tall_tiles(int v) { g_tall_tiles = v != 0; }
 void owc_gemm_set_small_tiles(int v) { g_small_tiles = v < 0 ? 1 : v; }

@@ -235,6 +235,7 @@ def test_gemm_mid_kernel_race_screen(gpu, m, n, k, epi):
 
 
 @pytest.mark.parametrize("m,n,k,epi", [(64, 3584, 18944, "residual"), (128, 3584, 3584, "residual"), (100, 4608, 3584, "none"),
+                                       (70, 1096, 8256, "residual"),   # K >= 8192: two K-tiles per stage, an odd number of K-tiles
                                        (40, 1096, 128, "none"), (130, 520, 64, "residual"), (96, 4736, 3584, "swiglu"),
                                        (33, 264, 1024, "none")])
 def test_gemm_small_tile_shapes_race_screen(gpu, m, n, k, epi):
