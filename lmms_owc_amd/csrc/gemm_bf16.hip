@@ -44,7 +44,7 @@ GemmProfile g_prof;
 int g_gemm_dbg = 0;       // timing-experiment knob (owc_tuning_set "gemm_dbg" of the -DOWC_TIMING_KNOBS build only), results are garbage unless 0 or 512:
                           // 1 no DMA, 2 DMA re-reads K-tiles 0/1 (all L2 hits), 4 no epilogue, 512 direct (un-staged) epilogue stores, 1024 streaming C stores (results unchanged),
                           // 2048 no per-K-tile barrier, 4096 no DMA wait at the barrier
-int g_skinny_max_m = 32;   // M at and below which the weight-streaming skinny kernel runs (0 disables: A-B knob "gemm_skinny_max_m"; up to 64 is legal):
+int g_skinny_max_m = 24;   // M at and below which the weight-streaming skinny kernel runs (0 disables: A-B knob "gemm_skinny_max_m"; up to 64 is legal):
                            // measured on the 7B decode step, ms: M = 33 6.4 skinny / 6.9 64x64 tiles, 40 7.0 / 6.7, 48 7.5 / 6.9, 64 9.8 / 6.6
 int g_mid_max_tiles = 256;  // fewer 128x128 tiles than this -> 64x64 tiles (0 disables: A-B knob "gemm_mid_max_tiles")
 int g_big_min_tiles = 144;  // fewer 256x256 tiles than this -> use the 128x128 kernel (measured: 160-162 tiles 256x256 +24...40 %, 126 tiles -3...8 %; knob "gemm_big_min_tiles")
@@ -1009,9 +1009,11 @@ bool launch_skinny(const void* A, long lda, const void* W, long ldw, const void*
     constexpr int ROWS = EPI == OWC_EPI_SWIGLU ? 32 : 16;
     if (M > 64 || (K & 127) || (N % ROWS) || g_skinny_max_m < M) return false;
     if (EPI == OWC_EPI_SWIGLU && bias != nullptr) return false;   // the gated vision MLP's biases: the tiled kernels' epilogue adds them
-    // more 16-row waves than CUs and more than one m tile each (the 7B qkv projection, N = 4608, at M = 17-32): the ring
-    // kernel's 32x32 tiles are faster (23.7 -> 15.5 us at M = 32; equal at M = 16)
-    if (EPI != OWC_EPI_SWIGLU && M > 16 && N / ROWS > 256 && (K % BK) == 0 && g_small_tiles && K <= 4096) return false;
+    // more 16-row waves than CUs (the 7B qkv projection, N = 4608): the ring kernel's 32x32 tiles with four K-tiles per stage are
+    // faster from M = 3 (M = 8 / 16: 13.8 / 15.7 -> 11.7 / 11.9 us; below that the RMSNorm-fused form of this kernel runs)
+    if (EPI != OWC_EPI_SWIGLU && M > 2 && N / ROWS > 256 && (K % BK) == 0 && g_small_tiles && g_k_pairs && K <= 4096 &&
+        K >= g_k_pairs_min_k)
+      return false;
     const dim3 grid(N / ROWS), block(64);
 #define OWC_SK(MT_, D_)                                                                                               \
   hipLaunchKernelGGL((gemm_bf16_skinny_kernel<EPI, MT_, D_>), grid, block, 0, s, (const bf16_t*)A, lda, (const bf16_t*)W, \
@@ -1313,7 +1315,7 @@ void owc_gemm_set_big_min_m(int m) { g_big_min_m = m; }
 void owc_gemm_set_dbg(int v) { g_gemm_dbg = OWC_TK(true) ? v : 0; }
 void owc_gemm_set_mid_max_tiles(int v) { g_mid_max_tiles = v; }
 void owc_gemm_set_big_min_tiles(int v) { g_big_min_tiles = v < 0 ? 144 : v; }
-void owc_gemm_set_skinny_max_m(int v) { g_skinny_max_m = v < 0 ? 32 : v; }  // negative: back to the default
+void owc_gemm_set_skinny_max_m(int v) { g_skinny_max_m = v < 0 ? 24 : v; }  // negative: back to the default
 void owc_gemm_set_pingpong(int v) { g_pingpong = v; }
 void owc_gemm_set_skinny_deep(int v) { g_skinny_deep = v; }
 void owc_gemm_set_k_pairs(int v) { g_k_pairs = v; }
