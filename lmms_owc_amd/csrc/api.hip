@@ -47,6 +47,7 @@ int owc_tuning_set(const char* name, int value) {
   else if (!strcmp(name, "attn_dbg")) owc_attn_set_dbg(value);
 #endif
   else if (!strcmp(name, "gemm_skinny_deep")) owc_gemm_set_skinny_deep(value);
+  else if (!strcmp(name, "decode_norm_fuse_ring")) owc_gemm_set_norm_fuse_ring(value);   // rows (<= 8) up to which the ring kernel folds the RMSNorm in; 0 = off
   else if (!strcmp(name, "gemm_k_pairs")) owc_gemm_set_k_pairs(value);   // 0: one K-tile per stage also for long K; 2: two instead of four
   else if (!strcmp(name, "gemm_k_pairs_min_k")) owc_gemm_set_k_pairs_min_k(value);
   else if (!strcmp(name, "gemm_wide_tiles")) owc_gemm_set_tall_tiles(value);   // 0: no 64x160 / 128x160 ring tiles for <= 128 rows x many columns

@@ -52,6 +52,7 @@ int g_small_tiles = 1;    // 64x64-tile kernel: also 32x64 / 64x32 / 32x32 tiles
 int g_tall_tiles = 1;     // 64x160 / 128x160 tiles of the ring kernel for launches of <= 128 rows x many columns (knob "gemm_wide_tiles")
 int g_k_pairs = 1;        // ring kernel, long K: four (knob value 2: two) K-tiles per stage (knob "gemm_k_pairs"; 0 off)
 int g_k_pairs_min_k = 2048;   // (knob "gemm_k_pairs_min_k")
+int g_norm_fuse_ring = 8;  // rows up to which the ring kernel normalises its own activations (knob "decode_norm_fuse_ring", 0 off, at most 8)
 int g_skinny_deep = 1;    // the skinny kernel's 9-deep ring for long-K launches of at most one wave per CU (knob "gemm_skinny_deep")
 int g_norm_fuse_max_m = 2; // rows up to which the decoder's RMSNorm is fused into the qkv / gate-up skinny GEMM (knob "decode_norm_fuse", 0 = off, at most 4).
                            // Measured, 7B decode step in ms, separate / fused: 1 row 3.78 / 3.44, 2 rows 3.78 / 3.65, 4 rows 3.88 / 4.11 - every wave
@@ -208,19 +209,23 @@ constexpr int TILE64_BYTES = B64 * BK * 2;  // 8 KiB per operand tile
 // cannot fill 256 CUs with 64x64 tiles is a narrower one (launch(): 32x32 for M <= 64, 64x32 for M <= 256 on the N = 3584
 // projections: the 7B down projection 122 -> 72 / 84 / 115 us at M = 64 / 128 / 256).  TM / 16 waves own one 16-row m tile x all TN
 // columns; with TM = 32 waves 2-3 only stage.  Same accumulation chain: bit-identical.
-template <int EPI, int NS64, bool KTAIL, int TM = 64, int TN = 64, int KPS = 1>
+template <int EPI, int NS64, bool KTAIL, int TM = 64, int TN = 64, int KPS = 1, bool NORMA = false>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
     const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
     const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv,
     long ldc, int M, int N, int K, const void* __restrict__ zeros, int tiles_m, int tiles_n, owc_gemm_aux aux) {
   extern __shared__ __attribute__((aligned(16))) char lds[];  // [stage][A: TM rows | W: TN rows][128 B]
-  constexpr int SUB = (TM + TN) * 128;        // bytes of one K-tile's A and W tiles
+  // NORMA (decode at <= 8 rows): A is not staged - the M raw residual rows are RMS-normalised once into LDS (row pitch K * 2 + 16)
+  // with the arithmetic of norm_kernel, bit for bit, and the ring carries W only; aux.gamma / aux.eps, K % 512 == 0.
+  constexpr int TMS = NORMA ? 0 : TM;         // A rows in a stage
+  constexpr int SUB = (TMS + TN) * 128;       // bytes of one K-tile's A and W tiles
   constexpr int STAGE = KPS * SUB;            // bytes per stage: KPS consecutive K-tiles behind ONE wait + barrier (long-K launches)
   static_assert(!KTAIL || KPS == 1, "the zero-page tail form stages one K-tile");
-  constexpr int NPA = TM / 8, NPT = (TM + TN) / 8, NPW = NPT / 4;   // 1-KiB DMA pieces: of A, in all, per wave (2, 3 or 4)
+  static_assert(!NORMA || (!KTAIL && TM == 32), "the norm-fused form: one 32-row tile (<= 8 of them real)");
+  constexpr int NPA = TMS / 8, NPT = (TMS + TN) / 8, NPW = NPT / 4;   // 1-KiB DMA pieces: of A, in all, per wave
   constexpr int NTW = TN / 16;                // n tiles of an active wave (4 or 2)
   constexpr int MTW = TM > 64 ? TM / 64 : 1;  // m tiles of a wave: TM = 128 gives every wave 32 rows (two tiles)
-  static_assert(TN % 32 == 0 && (TM + TN) % 32 == 0, "whole tile pairs; the DMA pieces of a stage divide over four waves");
+  static_assert(TN % 32 == 0 && (TMS + TN) % 32 == 0, "whole tile pairs; the DMA pieces of a stage divide over four waves");
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
@@ -254,8 +259,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
   const int nk = (K + BK - 1) / BK;
   // always NPW LDS-DMA instructions per wave and stage, also past the end of K (zero page: an L2 hit nobody reads), so that the
   // counted waits below hold on every iteration
+  const int pitchA = K * 2 + 16;
+  char* ring = NORMA ? lds + 8 * pitchA + K * 2 : lds;   // NORMA: [8 rows][pitchA] | gamma [K * 2] | ring
   auto stage = [&](int buf, int kt) {   // kt: index of the STAGE (KPS K-tiles)
-    char* dst = lds + buf * STAGE + w * 1024;
+    char* dst = ring + buf * STAGE + w * 1024;
     if constexpr (KTAIL) {
       const int k0 = kt * BK;
 #pragma unroll
@@ -280,9 +287,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
   };
   const int fr = l & 15, fq = l >> 4;
   const int swz = (fr >> 1) & 7;
-  const bool active = w * 16 * MTW < TM;   // wave w: rows [16 MTW w, +16 MTW) (waves 2-3 of a 32-row tile only stage)
+  const bool active = w * 16 * MTW < (NORMA ? min(M, TM) : TM);   // wave w: rows [16 MTW w, +16 MTW) (waves 2-3 of a 32-row tile only stage)
   const int offA0 = (w * 16 * MTW + fr) * 128 + (((0 + fq) ^ swz) << 4), offA1 = (w * 16 * MTW + fr) * 128 + (((4 + fq) ^ swz) << 4);
-  const int offW0 = TM * 128 + fr * 128 + (((0 + fq) ^ swz) << 4), offW1 = TM * 128 + fr * 128 + (((4 + fq) ^ swz) << 4);
+  const int offW0 = TMS * 128 + fr * 128 + (((0 + fq) ^ swz) << 4), offW1 = TMS * 128 + fr * 128 + (((4 + fq) ^ swz) << 4);
+  const char* arowN = lds + min(w * 16 + fr, M - 1) * pitchA + fq * 16;   // NORMA: this lane's normalised row (clamped: garbage rows are never stored)
 
   f32x4 acc[NTW < 4 ? 4 : NTW][MTW];
 #pragma unroll
@@ -292,8 +300,46 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
   // (Round 3 measured a software-pipelined form of this loop - next k-step's fragments read under the current MFMAs, hand-counted
   // lgkmcnt, one tile more look-ahead - and an 8-stage ring: both +-0 on every decode shape.  The simple form stays.)
   const int nst = (nk + KPS - 1) / KPS;   // stages
+  if constexpr (NORMA) {
+    // raw rows and gamma first (LDS-DMA, 1-KiB pieces): loads return in order, so issued behind the ring they would wait for it
+    const bf16_t* gam = (const bf16_t*)aux.gamma;
+    const int nj = K >> 9;
+    for (int j = w; j < nj; j += 4) glds16(gam + j * 512 + l * 8, lds + 8 * pitchA + j * 1024);
+    for (int m = w; m < M; m += 4)
+      for (int j = 0; j < nj; ++j) glds16(A + (long)m * lda + j * 512 + l * 8, lds + m * pitchA + j * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int i = 0; i < NS64 - 1; ++i) stage(i, i);
+  if constexpr (NORMA) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KPS * NPW * (NS64 - 1)) : "memory");   // this wave's rows / gamma pieces landed; the ring may fly
+    __syncthreads();                                                               // ... and everybody's gamma pieces
+    const char* gl = lds + 8 * pitchA;
+    const int nch = K >> 3;
+    for (int m = w; m < M; m += 4) {   // owc_rms_rstd / owc_rms_apply on the staged row, in place (lane l: chunks l, l + 64, ... ascending)
+      char* xrow = lds + m * pitchA;
+      float sq = 0.f;
+      for (int ch = l; ch < nch; ch += 64) {
+        const bf16x8 c = *(const bf16x8*)(xrow + ch * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = bf2f(c[e]);
+          sq = __builtin_fmaf(v, v, sq);
+        }
+      }
+      sq = wave_sum(sq);
+      const float rstd = rsqrtf(__builtin_fmaf(sq, 1.0f / (float)K, aux.eps));
+      for (int ch = l; ch < nch; ch += 64) {
+        const bf16x8 c = *(const bf16x8*)(xrow + ch * 16), g = *(const bf16x8*)(gl + ch * 16);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = owc_rms_apply(c[e], g[e], rstd);
+        *(bf16x8*)(xrow + ch * 16) = o;
+      }
+    }
+    // (the first loop barrier below - s_waitcnt lgkmcnt(0) + s_barrier - publishes the normalised rows)
+  }
   for (int st = 0; st < nst; ++st) {
     // this wave's pieces of stage st have landed (the KPS * NPW * (NS64 - 2) newer ones may fly); the barrier publishes everybody's
     // and tells that every wave is done reading stage st - 1, whose slot the next DMA overwrites
@@ -306,12 +352,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_64_kernel(
 #pragma unroll
       for (int u = 0; u < KPS; ++u) {
         if (KPS > 1 && st * KPS + u >= nk) break;   // an odd number of K-tiles: the last stage is half used
-        const char* la = lds + (st % NS64) * STAGE + u * SUB;
+        const char* la = ring + (st % NS64) * STAGE + u * SUB;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           bf16x8 fa[MTW], fw[NTW];
 #pragma unroll
-          for (int t = 0; t < MTW; ++t) fa[t] = *(const bf16x8*)(la + (ks ? offA1 : offA0) + t * 16 * 128);
+          for (int t = 0; t < MTW; ++t) {
+            if constexpr (NORMA) fa[t] = *(const bf16x8*)(arowN + ((st * KPS + u) * 64 + ks * 32) * 2);
+            else fa[t] = *(const bf16x8*)(la + (ks ? offA1 : offA0) + t * 16 * 128);
+          }
 #pragma unroll
           for (int t = 0; t < NTW; ++t) fw[t] = *(const bf16x8*)(la + (ks ? offW1 : offW0) + t * 16 * 128);
 #pragma unroll
@@ -1219,8 +1268,45 @@ int owc_launch_gemm_bf16_aux(const void* A, long lda, const void* W, long ldw, c
 
 // rmsnorm(X) . W^T (+bias | SwiGLU) for M <= OWC_NORM_FUSE_MAX_M rows in one launch; OWC_ERR_SHAPE when the shape is outside what the fused
 // kernel takes (the caller then runs the two separate kernels: same bits).
+// ring kernel, norm-fused form (M <= 8): W-only ring, the normalised rows resident in LDS
+template <int EPI, int NS_, int TN_, int KPS_>
+static int launch_ring_norma(const void* X, long ldx, const void* gamma, float eps, const void* W, long ldw, const void* bias, void* C,
+                             long ldc, int M, int N, int K, hipStream_t s) {
+  const int lds_bytes = 8 * (K * 2 + 16) + K * 2 + NS_ * KPS_ * TN_ * 128;
+  if (lds_bytes > 160 * 1024) return OWC_ERR_SHAPE;
+  static bool set_ = false;
+  if (!set_) {
+    if (hipFuncSetAttribute((const void*)gemm_bf16_nt_64_kernel<EPI, NS_, false, 32, TN_, KPS_, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return OWC_ERR_HIP;
+    set_ = true;
+  }
+  owc_gemm_aux aux = {nullptr, nullptr, nullptr, 0, 8};
+  aux.gamma = gamma;
+  aux.eps = eps;
+  const int tn_ = (N + TN_ - 1) / TN_;
+  const int prof = owc_gemm_profile_begin(2.0 * (double)M * (double)N * (double)K, 0, s);
+  hipLaunchKernelGGL((gemm_bf16_nt_64_kernel<EPI, NS_, false, 32, TN_, KPS_, true>), dim3(tn_), dim3(256), lds_bytes, s, (const bf16_t*)X,
+                     ldx, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)nullptr, 0, C, ldc, M, N, K, nullptr, 1, tn_, aux);
+  owc_gemm_profile_end(prof, s);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
 int owc_launch_gemm_bf16_rmsnorm(const void* X, long ldx, const void* gamma, float eps, const void* W, long ldw, const void* bias,
                                  void* C, long ldc, int M, int N, int K, int epi, hipStream_t s) {
+  // M <= 8 on the ring kernel (round 3): the wide gate/up tiles and the 32-column qkv tiles with the RMSNorm folded in
+  if (g_norm_fuse_ring && M > 0 && M <= g_norm_fuse_ring && M <= 8 && (K & 511) == 0 && !(ldx & 7) && !(ldw & 7) && g_norm_fuse_max_m > 0) {
+    if (epi == OWC_EPI_SWIGLU && bias == nullptr && g_tall_tiles && (N & 31) == 0 && (ldc & 3) == 0 && (N + 159) / 160 <= 256 &&
+        (N + 159) / 160 >= 128) {
+      const int rc = launch_ring_norma<OWC_EPI_SWIGLU, 4, 160, 1>(X, ldx, gamma, eps, W, ldw, bias, C, ldc, M, N, K, s);
+      if (rc != OWC_ERR_SHAPE) return rc;
+    }
+    if (epi == OWC_EPI_NONE && g_small_tiles && g_k_pairs && (N & 7) == 0 && (ldc & 7) == 0 && N / 16 > 256 && N / 32 <= 256 &&
+        K >= g_k_pairs_min_k) {
+      const int rc = launch_ring_norma<OWC_EPI_NONE, 4, 32, 4>(X, ldx, gamma, eps, W, ldw, bias, C, ldc, M, N, K, s);
+      if (rc != OWC_ERR_SHAPE) return rc;
+    }
+  }
   if (M <= 0 || M > g_norm_fuse_max_m || (K & 127) || K > 8192 || (ldx & 7) || (ldw & 7) || g_skinny_max_m < M) return OWC_ERR_SHAPE;
   const bool swiglu = epi == OWC_EPI_SWIGLU && (N & 31) == 0 && (ldc & 3) == 0;
   if (!swiglu && !(epi == OWC_EPI_NONE && (N & 15) == 0 && (ldc & 3) == 0)) return OWC_ERR_SHAPE;
@@ -1318,6 +1404,7 @@ void owc_gemm_set_big_min_tiles(int v) { g_big_min_tiles = v < 0 ? 144 : v; }
 void owc_gemm_set_skinny_max_m(int v) { g_skinny_max_m = v < 0 ? 24 : v; }  // negative: back to the default
 void owc_gemm_set_pingpong(int v) { g_pingpong = v; }
 void owc_gemm_set_skinny_deep(int v) { g_skinny_deep = v; }
+void owc_gemm_set_norm_fuse_ring(int v) { g_norm_fuse_ring = v < 0 ? 8 : (v > 8 ? 8 : v); }
 void owc_gemm_set_k_pairs(int v) { g_k_pairs = v; }
 void owc_gemm_set_k_pairs_min_k(int v) { g_k_pairs_min_k = v < 0 ? 2048 : v; }
 void owc_gemm_set_tall_tiles(int v) { g_tall_tiles = v != 0; }

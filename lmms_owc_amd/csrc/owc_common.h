@@ -88,6 +88,9 @@ struct owc_gemm_aux {
   const float* sin_t;
   int rope_cols;         // columns < rope_cols (q and k blocks) are rotated
   int head_dim;
+  // the ring kernel's RMSNorm-fused form (decode at <= 8 rows): A is the RAW residual rows, normalised on their way into LDS
+  const void* gamma = nullptr;
+  float eps = 0.f;
 };
 
 #define OWC_OK 0

@@ -325,3 +325,35 @@ def test_72b_width_fp8_decode_steps(gpu, B):
     """Config #5's fp8 decoder at 72B widths (K = 8192 / 29568 per-token scales): fp8 engine vs the numpy fp8 decoder."""
     _run_slice("72b", gpu, B, 6, decoder_dtype="fp8", frac=FP8_BOUND, special_frac=FP8_OUTLIER_BOUND, mean_frac=0.02, min_decisive=1,
                min_total=4)   # a 26 % margin is rare: the oracle offers 1 + 2 + 1 (B = 130) and 4 + 2 + 2 (B = 8) such steps
+
+
+@pytest.mark.parametrize("name", ["7b", "2b"])
+def test_ring_kernel_norm_fusion_is_bit_identical_and_batch_invariant(gpu, name):
+    """Decode at 1-8 sequences at config widths: the qkv and gate/up projections run the ring kernel's norm-fused form (the raw
+    residual rows are RMS-normalised into LDS by the block itself, the ring carries W only).  Every step's logits equal those with
+    the knob off (separate RMSNorm launches / the skinny kernel's own fused form), and a sequence decoded alone or in a batch of 3, 4
+    or 8 equals the same sequence inside a batch of 9 (no fusion: 9 rows)."""
+    from lmms_owc_amd import _lib
+
+    lib = _lib.load()
+    _, _, eng = _slice(name, gpu)
+    cfg, grid, pixs, prompts, pick, check, forced, refs = _slice_refs(name, 9, 6)
+    emb = eng.encode_images(torch.from_numpy(np.concatenate(pixs)).to(BF16).to(gpu), grid * 3)
+    rows = [4 * int(pick[b]) + np.arange(4) for b in range(9)]
+
+    def run(idx):
+        return eng.generate([prompts[i] for i in idx], emb, [grid] * len(idx), 6, img_rows=[rows[i] for i in idx],
+                            forced_tokens=forced[idx], return_step_logits=True)
+
+    big_t, big_l = run(list(range(9)))
+    for idx in ([0], [8, 4, 0], [1, 2, 3, 5], [0, 1, 2, 3, 4, 5, 6, 7]):
+        try:
+            assert lib.owc_tuning_set(b"decode_norm_fuse_ring", 0) == 0
+            t0, l0 = run(idx)
+            assert lib.owc_tuning_set(b"decode_norm_fuse_ring", 8) == 0
+            t1, l1 = run(idx)
+        finally:
+            lib.owc_tuning_set(b"decode_norm_fuse_ring", -1)
+        assert torch.equal(l0, l1) and torch.equal(t0, t1), idx
+        for j, i in enumerate(idx):
+            assert torch.equal(l1[:, j], big_l[:, i]) and torch.equal(t1[j], big_t[i]), (idx, i)
