@@ -1060,9 +1060,9 @@ bool launch_skinny(const void* A, long lda, const void* W, long ldw, const void*
     if (EPI == OWC_EPI_SWIGLU && bias != nullptr) return false;   // the gated vision MLP's biases: the tiled kernels' epilogue adds them
     // more 16-row waves than CUs (the 7B qkv projection, N = 4608): the ring kernel's 32x32 tiles with four K-tiles per stage are
     // faster from M = 3 (M = 8 / 16: 13.8 / 15.7 -> 11.7 / 11.9 us; below that the RMSNorm-fused form of this kernel runs)
-    if (EPI != OWC_EPI_SWIGLU && M > 2 && N / ROWS > 256 && (K % BK) == 0 && g_small_tiles && g_k_pairs && K <= 4096 &&
+    if (EPI != OWC_EPI_SWIGLU && M > 2 && N / ROWS > 256 && N / 32 <= 256 && (K % BK) == 0 && g_small_tiles && g_k_pairs && K <= 4096 &&
         K >= g_k_pairs_min_k)
-      return false;
+      return false;   // (N / 32 <= 256: one round of 32x32 tiles - not lm_head)
     const dim3 grid(N / ROWS), block(64);
 #define OWC_SK(MT_, D_)                                                                                               \
   hipLaunchKernelGGL((gemm_bf16_skinny_kernel<EPI, MT_, D_>), grid, block, 0, s, (const bf16_t*)A, lda, (const bf16_t*)W, \
