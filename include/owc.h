@@ -68,7 +68,7 @@ const char* owc_last_error(const owc_ctx* ctx);
  * skinny launches), "gemm_small_tiles" (the 64x64-tile kernel's 64x32 / 32x32 shapes for launches that cannot fill the chip: 0 off,
  * 1 = default: chosen by block count, 2 / 3 / 4 force 64x64 / 64x32 / 32x32), "decode_norm_fuse_ring" (rows, at most 8, up to which the ring kernel
  * folds the decoder's RMSNorm into the qkv / gate-up projection; 0 off), "gemm_k_pairs" / "gemm_k_pairs_min_k" (K-tiles per ring stage: 0 one,
- * default four from K >= 2048), "gemm_wide_tiles" (0: no 64x160 / 128x160 tiles of that
+ * default four from K >= 1024), "gemm_wide_tiles" (0: no 64x160 / 128x160 tiles of that
  * kernel for launches of at most 128 rows x tens of thousands of columns).
  * Every knob above selects between kernels that return the SAME results.  The timing-only experiment knobs "gemm_dbg" /
  * "attn_dbg" (parts of a kernel switched off to price them; outputs are garbage) exist only in libowc_hip_timing.so, which

@@ -51,8 +51,9 @@ int g_big_min_tiles = 144;  // fewer 256x256 tiles than this -> use the 128x128 
 int g_small_tiles = 1;    // 64x64-tile kernel: also 32x64 / 64x32 / 32x32 tiles where they shorten the launch (knob "gemm_small_tiles": 0 off, 2 / 3 / 4 force 64x64 / 64x32 / 32x32)
 int g_tall_tiles = 1;     // 64x160 / 128x160 tiles of the ring kernel for launches of <= 128 rows x many columns (knob "gemm_wide_tiles")
 int g_k_pairs = 1;        // ring kernel, long K: four (knob value 2: two) K-tiles per stage (knob "gemm_k_pairs"; 0 off)
-int g_k_pairs_min_k = 2048;   // (knob "gemm_k_pairs_min_k")
+int g_k_pairs_min_k = 1024;   // (knob "gemm_k_pairs_min_k"; 2B widths, K = 1536: step at batch 32 / 64 2.35 / 2.43 -> 2.27 / 2.35 ms)
 int g_norm_fuse_ring = 8;  // rows up to which the ring kernel normalises its own activations (knob "decode_norm_fuse_ring", 0 off, at most 8)
+int g_wide_min_blocks = 128;   // fewest 160-column blocks for which the wide ring tiles run (knob "gemm_wide_tiles" = n > 1 sets it)
 int g_skinny_deep = 1;    // the skinny kernel's 9-deep ring for long-K launches of at most one wave per CU (knob "gemm_skinny_deep")
 int g_norm_fuse_max_m = 2; // rows up to which the decoder's RMSNorm is fused into the qkv / gate-up skinny GEMM (knob "decode_norm_fuse", 0 = off, at most 4).
                            // Measured, 7B decode step in ms, separate / fused: 1 row 3.78 / 3.44, 2 rows 3.78 / 3.65, 4 rows 3.88 / 4.11 - every wave
@@ -1119,7 +1120,7 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
   const int prof = owc_gemm_profile_begin(2.0 * (double)M * (double)N * (double)K, 0, s);
   // (the wide ring tiles below beat the skinny kernel on their shapes at every M: 48.5 us against 53.9 ... 70.1 us at M = 1 ... 32)
   const bool wide = g_tall_tiles && (K % BK) == 0 && (EPI == OWC_EPI_NONE || EPI == OWC_EPI_SWIGLU) && M <= 128 &&
-                    (N + 159) / 160 <= 256 && (N + 159) / 160 >= 128;
+                    (N + 159) / 160 <= 256 && (N + 159) / 160 >= g_wide_min_blocks;
   if (!wide && launch_skinny<EPI>(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, s)) {
     owc_gemm_profile_end(prof, s);
     return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
@@ -1297,7 +1298,7 @@ int owc_launch_gemm_bf16_rmsnorm(const void* X, long ldx, const void* gamma, flo
   // M <= 8 on the ring kernel (round 3): the wide gate/up tiles and the 32-column qkv tiles with the RMSNorm folded in
   if (g_norm_fuse_ring && M > 0 && M <= g_norm_fuse_ring && M <= 8 && (K & 511) == 0 && !(ldx & 7) && !(ldw & 7) && g_norm_fuse_max_m > 0) {
     if (epi == OWC_EPI_SWIGLU && bias == nullptr && g_tall_tiles && (N & 31) == 0 && (ldc & 3) == 0 && (N + 159) / 160 <= 256 &&
-        (N + 159) / 160 >= 128) {
+        (N + 159) / 160 >= g_wide_min_blocks) {
       const int rc = launch_ring_norma<OWC_EPI_SWIGLU, 4, 160, 1>(X, ldx, gamma, eps, W, ldw, bias, C, ldc, M, N, K, s);
       if (rc != OWC_ERR_SHAPE) return rc;
     }
@@ -1406,6 +1407,6 @@ void owc_gemm_set_pingpong(int v) { g_pingpong = v; }
 void owc_gemm_set_skinny_deep(int v) { g_skinny_deep = v; }
 void owc_gemm_set_norm_fuse_ring(int v) { g_norm_fuse_ring = v < 0 ? 8 : (v > 8 ? 8 : v); }
 void owc_gemm_set_k_pairs(int v) { g_k_pairs = v; }
-void owc_gemm_set_k_pairs_min_k(int v) { g_k_pairs_min_k = v < 0 ? 2048 : v; }
-void owc_gemm_set_tall_tiles(int v) { g_tall_tiles = v != 0; }
+void owc_gemm_set_k_pairs_min_k(int v) { g_k_pairs_min_k = v < 0 ? 1024 : v; }
+void owc_gemm_set_tall_tiles(int v) { g_tall_tiles = v != 0; g_wide_min_blocks = v > 1 ? v : 128; }
 void owc_gemm_set_small_tiles(int v) { g_small_tiles = v < 0 ? 1 : v; }
