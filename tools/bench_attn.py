@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from lmms_owc_amd import ops  # noqa: E402
+from lmms_owc_amd import _lib, ops  # noqa: E402
 
 # timing experiments (`gemm_dbg` / `attn_dbg`: parts of a kernel switched off) exist only in the -DOWC_TIMING_KNOBS build
 if any(a.startswith(("--dbg", "--timing")) or "_dbg" in a for a in sys.argv[1:]):
