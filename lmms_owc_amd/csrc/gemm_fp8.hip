@@ -25,7 +25,7 @@ constexpr int GROUP_M2 = 4;
 int g_fp8_pingpong = 1;       // "gemm_pingpong" knob: 2 / default = on, 0 or 1 = the lock-step fp8 kernel.  Round 2 had it off (1.74 vs 2.44 PF on 7b.gateup);
                               // round 3 found why - LLVM sank the last K-tile's MFMAs into the epilogue's store blocks (scratch) - and gave it the
                               // bf16 kernel's two-set W layout: 7b.down 2573 -> 3001, 72b.gateup 2658 -> 3008, sq8192 2736 -> 3059 TFLOP/s
-int g_fp8_skinny_max_m = 64;  // follows the "gemm_skinny_max_m" knob
+int g_fp8_skinny_max_m = 16;  // follows the "gemm_skinny_max_m" knob (72B fp8 decode step at batch 24 / 32 / 48 / 64 with 64: 25.9 / 28.0 / 34.1 / 41.2 ms, with 16: 23.5 / 23.9 / 24.6 / 25.6)
 int g_fp8_mid_max_tiles = 128;  // fewer 256x256 tiles than this -> 64x64 tiles (follows "gemm_mid_max_tiles": 0 disables)
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;
 
@@ -731,7 +731,7 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
 
 }  // namespace
 
-void owc_gemm_fp8_set_skinny_max_m(int v) { g_fp8_skinny_max_m = v < 0 ? 64 : v; }  // negative: back to the default
+void owc_gemm_fp8_set_skinny_max_m(int v) { g_fp8_skinny_max_m = v < 0 ? 16 : v; }  // negative: back to the default
 void owc_gemm_fp8_set_pingpong(int v) { g_fp8_pingpong = v; }
 void owc_gemm_fp8_set_mid_max_tiles(int v) { g_fp8_mid_max_tiles = v ? 128 : 0; }
 
