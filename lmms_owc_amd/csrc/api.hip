@@ -51,7 +51,10 @@ int owc_tuning_set(const char* name, int value) {
   else if (!strcmp(name, "gemm_k_pairs")) owc_gemm_set_k_pairs(value);   // 0: one K-tile per stage also for long K; 2: two instead of four
   else if (!strcmp(name, "gemm_k_pairs_min_k")) owc_gemm_set_k_pairs_min_k(value);
   else if (!strcmp(name, "gemm_wide_tiles")) owc_gemm_set_tall_tiles(value);   // 0: no 64x160 / 128x160 ring tiles for <= 128 rows x many columns
-  else if (!strcmp(name, "gemm_small_tiles")) owc_gemm_set_small_tiles(value);   // 0: 64x64 tiles only; 1 (default): by block count; 2..4: force 64x64 / 64x32 / 32x32
+  else if (!strcmp(name, "gemm_small_tiles")) {
+    owc_gemm_set_small_tiles(value);
+    owc_gemm_fp8_set_shapes(value != 0);
+  }   // 0: 64x64 tiles only; 1 (default): by block count; 2..4: force 64x64 / 64x32 / 32x32
   else if (!strcmp(name, "decode_fuse")) owc_llm_set_decode_fuse(value);
   else if (!strcmp(name, "decode_norm_fuse")) owc_gemm_set_norm_fuse_max_m(value);   // max rows (<= 4) for the RMSNorm-fused skinny GEMM; 0 = off
   else if (!strcmp(name, "decode_attn_nbuf1")) owc_attn_set_decode_nbuf1(value);   // block count above which the fused decode attention single-buffers V

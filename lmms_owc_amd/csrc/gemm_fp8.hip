@@ -25,7 +25,8 @@ constexpr int GROUP_M2 = 4;
 int g_fp8_pingpong = 1;       // "gemm_pingpong" knob: 2 / default = on, 0 or 1 = the lock-step fp8 kernel.  Round 2 had it off (1.74 vs 2.44 PF on 7b.gateup);
                               // round 3 found why - LLVM sank the last K-tile's MFMAs into the epilogue's store blocks (scratch) - and gave it the
                               // bf16 kernel's two-set W layout: 7b.down 2573 -> 3001, 72b.gateup 2658 -> 3008, sq8192 2736 -> 3059 TFLOP/s
-int g_fp8_skinny_max_m = 16;  // follows the "gemm_skinny_max_m" knob (72B fp8 decode step at batch 24 / 32 / 48 / 64 with 64: 25.9 / 28.0 / 34.1 / 41.2 ms, with 16: 23.5 / 23.9 / 24.6 / 25.6)
+int g_fp8_skinny_max_m = 0;   // follows the "gemm_skinny_max_m" knob.  Off by default since round 3: the ring kernel's narrow / wide tiles beat it at every M (72B fp8 decode step at batch 1 / 8 / 16 / 32 / 64: 20.8 / 21.9 / 23.7 / 28.0 / 41.2 -> 19.9 / 20.1 / 20.0 / 20.9 / 22.9 ms)
+int g_fp8_shapes = 1;          // the ring kernel's other tile shapes / K grouping (follows "gemm_small_tiles")
 int g_fp8_mid_max_tiles = 128;  // fewer 256x256 tiles than this -> 64x64 tiles (follows "gemm_mid_max_tiles": 0 disables)
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;
 
@@ -488,12 +489,20 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256pp_kernel(
 constexpr int B64 = 64;
 constexpr int TILE64_BYTES = B64 * BKB;  // 8 KiB per operand tile
 
-template <int EPI>
+// Round 3: tile shape TM x TN and KPS K-tiles per stage as in gemm_bf16_nt_64_kernel (the measurements are in DESIGN.md section 4, "What
+// one CU can pull"): a launch that cannot fill the chip with 64x64 tiles takes 32x32 / 64x32 tiles, <= 128 rows x tens of thousands of
+// columns (gate/up) take 32/64/128 x 256 tiles (one block per CU, A re-read once per CU), and long K takes several K-tiles behind one
+// wait + barrier.  TM / 16 waves own a 16-row m tile x all TN columns (TM = 128: two m tiles per wave).  Same chain: bit-identical.
+template <int EPI, int NS8 = 4, int TM = 64, int TN = 64, int KPS = 1>
 __global__ __launch_bounds__(256) void gemm_fp8_nt_64_kernel(
     const uint8_t* __restrict__ A, long lda, const float* __restrict__ SA, const uint8_t* __restrict__ W, long ldw,
     const float* __restrict__ SW, const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv, long ldc,
     int M, int N, int K, int tiles_m, int tiles_n, owc_gemm_aux aux) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];  // [buf][A|W][64 rows][128 B]
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // [stage][K-tile][A: TM rows | W: TN rows][128 B]
+  constexpr int SUB = (TM + TN) * BKB, STAGE = KPS * SUB;
+  constexpr int NPA = TM / 8, NPT = (TM + TN) / 8, NPW = NPT / 4;   // 1-KiB DMA pieces of a K-tile: of A, in all, per wave
+  constexpr int NTW = TN / 16, MTW = TM > 64 ? TM / 64 : 1;
+  static_assert(TN % 32 == 0 && (TM + TN) % 32 == 0 && NPA % 4 == 0, "whole tile pairs; the DMA pieces divide over four waves");
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
@@ -506,34 +515,36 @@ __global__ __launch_bounds__(256) void gemm_fp8_nt_64_kernel(
   const int group = lid / width;
   const int first_m = group * 8;
   const int gsize = min(tiles_m - first_m, 8);
-  const int m0 = (first_m + (lid % width) % gsize) * B64, n0 = ((lid % width) / gsize) * B64;
-  // staging: wave w moves rows [16w, 16w+16) of both tiles, 2 pieces of 8 rows; scalar tile bases + 32-bit lane offsets (the DMA's
-  // scalar-base form: no vector address arithmetic in the loop)
+  const int m0 = (first_m + (lid % width) % gsize) * TM, n0 = ((lid % width) / gsize) * TN;
+  // staging: piece p = w + 4 i (i < NPW) of a K-tile; pieces [0, NPA) are 8-row slabs of the A tile, the rest of the W tile; scalar
+  // tile bases + 32-bit lane offsets (the DMA's scalar-base form: no vector address arithmetic in the loop)
   const char* abase = (const char*)(A + (long)m0 * lda);
   const char* wbase = (const char*)(W + (long)n0 * ldw);
-  unsigned aoff[2], woff[2];
+  unsigned off[NPW];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = 16 * w + 8 * j + (l >> 3);
+  for (int i = 0; i < NPW; ++i) {
+    const bool is_a = 4 * i < NPA;
+    const int row = 8 * (w + 4 * i - (is_a ? 0 : NPA)) + (l >> 3);
     const int c = (l & 7) ^ ((row >> 1) & 7);
-    aoff[j] = (unsigned)((long)min(row, M - 1 - m0) * lda + c * 16);
-    woff[j] = (unsigned)((long)min(row, N - 1 - n0) * ldw + c * 16);
+    off[i] = is_a ? (unsigned)((long)min(row, M - 1 - m0) * lda + c * 16) : (unsigned)((long)min(row, N - 1 - n0) * ldw + c * 16);
   }
   const int nk = K / BKB;
-  // ring of NS8 stages like gemm_bf16_nt_64_kernel: NS8 - 1 K-tiles in flight behind a counted vmcnt, one raw barrier per K-tile
-  // (round 1: two stages and a full drain per K-tile); the pieces issued past the end of K re-read the last K-tile (nobody reads them)
-  constexpr int NS8 = 4;
-  auto stage = [&](int buf, int kt) {
-    char* la = lds + buf * (2 * TILE64_BYTES) + w * 2048;
-    const long kb = (long)min(kt, nk - 1) * BKB;
-    const char* ab = abase + kb;
-    const char* wb = wbase + kb;
-    asm volatile("" : "+s"(ab), "+s"(wb));
+  const int nst = (nk + KPS - 1) / KPS;
+  // ring of NS8 stages: NS8 - 1 stages in flight behind a counted vmcnt, one raw barrier per stage; the pieces issued past the end of K
+  // re-read the last K-tile (nobody reads them)
+  auto stage = [&](int buf, int st) {
+    char* dst = lds + buf * STAGE + w * 1024;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      asm volatile("" : "+v"(aoff[j]), "+v"(woff[j]));
-      glds16(ab + aoff[j], la + j * 1024);
-      glds16(wb + woff[j], la + TILE64_BYTES + j * 1024);
+    for (int u = 0; u < KPS; ++u) {
+      const long kb = (long)min(st * KPS + u, nk - 1) * BKB;
+      const char* ab = abase + kb;
+      const char* wb = wbase + kb;
+      asm volatile("" : "+s"(ab), "+s"(wb));
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) {
+        asm volatile("" : "+v"(off[i]));
+        glds16((4 * i < NPA ? ab : wb) + off[i], dst + u * SUB + i * 4096);
+      }
     }
   };
   const int fr = l & 15, fq = l >> 4;
@@ -544,34 +555,59 @@ __global__ __launch_bounds__(256) void gemm_fp8_nt_64_kernel(
     const i32x4 lo = *(const i32x4*)(p + chlo), hi = *(const i32x4*)(p + chhi);
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   };
-  f32x4 acc[4][1];
+  const bool active = w * 16 * MTW < TM;
+  f32x4 acc[NTW < 4 ? 4 : NTW][MTW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < (NTW < 4 ? 4 : NTW); ++i)
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < NS8 - 1; ++i) stage(i, i);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 * (NS8 - 2)) : "memory");   // lgkmcnt(0): WAR on the slot restaged next, in the source
+  for (int st = 0; st < nst; ++st) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(KPS * NPW * (NS8 - 2)) : "memory");   // lgkmcnt(0): WAR on the slot restaged next, in the source
     __builtin_amdgcn_sched_barrier(0);
-    stage((kt + NS8 - 1) % NS8, kt + NS8 - 1);
-    const char* la = lds + (kt % NS8) * (2 * TILE64_BYTES);
-    const i32x8 fa = rd(la + (w * 16 + fr) * 128);
+    stage((st + NS8 - 1) % NS8, st + NS8 - 1);
+    if (active) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const i32x8 fw = rd(la + TILE64_BYTES + (nt * 16 + fr) * 128);
-      acc[nt][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw, fa, acc[nt][0], 0, 0, 0, 0x7f, 0, 0x7f);
+      for (int u = 0; u < KPS; ++u) {
+        if (KPS > 1 && st * KPS + u >= nk) break;
+        const char* la = lds + (st % NS8) * STAGE + u * SUB;
+        i32x8 fa[MTW];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) fa[mt] = rd(la + (w * 16 * MTW + mt * 16 + fr) * 128);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const i32x8 fw = rd(la + TM * BKB + (nt * 16 + fr) * 128);
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw, fa[mt], acc[nt][mt], 0, 0, 0, 0x7f, 0, 0x7f);
+        }
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  {
-    const float sa = SA[min(m0 + w * 16 + fr, M - 1)];
+  if (!active) return;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+  for (int mt = 0; mt < MTW; ++mt) {
+    const float sa = SA[min(m0 + w * 16 * MTW + mt * 16 + fr, M - 1)];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
       const f32x4 swv = *(const f32x4*)(SW + min(n0 + nt * 16 + fq * 4, N - 4));
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[nt][0][e] = acc[nt][0][e] * sa * swv[e];
+      for (int e = 0; e < 4; ++e) acc[nt][mt][e] = acc[nt][mt][e] * sa * swv[e];
     }
   }
-  gemm_epilogue<EPI, 1>(acc, m0 + w * 16, n0, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
+  if constexpr (NTW <= 4) {
+    gemm_epilogue<EPI, MTW, false, NTW / 2>(*(const f32x4(*)[4][MTW])&acc[0], m0 + w * 16 * MTW, n0, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
+  } else {
+#pragma unroll
+    for (int g = 0; g < NTW / 4; ++g)
+      gemm_epilogue<EPI, MTW, false, 2>(*(const f32x4(*)[4][MTW])&acc[4 * g], m0 + w * 16 * MTW, n0 + 64 * g, fr, fq, bias, R, ldr, Cv, ldc, M,
+                                        N, aux);
+    if constexpr (NTW % 4 != 0)
+      gemm_epilogue<EPI, MTW, false, 1>(*(const f32x4(*)[4][MTW])&acc[NTW - 2], m0 + w * 16 * MTW, n0 + 16 * (NTW - 2), fr, fq, bias, R, ldr, Cv,
+                                        ldc, M, N, aux);
+  }
 }
 
 // ---- skinny-M variant (M <= 64, decode at small batch): the fp8 twin of gemm_bf16_skinny_kernel.  One wave owns 16 rows of W8
@@ -698,8 +734,7 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
                             LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)gemm_fp8_nt_256pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemm_fp8_nt_64_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            8 * TILE64_BYTES) != hipSuccess)
+        false)
       return OWC_ERR_HIP;
     attr_set = true;
   }
@@ -710,13 +745,43 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
     owc_gemm_profile_end(prof, s);
     return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
   }
-  if (g_fp8_mid_max_tiles > 0 && tiles_m * tiles_n < g_fp8_mid_max_tiles) {  // too few 256x256 tiles for the 256 CUs
-    const int tm64 = (M + B64 - 1) / B64, tn64 = (N + B64 - 1) / B64;
-    hipLaunchKernelGGL(gemm_fp8_nt_64_kernel<EPI>, dim3(tm64 * tn64), dim3(256), 8 * TILE64_BYTES, s, (const uint8_t*)A, lda, sa,
-                       (const uint8_t*)W, ldw, sw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C, ldc, M, N, K, tm64, tn64, aux);
+#define OWC_L8(NS_, TM_, TN_, KPS_)                                                                                            \
+  do {                                                                                                                         \
+    constexpr int lds_ = NS_ * KPS_ * (TM_ + TN_) * BKB;                                                                       \
+    static bool set_ = false;                                                                                                  \
+    if (!set_) {                                                                                                               \
+      if (hipFuncSetAttribute((const void*)gemm_fp8_nt_64_kernel<EPI, NS_, TM_, TN_, KPS_>,                                    \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) return OWC_ERR_HIP;             \
+      set_ = true;                                                                                                             \
+    }                                                                                                                          \
+    const int tm_ = (M + TM_ - 1) / TM_, tn_ = (N + TN_ - 1) / TN_;                                                            \
+    hipLaunchKernelGGL((gemm_fp8_nt_64_kernel<EPI, NS_, TM_, TN_, KPS_>), dim3(tm_ * tn_), dim3(256), lds_, s, (const uint8_t*)A, \
+                       lda, sa, (const uint8_t*)W, ldw, sw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C, ldc, M, N, K, tm_,  \
+                       tn_, aux);                                                                                              \
+  } while (0)
+  // <= 128 rows x tens of thousands of columns (the 72B gate/up projection: N = 59 392): 256-column tiles, one block per CU
+  const int wide_blocks = (N + 255) / 256;
+  if (g_fp8_shapes && M <= 128 && wide_blocks <= 256 && wide_blocks >= 128) {
+    if (M <= 32) OWC_L8(4, 32, 256, 1); else if (M <= 64) OWC_L8(3, 64, 256, 1); else OWC_L8(3, 128, 256, 1);
     owc_gemm_profile_end(prof, s);
     return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
   }
+  if (g_fp8_mid_max_tiles > 0 && tiles_m * tiles_n < g_fp8_mid_max_tiles) {  // too few 256x256 tiles for the 256 CUs
+    auto blocks = [&](int tm, int tn) { return (long)((M + tm - 1) / tm) * ((N + tn - 1) / tn); };
+    const bool longk = g_fp8_shapes && K >= 2048;
+    if (g_fp8_shapes && EPI != OWC_EPI_SWIGLU && blocks(64, 64) <= 256 && blocks(32, 32) <= 256) {
+      if (longk) OWC_L8(4, 32, 32, 4); else OWC_L8(8, 32, 32, 1);
+    } else if (g_fp8_shapes && EPI != OWC_EPI_SWIGLU && blocks(64, 64) <= 256 && blocks(64, 32) <= 256) {
+      if (longk) OWC_L8(3, 64, 32, 4); else OWC_L8(6, 64, 32, 1);
+    } else if (longk && blocks(64, 64) <= 512) {
+      OWC_L8(3, 64, 64, 2);
+    } else {
+      OWC_L8(4, 64, 64, 1);
+    }
+    owc_gemm_profile_end(prof, s);
+    return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+  }
+#undef OWC_L8
   if (g_fp8_pingpong && K >= 2 * BKB && (K % (2 * BKB)) == 0)
     hipLaunchKernelGGL(gemm_fp8_nt_256pp_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), LDS_BYTES, s,
                        (const uint8_t*)A, lda, sa, (const uint8_t*)W, ldw, sw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C,
@@ -731,8 +796,9 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
 
 }  // namespace
 
-void owc_gemm_fp8_set_skinny_max_m(int v) { g_fp8_skinny_max_m = v < 0 ? 16 : v; }  // negative: back to the default
+void owc_gemm_fp8_set_skinny_max_m(int v) { g_fp8_skinny_max_m = v < 0 ? 0 : v; }  // negative: back to the default
 void owc_gemm_fp8_set_pingpong(int v) { g_fp8_pingpong = v; }
+void owc_gemm_fp8_set_shapes(int v) { g_fp8_shapes = v; }
 void owc_gemm_fp8_set_mid_max_tiles(int v) { g_fp8_mid_max_tiles = v ? 128 : 0; }
 
 int owc_launch_quant_rows_fp8(const void* X, long ldx, void* Q, long ldq, float* S, int rows, int cols, hipStream_t st) {

@@ -99,8 +99,8 @@ def test_rmsnorm_quant_is_the_two_kernels_fused(gpu, rows, d):
 @pytest.mark.parametrize("m", [1, 16, 33, 64])
 @pytest.mark.parametrize("epi", ["bias", "res", "swiglu"])
 def test_gemm_fp8_skinny_kernel(gpu, m, epi):
-    """M <= 64 runs the weight-streaming fp8 kernel (decode at small batch): oracle parity, BIT-IDENTICAL to the tiled fp8 kernel,
-    and row 0 alone equals row 0 inside the batch."""
+    """The weight-streaming fp8 kernel for M <= 64 (behind "gemm_skinny_max_m" since round 3): oracle parity, BIT-IDENTICAL to the tiled
+    fp8 kernels, and row 0 alone equals row 0 inside the batch."""
     from lmms_owc_amd import _lib, ops
     from lmms_owc_amd.engine.qwen2vl import interleave_gate_up
 
@@ -118,14 +118,17 @@ def test_gemm_fp8_skinny_kernel(gpu, m, epi):
         ws = interleave_gate_up(ws[:f, None], ws[f:, None])[:, 0].contiguous()
     kw = dict(epilogue={"bias": _lib.EPI_NONE, "res": _lib.EPI_RESIDUAL, "swiglu": _lib.EPI_SWIGLU}[epi])
     run = lambda q, s_, rr: ops.gemm_fp8(q, s_, wq, ws, bias, residual=rr, **kw)  # noqa: E731
-    out = run(xq, xs, r)
-    lib.owc_tuning_set(b"gemm_skinny_max_m", 0)
     try:
+        lib.owc_tuning_set(b"gemm_skinny_max_m", 64)   # (off by default since round 3: the ring kernel is faster; kept behind the knob)
+        out = run(xq, xs, r)
+        row0 = run(xq[:1], xs[:1], None if r is None else r[:1])[0]
+        lib.owc_tuning_set(b"gemm_skinny_max_m", 0)
         tiled = run(xq, xs, r)
     finally:
         lib.owc_tuning_set(b"gemm_skinny_max_m", -1)
     assert torch.equal(out, tiled)
-    assert torch.equal(run(xq[:1], xs[:1], None if r is None else r[:1])[0], out[0])
+    assert torch.equal(row0, out[0])
+    assert torch.equal(run(xq[:1], xs[:1], None if r is None else r[:1])[0], out[0])   # the default dispatch (ring kernel), one row
     if epi == "bias":
         want = F.linear_fp8(None, wq.cpu().numpy(), to_np(ws), to_np(bias), xq=xq.cpu().numpy(), xs=to_np(xs))
         assert_bf16_close(to_np(out), want, ulps=2.0, min_exact=0.95, atol=2.0 ** -9 * np.abs(want).max())
@@ -176,6 +179,40 @@ def test_gemm_fp8_mid_kernel_race_screen(gpu, m, n, k, epi):
             got = ops.gemm_fp8(xq, xs, wq, ws, bias, epilogue=e, residual=r)
             assert torch.equal(got, want), (i, int((got != want).sum()))
     finally:
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 256)
+        lib.owc_tuning_set(b"gemm_skinny_max_m", -1)
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(64, 8192, 29696, "res"), (40, 1096, 128, "bias"), (130, 8192, 8192, "res"), (100, 10240, 8192, "bias"),
+                                       (128, 59392, 8192, "swiglu"), (24, 40000, 256, "bias"), (70, 33024, 3584, "swiglu"), (300, 2048, 8192, "res")])
+def test_gemm_fp8_ring_shapes_race_screen(gpu, m, n, k, epi):
+    """The fp8 ring kernel's round-3 forms - 32x32 / 64x32 tiles and several K-tiles per stage for the narrow projections (72B o / down /
+    qkv at decode batch 17-256), 32/64/128 x 256 tiles for <= 128 rows x tens of thousands of columns (gate/up), 64x64 with two K-tiles
+    per stage - against the 256x256 kernel, 8 times per shape: ragged M / N, 1 and 2 K-tiles (fewer than stages), SwiGLU.  Bit-identical."""
+    from lmms_owc_amd import _lib, ops
+
+    lib = _lib.load()
+    x = bf16_randn((m, k), 280 + m, 1.0, gpu)
+    w = bf16_randn((n, k), 281, 0.05, gpu)
+    xq, xs = ops.quantize_rows_fp8(x)
+    wq, ws = ops.quantize_rows_fp8(w)
+    bias = bf16_randn((n,), 5, 0.5, gpu) if epi == "bias" else None
+    r = bf16_randn((m, n), 9, 1.0, gpu) if epi == "res" else None
+    e = {"bias": _lib.EPI_NONE, "res": _lib.EPI_RESIDUAL, "swiglu": _lib.EPI_SWIGLU}[epi]
+    try:
+        lib.owc_tuning_set(b"gemm_skinny_max_m", 0)
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 0)
+        lib.owc_tuning_set(b"gemm_small_tiles", 0)
+        want = ops.gemm_fp8(xq, xs, wq, ws, bias, epilogue=e, residual=r)      # 256x256 kernels
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 256)
+        mid = ops.gemm_fp8(xq, xs, wq, ws, bias, epilogue=e, residual=r)       # 64x64 tiles, one K-tile per stage
+        assert torch.equal(mid, want)
+        lib.owc_tuning_set(b"gemm_small_tiles", 1)
+        for i in range(8):
+            got = ops.gemm_fp8(xq, xs, wq, ws, bias, epilogue=e, residual=r)
+            assert torch.equal(got, want), (i, int((got != want).sum()))
+    finally:
+        lib.owc_tuning_set(b"gemm_small_tiles", 1)
         lib.owc_tuning_set(b"gemm_mid_max_tiles", 256)
         lib.owc_tuning_set(b"gemm_skinny_max_m", -1)
 
