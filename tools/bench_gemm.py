@@ -110,9 +110,12 @@ def main():
     if "--dbg" in sys.argv:  # timing experiments (--vals=0,512,4): 0 normal, 1 no DMA, 2 DMA re-reads K-tiles 0/1 (L2 hits), 4 no epilogue, 512 direct epilogue stores
         lib = _lib.load()
         only = next((a for a in sys.argv[1:] if not a.startswith("--")), None)
+        m_dbg = next((int(a[4:]) for a in sys.argv[1:] if a.startswith("--m=")), 0)
+        epi_dbg = {"none": ops.EPI_NONE, "quick_gelu": _lib.EPI_QUICK_GELU}[next((a[6:] for a in sys.argv[1:] if a.startswith("--epi=")), "none")]
         for name, m, n, k in SHAPES:
             if only and name != only:
                 continue
+            m = m_dbg or m
             a = torch.randn(m, k, device=dev).to(torch.bfloat16)
             w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
             out = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
@@ -122,10 +125,10 @@ def main():
                 for v in [int(x) for x in next((a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('--vals=')), '0,4').split(',')]:
                     lib.owc_tuning_set(b"gemm_dbg", v)
                     for _ in range(2):
-                        ops.gemm_bf16(a, w, out=out)
+                        ops.gemm_bf16(a, w, out=out, epilogue=epi_dbg)
                     e0.record()
                     for _ in range(10):
-                        ops.gemm_bf16(a, w, out=out)
+                        ops.gemm_bf16(a, w, out=out, epilogue=epi_dbg)
                     e1.record()
                     torch.cuda.synchronize()
                     if rnd:
