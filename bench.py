@@ -294,6 +294,63 @@ def ragged_leg(engine, dims, name: str, n: int, T: int, steps: int, device, sync
                     "ragged cu_seqlens vision launch groups + unequal prompts (shared 14-token prefix); uniform-noise pixels; never `value`"}
 
 
+EOS_ID = 151645   # <|im_end|>: Qwen2-VL's EOS token id
+
+
+def ragged_answer_lengths(B: int, cap: int, mean_len: float, cap_frac: float, seed: int):
+    """Seeded per-sequence continuations for the `eos_terminated` leg: stop lengths geometric with mean `mean_len` (the answer + its
+    EOS; classification answers are a few tokens), `cap_frac` of the sequences never stop inside the cap (a rambling answer), EOS at
+    the stop column of the forced continuation."""
+    r = np.random.default_rng(seed)
+    lens = np.minimum(r.geometric(1.0 / mean_len, B), cap)
+    lens[r.random(B) < cap_frac] = cap + 1
+    forced = r.integers(1000, 150000, (B, cap)).astype(np.int32)
+    for b in np.flatnonzero(lens <= cap):
+        forced[b, lens[b] - 1] = EOS_ID
+    return forced, lens
+
+
+def eos_terminated_leg(engine, pix, flat_grids, prompts, grids, B: int, sync, headline_images_per_s: float, rank: int,
+                       caps=(64, 256), mean_len: float = 8.0, cap_frac: float = 0.01, plain_caps=(64,)) -> dict:
+    """Ragged answer lengths (never `value`).  In the reference every image is its own `generate` call that stops at its own EOS
+    (/root/reference/src/models/_qwen2_vl.py:319-337; `max_new_tokens` 64 in src/data/tasks/_classification/caltech101/base.yaml:9-11,
+    256 in the zero_shot_cot / llava_cot / llamav_o1 YAMLs).  The same B images as the main leg, EOS handling ON, seeded stop
+    lengths injected through the forced-token path: one pass with the finished rows dropped from the following decode steps
+    (`compact_rows`, the default) and one where all B rows decode until the last sequence stops - same tokens, bit for bit."""
+    out = {"answer_lengths": f"geometric, mean {mean_len} tokens incl. EOS, {cap_frac:.0%} of the sequences never stop inside the cap; seeded per rank",
+           "headline_images_per_s_forced_16": headline_images_per_s, "by_cap": []}
+    d = engine.d
+    for cap in caps:
+        kv_bytes = 4.0 * d.n_layers * B * d.n_kv_heads * d.head_dim * (len(prompts[0]) + cap)
+        torch.cuda.empty_cache()
+        if kv_bytes + (8 << 30) > torch.cuda.mem_get_info()[0]:
+            out["by_cap"].append({"max_new_tokens": cap, "skipped": f"KV cache of {kv_bytes / 2**30:.0f} GiB does not fit beside the weights at this batch"})
+            continue
+        forced, lens = ragged_answer_lengths(B, cap, mean_len, cap_frac, 4242 + rank)
+        row = {"max_new_tokens": cap, "mean_answer_tokens": float(np.minimum(lens, cap).mean()), "sequences_at_cap": int((lens > cap).sum())}
+        toks = {}
+        for compact in ((True, False) if cap in plain_caps else (True,)):
+            st = {}
+            sync()
+            t0 = time.perf_counter()
+            emb = engine.encode_images(pix, flat_grids)
+            toks[compact] = engine.generate(prompts, emb, grids, cap, eos_token_id=EOS_ID, pad_token_id=0, forced_tokens=forced,
+                                            compact_rows=compact, stats=st).cpu()
+            sync()
+            dt = time.perf_counter() - t0
+            live = st["live_rows_per_step"]
+            row["compacted" if compact else "all_rows_every_step"] = {
+                "seconds": dt, "images_per_s": B / dt, "vs_headline": B / dt / headline_images_per_s, "decode_steps_run": len(live) - 1,
+                "row_steps": int(sum(live[1:])), "live_rows_at_step": {str(j): int(live[j]) for j in (1, 4, 8, 16, 32, 63, 128, 255) if j < len(live)}}
+            del emb
+        if len(toks) == 2:
+            row["tokens_identical_with_and_without_compaction"] = bool(torch.equal(toks[True], toks[False]))
+        pad_ok = all(bool((toks[True][b, min(int(lens[b]), cap):] == 0).all()) for b in range(0, B, max(1, B // 64)))
+        row["pad_behind_stop_column"] = pad_ok
+        out["by_cap"].append(row)
+    return out
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: this (parent) process has not touched the GPU; it starts N children
     of the same command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (one process per GPU, the analogue of the
@@ -396,6 +453,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pil-leg", action="store_true", help="skip the PIL -> generate_until -> strings leg")
     ap.add_argument("--no-decode-leg", action="store_true", help="skip the HBM-regime decode leg (decode step at batch 1 / 32 / 128)")
+    ap.add_argument("--no-eos-leg", action="store_true", help="skip the EOS-terminated ragged-answer-length leg (max_new_tokens 64 / 256)")
     ap.add_argument("--image-sizes", default=None, choices=sorted(DATASET_SIZES),
                     help="extra leg (never `value`): images of the dataset's real size distribution through smart_resize "
                          "(64...1024 image tokens per image, ragged vision / prefill launch groups); reports images/s and image-tokens/s")
@@ -541,6 +599,21 @@ def main() -> None:
     alone = engine.generate(prompts[:1], emb0, grids[:1], T, eos_token_id=-1, pad_token_id=0).cpu()
     invariant = bool(torch.equal(alone[0], out[0]))
 
+    # ---- EOS-terminated leg (never `value`): seeded ragged answer lengths at the task configs' caps, with / without row compaction
+    eos_leg = None
+    if not args.no_eos_leg and T >= 2:
+        eos_leg = eos_terminated_leg(engine, pix, flat_grids, prompts, grids, B, sync, B * args.steps / dt_own, rank)
+        if dist is not None:   # whole-job rate of every pass = all ranks' images / the slowest rank's time
+            for row in eos_leg["by_cap"]:
+                for k in ("compacted", "all_rows_every_step"):
+                    if k in row:
+                        t = torch.tensor([row[k]["seconds"]], device=cdev, dtype=torch.float64)
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                        row[k]["seconds"] = float(t.item())
+                        row[k]["images_per_s"] = world * B / row[k]["seconds"]
+                        row[k]["vs_headline"] = row[k]["images_per_s"] / images_per_s
+            eos_leg["headline_images_per_s_forced_16"] = images_per_s
+
     # ---- PCIe-inclusive leg (never `value`): the same step fed from host uint8 images (what the boundary hands over in a
     # real run): pinned H2D copy + GPU rescale/normalise/patchify + the step above
     host_u8 = torch.randint(0, 256, (B, 3, 448, 448), dtype=torch.uint8).pin_memory()
@@ -656,6 +729,7 @@ def main() -> None:
                          "method": "HIP events around every launch of the timed region on the launch stream; achieved = sum(2MNK) / sum(t)"},
             "roofline_attention": attention_rooflines(prof, dims, B, T, args.steps, dt),
             "roofline_decode": decode_leg,
+            "eos_terminated": eos_leg,
             "real_image_sizes": ragged,
             "roofline_label_cosine": scorer_rooflines(sprof, n_lab, args.scorer_classes, 5, args.steps, float(sdt.item())),
         }

@@ -61,6 +61,11 @@ def parse_args(argv=None) -> argparse.Namespace:
     p.add_argument("--seed", type=str, default="0,1234,1234,1234")
     p.add_argument("--trust_remote_code", action="store_true")
     p.add_argument("--data_root", type=str, default="data")
+    # reference eval_model.py:582.  Its only reader (src/engine/_engine.py:221-228) picks a media-free doc iterator when the
+    # flag is absent, and line 230 then overwrites that choice with `task.doc_iterator(...)` unconditionally - the flag changes
+    # nothing in the reference, so it is accepted here and changes nothing either (the post-processing loop always iterates
+    # the task's documents, engine/evaluate.py)
+    p.add_argument("--process_with_media", action="store_true", help="accepted for command-line compatibility (no effect, as in the reference)")
     return p.parse_args(argv)
 
 

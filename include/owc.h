@@ -334,17 +334,20 @@ size_t owc_llm_workspace_bytes(const owc_llm_weights* w, int T, int n_seq);
  *   prefix is computed ONCE as segment n_seq-1 (tok_slot = -1 on its rows: the K/V rows are written to all slots
  *   [bcast_first_slot, +bcast_n_slots)), the other segments hold only the per-image suffixes.
  *   last_index: int32[n_out] = row of each prompt's last token (n_out = number of real prompts <= n_seq).
- *   Scoring mode (n_out > n_seq, at most T): last_index names ANY n_out packed rows - the positions whose logits a
- *   loglikelihood request needs (reference src/models/_llava_hf.py:243-252 reads outputs["logits"] of every position) - and the
- *   last layer then runs on every row; the workspace must be sized with owc_llm_workspace_bytes(w, T, n_out).
+ *   score_mode: OWC_PREFILL_LAST_TOKENS - last_index[j] MUST be the last row of sequence j (n_out <= n_seq); the last layer
+ *   is then pruned to those rows (they attend every key of their sequence: the wrong thing for any other row, hence the explicit
+ *   mode instead of an inference from the counts).  OWC_PREFILL_SCORE_ROWS - last_index names ANY n_out <= T packed rows, the
+ *   positions whose logits a loglikelihood request needs (reference src/models/_llava_hf.py:243-252 reads outputs["logits"] of
+ *   every position); the last layer then runs on every row and the workspace must be sized with owc_llm_workspace_bytes(w, T, n_out).
  * Writes the KV cache and next_tok[n_out] = argmax of those rows' logits.
  * `logits_out` (optional, [n_out, vocab] bf16) receives the logits. */
+enum { OWC_PREFILL_LAST_TOKENS = 0, OWC_PREFILL_SCORE_ROWS = 1 };
 int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* cache,
                     const int32_t* ids, const int32_t* img_index, const void* img_embeds,
                     const int32_t* pos3, const int32_t* tok_slot, const int32_t* tok_idx,
                     const int32_t* seq_start, const int32_t* seq_len, const int32_t* q_len,
                     const int32_t* k_start, const int32_t* last_index, int n_seq, int n_out, int T,
-                    int max_len, int bcast_first_slot, int bcast_n_slots, int32_t* next_tok,
+                    int max_len, int bcast_first_slot, int bcast_n_slots, int score_mode, int32_t* next_tok,
                     void* logits_out, void* workspace, size_t ws_bytes, void* stream);
 
 /* One greedy decode step for B sequences (HF GenerationMixin loop body, one token each):
@@ -352,7 +355,14 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
  *   pos: int32[B] rope position of the fed token (same for the 3 mrope streams);
  *   slot/write_idx/k_start/k_len/q_start/o_start/q_len: int32[B] cache addressing
  *     (k_len = write_idx + 1; q_start[b] = b * (Hq + 2 Hkv); o_start[b] = b * Hq; q_len[b] = Hq / Hkv);
- *   done: uint8[B]; out_tokens[b * out_stride + step] receives the emitted token.
+ *   done: uint8[B]; out_tokens[row * out_stride + step] receives the emitted token, row = out_row ? out_row[b] : b.
+ *   out_row (optional, int32[B]): the ORIGINAL batch row of compact row b.  In the reference every image is its own
+ *     `generate` call and stops at its own EOS (src/models/_qwen2_vl.py:319-337); here the batch decodes together, and
+ *     once sequences have finished the caller may drop their rows (owc_decode_compact) so that a step's GEMMs and
+ *     attention grid shrink to the live rows.  Every kernel of the step computes a row independently of its
+ *     neighbours, so the tokens of the surviving rows are bit-identical to the uncompacted run (tested).
+ *   forced_tok (optional, int32 indexed by ORIGINAL row): teacher forcing - the token fed to the next step, and the
+ *     one whose EOS finishes the sequence, is forced_tok[row]; out_tokens still receives the step's own argmax.
  *   step_state (optional, int32[1] on the device): when non-NULL the output column is read from step_state[0] (`step` is
  *     ignored) and, after the step, pos[b], write_idx[b], k_len[b] and step_state[0] are incremented IN PLACE, so that
  *     consecutive decode steps are byte-identical launch sequences: capture one in a hipGraph and replay it. */
@@ -361,13 +371,23 @@ int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cac
                         int32_t* write_idx, const int32_t* k_start, int32_t* k_len,
                         const int32_t* q_start, const int32_t* o_start, const int32_t* q_len,
                         uint8_t* done, int32_t* out_tokens, int out_stride, int step, int32_t* step_state, int B,
-                        int eos_id0, int eos_id1, int pad_id, void* logits_out, void* workspace,
-                        size_t ws_bytes, void* stream);
+                        int eos_id0, int eos_id1, int pad_id, const int32_t* out_row, const int32_t* forced_tok,
+                        void* logits_out, void* workspace, size_t ws_bytes, void* stream);
 
 /* first-token bookkeeping after prefill: same done/pad/out_tokens update as a decode step. */
 int owc_decode_update(owc_ctx* ctx, int32_t* next_tok, uint8_t* done, int32_t* out_tokens,
                       int out_stride, int step, int B, int eos_id0, int eos_id1, int pad_id,
-                      void* stream);
+                      const int32_t* out_row, const int32_t* forced_tok, void* stream);
+
+/* EOS-aware row compaction between decode steps: the per-row decode state of the n_live surviving rows
+ * (live: int32[n_live], ascending indices into the CURRENT rows) is gathered into rows 0..n_live-1 of a second
+ * set of buffers (`*_c`; a gather cannot run in place, the caller ping-pongs two sets).  q_start / o_start / q_len
+ * depend on the compact row index only, so their first n_live entries stay valid; the KV cache is not moved
+ * (slot / k_start indirection). */
+int owc_decode_compact(owc_ctx* ctx, const int32_t* live, int n_live, const int32_t* tok, const int32_t* pos,
+                       const int32_t* write_idx, const int32_t* k_len, const int32_t* slot, const int32_t* k_start,
+                       const int32_t* out_row, const uint8_t* done, int32_t* tok_c, int32_t* pos_c, int32_t* write_idx_c,
+                       int32_t* k_len_c, int32_t* slot_c, int32_t* k_start_c, int32_t* out_row_c, uint8_t* done_c, void* stream);
 
 /* ---- model level: sentence encoder + cosine scorer (fp32) ------------------------------------- */
 typedef struct owc_bert_layer {

@@ -21,7 +21,7 @@ _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
 _timing_ok = False
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = range(6)
 
@@ -76,6 +76,7 @@ class LlmWeights(C.Structure):
 
 
 WEIGHTS_BF16, WEIGHTS_FP8 = 0, 1
+PREFILL_LAST_TOKENS, PREFILL_SCORE_ROWS = 0, 1   # owc_llm_prefill score_mode
 
 
 class KvCache(C.Structure):
@@ -130,10 +131,11 @@ SIGNATURES: dict[str, tuple] = {
     "owc_clip_patchify_u8": (i32, [vp, vp, vp, i64, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp]),
     "owc_llm_workspace_bytes": (sz, [C.POINTER(LlmWeights), i32, i32]),
     "owc_llm_prefill": (i32, [vp, C.POINTER(LlmWeights), C.POINTER(KvCache), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                              i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
+                              i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "owc_llm_decode_step": (i32, [vp, C.POINTER(LlmWeights), C.POINTER(KvCache), vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                                  vp, vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
-    "owc_decode_update": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+                                  vp, vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
+    "owc_decode_update": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "owc_decode_compact": (i32, [vp, vp, i32] + [vp] * 17),
     "owc_bert_workspace_bytes": (sz, [C.POINTER(BertWeights), i32, i32]),
     "owc_bert_embed": (i32, [vp, C.POINTER(BertWeights), vp, vp, i32, i32, vp, vp, sz, vp]),
     "owc_bert_packed_workspace_bytes": (sz, [C.POINTER(BertWeights), i32]),

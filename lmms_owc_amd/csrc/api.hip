@@ -16,7 +16,7 @@
 
 extern "C" {
 
-int owc_abi_version(void) { return 13; }
+int owc_abi_version(void) { return 14; }
 
 int owc_has_timing_knobs(void) {   // 1 only in libowc_hip_timing.so (tools/); the product library answers 0
 #ifdef OWC_TIMING_KNOBS
@@ -216,10 +216,26 @@ int owc_gemm_fp8(owc_ctx* ctx, const void* A, int64_t lda, const float* a_scale,
 
 int owc_decode_update(owc_ctx* ctx, int32_t* next_tok, uint8_t* done, int32_t* out_tokens,
                       int out_stride, int step, int B, int eos_id0, int eos_id1, int pad_id,
-                      void* stream) {
+                      const int32_t* out_row, const int32_t* forced_tok, void* stream) {
   if (!ctx || !next_tok || !done || !out_tokens) return OWC_ERR_ARG;
   RET(ctx, "owc_decode_update",
-      owc_launch_decode_update(next_tok, done, out_tokens, out_stride, step, nullptr, B, eos_id0, eos_id1, pad_id, ST(stream)));
+      owc_launch_decode_update(next_tok, done, out_tokens, out_stride, step, nullptr, B, eos_id0, eos_id1, pad_id, out_row,
+                               forced_tok, ST(stream)));
+}
+
+int owc_decode_compact(owc_ctx* ctx, const int32_t* live, int n_live, const int32_t* tok, const int32_t* pos,
+                       const int32_t* write_idx, const int32_t* k_len, const int32_t* slot, const int32_t* k_start,
+                       const int32_t* out_row, const uint8_t* done, int32_t* tok_c, int32_t* pos_c, int32_t* write_idx_c,
+                       int32_t* k_len_c, int32_t* slot_c, int32_t* k_start_c, int32_t* out_row_c, uint8_t* done_c, void* stream) {
+  if (!ctx || !live || !tok || !pos || !write_idx || !k_len || !slot || !k_start || !out_row || !done || !tok_c || !pos_c ||
+      !write_idx_c || !k_len_c || !slot_c || !k_start_c || !out_row_c || !done_c)
+    return OWC_ERR_ARG;
+  const int32_t* src[7] = {tok, pos, write_idx, k_len, slot, k_start, out_row};
+  int32_t* dst[7] = {tok_c, pos_c, write_idx_c, k_len_c, slot_c, k_start_c, out_row_c};
+  for (int a = 0; a < 7; ++a)
+    if (src[a] == dst[a]) OWC_FAIL(ctx, OWC_ERR_ARG, "owc_decode_compact: a gather cannot run in place");
+  if ((const uint8_t*)done_c == done) OWC_FAIL(ctx, OWC_ERR_ARG, "owc_decode_compact: a gather cannot run in place");
+  RET(ctx, "owc_decode_compact", owc_launch_decode_compact(src, dst, done, done_c, live, n_live, ST(stream)));
 }
 
 int owc_gemm_profile_enable(owc_ctx* ctx, int on) {

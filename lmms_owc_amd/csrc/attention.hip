@@ -499,7 +499,12 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
   if (NBUF == 2 && w < ntiles) stage_v(0, w);
   for (int t = w; t < ntiles; t += 4) {
     load_k(t);
-    if (NBUF == 1) stage_v(0, t);     // (the previous tile's V reads have retired: their MFMAs were issued)
+    // WAR guard in the SOURCE (as in the ring GEMMs): the buffer restaged below was last read by the previous tile's transposing
+    // LDS reads; they were consumed by its MFMAs a whole softmax ago, so the wait is free - but nothing else stops a scheduler or
+    // unroll change from hoisting the DMA above them
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (NBUF == 1) stage_v(0, t);
     else if (t + 4 < ntiles) stage_v(buf ^ 1, t + 4);
     // ---- S^T = K . Q^T (waits for the K fragments only: the V tiles may still fly)
     f32x4 s[4];

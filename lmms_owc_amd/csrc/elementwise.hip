@@ -337,17 +337,41 @@ __global__ __launch_bounds__(ARGMAX_T) void argmax_kernel(const bf16_t* __restri
 }
 
 // Decode bookkeeping (HF GenerationMixin greedy loop): finished sequences emit pad, EOS marks done.
+//   out_row (optional): row of out_tokens (and index into `forced`) that compact row b belongs to - after an EOS-aware
+//     row compaction the B live rows are a subset of the original batch (NULL: identity);
+//   forced (optional, indexed by ORIGINAL row): teacher forcing - the token FED to the next step (and the one whose EOS ends
+//     the sequence) is forced[row] instead of the step's own argmax, which is still what out_tokens receives.
 __global__ void decode_update_kernel(int* __restrict__ next_tok, uint8_t* __restrict__ done,
                                      int* __restrict__ out_tokens, int out_stride, int step,
-                                     const int* __restrict__ step_state, int B, int eos0, int eos1, int pad) {
+                                     const int* __restrict__ step_state, int B, int eos0, int eos1, int pad,
+                                     const int* __restrict__ out_row, const int* __restrict__ forced) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   if (step_state) step = step_state[0];  // graph-replayed decode: the column lives on the device
+  const int row = out_row ? out_row[b] : b;
   int t = next_tok[b];
-  if (done[b]) t = pad;
-  out_tokens[(long)b * out_stride + step] = t;
-  if (t == eos0 || t == eos1) done[b] = 1;
-  next_tok[b] = t;
+  int feed = forced ? forced[row] : t;
+  if (done[b]) t = feed = pad;
+  out_tokens[(long)row * out_stride + step] = t;
+  if (feed == eos0 || feed == eos1) done[b] = 1;
+  next_tok[b] = feed;
+}
+
+// EOS-aware row compaction of the decode batch: the per-row state of the `n` surviving rows `live[i]` (ascending indices into
+// the CURRENT rows) moves to rows 0..n-1 of a second set of buffers (a gather cannot run in place).  Seven int32 vectors (fed
+// token, rope position, cache write index, key count, cache slot, key start, output row) and the done flags.
+struct compact_ptrs {
+  const int* src[7];
+  int* dst[7];
+};
+__global__ void decode_compact_kernel(compact_ptrs p, const uint8_t* __restrict__ done_src, uint8_t* __restrict__ done_dst,
+                                      const int* __restrict__ live, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int r = live[i];
+#pragma unroll
+  for (int a = 0; a < 7; ++a) p.dst[a][i] = p.src[a][r];
+  done_dst[i] = done_src[r];
 }
 
 // Graph-replayed decode: advance the per-sequence rope position / cache write index / key count and the output column on
@@ -631,9 +655,22 @@ int owc_launch_argmax(const void* logits, long ld, int rows, int V, int* out, hi
 }
 
 int owc_launch_decode_update(int* next_tok, uint8_t* done, int* out_tokens, int out_stride, int step,
-                             const int* step_state, int B, int eos0, int eos1, int pad, hipStream_t st) {
+                             const int* step_state, int B, int eos0, int eos1, int pad, const int* out_row, const int* forced,
+                             hipStream_t st) {
   hipLaunchKernelGGL(decode_update_kernel, dim3((B + 255) / 256), dim3(256), 0, st, next_tok, done,
-                     out_tokens, out_stride, step, step_state, B, eos0, eos1, pad);
+                     out_tokens, out_stride, step, step_state, B, eos0, eos1, pad, out_row, forced);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_decode_compact(const int* const* src, int* const* dst, const uint8_t* done_src, uint8_t* done_dst,
+                              const int* live, int n, hipStream_t st) {
+  if (n <= 0) return OWC_ERR_SHAPE;
+  compact_ptrs p;
+  for (int a = 0; a < 7; ++a) {
+    p.src[a] = src[a];
+    p.dst[a] = dst[a];
+  }
+  hipLaunchKernelGGL(decode_compact_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, done_src, done_dst, live, n);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 

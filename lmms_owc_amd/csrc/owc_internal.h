@@ -56,7 +56,10 @@ int owc_launch_embed(const int* ids, const int* img_index, const void* table, co
 int owc_launch_argmax(const void* logits, long ld, int rows, int V, int* out, hipStream_t st);
 int owc_launch_token_logprob(const void* logits, long ld, const int* target, int rows, int V, float* out, hipStream_t st);
 int owc_launch_decode_update(int* next_tok, uint8_t* done, int* out_tokens, int out_stride, int step,
-                             const int* step_state, int B, int eos0, int eos1, int pad, hipStream_t st);
+                             const int* step_state, int B, int eos0, int eos1, int pad, const int* out_row, const int* forced,
+                             hipStream_t st);
+int owc_launch_decode_compact(const int* const* src, int* const* dst, const uint8_t* done_src, uint8_t* done_dst,
+                              const int* live, int n, hipStream_t st);
 int owc_launch_decode_advance(int* pos, int* widx, int* klen, int* step_state, int B, hipStream_t st);
 int owc_launch_patchify(const uint8_t* img, void* out, long ldo, int n_img, int H, int W,
                         const float* mean, const float* stdv, hipStream_t st);

@@ -205,7 +205,11 @@ static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache
     const bool tail = last_index && g_prune_last && i == w->n_layers - 1;  // last prefill layer: only the n_out last-token rows go on
     // self-attention block (HF:601-614); a handful of rows (decode at the reference's batch size): the projection normalises its own
     // activations (gemm_bf16_skinny_norm_kernel) - same bits as the two launches, one launch less
-    if (fp8 || owc_launch_gemm_bf16_rmsnorm(x, d, L.ln1_w, w->rms_eps, L.qkv_w, d, L.qkv_b, qkv, NQKV, T, NQKV, d, OWC_EPI_NONE, st) != OWC_OK) {
+    // (OWC_ERR_SHAPE = "not a shape the fused form takes": the two launches below; any other failure is a real one)
+    int rc_f = fp8 ? OWC_ERR_SHAPE
+                   : owc_launch_gemm_bf16_rmsnorm(x, d, L.ln1_w, w->rms_eps, L.qkv_w, d, L.qkv_b, qkv, NQKV, T, NQKV, d, OWC_EPI_NONE, st);
+    if (rc_f != OWC_OK && rc_f != OWC_ERR_SHAPE) return rc_f;
+    if (rc_f == OWC_ERR_SHAPE) {
       OWC_TRY(norm(T, x, L.ln1_w));
       OWC_TRY(linear(T, fp8 ? nullptr : h, d, L.qkv_w, L.qkv_s, L.qkv_b, nullptr, qkv, NQKV, NQKV, d, OWC_EPI_NONE));
     }
@@ -244,7 +248,10 @@ static int llm_layers(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache
     }
     OWC_TRY(linear(M, attn, (long)Hq * hd, L.o_w, L.o_s, nullptr, xr, xr, d, d, Hq * hd, OWC_EPI_RESIDUAL));
     // MLP block (HF:617-620, :464-466)
-    if (fp8 || owc_launch_gemm_bf16_rmsnorm(xr, d, L.ln2_w, w->rms_eps, L.gateup_w, d, nullptr, mlp, F, M, 2 * F, d, OWC_EPI_SWIGLU, st) != OWC_OK) {
+    rc_f = fp8 ? OWC_ERR_SHAPE
+               : owc_launch_gemm_bf16_rmsnorm(xr, d, L.ln2_w, w->rms_eps, L.gateup_w, d, nullptr, mlp, F, M, 2 * F, d, OWC_EPI_SWIGLU, st);
+    if (rc_f != OWC_OK && rc_f != OWC_ERR_SHAPE) return rc_f;
+    if (rc_f == OWC_ERR_SHAPE) {
       OWC_TRY(norm(M, xr, L.ln2_w));
       OWC_TRY(linear(M, fp8 ? nullptr : h, d, L.gateup_w, L.gateup_s, nullptr, nullptr, mlp, F, 2 * F, d, OWC_EPI_SWIGLU));
     }
@@ -258,13 +265,18 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
                     const int32_t* pos3, const int32_t* tok_slot, const int32_t* tok_idx,
                     const int32_t* seq_start, const int32_t* seq_len, const int32_t* q_len,
                     const int32_t* k_start, const int32_t* last_index, int n_seq, int n_out, int T,
-                    int max_len, int bcast_first_slot, int bcast_n_slots, int32_t* next_tok,
+                    int max_len, int bcast_first_slot, int bcast_n_slots, int score_mode, int32_t* next_tok,
                     void* logits_out, void* workspace, size_t ws_bytes, void* stream) {
   if (!ctx || !w || !cache || !ids || !pos3 || !tok_slot || !tok_idx || !seq_start || !seq_len ||
       !k_start || !last_index || !next_tok || !workspace)
     return OWC_ERR_ARG;
   if (n_out <= 0 || n_out > T) OWC_FAIL(ctx, OWC_ERR_ARG, "owc_llm_prefill: 0 < n_out <= T");
-  const bool scoring = n_out > n_seq;   // logits of arbitrary rows: no pruned last layer (its rows attend like last tokens)
+  if (score_mode != OWC_PREFILL_LAST_TOKENS && score_mode != OWC_PREFILL_SCORE_ROWS)
+    OWC_FAIL(ctx, OWC_ERR_ARG, "owc_llm_prefill: score_mode must be OWC_PREFILL_LAST_TOKENS or OWC_PREFILL_SCORE_ROWS");
+  if (score_mode == OWC_PREFILL_LAST_TOKENS && n_out > n_seq)
+    OWC_FAIL(ctx, OWC_ERR_ARG, "owc_llm_prefill: more output rows than sequences needs OWC_PREFILL_SCORE_ROWS");
+  // scoring: logits of ARBITRARY rows - the last layer runs on every row (a pruned last layer lets its rows attend like last tokens)
+  const bool scoring = score_mode == OWC_PREFILL_SCORE_ROWS;
   const int n_rows = scoring ? n_out : n_seq;
   if (w->head_dim != 128) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_llm_prefill: head_dim must be 128");
   if (w->weight_dtype == OWC_WEIGHTS_FP8 && ((w->d_model % 128) || (w->d_ff % 128)))
@@ -312,8 +324,8 @@ int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cac
                         int32_t* write_idx, const int32_t* k_start, int32_t* k_len,
                         const int32_t* q_start, const int32_t* o_start, const int32_t* q_len,
                         uint8_t* done, int32_t* out_tokens, int out_stride, int step, int32_t* step_state, int B,
-                        int eos_id0, int eos_id1, int pad_id, void* logits_out, void* workspace,
-                        size_t ws_bytes, void* stream) {
+                        int eos_id0, int eos_id1, int pad_id, const int32_t* out_row, const int32_t* forced_tok,
+                        void* logits_out, void* workspace, size_t ws_bytes, void* stream) {
   if (!ctx || !w || !cache || !tok_io || !pos || !slot || !write_idx || !k_start || !k_len ||
       !q_start || !o_start || !q_len || !done || !out_tokens || !workspace)
     return OWC_ERR_ARG;
@@ -347,7 +359,7 @@ int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cac
                                w->vocab, d, OWC_EPI_NONE, ctx->zeros, st));
   OWC_TRY(owc_launch_argmax(logits, w->vocab, B, w->vocab, tok_io, st));
   OWC_TRY(owc_launch_decode_update(tok_io, done, out_tokens, out_stride, step, step_state, B, eos_id0, eos_id1,
-                                   pad_id, st));
+                                   pad_id, out_row, forced_tok, st));
   if (step_state) OWC_TRY(owc_launch_decode_advance(pos, write_idx, k_len, step_state, B, st));
   return OWC_OK;
 }

@@ -405,9 +405,9 @@ class Qwen2VLEngine:
 
     # -- decoder -----------------------------------------------------------------------
     def generate(self, prompts: list, img_embeds: torch.Tensor | None, grids_per_prompt: list, max_new_tokens: int,
-                 *, eos_token_id: int = -1, pad_token_id: int = 0, stop_check_every: int = 8,
+                 *, eos_token_id: int = -1, pad_token_id: int = 0, stop_check_every: int = 1, compact_rows: bool = True,
                  return_logits: bool = False, img_rows: list | None = None, forced_tokens=None,
-                 return_step_logits: bool = False):
+                 return_step_logits: bool = False, stats: dict | None = None):
         """Greedy generation for a batch of prompts.
 
         prompts[b]: 1-D int array of token ids holding image_token_id placeholders;
@@ -415,9 +415,17 @@ class Qwen2VLEngine:
         img_embeds: rows for all image tokens of all prompts, in prompt order;
         img_rows[b] (optional): explicit row of `img_embeds` for every image token of prompt b (engines whose
         feature buffer is not already in token order, e.g. LLaVA's CLS-skipping / anyres packing).
-        forced_tokens (optional, int [B, max_new_tokens]): teacher forcing for parity tests - the token FED at step
-        j+1 is forced_tokens[b][j] instead of the engine's own argmax (which is still what the returned tokens hold),
-        so every step's logits are conditional on the reference's continuation; EOS handling must be off.
+        forced_tokens (optional, int [B, max_new_tokens]): teacher forcing - the token FED at step j+1 is
+        forced_tokens[b][j] instead of the engine's own argmax (which is still what the returned tokens hold), so every
+        step's logits are conditional on the reference's continuation.  With EOS handling on, a sequence ends where its
+        FORCED continuation holds EOS (seeded answer lengths for the ragged-length bench leg and the compaction tests).
+        EOS handling (eos_token_id >= 0): the reference runs one `generate` per image, each stopping at its own EOS
+        (/root/reference/src/models/_qwen2_vl.py:319-337); here the batch decodes together, the done flags are read back
+        every `stop_check_every` steps one step behind the GPU (no stall), and with `compact_rows` the finished rows are
+        DROPPED from the following steps (as soon as >= 1/64 of the live rows are done): GEMM M and the attention grid shrink,
+        the KV cache stays in place (slot indirection), tokens land in their original rows.  Every kernel computes a row
+        independently of its neighbours, so the tokens equal the uncompacted run bit for bit (tested).
+        `stats` (optional dict) receives the live-row count of every step.
         Returns int32 [B, max_new_tokens] (pad after EOS) and, optionally, the first-step logits [B, vocab]
         (`return_logits`) or every step's logits [max_new_tokens, B, vocab] (`return_step_logits`).
         """
@@ -460,14 +468,20 @@ class Qwen2VLEngine:
         if int(max_pos.max()) + max_new_tokens + 1 > d.max_positions:
             raise ValueError("prompt + generation exceeds the rope table (raise Qwen2VLDims.max_positions)")
 
-        next_tok = torch.empty(B, dtype=I32, device=self.device)
+        # per-row decode state, two sets (a row compaction gathers from one into the other):
+        # [set][fed token, rope position, cache write index, key count, cache slot, key start, output row][B] + the done flags
+        ar = np.arange(B, dtype=np.int64)
+        st_host = np.stack([np.zeros(B, np.int64), max_pos + 1, lens, lens + 1, ar, ar * Hkv * s_max, ar]).astype(np.int32)
+        state = torch.empty((2, 7, B), dtype=I32, device=self.device)
+        state[0].copy_(self._i32(st_host))
+        done2 = torch.zeros((2, B), dtype=torch.uint8, device=self.device)
+        cur = 0
+        next_tok = state[0, 0]
         step_logits = torch.empty((max_new_tokens, B, d.vocab), dtype=BF16, device=self.device) if return_step_logits else None
         first_logits = step_logits[0] if return_step_logits else (
             torch.empty((B, d.vocab), dtype=BF16, device=self.device) if return_logits else None)
         forced = None
         if forced_tokens is not None:
-            if eos_token_id >= 0:
-                raise ValueError("forced_tokens needs EOS handling off (eos_token_id = -1)")
             forced = self._i32(np.asarray(forced_tokens).reshape(B, max_new_tokens).T)   # [T, B]: one contiguous row per step
 
         # ---- prefill in chunks of whole prompts (chunk size counted in packed ROWS: with a shared prefix every
@@ -482,68 +496,83 @@ class Qwen2VLEngine:
             self._prefill_chunk(prompts, pos_list, img_index, img_embeds, lens, b0, b1, cache, next_tok, first_logits)
             b0 = b1
 
-        # ---- greedy decode, whole batch per step
+        # ---- greedy decode: the live rows of the batch per step
         out_tokens = torch.empty((B, max_new_tokens), dtype=I32, device=self.device)
-        done = torch.zeros(B, dtype=torch.uint8, device=self.device)
+        out_tokens.fill_(pad_token_id)              # rows dropped by a compaction keep pad behind their last column
         eos1 = -1
-        rc = self._lib.owc_decode_update(self._ctx, next_tok.data_ptr(), done.data_ptr(), out_tokens.data_ptr(),
-                                         max_new_tokens, 0, B, eos_token_id, eos1, pad_token_id, _lib.stream_ptr())
+        rc = self._lib.owc_decode_update(self._ctx, next_tok.data_ptr(), done2[0].data_ptr(), out_tokens.data_ptr(),
+                                         max_new_tokens, 0, B, eos_token_id, eos1, pad_token_id, None,
+                                         forced[0].data_ptr() if forced is not None else None, _lib.stream_ptr())
         _lib.check(rc, self.dev_index)
-        if forced is not None:
-            next_tok.copy_(forced[0])
+        live_per_step = [B]
         if max_new_tokens > 1:
-            steps = np.arange(max_new_tokens - 1, dtype=np.int64)[:, None]
-            pos_all = self._i32(max_pos[None, :] + 1 + steps)      # rope position of the token fed at step j+1
-            widx_all = self._i32(lens[None, :] + steps)            # cache row it is written to
-            klen_all = self._i32(lens[None, :] + steps + 1)
-            ar = np.arange(B, dtype=np.int64)
-            slot = self._i32(ar)
-            k_start = self._i32(ar * Hkv * s_max)
-            q_start = self._i32(ar * (d.n_q_heads + 2 * Hkv))
+            q_start = self._i32(ar * (d.n_q_heads + 2 * Hkv))      # functions of the compact row index: prefixes stay valid
             o_start = self._i32(ar * d.n_q_heads)
             q_len = self._i32(np.full(B, G))
             nbytes = self._lib.owc_llm_workspace_bytes(C.byref(self.w.llm), B, B)
             ws = self._workspace(nbytes)
-            def step(j, pos_t, widx_t, klen_t, state):
+            col = torch.ones(1, dtype=I32, device=self.device)     # the step's output column, advanced on the device
+            n = B                                                  # live rows
+
+            def step(j):
+                v, dn = state[cur], done2[cur]
                 rc = self._lib.owc_llm_decode_step(
-                    self._ctx, C.byref(self.w.llm), C.byref(cache), next_tok.data_ptr(), pos_t.data_ptr(),
-                    slot.data_ptr(), widx_t.data_ptr(), k_start.data_ptr(), klen_t.data_ptr(),
-                    q_start.data_ptr(), o_start.data_ptr(), q_len.data_ptr(), done.data_ptr(), out_tokens.data_ptr(),
-                    max_new_tokens, j, _lib.ptr(state), B, eos_token_id, eos1, pad_token_id,
+                    self._ctx, C.byref(self.w.llm), C.byref(cache), v[0].data_ptr(), v[1].data_ptr(), v[4].data_ptr(),
+                    v[2].data_ptr(), v[5].data_ptr(), v[3].data_ptr(), q_start.data_ptr(), o_start.data_ptr(), q_len.data_ptr(),
+                    dn.data_ptr(), out_tokens.data_ptr(), max_new_tokens, j, col.data_ptr(), n, eos_token_id, eos1, pad_token_id,
+                    v[6].data_ptr(), forced[j].data_ptr() if forced is not None else None,
                     step_logits[j].data_ptr() if step_logits is not None else None, ws.data_ptr(), ws.numel(),
                     _lib.stream_ptr())
                 _lib.check(rc, self.dev_index)
-                if forced is not None:
-                    next_tok.copy_(forced[j])
 
-            def all_done(j):
-                return eos_token_id >= 0 and stop_check_every and j % stop_check_every == 0 and bool(done.all().item())
-
-            j = 1
+            watch = eos_token_id >= 0 and stop_check_every > 0
+            compact = compact_rows and step_logits is None
             if self.graph_decode and B <= self.graph_max_batch and max_new_tokens >= 4 and forced is None and step_logits is None:
                 # Small batches are launch-bound (~250 tiny launches per step): steps 2.. replay ONE captured hipGraph.  The
-                # step keeps its own rope position / write index / key count / output column on the device
-                # (`step_state`), so every replay is the same launch sequence with the same arguments.
-                step(1, pos_all[0], widx_all[0], klen_all[0], None)        # eager: loads code objects, sets kernel attributes
-                pos_c, widx_c, klen_c = pos_all[1].clone(), widx_all[1].clone(), klen_all[1].clone()
-                state = torch.tensor([2], dtype=I32, device=self.device)
+                # step keeps its own rope position / write index / key count / output column on the device, so every replay
+                # is the same launch sequence with the same arguments (no row compaction on this path).
+                step(1)                                             # eager: loads code objects, sets kernel attributes
                 graph = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize(self.device)
                 with torch.cuda.graph(graph):
-                    step(0, pos_c, widx_c, klen_c, state)
+                    step(0)
                 # the capture did not execute anything: replay for steps 2 .. T-1
                 for j in range(2, max_new_tokens):
                     graph.replay()
-                    if all_done(j):
-                        out_tokens[:, j + 1:] = pad_token_id
+                    live_per_step.append(B)
+                    if watch and j % max(stop_check_every, 8) == 0 and int(done2[0].cpu().numpy().min()) == 1:
                         break
                 del graph
             else:
+                flags = torch.empty(B, dtype=torch.uint8).pin_memory() if watch else None
+                pending = None                                      # (event, rows) of a done-flag snapshot in flight
                 for j in range(1, max_new_tokens):
-                    step(j, pos_all[j - 1], widx_all[j - 1], klen_all[j - 1], None)
-                    if all_done(j):
-                        out_tokens[:, j + 1:] = pad_token_id
-                        break
+                    step(j)
+                    live_per_step.append(n)
+                    if pending is not None:
+                        # the flags as of the step BEFORE the one just enqueued: the GPU is busy while the host looks at them
+                        pending[0].synchronize()
+                        alive = np.flatnonzero(flags[:pending[1]].numpy() == 0)
+                        pending = None
+                        if len(alive) == 0:
+                            break
+                        if compact and n - len(alive) >= max(1, n // 64):
+                            live = self._i32(alive)
+                            a, b_ = state[cur], state[cur ^ 1]
+                            rc = self._lib.owc_decode_compact(
+                                self._ctx, live.data_ptr(), len(alive), *(a[i].data_ptr() for i in (0, 1, 2, 3, 4, 5, 6)),
+                                done2[cur].data_ptr(), *(b_[i].data_ptr() for i in (0, 1, 2, 3, 4, 5, 6)),
+                                done2[cur ^ 1].data_ptr(), _lib.stream_ptr())
+                            _lib.check(rc, self.dev_index)
+                            cur ^= 1
+                            n = len(alive)
+                    if watch and j % stop_check_every == 0 and j + 1 < max_new_tokens:
+                        flags[:n].copy_(done2[cur, :n], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        pending = (ev, n)
+        if stats is not None:
+            stats["live_rows_per_step"] = live_per_step
         if return_step_logits:
             return out_tokens, step_logits
         return (out_tokens, first_logits) if return_logits else out_tokens
@@ -586,10 +615,10 @@ class Qwen2VLEngine:
         rc = self._lib.owc_llm_prefill(
             self._ctx, C.byref(self.w.llm), C.byref(cache), t_ids.data_ptr(), t_iidx.data_ptr(), _lib.ptr(img_embeds),
             t_pos3.data_ptr(), t_slot.data_ptr(), t_idx.data_ptr(), t_start.data_ptr(), t_len.data_ptr(), t_len.data_ptr(),
-            t_kstart.data_ptr(), t_want.data_ptr(), 1, n_out, S, S, 0, 1, top.data_ptr(), logits.data_ptr(), ws.data_ptr(),
+            t_kstart.data_ptr(), t_want.data_ptr(), 1, n_out, S, S, 0, 1, _lib.PREFILL_SCORE_ROWS, top.data_ptr(), logits.data_ptr(), ws.data_ptr(),
             ws.numel(), _lib.stream_ptr())
         _lib.check(rc, self.dev_index)
-        if n_out == 1:      # one row is the ordinary last-token prefill (n_out == n_seq): nothing to score
+        if n_out == 1:      # only the last position was asked for: nothing to score
             return np.zeros(0, np.float32), np.zeros(0, np.int32)
         target = self._i32(np.concatenate([ids[start:], [-1]]).astype(np.int32))
         lp = ops.token_logprob_bf16(logits, target)
@@ -650,6 +679,6 @@ class Qwen2VLEngine:
             self._ctx, C.byref(self.w.llm), C.byref(cache), t_ids.data_ptr(), t_iidx.data_ptr(),
             _lib.ptr(img_embeds), t_pos3.data_ptr(), t_slot.data_ptr(), t_idx.data_ptr(), t_start.data_ptr(),
             t_klen.data_ptr(), t_qlen.data_ptr(), t_kstart.data_ptr(), t_last.data_ptr(), n_seq, n, T,
-            int(q_len.max()), b0, n, next_tok[b0:b1].data_ptr(), logits_ptr, ws.data_ptr(), ws.numel(),
+            int(q_len.max()), b0, n, _lib.PREFILL_LAST_TOKENS, next_tok[b0:b1].data_ptr(), logits_ptr, ws.data_ptr(), ws.numel(),
             _lib.stream_ptr())
         _lib.check(rc, self.dev_index)

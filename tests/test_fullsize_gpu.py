@@ -165,6 +165,22 @@ def test_full_7b_properties(gpu):
     for b in (0, 120, 239, 240, 249):                                  # 240.. : the second prefill launch group
         single = eng.generate([ids[b]], emb_img, [grids[b]], 6, img_rows=[rows[b]])
         assert torch.equal(single[0], batch[b]), (b, single[0].tolist(), batch[b].tolist())
+    # EOS-aware row compaction at full width (reference: one `generate` per image, each stopping at its own EOS,
+    # src/models/_qwen2_vl.py:319-337): 700 rows (the 250 image prompts + 450 text prompts) with seeded ragged answer lengths
+    # shrink through the 256x256, 128x128, ring and skinny GEMM regimes; no token of any row may change
+    from tests.test_qwen2vl_gpu import _ragged_forced
+
+    eos, T = 151645, 28
+    ids2 = ids + [r.integers(1000, 150000, 20 + i % 11) for i in range(450)]
+    rows2 = rows + [np.zeros(0, np.int64)] * 450
+    grids2 = grids + [[]] * 450
+    forced, lens = _ragged_forced(r, len(ids2), T, eos, 150000, 7)
+    st = {}
+    plain = eng.generate(ids2, emb_img, grids2, T, img_rows=rows2, eos_token_id=eos, forced_tokens=forced, compact_rows=False)
+    comp = eng.generate(ids2, emb_img, grids2, T, img_rows=rows2, eos_token_id=eos, forced_tokens=forced, compact_rows=True, stats=st)
+    assert torch.equal(plain, comp)
+    live = st["live_rows_per_step"]
+    assert live[0] == 700 and min(live) <= 64 and all(x >= y for x, y in zip(live, live[1:])), live
 
 
 def test_full_7b_properties_ragged(gpu):

@@ -155,6 +155,26 @@ def test_product_never_imports_oracle():
         assert "oracle" not in f.read_text()
 
 
+def test_eval_model_cli_accepts_every_reference_flag():
+    """Every option string of the reference's `eval_model.py` parser (/root/reference/eval_model.py:386-585; list extracted from it)
+    parses here: a copied command line never dies in argparse."""
+    import eval_model
+
+    ref_flags = ["--apply_chat_template", "--batch_size", "--cache_requests", "--check_integrity", "--config", "--fewshot_as_multiturn",
+                 "--gen_kwargs", "--hf_hub_log_args", "--include_path", "--limit", "--log_level", "--log_samples", "--log_samples_suffix",
+                 "--model", "--model_args", "--num_fewshot", "--output_path", "--predict_only", "--process_with_media", "--seed",
+                 "--show_config", "--system_instruction", "--tasks", "--timezone", "--use_cache", "--wandb_args", "--wandb_log_samples",
+                 "--write_out"]
+    switches = {"--apply_chat_template", "--check_integrity", "--fewshot_as_multiturn", "--log_samples", "--predict_only",
+                "--process_with_media", "--show_config", "--wandb_log_samples", "--write_out"}
+    values = {"--cache_requests": "true", "--limit": "8", "--num_fewshot": "0"}
+    argv = []
+    for f in ref_flags:
+        argv += [f] if f in switches else [f, values.get(f, "x")]
+    args = eval_model.parse_args(argv)
+    assert args.process_with_media is True and args.limit == 8.0 and args.tasks == "x"
+
+
 def test_smart_resize_and_prompt_ids():
     from lmms_owc_amd.models import imageproc
 

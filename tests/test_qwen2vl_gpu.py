@@ -183,6 +183,63 @@ def test_graph_replayed_decode_equals_eager(setup, gpu):
     assert torch.equal(a2, b2) and int((a2[0, 4:] != 0).sum()) == 0
 
 
+def _ragged_forced(rng, B, T, eos, vocab, mean_len, cap_frac=0.02):
+    """Seeded per-sequence continuations: geometric stop lengths (a few forced to the cap), EOS at the stop column."""
+    lens = np.minimum(rng.geometric(1.0 / mean_len, B), T)
+    lens[rng.random(B) < cap_frac] = T + 1                       # never stops inside the cap
+    forced = rng.integers(1, vocab, (B, T))
+    forced[forced == eos] = eos - 1
+    for b in range(B):
+        if lens[b] <= T:
+            forced[b, lens[b] - 1] = eos
+    return forced.astype(np.int32), lens
+
+
+def test_row_compaction_is_bit_identical(setup, gpu):
+    """EOS-aware row compaction of the decode batch (reference: every image is its own `generate` call that stops at its own
+    EOS, src/models/_qwen2_vl.py:319-337): dropping the finished rows from the following steps changes no token of any row -
+    forced (seeded ragged answer lengths) and free-running, with image prompts of unequal length, across the kernel switches
+    the shrinking batch goes through (256x256 / ring / skinny GEMMs, both decode-attention forms)."""
+    cfg, w, eng, g = setup
+    r = np.random.default_rng(77)
+    B, T, eos = 150, 40, 9
+    prompts = [r.integers(10, 400, 6 + (i % 9)).astype(np.int64) for i in range(B)]
+    none = [[] for _ in prompts]
+    forced, lens = _ragged_forced(r, B, T, eos, 400, 6)
+    st_a, st_b = {}, {}
+    a = to_np(eng.generate(prompts, None, none, T, eos_token_id=eos, pad_token_id=0, forced_tokens=forced, compact_rows=False, stats=st_a))
+    b = to_np(eng.generate(prompts, None, none, T, eos_token_id=eos, pad_token_id=0, forced_tokens=forced, compact_rows=True, stats=st_b))
+    assert np.array_equal(a, b)
+    for i in range(B):                                         # a row is padded behind the column its forced continuation ends at
+        assert (a[i, min(lens[i], T):] == 0).all() and (lens[i] > T or a[i, :lens[i]].min() >= 0)
+    la, lb = st_a["live_rows_per_step"], st_b["live_rows_per_step"]
+    assert max(la) == B and lb[0] == B and min(lb) < B // 8 and sum(lb) < 0.5 * sum(la), (la, lb)
+    assert all(x >= y for x, y in zip(lb, lb[1:]))
+    # every `stop_check_every` gives the same tokens (rows only leave later)
+    c = to_np(eng.generate(prompts, None, none, T, eos_token_id=eos, pad_token_id=0, forced_tokens=forced, stop_check_every=5))
+    assert np.array_equal(a, c)
+    # free-running with a frequent token as EOS, image prompts
+    grids = [[(1, 4, 4)], [(1, 6, 4)], [(1, 4, 8)], [(1, 4, 4)], [(1, 8, 4)]] * 4
+    ps, pixs = [], []
+    for i, grid in enumerate(grids):
+        n_img = grid[0][1] * grid[0][2] // 4
+        ps.append(np.concatenate([r.integers(1, 400, 3 + i % 4), np.full(n_img, cfg.image_token_id), r.integers(1, 400, 2 + i % 3)]))
+        pixs.append(recipes.pixel_values(grid, 60 + i))
+    emb = eng.encode_images(torch.from_numpy(np.concatenate(pixs)).to(torch.bfloat16).to(gpu), [gg for gs in grids for gg in gs])
+    free = to_np(eng.generate(ps, emb, grids, 16))
+    vals, counts = np.unique(free[:, 1:12], return_counts=True)
+    eos2 = int(vals[np.argmax(counts)])
+    s2 = {}
+    x = to_np(eng.generate(ps, emb, grids, 16, eos_token_id=eos2, pad_token_id=0, compact_rows=False))
+    y = to_np(eng.generate(ps, emb, grids, 16, eos_token_id=eos2, pad_token_id=0, compact_rows=True, stats=s2))
+    assert np.array_equal(x, y)
+    for i in range(len(ps)):                                   # and both equal the free run up to the first EOS, pad behind it
+        hit = np.flatnonzero(free[i] == eos2)
+        k = int(hit[0]) + 1 if len(hit) else 16
+        assert np.array_equal(x[i, :k], free[i, :k]) and (x[i, k:] == 0).all()
+    assert min(s2["live_rows_per_step"]) < len(ps)
+
+
 def test_rmsnorm_fused_into_the_skinny_gemm_is_bit_identical(setup, gpu):
     """Decode at 1-2 sequences (the kernel takes up to 4: the knob's maximum is exercised here): the qkv / gate-up projections
     normalise their own activations (gemm_bf16_skinny_norm_kernel, one launch less per RMSNorm).  Same bits as rmsnorm + GEMM - for
