@@ -53,7 +53,7 @@ int owc_tuning_set(const char* name, int value) {
   else if (!strcmp(name, "gemm_wide_tiles")) owc_gemm_set_tall_tiles(value);   // 0: no 64x160 / 128x160 ring tiles for <= 128 rows x many columns
   else if (!strcmp(name, "gemm_small_tiles")) {
     owc_gemm_set_small_tiles(value);
-    owc_gemm_fp8_set_shapes(value != 0);
+    owc_gemm_fp8_set_shapes(value != 0 && value != 2);   // (2 forces 64x64 for both dtypes)
   }   // 0: 64x64 tiles only; 1 (default): by block count; 2..4: force 64x64 / 64x32 / 32x32
   else if (!strcmp(name, "decode_fuse")) owc_llm_set_decode_fuse(value);
   else if (!strcmp(name, "decode_norm_fuse")) owc_gemm_set_norm_fuse_max_m(value);   // max rows (<= 4) for the RMSNorm-fused skinny GEMM; 0 = off

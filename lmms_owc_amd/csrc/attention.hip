@@ -400,6 +400,11 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
     const float* __restrict__ sin_t, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, const int* __restrict__ slot,
     const int* __restrict__ write_idx, const int* __restrict__ k_len, bf16_t* __restrict__ O, long ldo, int n_q, int n_kv,
     int s_max, float scale_log2e) {
+  // The two instantiations (NBUF 1 / 2) must give the SAME BITS: a decode batch that shrinks (EOS-aware row compaction) crosses
+  // from one to the other in the middle of a sequence.  Under -ffp-contract=fast the compiler decided per instantiation which
+  // mul + add pairs become an fma (round 4: the disassemblies differed by one v_fma_f32 / v_sub_f32, and ~1 % of the row-steps of
+  // a 7B decode at >= 5 key tiles flipped a near-tie argmax), so contraction is OFF here and every fused multiply-add below is spelled out.
+#pragma clang fp contract(off)
   using C = Cfg<128>;
   extern __shared__ __attribute__((aligned(16))) char lds[];  // [4 waves][2 buffers][V tile 16 KiB]; reused for the merge
   const int tid = threadIdx.x;
@@ -539,10 +544,10 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        x[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] * scale_log2e + neg);
+        x[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], scale_log2e, neg));
         sum += x[kt][r];
       }
-    lrun = lrun * alpha + sum;
+    lrun = __builtin_fmaf(lrun, alpha, sum);
 #pragma unroll
     for (int d = 0; d < C::DT; ++d) {
       o[d][0] *= alpha;
@@ -604,7 +609,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       f[k] = __builtin_amdgcn_exp2f((mg[(size_t)k * 34 * 64 + l] - M) * scale_log2e);   // 0 for a wave without tiles
-      Lt += mg[(size_t)k * 34 * 64 + 64 + l] * f[k];
+      Lt = __builtin_fmaf(mg[(size_t)k * 34 * 64 + 64 + l], f[k], Lt);
     }
     const float inv = 1.0f / Lt;
     bf16_t* op = O + (long)b * ldo + (long)(hk * G + fr) * 128 + g * 4;
@@ -615,7 +620,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
       for (int r = 0; r < 4; ++r) {
         float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc += mg[(size_t)k * 34 * 64 + (2 + d * 4 + r) * 64 + l] * f[k];
+        for (int k = 0; k < 4; ++k) acc = __builtin_fmaf(mg[(size_t)k * 34 * 64 + (2 + d * 4 + r) * 64 + l], f[k], acc);
         ov[r] = f2bf(acc * inv);
       }
       *(bf16x4*)(op + d * 16) = ov;

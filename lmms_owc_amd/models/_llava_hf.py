@@ -202,6 +202,9 @@ class LLaVA(Model):
                 if round_idx:
                     outs = [doc_to_text[0](d, round_idx=round_idx, previous_round_results=[r[i] for r in round_results],
                                            last_round_info=None) for i, d in enumerate(docs)]
+                    # the per-round results continue from what the task RETURNS (item 3), as in the reference (:496-506): a task may
+                    # rewrite or truncate earlier answers
+                    round_results = [list(r) for r in zip(*[o[3] for o in outs], strict=True)]
                     if outs[0][2]:   # terminal signal of the first document of the batch (:496)
                         break
                     visuals_per_doc = [list(o[0]) if o[0] is not None else [] for o in outs]

@@ -228,6 +228,9 @@ class Qwen2VL(Model):
                 if round_idx:
                     outs = [doc_to_text[0](d, round_idx=round_idx, previous_round_results=[r[i] for r in round_results],
                                            last_round_info=None) for i, d in enumerate(docs)]
+                    # the per-round results continue from what the task RETURNS (item 3), as in the reference (:455-461): a task may
+                    # rewrite or truncate earlier answers
+                    round_results = [list(r) for r in zip(*[o[3] for o in outs], strict=True)]
                     if outs[0][2]:  # terminal signal (the reference looks at the first document of the batch, :462)
                         break
                     texts = [o[1].replace("<image>", "") for o in outs]

@@ -15,6 +15,8 @@ shapes = [("qkv", d + 2 * kv, d, "bias"), ("o", d, d, "residual"), ("gateup", 2 
           ("lm_head", vocab, d, "none"), ("vit.qkv", 3840, 1280, "bias"), ("vit.fc1", 5120, 1280, "quick_gelu"),
           ("vit.fc2", 1280, 5120, "residual"), ("vit.patch", 1280, 1176, "none")]
 Ms = [1, 8, 32, 33, 64, 65, 128, 286, 512, 1024, 2048, 18304]
+if len(sys.argv) > 2:   # e.g. 1,700,1025,1424,1793,2048: the row counts a compacting decode batch walks through
+    Ms = [int(x) for x in sys.argv[2].split(",")]
 g = torch.Generator(device=dev).manual_seed(5)
 bad = 0
 for name, n, k, epi in shapes:
@@ -29,8 +31,13 @@ for name, n, k, epi in shapes:
         row = out[0].clone()
         if ref is None:
             ref = row
+            full = ops.gemm_bf16(a, w, None if epi in ("none", "swiglu") else b, epilogue=E, residual=r if epi == "residual" else None)
         elif not torch.equal(row, ref):
             bad += 1
             print(f"{model} {name} N={n} K={k} {epi}: row 0 at M={m} differs from M={Ms[0]} in {(row != ref).sum().item()} of {row.numel()} elements", flush=True)
+        if not torch.equal(out, full[:m]):   # EVERY row of the M-row launch against the same rows of the largest launch
+            bad += 1
+            rows = (out != full[:m]).any(dim=1).nonzero().flatten()
+            print(f"{model} {name} N={n} K={k} {epi}: M={m}: {len(rows)} rows differ from the M={max(Ms)} launch, first {rows[:6].tolist()}", flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
