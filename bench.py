@@ -233,7 +233,16 @@ def _sizes_flowers102(r, n):
 DATASET_SIZES = {"food101": _sizes_food101, "dtd": _sizes_dtd, "flowers102": _sizes_flowers102}
 
 
-def ragged_leg(engine, dims, name: str, n: int, T: int, steps: int, device, sync, min_pixels: int = 4 * 784, max_pixels: int = 1024 * 784) -> dict:
+def gemm_roofline(p: dict, dt_total: float, what: str) -> dict:
+    """`roofline` object of a leg from the library's bf16-GEMM launch class (HIP events around every launch of the leg)."""
+    tf = p["work"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
+    return {"bound": "mfma", "kernel": "gemm_bf16_nt_* (all epilogues) " + what, "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / PEAK_BF16_TFLOPS, "traffic": None, "launches": p["launches"], "kernel_ms_total": p["ms"],
+            "share_of_leg_time": p["ms"] * 1e-3 / time_or(dt_total)}
+
+
+def ragged_leg(engine, dims, name: str, n: int, T: int, steps: int, device, sync, min_pixels: int = 4 * 784, max_pixels: int = 1024 * 784,
+               profile=None) -> dict:
     """The reference resizes every image inside [min_pixels, max_pixels] (`_qwen2_vl.py:64-65, 299-305`) -> 64...1024 image tokens
     per image.  `n` images with the dataset's size distribution -> smart_resize (two stages, like `imageproc.prepare_image`) ->
     uint8 uniform pixels -> owc_patchify_u8 -> ragged vision launch groups -> prompts of 14 + n_tok + 16 tokens (unequal lengths:
@@ -270,11 +279,14 @@ def ragged_leg(engine, dims, name: str, n: int, T: int, steps: int, device, sync
 
     out = step()
     sync()
+    if profile:
+        profile(True)
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
     sync()
     dt = (time.perf_counter() - t0) / steps
+    prof = profile(False) if profile else None
     # property checks outside the timed region: determinism, and a short + a long image alone == inside the ragged batch
     again = step()
     lo, hi = int(np.argmin(n_tok)), int(np.argmax(n_tok))
@@ -290,9 +302,96 @@ def ragged_leg(engine, dims, name: str, n: int, T: int, steps: int, device, sync
             "distinct_grids": len(by_size), "prompt_tokens": {"min": 30 + min(n_tok), "max": 30 + max(n_tok)},
             "model_flops_per_image_mean": flops / n, "mfma_frac_end_to_end_nominal": flops / dt / (PEAK_BF16_TFLOPS * 1e12),
             "deterministic_and_batch_invariant": inv,
+            "roofline": gemm_roofline(prof["gemm_bf16"], dt * steps, "of the ragged launch groups") if prof else None,
             "what": "seeded (height, width) model of the dataset's published sizing rule -> smart_resize within [3136, 802816] px -> "
                     "ragged cu_seqlens vision launch groups + unequal prompts (shared 14-token prefix); uniform-noise pixels; never `value`"}
 
+
+def config2_leg(device, T: int, sync, profile, images: int = 512, passes: int = 3) -> dict:
+    """BASELINE.json configs[1] (never `value`): Qwen2-VL-2B bf16, 512 images (Caltech-101 --limit 512 at the synthetic 448x448 size),
+    one GPU: its own weights and engine beside the headline model's, `passes` timed passes after one warm-up."""
+    from lmms_owc_amd import ops as owc_ops
+    from lmms_owc_amd.engine.qwen2vl import DIMS, Qwen2VLEngine, Qwen2VLWeights
+    from lmms_owc_amd.models import imageproc
+
+    d2 = DIMS["qwen2-vl-2b"]
+    eng = Qwen2VLEngine(Qwen2VLWeights.random(d2, device, seed=1234))
+    gen = torch.Generator(device=device).manual_seed(77)
+    u8 = torch.randint(0, 256, (images, 3, 448, 448), generator=gen, device=device, dtype=torch.uint8)
+    pix = owc_ops.patchify_u8(u8, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD)
+    del u8
+    ids = prompt_ids(d2.image_token_id)
+    prompts, grids, flat = [ids] * images, [[(1, 32, 32)]] * images, [(1, 32, 32)] * images
+
+    def step():
+        return eng.generate(prompts, eng.encode_images(pix, flat), grids, T, eos_token_id=-1, pad_token_id=0).cpu()
+
+    step()
+    sync()
+    profile(True)
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        out = step()
+    sync()
+    dt = (time.perf_counter() - t0) / passes
+    prof = profile(False)
+    solo = eng.generate(prompts[:1], eng.encode_images(pix[:1024], flat[:1]), grids[:1], T, eos_token_id=-1, pad_token_id=0).cpu()
+    f = flops_per_image(d2, T)
+    per_chunk = max(1, min(images, (eng.prefill_chunk_tokens - S_TEXT_BEFORE) // (S_IMG + S_TEXT_AFTER)))
+    f_exec = f - pruned_flops_per_image(d2, per_chunk)
+    return {"config": "BASELINE.json configs[1]: Qwen2-VL-2B bf16, 512 synthetic 448x448 images per pass, 1 GPU", "images": images, "new_tokens": T,
+            "seconds_per_pass": dt, "images_per_s": images / dt, "model_flops_per_image": f, "executed_flops_per_image": f_exec,
+            "mfma_frac_end_to_end": images / dt * f_exec / (PEAK_BF16_TFLOPS * 1e12),
+            "batch_invariance_check": bool(torch.equal(solo[0], out[0])),
+            "roofline": gemm_roofline(prof["gemm_bf16"], dt * passes, "of the 2B pass")}
+
+
+def cosine_10k_leg(scorer, device, sync, profile, n_pred: int = 65536, n_cls: int = 10000, k: int = 5, passes: int = 5) -> dict:
+    """BASELINE.json configs[4]'s scorer side (never `value`): class-name embedding of a ~10k-class vocabulary on the GPU + cosine
+    top-k of `n_pred` predictions against it (the N x C similarity matrix is never materialised)."""
+    r = np.random.default_rng(5)
+    L = 16
+    ids = r.integers(1000, 30000, (n_cls, L)).astype(np.int32)
+    lens = r.integers(2, L + 1, n_cls)
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int32)
+    sync()
+    t0 = time.perf_counter()
+    cls_z = scorer.embed(ids, mask)
+    sync()
+    t_cls = time.perf_counter() - t0
+    g = torch.Generator(device=device).manual_seed(9)
+    z = torch.randn((n_pred, 384), generator=g, device=device, dtype=torch.float32)
+    z = z / z.norm(dim=1, keepdim=True)              # synthetic unit-norm prediction embeddings (input preparation, not the path)
+    label = torch.from_numpy(r.integers(0, n_cls, n_pred).astype(np.int32)).to(device)
+    scorer.topk(z, cls_z, k, label)
+    sync()
+    profile(True)
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        tv, ti, paired = scorer.topk(z, cls_z, k, label)
+    sync()
+    dt = (time.perf_counter() - t0) / passes
+    ck = profile(False)["cosine_topk"]
+    tf = ck["work"] / (ck["ms"] * 1e-3) / 1e12 if ck["ms"] > 0 else 0.0
+    byt = passes * (4.0 * 384 * (n_pred + n_cls) + 8.0 * k * n_pred)
+    # self-check on a slice (the full N x C matrix is exactly what the kernel avoids): top-1 of 256 predictions against torch
+    ref = (z[:256] @ cls_z.T).max(dim=1)
+    ok = bool(torch.equal(ref.indices.to(torch.int32), ti[:256, 0])) and bool(torch.allclose(ref.values, tv[:256, 0], atol=2e-6))
+    return {"config": "BASELINE.json configs[4], scorer side: on-GPU class-name embed + cosine top-k at a ~10k-class vocabulary",
+            "classes": n_cls, "predictions": n_pred, "top_k": k, "class_embed_seconds": t_cls, "class_labels_per_s": n_cls / t_cls,
+            "label_cosine_per_sec": n_pred / dt, "top1_matches_dense_matmul_on_256_rows": ok,
+            "roofline": {"bound": "mfma", "kernel": "cosine_topk_kernel (C = 10 000)", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": tf / 157.3, "traffic": None, "launches": ck["launches"], "kernel_ms_total": ck["ms"],
+                         "hbm_gbs_on_algorithmic_bytes": byt / (ck["ms"] * 1e-3) / 1e9 if ck["ms"] > 0 else 0.0,
+                         "note": "2 N C D on the f32-input MFMA (157 TF dense f32 matrix peak); algorithmic bytes 4 D (N + C) + 8 k N"}}
+
+
+BUILDER_RUN_CONFIGS = {
+    "configs[3] LLaVA-NeXT-34B (CLIP-L/336 + Yi-34B dims, 69.5 GB of weights: load time keeps it out of the default run)":
+        "python tools/bench_llava.py --model llava-next-34b --batch 48 --image-size 480x640",
+    "configs[4] Qwen2-VL-72B fp8 decoder (73 GB of fp8 + bf16 weights)":
+        "python bench.py --model 72b --decoder-dtype fp8 --batch 1024 --no-cpu-baseline --no-pil-leg --no-extra-legs",
+}
 
 EOS_ID = 151645   # <|im_end|>: Qwen2-VL's EOS token id
 
@@ -321,11 +420,17 @@ def eos_terminated_leg(engine, pix, flat_grids, prompts, grids, B: int, sync, he
            "headline_images_per_s_forced_16": headline_images_per_s, "by_cap": []}
     d = engine.d
     for cap in caps:
-        kv_bytes = 4.0 * d.n_layers * B * d.n_kv_heads * d.head_dim * (len(prompts[0]) + cap)
-        torch.cuda.empty_cache()
+        kv_elems = d.n_layers * B * d.n_kv_heads * d.head_dim * (len(prompts[0]) + cap)
+        kv_bytes = 4.0 * kv_elems
+        if kv_bytes + (8 << 30) > torch.cuda.mem_get_info()[0]:
+            torch.cuda.empty_cache()
         if kv_bytes + (8 << 30) > torch.cuda.mem_get_info()[0]:
             out["by_cap"].append({"max_new_tokens": cap, "skipped": f"KV cache of {kv_bytes / 2**30:.0f} GiB does not fit beside the weights at this batch"})
             continue
+        # the K / V caches of this cap are new sizes for torch's caching allocator: take the blocks from the driver once, outside the
+        # timed passes (a task pays this once, whatever its length; measured: up to 1 s of hipMalloc for 2 x 20 GB)
+        warm = [torch.empty(kv_elems, dtype=torch.bfloat16, device=pix.device) for _ in range(2)]
+        del warm
         forced, lens = ragged_answer_lengths(B, cap, mean_len, cap_frac, 4242 + rank)
         row = {"max_new_tokens": cap, "mean_answer_tokens": float(np.minimum(lens, cap).mean()), "sequences_at_cap": int((lens > cap).sum())}
         toks = {}
@@ -341,6 +446,7 @@ def eos_terminated_leg(engine, pix, flat_grids, prompts, grids, B: int, sync, he
             live = st["live_rows_per_step"]
             row["compacted" if compact else "all_rows_every_step"] = {
                 "seconds": dt, "images_per_s": B / dt, "vs_headline": B / dt / headline_images_per_s, "decode_steps_run": len(live) - 1,
+                "decode_loop_seconds": st["decode_events"][0].elapsed_time(st["decode_events"][1]) * 1e-3,
                 "row_steps": int(sum(live[1:])), "live_rows_at_step": {str(j): int(live[j]) for j in (1, 4, 8, 16, 32, 63, 128, 255) if j < len(live)}}
             del emb
         if len(toks) == 2:
@@ -454,7 +560,9 @@ def main() -> None:
     ap.add_argument("--no-pil-leg", action="store_true", help="skip the PIL -> generate_until -> strings leg")
     ap.add_argument("--no-decode-leg", action="store_true", help="skip the HBM-regime decode leg (decode step at batch 1 / 32 / 128)")
     ap.add_argument("--no-eos-leg", action="store_true", help="skip the EOS-terminated ragged-answer-length leg (max_new_tokens 64 / 256)")
-    ap.add_argument("--image-sizes", default=None, choices=sorted(DATASET_SIZES),
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the other configs' short legs (Food-101 image sizes, Qwen2-VL-2B / 512 images, label-cosine at C = 10 000)")
+    ap.add_argument("--image-sizes", default="food101", choices=sorted(DATASET_SIZES) + ["none"],
                     help="extra leg (never `value`): images of the dataset's real size distribution through smart_resize "
                          "(64...1024 image tokens per image, ragged vision / prefill launch groups); reports images/s and image-tokens/s")
     ap.add_argument("--ragged-images", type=int, default=1024, help="images of the --image-sizes leg")
@@ -649,9 +757,18 @@ def main() -> None:
     if dist is not None:
         dist.barrier()
 
+    def profile(on: bool):
+        """Leg-level kernel profile: start (True) / stop and read (False) the library's per-launch-class HIP-event recording."""
+        if on:
+            lib.owc_gemm_profile_enable(ctx, 1)
+            return None
+        p = read_profile()
+        lib.owc_gemm_profile_enable(ctx, 0)
+        return p
+
     ragged = None
-    if args.image_sizes:
-        ragged = ragged_leg(engine, dims, args.image_sizes, args.ragged_images, T, max(1, args.steps - 1), device, sync)
+    if args.image_sizes != "none" and not (args.no_extra_legs and args.image_sizes == "food101"):
+        ragged = ragged_leg(engine, dims, args.image_sizes, args.ragged_images, T, min(2, max(1, args.steps - 1)), device, sync, profile=profile)
         if dist is not None:
             t = torch.tensor([ragged["seconds_per_pass"]], device=cdev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -687,6 +804,15 @@ def main() -> None:
         dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
     labels_per_s = world * n_lab * args.steps / float(sdt.item())
     label_tokens = int(lens.sum())
+
+    # ---- the other BASELINE configs in front of the driver (never `value`): configs[1] and the scorer side of configs[4]
+    cfg2 = cos10k = None
+    if not args.no_extra_legs and rank == 0:
+        cos10k = cosine_10k_leg(scorer, device, sync if dist is None else torch.cuda.synchronize, profile)
+        if args.model != "2b":
+            cfg2 = config2_leg(device, T, sync if dist is None else torch.cuda.synchronize, profile)
+    if dist is not None:
+        dist.barrier()
 
     parity_failure = None
     if rank == 0:
@@ -731,6 +857,9 @@ def main() -> None:
             "roofline_decode": decode_leg,
             "eos_terminated": eos_leg,
             "real_image_sizes": ragged,
+            "config2_qwen2vl_2b": cfg2,
+            "label_cosine_10k_classes": cos10k,
+            "builder_run_configs": BUILDER_RUN_CONFIGS,
             "roofline_label_cosine": scorer_rooflines(sprof, n_lab, args.scorer_classes, 5, args.steps, float(sdt.item())),
         }
         if args.one_gpu_value:

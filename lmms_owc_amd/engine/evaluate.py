@@ -11,17 +11,18 @@ The results dict carries the reference's keys (`results` incl. `alias`, `group_s
 tests/golden/engine_formats.json).
 
 Multi-GPU: one process per GPU, no data-path collective.  The reference moves pickled per-doc dicts with two
-`gather_object` calls per task (`_engine.py:298-315`); here every rank contributes a FIXED-WIDTH int32 record per document,
+`gather_object` calls per task (`_engine.py:298-315`) and scores every document on rank 0; here every rank SCORES ITS OWN
+documents (take_first filter, `process_results`, the sample record with its hashes - round 4: on rank 0 alone that tail ran at
+~10 k documents/s, i.e. 18 % on top of the GPU time of an 8-rank task, `tools/time_rank_tail.py`) and contributes ONE
+FIXED-WIDTH int32 record per document,
 
-    { doc_id, n, payload[width] }      payload = generated token ids (models with `generate_until_tokens`: the ids go
-                                        to rank 0 over RCCL and are detokenised there) or the UTF-8 bytes of the
-                                        JSON-encoded answer (any other `Model` plug-in, multi-round tuples included),
+    { doc_id, n, payload[width] }      payload = the UTF-8 bytes of the JSON-encoded [sample record, metric values],
 
 all ranks pad their shard to the largest shard (sizes follow from the shard function; the record width is agreed by one
-8-byte all_reduce(MAX)) and ONE `all_gather_into_tensor` (RCCL over xGMI; gloo in the CPU tests) brings them together.  Rank 0 then builds the records for ALL
-documents in doc_id order, so an N-rank run writes byte-identical files to a 1-rank run (the reference's N-rank file holds
-the same lines in rank-major order).  Uneven shards need no padding requests (the reference re-runs the last request,
-`_engine.py:176-191`, and discards the extras).
+8-byte all_reduce(MAX)) and ONE `all_gather_into_tensor` (RCCL over xGMI; gloo in the CPU tests) brings them together.  Rank 0
+only parses the records and lines them up in doc_id order, so an N-rank run writes byte-identical files to a 1-rank run (the
+reference's N-rank file holds the same lines in rank-major order).  Uneven shards need no padding requests (the reference
+re-runs the last request, `_engine.py:176-191`, and discards the extras).
 """
 
 from __future__ import annotations
@@ -96,9 +97,8 @@ def shard_sizes(n_docs: int, limit: int | None, world: int) -> list[int]:
     return [len(range(r, stop, world)) for r in range(world)]
 
 
-def _pack_bytes(resps: list) -> tuple[np.ndarray, np.ndarray]:
-    """JSON -> UTF-8 -> int32 words, one row per answer (the generic `Model` plug-in path)."""
-    blobs = [json.dumps(x, ensure_ascii=False).encode("utf-8") for x in resps]
+def _pack_bytes(blobs: list[bytes]) -> tuple[np.ndarray, np.ndarray]:
+    """UTF-8 blobs -> int32 words, one zero-padded row per document."""
     width = max([1] + [(len(b) + 3) // 4 for b in blobs])
     mat = np.zeros((len(blobs), width), np.int32)
     for i, b in enumerate(blobs):
@@ -106,20 +106,11 @@ def _pack_bytes(resps: list) -> tuple[np.ndarray, np.ndarray]:
     return mat, np.array([len(b) for b in blobs], np.int32)
 
 
-def _unpack_bytes(row: np.ndarray, n: int):
-    out = json.loads(np.ascontiguousarray(row).view(np.uint8)[:n].tobytes().decode("utf-8"))
-    return tuple(out) if isinstance(out, list) else out   # multi-round answers are tuples of per-round strings
-
-
-def gather_answers(lm, reqs: list, resps, sizes: list[int], rank: int, world: int, dist, token_mode: bool) -> dict | None:
-    """All ranks: contribute this shard's answers as fixed-width records; rank 0 returns {doc_id: answer}."""
-    if token_mode:
-        payload, n = resps                       # int32 [n_local, T] (torch, on lm.device, or numpy) and lengths
-        payload = torch.as_tensor(payload, dtype=torch.int32)
-        n = torch.as_tensor(n, dtype=torch.int32)
-    else:
-        mat, nb = _pack_bytes(list(resps))
-        payload, n = torch.from_numpy(mat), torch.from_numpy(nb)
+def gather_records(lm, doc_ids: list[int], blobs: list[bytes], sizes: list[int], rank: int, world: int, dist) -> dict | None:
+    """All ranks: contribute one JSON document (UTF-8 bytes) per owned document as a fixed-width record; rank 0 returns
+    {doc_id: parsed object}."""
+    mat, nb = _pack_bytes(blobs)
+    payload, n = torch.from_numpy(mat), torch.from_numpy(nb)
     # RCCL moves device memory, gloo (CPU tests) host memory
     device = torch.device(lm.device) if dist is not None and dist.get_backend() == "nccl" else torch.device("cpu")
     width = torch.tensor([payload.shape[1] if payload.ndim == 2 and payload.shape[0] else 0], dtype=torch.int64, device=device)
@@ -130,9 +121,9 @@ def gather_answers(lm, reqs: list, resps, sizes: list[int], rank: int, world: in
     if rows == 0:   # no rank owns a document (limit 0 / empty task)
         return {} if rank == 0 else None
     rec = torch.zeros((rows, 2 + W), dtype=torch.int32, device=device)
-    k = len(reqs)
+    k = len(doc_ids)
     if k:
-        rec[:k, 0] = torch.tensor([r.doc_id for r in reqs], dtype=torch.int32, device=device)
+        rec[:k, 0] = torch.tensor(doc_ids, dtype=torch.int32, device=device)
         rec[:k, 1] = n.to(device)
         rec[:k, 2:2 + payload.shape[1]] = payload.to(device)
     if dist is not None:
@@ -142,18 +133,39 @@ def gather_answers(lm, reqs: list, resps, sizes: list[int], rank: int, world: in
         allrec = rec
     if rank != 0:
         return None
-    allrec = allrec.cpu().numpy().reshape(world, rows, 2 + W)
+    allrec = np.ascontiguousarray(allrec.cpu().numpy().reshape(world, rows, 2 + W))
     out = {}
-    for r in range(world):
+    for r in range(world):   # one JSON parse per rank: its records joined into an array (a parse per record costs 5x as much)
         part = allrec[r, : sizes[r]]
-        if token_mode:
-            texts = lm.decode_tokens([row[2:2 + int(row[1])] for row in part]) if len(part) else []
-            for row, text in zip(part, texts):
-                out[int(row[0])] = text
-        else:
-            for row in part:
-                out[int(row[0])] = _unpack_bytes(row[2:], int(row[1]))
+        if not len(part):
+            continue
+        raw = part[:, 2:].view(np.uint8).reshape(len(part), 4 * W)
+        objs = json.loads(b"[" + b",".join(raw[i, : part[i, 1]].tobytes() for i in range(len(part))) + b"]")
+        out.update(zip(part[:, 0].tolist(), objs))
     return out
+
+
+def doc_record(task, req, log_samples: bool) -> tuple[dict | None, dict]:
+    """One document's share of the post-processing (`_engine.py:244-292`): metric values and, with `log_samples`, the sample record."""
+    doc = req.doc
+    metrics = task.process_results(doc, [req.filtered_resps["none"]])
+    if not log_samples:
+        return None, metrics
+    target = task.doc_to_target(doc)
+    example = {
+        # the reference's filter (`_engine.py:263`) plus: values that JSON cannot carry are dropped (a decoded PIL
+        # image under `visual` would be written as its repr, memory address included; the reference's rows hold a path)
+        "doc_id": req.doc_id,
+        "doc": {k: v for k, v in doc.items() if "image" not in k and isinstance(v, _SERIALIZABLE)}, "target": target,
+        "arguments": [a for a in req.args if isinstance(a, _SERIALIZABLE)],
+        "resps": [req.resps], "filtered_resps": [req.filtered_resps["none"]],
+        # the reference hashes `requests[0].doc`, which its TaskInstance never sets (tasks/_manager.py:881 `# doc=doc`):
+        # every record carries sha256("null") (`_engine.py:267-274`); kept for file compatibility
+        "doc_hash": DOC_HASH_OF_NONE,
+        "prompt_hash": utils.hash_string(req.args[0]), "target_hash": utils.hash_string(str(target)),
+    }
+    example.update(metrics)
+    return example, metrics
 
 
 def evaluate(lm, task_dict: dict, limit: int | float | None = None, log_samples: bool = True,
@@ -171,49 +183,21 @@ def evaluate(lm, task_dict: dict, limit: int | float | None = None, log_samples:
         sizes = shard_sizes(n_docs, limit, world)
         assert len(reqs) == sizes[rank]
         # requests of a task share one type (generate_until | generate_until_multi_round): dispatch like _engine.py:180-198
-        token_mode = world > 1 and task.OUTPUT_TYPE == "generate_until" and hasattr(lm, "generate_until_tokens")
-        if token_mode:
-            resps = lm.generate_until_tokens(reqs)
-        else:
-            resps = getattr(lm, task.OUTPUT_TYPE)(reqs) if reqs else []
-        if world > 1:
-            answers = gather_answers(lm, reqs, resps, sizes, rank, world, dist, token_mode)
-        else:
-            answers = {r.doc_id: x for r, x in zip(reqs, resps, strict=True)}
-        if rank != 0:
-            continue
-        # ---- rank 0: records for ALL documents, in doc_id order
-        if world > 1:
-            own_args = {r.doc_id: r.arguments for r in reqs}   # keeps what the model did to its own requests' gen_kwargs
-            task.build_all_requests(limit=limit, rank=0, world_size=1)
-            for r in task.instances:
-                if r.doc_id in own_args:
-                    r.arguments = own_args[r.doc_id]
-                else:   # another rank's request: its model popped `until` the same way (models/_qwen2_vl.py)
-                    r.args[1].pop("until", None)
-            reqs = task.instances
-        for r in reqs:
-            r.resps.append(answers[r.doc_id])
+        resps = getattr(lm, task.OUTPUT_TYPE)(reqs) if reqs else []
+        for r, x in zip(reqs, resps, strict=True):
+            r.resps.append(x)
         task.apply_filters()
+        # every rank post-processes the documents it owns ...
+        local = [doc_record(task, req, log_samples) for req in reqs]
+        if world > 1:   # ... and rank 0 receives [sample record, metric values] per document, ordered by doc_id below
+            blobs = [json.dumps([e, m], default=utils.convert_non_serializable, ensure_ascii=False).encode("utf-8") for e, m in local]
+            got = gather_records(lm, [r.doc_id for r in reqs], blobs, sizes, rank, world, dist)
+            if rank != 0:
+                continue
+            local = [tuple(got[i]) for i in sorted(got)]
         samples, metric_items = [], defaultdict(list)
-        for req in reqs:
-            doc = req.doc
-            metrics = task.process_results(doc, [req.filtered_resps["none"]])
+        for example, metrics in local:
             if log_samples:
-                target = task.doc_to_target(doc)
-                example = {
-                    # the reference's filter (`_engine.py:263`) plus: values that JSON cannot carry are dropped (a decoded PIL
-                    # image under `visual` would be written as its repr, memory address included; the reference's rows hold a path)
-                    "doc_id": req.doc_id,
-                    "doc": {k: v for k, v in doc.items() if "image" not in k and isinstance(v, _SERIALIZABLE)}, "target": target,
-                    "arguments": [a for a in req.args if isinstance(a, _SERIALIZABLE)],
-                    "resps": [req.resps], "filtered_resps": [req.filtered_resps["none"]],
-                    # the reference hashes `requests[0].doc`, which its TaskInstance never sets (tasks/_manager.py:881 `# doc=doc`):
-                    # every record carries sha256("null") (`_engine.py:267-274`); kept for file compatibility
-                    "doc_hash": DOC_HASH_OF_NONE,
-                    "prompt_hash": utils.hash_string(req.args[0]), "target_hash": utils.hash_string(str(target)),
-                }
-                example.update(metrics)
                 samples.append(example)
             for m, v in metrics.items():
                 metric_items[m].append(v)

@@ -497,6 +497,9 @@ class Qwen2VLEngine:
             b0 = b1
 
         # ---- greedy decode: the live rows of the batch per step
+        if stats is not None:    # (events only: the caller reads `decode_ms` after it has synchronised)
+            stats["decode_events"] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            stats["decode_events"][0].record()
         out_tokens = torch.empty((B, max_new_tokens), dtype=I32, device=self.device)
         out_tokens.fill_(pad_token_id)              # rows dropped by a compaction keep pad behind their last column
         eos1 = -1
@@ -573,6 +576,7 @@ class Qwen2VLEngine:
                         pending = (ev, n)
         if stats is not None:
             stats["live_rows_per_step"] = live_per_step
+            stats["decode_events"][1].record()
         if return_step_logits:
             return out_tokens, step_logits
         return (out_tokens, first_logits) if return_logits else out_tokens

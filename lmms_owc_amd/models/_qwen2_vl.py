@@ -143,7 +143,7 @@ class Qwen2VL(Model):
         from concurrent.futures import ThreadPoolExecutor
 
         # host preparation: `OWC_PREP_THREADS` PIL workers (JPEG round trip + bicubic resize release the GIL) behind ONE
-        # preparation thread that runs up to `_lookahead` chunks ahead of the GPU (`_generate_rows`)
+        # preparation thread that runs up to two engine batches ahead of the GPU (`_generate_rows`)
         # 8 workers prepare ~900 images/s per rank (JPEG round trip of a 448x448 image ~ 8 ms per worker), several times the GPU's
         # rate; more workers only take the GIL away from the thread that launches the kernels (measured on the bench's PIL leg:
         # 4-8 workers 0.89 of the engine rate, 32 workers 0.85, 64 workers 0.80)
@@ -151,7 +151,6 @@ class Qwen2VL(Model):
         self._prep_threads = int(os.environ.get("OWC_PREP_THREADS", max(2, min(8, (os.cpu_count() or 8) // ranks_here))))
         self._pool = ThreadPoolExecutor(max_workers=self._prep_threads)
         self._prep_thread = ThreadPoolExecutor(max_workers=1)
-        self._lookahead = 2
         import threading
 
         self._pinned_free, self._pinned_lock = [], threading.Lock()
@@ -379,10 +378,21 @@ class Qwen2VL(Model):
                 del self._pinned_free[0]   # ... within a byte cap: page-locked host memory is per rank, eight ranks share a host
 
     def _generate_rows(self, requests: list) -> list[np.ndarray]:
-        """Token rows (cut at EOS) per request, in request order.  Chunks of `batch_size` requests flow through a two-stage
-        pipeline: a preparation thread readies chunk k+1 (and k+2) while this thread enqueues chunk k's H2D copy, patchify,
-        vision tower, prefill and decode; chunk k's ids come back through a pinned buffer + event one chunk later, so the
-        stream always holds the next chunk's work when the host waits."""
+        """Token rows (cut at EOS) per request, in request order.
+
+        Two-stage pipeline.  A preparation thread readies the requests in small UNITS (engine_batch / 16, at least 64 requests:
+        image fetch + JPEG round trip + resize on the PIL pool, prompt ids, pinned staging) strictly in order and runs up to
+        two engine batches ahead.  This thread assembles the prepared units into engine passes ADAPTIVELY: the first pass takes
+        whatever is ready when the GPU is idle (so the GPU starts after one unit, not after a whole chunk's preparation), every
+        later pass waits until 1.5x the previous pass's requests are ready - or a full engine batch, or everything that is left -
+        unless the GPU runs dry first, in which case it takes what is there.  With a host that prepares faster than the GPU
+        consumes the passes grow geometrically to `engine_batch` and stay there; with a slower host the GPU is fed as the units
+        arrive.  (Round 3 cut the first chunk 1/4 + 3/4: on one rank with 448 x 448 images - 900 prepared images/s against 240 -
+        that hides everything, but eight ranks on real image sizes prepare 320 images/s per rank against 205, a task is 1.5-3
+        engine batches per rank, and the ramp was a fifth of the run: tools/soak_host_ranks.py.)  Tokens do not depend on how
+        the requests are grouped into passes (batch invariance, tested bit for bit).  A pass's ids come back through a pinned
+        buffer + event one pass later, so the stream always holds the next pass's work when the host waits."""
+        import time
         from collections import deque
 
         def _collate(x):
@@ -390,54 +400,106 @@ class Qwen2VL(Model):
 
         reordered = utils.Collator([reg.args for reg in requests], _collate, grouping=True)
         max_new = max([int(r.args[1].get("max_new_tokens", 128)) for r in requests] + [1])
-        chunks = list(reordered.get_batched(n=self.engine_batch(max_new), batch_fn=None))
-        if chunks and len(chunks[0]) >= 256:
-            # the very first chunk has nothing to hide its host preparation behind (~1.1 ms per image per process on 8 workers):
-            # cut it 1/4 + 3/4 so that the GPU starts after a quarter chunk.  (A finer ramp - 1/8, 1/8, 1/4, 1/2 - was measured
-            # and lost: small pieces run the decoder well below its large-batch rate.)
-            first, q = chunks[0], len(chunks[0]) // 4
-            chunks = [first[:q], first[q:]] + chunks[1:]
+        eb = self.engine_batch(max_new)
+        unit = eb if eb < 256 else max(64, eb // 16)
+        units = list(reordered.get_batched(n=unit, batch_fn=None))
         tok = self._tokenizer
         pad = tok.pad_token_id if tok.pad_token_id is not None else 0
         rows: list[np.ndarray] = []
-        ahead, inflight = deque(), deque()
+        ahead, inflight = deque(), deque()      # futures of submitted units (in order); launched passes (host ids, event, groups)
         nxt = 0
+        ahead_n = 0                             # requests submitted for preparation and not launched yet
 
         def finish(item) -> None:
             host, ev, groups = item
-            ev.synchronize()          # the chunk's GPU work is complete: its staging buffers can be reused
+            ev.synchronize()          # the pass's GPU work is complete: its staging buffers can be reused
             self._pinned_give(groups)
             for r in host.numpy():
                 stop = np.flatnonzero(r == tok.eos_token_id)
                 rows.append(r[: stop[0]].copy() if len(stop) else r.copy())
 
-        import time
+        def top_up() -> None:
+            nonlocal nxt, ahead_n
+            while nxt < len(units) and (ahead_n < 2 * eb or not ahead):
+                ahead.append((len(units[nxt]), self._prep_thread.submit(self._prepare_chunk, units[nxt])))
+                ahead_n += len(units[nxt])
+                nxt += 1
+
+        def ready_prefix() -> tuple[int, bool]:
+            """Requests in the leading run of prepared units that one pass can take (same generation length, <= engine_batch), and
+            whether the run ends at such a limit (then waiting for more units cannot make the pass larger)."""
+            n, first = 0, None
+            for size, fut in ahead:
+                if not fut.done():
+                    return n, False
+                if n + size > eb:
+                    return n, True
+                mn = fut.result()["max_new"]
+                if first is None:
+                    first = mn
+                elif mn != first:
+                    return n, True
+                n += size
+            return n, nxt >= len(units)
 
         t_begin = time.perf_counter()
-        self.last_timing = {"chunks": len(chunks)}
-        for k in range(len(chunks)):
-            while nxt < len(chunks) and len(ahead) < self._lookahead:
-                ahead.append(self._prep_thread.submit(self._prepare_chunk, chunks[nxt]))
-                nxt += 1
-            prep = ahead.popleft().result()
-            if k == 0:   # nothing hides the first chunk's host preparation; every later chunk is prepared under GPU work
-                self.last_timing["first_chunk_prep_s"] = time.perf_counter() - t_begin
-            emb = None
-            if prep["groups"]:
-                emb = self._model.encode_images(self._pixel_values(prep["groups"]), [g for gs in prep["grids"] for g in gs])
-            out = self._model.generate(prep["prompts"], emb, prep["grids"], prep["max_new"], eos_token_id=tok.eos_token_id,
-                                       pad_token_id=pad)
-            host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
-            host.copy_(out, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
+        self.last_timing = {"chunks": 0, "pass_sizes": []}
+        last_size, left = 0, len(requests)
+        while left:
+            top_up()
+            gpu_busy = bool(inflight) and not inflight[-1][1].query()
+            have, closed = ready_prefix()
+            if have == 0 and not gpu_busy:
+                t_wait = time.perf_counter()
+                ahead[0][1].result()            # nothing ready and the GPU is (about to be) idle: stand and wait for the next unit
+                key = "first_chunk_prep_s" if not self.last_timing["chunks"] else "prep_wait_s"
+                self.last_timing[key] = self.last_timing.get(key, 0.0) + time.perf_counter() - t_wait
+                continue
+            want = min(eb, left, max(unit, int(1.5 * last_size)))
+            if left <= eb and left - want < want // 2:
+                want = left                     # no small pass at the end of a task: it would run the decoder far below its rate
+            if gpu_busy and have < want and not closed:
+                if len(inflight) > 1:           # use the wait: collect the pass before the one that is running
+                    finish(inflight.popleft())
+                else:
+                    time.sleep(0.002)
+                continue
+            preps = []
+            while ahead and sum(p["n"] for p in preps) < have:
+                size, fut = ahead.popleft()
+                preps.append(fut.result())
+                ahead_n -= size
+            prep = preps[0] if len(preps) == 1 else {
+                "prompts": [x for p in preps for x in p["prompts"]], "grids": [x for p in preps for x in p["grids"]],
+                "groups": [x for p in preps for x in p["groups"]], "max_new": preps[0]["max_new"], "n": sum(p["n"] for p in preps)}
+            top_up()
+            host, ev = self._launch_chunk(prep, tok.eos_token_id, pad)
             inflight.append((host, ev, prep["groups"]))
-            if len(inflight) > 1:
+            last_size = prep["n"]
+            left -= prep["n"]
+            self.last_timing["chunks"] += 1
+            self.last_timing["pass_sizes"].append(prep["n"])
+            if len(inflight) > 2:
                 finish(inflight.popleft())
         while inflight:
             finish(inflight.popleft())
         self.last_timing["total_s"] = time.perf_counter() - t_begin
+        self.last_timing.setdefault("first_chunk_prep_s", 0.0)
         return reordered.get_original(rows)
+
+    def _launch_chunk(self, prep: dict, eos_token_id: int, pad: int):
+        """GPU stage of one prepared chunk: H2D + patchify + vision tower + prefill + decode are ENQUEUED (nothing waits), the ids
+        come back through a pinned buffer; returns (host int32 [n, T], event that passes when the buffer is filled).
+        (tools/soak_host_ranks.py replaces exactly this method by a timed stand-in to soak the host side of 8 ranks.)"""
+        emb = None
+        if prep["groups"]:
+            emb = self._model.encode_images(self._pixel_values(prep["groups"]), [g for gs in prep["grids"] for g in gs])
+        out = self._model.generate(prep["prompts"], emb, prep["grids"], prep["max_new"], eos_token_id=eos_token_id, pad_token_id=pad)
+        host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+        host.copy_(out, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return host, ev
 
     def _pixel_values(self, images: list) -> torch.Tensor:
         """uint8 images (sides % 28 == 0) -> packed pixel_values rows on the GPU.  `images`: CHW numpy arrays (same-size

@@ -44,3 +44,15 @@ def test_two_ranks_share_one_gpu(gpu):
     dec = out["roofline_decode"]
     assert dec["bound"] == "hbm" and dec["batch"] == 1 and [r["batch"] for r in dec["by_batch"]] == [1, 32, 128]
     assert all(0 < r["frac"] < 1 and r["ms_per_step"] > 0 for r in dec["by_batch"])
+    # round 4: ragged answer lengths with / without row compaction (same tokens), the other configs' legs in the default line
+    eos = out["eos_terminated"]
+    assert [r["max_new_tokens"] for r in eos["by_cap"]] == [64, 256]
+    c64 = eos["by_cap"][0]
+    assert c64["tokens_identical_with_and_without_compaction"] is True and c64["pad_behind_stop_column"] is True
+    assert c64["compacted"]["row_steps"] < 0.5 * c64["all_rows_every_step"]["row_steps"] and c64["compacted"]["images_per_s"] > 0
+    assert eos["by_cap"][1]["compacted"]["decode_steps_run"] == 255
+    rag = out["real_image_sizes"]
+    assert rag["dataset_size_model"] == "food101" and rag["deterministic_and_batch_invariant"] and rag["roofline"]["launches"] > 0
+    cos = out["label_cosine_10k_classes"]
+    assert cos["classes"] == 10000 and cos["top1_matches_dense_matmul_on_256_rows"] and 0 < cos["roofline"]["frac"] < 1
+    assert out["config2_qwen2vl_2b"] is None and len(out["builder_run_configs"]) == 2     # (this run IS the 2B model)
