@@ -110,22 +110,24 @@ def gather_records(lm, doc_ids: list[int], blobs: list[bytes], sizes: list[int],
     """All ranks: contribute one JSON document (UTF-8 bytes) per owned document as a fixed-width record; rank 0 returns
     {doc_id: parsed object}."""
     mat, nb = _pack_bytes(blobs)
-    payload, n = torch.from_numpy(mat), torch.from_numpy(nb)
     # RCCL moves device memory, gloo (CPU tests) host memory
     device = torch.device(lm.device) if dist is not None and dist.get_backend() == "nccl" else torch.device("cpu")
-    width = torch.tensor([payload.shape[1] if payload.ndim == 2 and payload.shape[0] else 0], dtype=torch.int64, device=device)
+    width = torch.tensor([mat.shape[1] if len(blobs) else 0], dtype=torch.int64, device=device)
     if dist is not None:
         dist.all_reduce(width, op=dist.ReduceOp.MAX)   # the widest record of any rank (8 bytes; a rank may own no document)
     W = max(int(width.item()), 1)
     rows = max(sizes)
     if rows == 0:   # no rank owns a document (limit 0 / empty task)
         return {} if rank == 0 else None
-    rec = torch.zeros((rows, 2 + W), dtype=torch.int32, device=device)
+    # the record block is put together on the host with numpy (torch's CPU kernels would first spin up one OpenMP thread per core -
+    # 0.8 s on a 256-core host) and crosses to the device, when the backend wants device memory, as ONE copy
+    rec_h = np.zeros((rows, 2 + W), np.int32)
     k = len(doc_ids)
     if k:
-        rec[:k, 0] = torch.tensor(doc_ids, dtype=torch.int32, device=device)
-        rec[:k, 1] = n.to(device)
-        rec[:k, 2:2 + payload.shape[1]] = payload.to(device)
+        rec_h[:k, 0] = doc_ids
+        rec_h[:k, 1] = nb
+        rec_h[:k, 2:2 + mat.shape[1]] = mat
+    rec = torch.from_numpy(rec_h).to(device)
     if dist is not None:
         allrec = torch.empty((world * rows, 2 + W), dtype=torch.int32, device=device)
         dist.all_gather_into_tensor(allrec, rec)

@@ -458,6 +458,8 @@ class Qwen2VL(Model):
             want = min(eb, left, max(unit, int(1.5 * last_size)))
             if left <= eb and left - want < want // 2:
                 want = left                     # no small pass at the end of a task: it would run the decoder far below its rate
+            elif eb < left < eb + eb // 2:
+                want = min(want, (left + 1) // 2)   # ... nor a full pass followed by a sliver: two halves
             if gpu_busy and have < want and not closed:
                 if len(inflight) > 1:           # use the wait: collect the pass before the one that is running
                     finish(inflight.popleft())

@@ -5,8 +5,8 @@ per-doc process_results -> sample records -> aggregation; src/engine/_tracker.py
 N gloo ranks run the real `evaluate()` + `EngineTracker` with a model stand-in whose `generate_until` returns its shard's answers
 at once, so the wall time IS the tail: every rank scores its own documents (`process_results`, sample records with their sha256
 hashes), fixed-width `all_gather_into_tensor` of N x docs_per_rank JSON records -> rank 0: parse, order by doc_id, aggregation,
-results JSON + samples JSONL.  (Round 3 scored every document on rank 0: `--legacy` times that arrangement - the same work on
-one rank - for comparison.)  Reported against the time the GPUs need for the same
+results JSON + samples JSONL.  (Round 3 scored every document on rank 0: 10.4 k documents/s in the build container, i.e. 18 % on
+top of an 8-rank task's GPU time - DESIGN.md section 6.)  Reported against the time the GPUs need for the same
 documents (`--gpu-rate` images/s per rank), i.e. the share of a task the other ranks would stand idle for.
 
   python tools/time_rank_tail.py --ranks 8 --docs-per-rank 2048
@@ -76,6 +76,16 @@ def child(args) -> None:
     ev.gather_records = timed_gather
     import torch
 
+    stamps["collective_s"] = 0.0
+    for name in ("all_reduce", "all_gather_into_tensor"):   # the collectives themselves: gloo over loopback TCP on host tensors
+        def timed(*a, _f=getattr(dist, name), **k):         # here, RCCL on device tensors in a real run - reported separately
+            t0 = time.perf_counter()
+            out = _f(*a, **k)
+            stamps["collective_s"] += time.perf_counter() - t0
+            return out
+
+        setattr(dist, name, timed)
+
     # the first collective of each kind sets up the backend's connections (seconds with gloo's full mesh, once per run with RCCL
     # too): not part of a task's tail
     w = torch.zeros(1, dtype=torch.int64)
@@ -84,7 +94,15 @@ def child(args) -> None:
     dist.all_gather_into_tensor(g, torch.zeros(1024, dtype=torch.int32))
     dist.barrier()
     t0 = time.perf_counter()
-    res = ev.evaluate(lm, {"tail": task}, limit=None, log_samples=True)
+    if args.profile and rank == 0:
+        import cProfile
+        import pstats
+
+        pr = cProfile.Profile()
+        res = pr.runcall(ev.evaluate, lm, {"tail": task}, limit=None, log_samples=True)
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(18)
+    else:
+        res = ev.evaluate(lm, {"tail": task}, limit=None, log_samples=True)
     t_eval = time.perf_counter() - t0
     if res is not None:
         tracker = EngineTracker(output_path=str(out_dir))
@@ -95,9 +113,11 @@ def child(args) -> None:
         tracker.save_results_samples(task_name="tail", samples=samples["tail"])
         t_files = time.perf_counter() - t1
         print(json.dumps({"ranks": world, "documents": n, "evaluate_s": t_eval, **stamps, "files_s": t_files,
-                          "tail_s": t_eval + t_files, "documents_per_s": n / (t_eval + t_files),
+                          "tail_s": t_eval + t_files, "tail_without_collective_s": t_eval + t_files - stamps["collective_s"],
+                          "documents_per_s_without_collective": n / (t_eval + t_files - stamps["collective_s"]),
                           "gpu_seconds_for_the_same_documents": n / (world * args.gpu_rate),
-                          "tail_over_gpu_time": (t_eval + t_files) / (n / (world * args.gpu_rate))}), flush=True)
+                          "tail_without_collective_over_gpu_time": (t_eval + t_files - stamps["collective_s"]) / (n / (world * args.gpu_rate))}),
+              flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -107,6 +127,7 @@ def main() -> None:
     ap.add_argument("--ranks", type=int, default=8)
     ap.add_argument("--docs-per-rank", type=int, default=2048)
     ap.add_argument("--gpu-rate", type=float, default=240.0)
+    ap.add_argument("--profile", action="store_true", help="cProfile of rank 0's evaluate() on stderr")
     ap.add_argument("--child", action="store_true")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -123,7 +144,7 @@ def main() -> None:
             env = dict(os.environ, RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE=str(args.ranks), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
             procs.append(subprocess.Popen([sys.executable, __file__, *sys.argv[1:], "--child", "--out", td], env=env,
-                                          stdout=subprocess.PIPE if rk == 0 else subprocess.DEVNULL, text=True))
+                                          stdout=subprocess.PIPE if rk == 0 else subprocess.DEVNULL, text=True))   # (stderr inherited)
         out, _ = procs[0].communicate()
         for p in procs[1:]:
             p.wait()
