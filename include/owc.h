@@ -197,6 +197,26 @@ int owc_gemm_fp8(owc_ctx* ctx, const void* A, int64_t lda, const float* a_scale,
 int owc_embed_tokens(owc_ctx* ctx, const int32_t* ids, const int32_t* img_index, const void* table,
                      const void* img_embeds, void* out, int T, int d, void* stream);
 
+/* Sampling parameters of a generation (NULL wherever one is taken: greedy argmax).  HF GenerationMixin._sample, reached from the
+ * reference with do_sample = temperature > 0 (src/models/_qwen2_vl.py:319-329, _llava_hf.py:365-376): logits / temperature ->
+ * top-k (0: off) -> top-p on the survivors (<= 0 or >= 1: off) -> softmax -> one multinomial draw.
+ *   Random stream (documented, NOT torch's): Philox4x32-10, key = seed, counter = (stream id of the sequence, step, 0, 0);
+ *   stream_id (optional, int32 per ORIGINAL batch row; NULL: the row index): a sequence's draws depend on (seed, its stream id,
+ *   step) only - not on the batch it runs in, not on row compaction, not on the rank count when the caller passes document ids.
+ *   Weights are exact integers floor(2^40 exp((l - max) / T)); the kept set is cut by logit VALUE, so where HF's sort would split
+ *   a run of equal bf16 logits at the top-k / top-p cut, all of them stay eligible (a superset by ties only). */
+typedef struct owc_sampling {
+  float temperature; /* > 0 */
+  int32_t top_k;
+  float top_p;
+  uint64_t seed;
+  const int32_t* stream_id;
+} owc_sampling;
+
+/* one token per row of bf16 logits by owc_sampling (row_map: optional ORIGINAL row of each row, see owc_llm_decode_step). */
+int owc_sample_bf16(owc_ctx* ctx, const void* logits, int64_t ld, int rows, int vocab, const owc_sampling* sampling,
+                    const int32_t* row_map, int step, int32_t* out, void* stream);
+
 /* greedy argmax over bf16 logits rows (lowest index on ties). */
 int owc_argmax_bf16(owc_ctx* ctx, const void* logits, int64_t ld, int rows, int vocab,
                     int32_t* out, void* stream);
@@ -339,7 +359,8 @@ size_t owc_llm_workspace_bytes(const owc_llm_weights* w, int T, int n_seq);
  *   mode instead of an inference from the counts).  OWC_PREFILL_SCORE_ROWS - last_index names ANY n_out <= T packed rows, the
  *   positions whose logits a loglikelihood request needs (reference src/models/_llava_hf.py:243-252 reads outputs["logits"] of
  *   every position); the last layer then runs on every row and the workspace must be sized with owc_llm_workspace_bytes(w, T, n_out).
- * Writes the KV cache and next_tok[n_out] = argmax of those rows' logits.
+ * Writes the KV cache and next_tok[n_out] = argmax of those rows' logits - or, with `sampling`, one draw per row at step 0
+ * (row j of this launch is original batch row sampling_row0 + j for the random stream).
  * `logits_out` (optional, [n_out, vocab] bf16) receives the logits. */
 enum { OWC_PREFILL_LAST_TOKENS = 0, OWC_PREFILL_SCORE_ROWS = 1 };
 int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* cache,
@@ -347,8 +368,8 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
                     const int32_t* pos3, const int32_t* tok_slot, const int32_t* tok_idx,
                     const int32_t* seq_start, const int32_t* seq_len, const int32_t* q_len,
                     const int32_t* k_start, const int32_t* last_index, int n_seq, int n_out, int T,
-                    int max_len, int bcast_first_slot, int bcast_n_slots, int score_mode, int32_t* next_tok,
-                    void* logits_out, void* workspace, size_t ws_bytes, void* stream);
+                    int max_len, int bcast_first_slot, int bcast_n_slots, int score_mode, const owc_sampling* sampling,
+                    int sampling_row0, int32_t* next_tok, void* logits_out, void* workspace, size_t ws_bytes, void* stream);
 
 /* One greedy decode step for B sequences (HF GenerationMixin loop body, one token each):
  *   tok_io: int32[B] in = tokens to feed, out = next tokens (pad once a sequence is done);
@@ -363,6 +384,7 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
  *     neighbours, so the tokens of the surviving rows are bit-identical to the uncompacted run (tested).
  *   forced_tok (optional, int32 indexed by ORIGINAL row): teacher forcing - the token fed to the next step, and the
  *     one whose EOS finishes the sequence, is forced_tok[row]; out_tokens still receives the step's own argmax.
+ *   sampling (optional): the next token is a draw (owc_sampling) at step = the output column instead of the argmax.
  *   step_state (optional, int32[1] on the device): when non-NULL the output column is read from step_state[0] (`step` is
  *     ignored) and, after the step, pos[b], write_idx[b], k_len[b] and step_state[0] are incremented IN PLACE, so that
  *     consecutive decode steps are byte-identical launch sequences: capture one in a hipGraph and replay it. */
@@ -372,7 +394,7 @@ int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cac
                         const int32_t* q_start, const int32_t* o_start, const int32_t* q_len,
                         uint8_t* done, int32_t* out_tokens, int out_stride, int step, int32_t* step_state, int B,
                         int eos_id0, int eos_id1, int pad_id, const int32_t* out_row, const int32_t* forced_tok,
-                        void* logits_out, void* workspace, size_t ws_bytes, void* stream);
+                        const owc_sampling* sampling, void* logits_out, void* workspace, size_t ws_bytes, void* stream);
 
 /* first-token bookkeeping after prefill: same done/pad/out_tokens update as a decode step. */
 int owc_decode_update(owc_ctx* ctx, int32_t* next_tok, uint8_t* done, int32_t* out_tokens,

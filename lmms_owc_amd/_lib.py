@@ -21,7 +21,7 @@ _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
 _timing_ok = False
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = range(6)
 
@@ -83,6 +83,11 @@ class KvCache(C.Structure):
     _fields_ = [("k", vp), ("v", vp), ("n_slots", C.c_int32), ("s_max", C.c_int32)]
 
 
+class Sampling(C.Structure):
+    """owc_sampling: temperature / top-k / top-p + the Philox key and the per-sequence stream ids (include/owc.h)."""
+    _fields_ = [("temperature", f32), ("top_k", C.c_int32), ("top_p", f32), ("seed", C.c_uint64), ("stream_id", vp)]
+
+
 class BertLayer(C.Structure):
     _fields_ = [(n, vp) for n in (
         "qkv_w", "qkv_b", "o_w", "o_b", "ln1_w", "ln1_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
@@ -121,6 +126,7 @@ SIGNATURES: dict[str, tuple] = {
     "owc_gemm_fp8": (i32, [vp, vp, i64, vp, vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "owc_embed_tokens": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "owc_argmax_bf16": (i32, [vp, vp, i64, i32, i32, vp, vp]),
+    "owc_sample_bf16": (i32, [vp, vp, i64, i32, i32, C.POINTER(Sampling), vp, i32, vp, vp]),
     "owc_token_logprob_bf16": (i32, [vp, vp, i64, vp, i32, i32, vp, vp]),
     "owc_patchify_u8": (i32, [vp, vp, vp, i64, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp]),
     "owc_vit_workspace_bytes": (sz, [C.POINTER(VitWeights), i32]),
@@ -131,9 +137,9 @@ SIGNATURES: dict[str, tuple] = {
     "owc_clip_patchify_u8": (i32, [vp, vp, vp, i64, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp]),
     "owc_llm_workspace_bytes": (sz, [C.POINTER(LlmWeights), i32, i32]),
     "owc_llm_prefill": (i32, [vp, C.POINTER(LlmWeights), C.POINTER(KvCache), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                              i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
+                              i32, i32, i32, i32, i32, i32, i32, C.POINTER(Sampling), i32, vp, vp, vp, sz, vp]),
     "owc_llm_decode_step": (i32, [vp, C.POINTER(LlmWeights), C.POINTER(KvCache), vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                                  vp, vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
+                                  vp, vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, C.POINTER(Sampling), vp, vp, sz, vp]),
     "owc_decode_update": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "owc_decode_compact": (i32, [vp, vp, i32] + [vp] * 17),
     "owc_bert_workspace_bytes": (sz, [C.POINTER(BertWeights), i32, i32]),

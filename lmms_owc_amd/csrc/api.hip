@@ -16,7 +16,7 @@
 
 extern "C" {
 
-int owc_abi_version(void) { return 14; }
+int owc_abi_version(void) { return 15; }
 
 int owc_has_timing_knobs(void) {   // 1 only in libowc_hip_timing.so (tools/); the product library answers 0
 #ifdef OWC_TIMING_KNOBS
@@ -180,6 +180,13 @@ int owc_argmax_bf16(owc_ctx* ctx, const void* logits, int64_t ld, int rows, int 
                     void* stream) {
   if (!ctx || !logits || !out) return OWC_ERR_ARG;
   RET(ctx, "owc_argmax_bf16", owc_launch_argmax(logits, ld, rows, vocab, out, ST(stream)));
+}
+
+int owc_sample_bf16(owc_ctx* ctx, const void* logits, int64_t ld, int rows, int vocab, const owc_sampling* sampling,
+                    const int32_t* row_map, int step, int32_t* out, void* stream) {
+  if (!ctx || !logits || !out || !sampling) return OWC_ERR_ARG;
+  if (!(sampling->temperature > 0.f)) OWC_FAIL(ctx, OWC_ERR_ARG, "owc_sample_bf16: temperature must be > 0 (0 = greedy: owc_argmax_bf16)");
+  RET(ctx, "owc_sample_bf16", owc_launch_sample(logits, ld, rows, vocab, sampling, row_map, step, nullptr, out, ST(stream)));
 }
 
 int owc_token_logprob_bf16(owc_ctx* ctx, const void* logits, int64_t ld, const int32_t* target, int rows, int vocab, float* out,

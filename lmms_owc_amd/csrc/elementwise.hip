@@ -336,6 +336,189 @@ __global__ __launch_bounds__(ARGMAX_T) void argmax_kernel(const bf16_t* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Temperature / top-k / top-p sampling of one token per row (HF GenerationMixin._sample with TemperatureLogitsWarper ->
+// TopKLogitsWarper -> TopPLogitsWarper -> softmax -> multinomial; reached from the reference at src/models/_qwen2_vl.py:319-329
+// with do_sample = temperature > 0, and _llava_hf.py:365-376).  One block of 1024 threads per row, everything that decides the
+// result in INTEGER arithmetic, so a row's token depends on (its logits, seed, stream id, step) only - not on its neighbours, not
+// on the order in which threads arrive:
+//   * weight of token i: q_i = floor(2^40 * exp2((l_i - max) * log2(e) / T)), a 64-bit integer (sum over 152 k tokens < 2^58);
+//   * the kept set is cut by VALUE: bf16 logits have 65 536 possible values, an order-preserving 16-bit key is histogrammed by its
+//     high byte (counts + integer mass, LDS atomics on integers are order-independent), then by its low byte inside the bin that
+//     holds the cut: top-k keeps every token whose value is >= the k-th largest value, top-p (on the top-k survivors, as HF applies
+//     it) every token whose value is >= the value at which the descending cumulative mass reaches top_p.  Where HF's sort would
+//     split a run of EQUAL logits at the cut, all of them are kept (a superset by ties only; stated in include/owc.h);
+//   * the draw: Philox4x32-10 keyed by the 64-bit seed, counter (stream id, step, 0, 0) -> r in [0, 2^64);
+//     target = floor(r * Z_kept / 2^64); the token is the first one, in INDEX order, whose running kept mass exceeds target.
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0;
+  out[1] = c1;
+  out[2] = c2;
+  out[3] = c3;
+}
+
+constexpr int SAMPLE_T = 1024;
+__device__ inline uint32_t sample_key(bf16_t v) {   // order-preserving 16-bit key of a bf16 value (ascending)
+  const uint32_t b = (uint32_t)__builtin_bit_cast(unsigned short, v);
+  return (b & 0x8000u) ? (0xFFFFu ^ b) : (b | 0x8000u);
+}
+
+__global__ __launch_bounds__(SAMPLE_T) void sample_kernel(const bf16_t* __restrict__ logits, long ld, int V, float inv_temp_log2e,
+                                                          int top_k, float top_p, uint32_t seed_lo, uint32_t seed_hi,
+                                                          const int* __restrict__ row_map, const int* __restrict__ stream_id,
+                                                          int step, const int* __restrict__ step_state, int* __restrict__ out) {
+  __shared__ unsigned int cnt[256];
+  __shared__ unsigned long long mass[256];
+  __shared__ float red[SAMPLE_T / 64];
+  __shared__ unsigned long long part[SAMPLE_T];
+  __shared__ unsigned long long sh_u64[2];
+  __shared__ int sh_i[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const bf16_t* x = logits + (long)row * ld;
+  if (step_state) step = step_state[0];
+  // ---- row maximum
+  float mx = -INFINITY;
+  for (int i = tid; i < V; i += SAMPLE_T) mx = fmaxf(mx, bf2f(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = red[0];
+  for (int k = 1; k < SAMPLE_T / 64; ++k) mx = fmaxf(mx, red[k]);
+  auto weight = [&](bf16_t v) -> unsigned long long {
+    const float e = __builtin_amdgcn_exp2f((bf2f(v) - mx) * inv_temp_log2e);   // in [0, 1]
+    return (unsigned long long)(e * 1099511627776.0f);                          // 2^40
+  };
+  // histogram of the tokens whose key lies in [lo_key, 0xFFFF] by byte `shift` (8: high byte, 0: low byte inside high byte `hb`)
+  auto histogram = [&](int shift, uint32_t hb, uint32_t lo_key) {
+    __syncthreads();
+    if (tid < 256) {
+      cnt[tid] = 0;
+      mass[tid] = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < V; i += SAMPLE_T) {
+      const bf16_t v = x[i];
+      const uint32_t k = sample_key(v);
+      if (k < lo_key || (shift == 0 && (k >> 8) != hb)) continue;
+      const uint32_t b = shift ? (k >> 8) : (k & 0xFF);
+      atomicAdd(&cnt[b], 1u);
+      atomicAdd(&mass[b], weight(v));
+    }
+    __syncthreads();
+  };
+  // ---- top-k: the smallest key such that at least k tokens have a key >= it (top_k <= 0 or >= V: everything)
+  uint32_t key_cut = 0;
+  if (top_k > 0 && top_k < V) {
+    histogram(8, 0, 0);
+    if (tid == 0) {
+      unsigned int c = 0;
+      int b = 255;
+      for (; b > 0 && c + cnt[b] < (unsigned)top_k; --b) c += cnt[b];
+      sh_i[0] = b;
+      sh_i[1] = (int)c;   // tokens in the bins above b
+    }
+    __syncthreads();
+    const uint32_t hb = sh_i[0];
+    const unsigned int above = sh_i[1];
+    histogram(0, hb, 0);
+    if (tid == 0) {
+      unsigned int c = above;
+      int b = 255;
+      for (; b > 0 && c + cnt[b] < (unsigned)top_k; --b) c += cnt[b];
+      sh_i[2] = (int)((hb << 8) | (uint32_t)b);
+    }
+    __syncthreads();
+    key_cut = (uint32_t)sh_i[2];
+  }
+  // ---- top-p on the survivors: descending cumulative mass reaches top_p * Z at which value?
+  histogram(8, 0, key_cut);
+  if (tid == 0) {
+    unsigned long long z = 0;
+    for (int b = 0; b < 256; ++b) z += mass[b];
+    sh_u64[0] = z;
+  }
+  __syncthreads();
+  unsigned long long Z = sh_u64[0];
+  if (top_p > 0.f && top_p < 1.f) {
+    const unsigned long long need = (unsigned long long)((double)Z * (double)top_p);
+    if (tid == 0) {
+      unsigned long long c = 0;
+      int b = 255;
+      for (; b > 0 && c + mass[b] < need; --b) c += mass[b];
+      sh_i[0] = b;
+      sh_u64[1] = c;   // mass in the bins above b
+    }
+    __syncthreads();
+    const uint32_t hb = sh_i[0];
+    const unsigned long long above = sh_u64[1];
+    histogram(0, hb, key_cut);
+    if (tid == 0) {
+      unsigned long long c = above;
+      int b = 255;
+      for (; b > 0 && c + mass[b] < need; --b) c += mass[b];
+      const uint32_t kp = (hb << 8) | (uint32_t)b;
+      sh_i[2] = (int)(kp > key_cut ? kp : key_cut);
+      sh_u64[0] = c + mass[b];   // kept mass (bins above + the cut value's own)
+    }
+    __syncthreads();
+    key_cut = (uint32_t)sh_i[2];
+    Z = sh_u64[0];
+    __syncthreads();
+  }
+  // ---- the draw
+  uint32_t rnd[4];
+  const int orig = row_map ? row_map[row] : row;   // the sequence's ORIGINAL batch row (row compaction moves it)
+  philox4x32_10((uint32_t)(stream_id ? stream_id[orig] : orig), (uint32_t)step, 0u, 0u, seed_lo, seed_hi, rnd);
+  const unsigned long long r = ((unsigned long long)rnd[0] << 32) | rnd[1];
+  const unsigned long long target = (unsigned long long)(((unsigned __int128)r * (unsigned __int128)Z) >> 64);   // < Z
+  // ---- first token, in index order, whose running kept mass exceeds target: contiguous chunk per thread, block scan, rescan
+  const int chunk = (V + SAMPLE_T - 1) / SAMPLE_T;
+  const int i0 = tid * chunk, i1 = min(V, i0 + chunk);
+  unsigned long long mine = 0;
+  for (int i = i0; i < i1; ++i) {
+    const bf16_t v = x[i];
+    if (sample_key(v) >= key_cut) mine += weight(v);
+  }
+  part[tid] = mine;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long c = 0;
+    int t = 0;
+    for (; t < SAMPLE_T - 1 && c + part[t] <= target; ++t) c += part[t];
+    sh_i[0] = t;
+    sh_u64[1] = c;
+  }
+  __syncthreads();
+  if (tid == sh_i[0]) {
+    unsigned long long c = sh_u64[1];
+    int pick = -1, last_kept = -1;
+    for (int i = i0; i < i1; ++i) {
+      const bf16_t v = x[i];
+      if (sample_key(v) < key_cut) continue;
+      last_kept = i;
+      c += weight(v);
+      if (c > target) {
+        pick = i;
+        break;
+      }
+    }
+    out[row] = pick >= 0 ? pick : last_kept;   // (pick < 0 cannot happen: target < Z = the sum of exactly these weights)
+  }
+}
+
 // Decode bookkeeping (HF GenerationMixin greedy loop): finished sequences emit pad, EOS marks done.
 //   out_row (optional): row of out_tokens (and index into `forced`) that compact row b belongs to - after an EOS-aware
 //     row compaction the B live rows are a subset of the original batch (NULL: identity);
@@ -651,6 +834,14 @@ int owc_launch_token_logprob(const void* logits, long ld, const int* target, int
 int owc_launch_argmax(const void* logits, long ld, int rows, int V, int* out, hipStream_t st) {
   if (rows <= 0 || V <= 0 || (ld & 7)) return OWC_ERR_SHAPE;
   hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(ARGMAX_T), 0, st, (const bf16_t*)logits, ld, V, out);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_sample(const void* logits, long ld, int rows, int V, const owc_sampling* sp, const int* row_map, int step,
+                      const int* step_state, int* out, hipStream_t st) {
+  if (rows <= 0 || V <= 0 || !sp || !(sp->temperature > 0.f)) return OWC_ERR_SHAPE;
+  hipLaunchKernelGGL(sample_kernel, dim3(rows), dim3(SAMPLE_T), 0, st, (const bf16_t*)logits, ld, V, 1.4426950408889634f / sp->temperature,
+                     sp->top_k, sp->top_p, (uint32_t)sp->seed, (uint32_t)(sp->seed >> 32), row_map, sp->stream_id, step, step_state, out);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 

@@ -1,6 +1,7 @@
 // Internal (non-ABI) declarations shared by the translation units of libowc_hip.so.
 #pragma once
 #include "owc_common.h"
+#include "../../include/owc.h"
 #include <string>
 
 struct owc_ctx {
@@ -54,6 +55,8 @@ int owc_launch_mrope_kv(void* qkv, long ld, const int* pos3, long pos_stride, co
 int owc_launch_embed(const int* ids, const int* img_index, const void* table, const void* img,
                      void* out, int T, int d, hipStream_t st);
 int owc_launch_argmax(const void* logits, long ld, int rows, int V, int* out, hipStream_t st);
+int owc_launch_sample(const void* logits, long ld, int rows, int V, const owc_sampling* sp, const int* row_map, int step,
+                      const int* step_state, int* out, hipStream_t st);
 int owc_launch_token_logprob(const void* logits, long ld, const int* target, int rows, int V, float* out, hipStream_t st);
 int owc_launch_decode_update(int* next_tok, uint8_t* done, int* out_tokens, int out_stride, int step,
                              const int* step_state, int B, int eos0, int eos1, int pad, const int* out_row, const int* forced,

@@ -265,8 +265,8 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
                     const int32_t* pos3, const int32_t* tok_slot, const int32_t* tok_idx,
                     const int32_t* seq_start, const int32_t* seq_len, const int32_t* q_len,
                     const int32_t* k_start, const int32_t* last_index, int n_seq, int n_out, int T,
-                    int max_len, int bcast_first_slot, int bcast_n_slots, int score_mode, int32_t* next_tok,
-                    void* logits_out, void* workspace, size_t ws_bytes, void* stream) {
+                    int max_len, int bcast_first_slot, int bcast_n_slots, int score_mode, const owc_sampling* sampling,
+                    int sampling_row0, int32_t* next_tok, void* logits_out, void* workspace, size_t ws_bytes, void* stream) {
   if (!ctx || !w || !cache || !ids || !pos3 || !tok_slot || !tok_idx || !seq_start || !seq_len ||
       !k_start || !last_index || !next_tok || !workspace)
     return OWC_ERR_ARG;
@@ -315,7 +315,14 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
   OWC_TRY(owc_launch_rmsnorm(xl, d, w->final_norm_w, last, d, n_out, d, w->rms_eps, nullptr, st));
   OWC_TRY(owc_launch_gemm_bf16(last, d, w->lm_head_w, d, nullptr, nullptr, 0, logits, w->vocab, n_out,
                                w->vocab, d, OWC_EPI_NONE, ctx->zeros, st));
-  OWC_TRY(owc_launch_argmax(logits, w->vocab, n_out, w->vocab, next_tok, st));
+  if (sampling && !scoring) {   // first new token by a draw at step 0; the stream ids are indexed by original batch row
+    if (!sampling->stream_id && sampling_row0) OWC_FAIL(ctx, OWC_ERR_ARG, "owc_llm_prefill: sampling_row0 != 0 needs explicit stream ids");
+    owc_sampling sp = *sampling;
+    if (sp.stream_id) sp.stream_id += sampling_row0;
+    OWC_TRY(owc_launch_sample(logits, w->vocab, n_out, w->vocab, &sp, nullptr, 0, nullptr, next_tok, st));
+  } else {
+    OWC_TRY(owc_launch_argmax(logits, w->vocab, n_out, w->vocab, next_tok, st));
+  }
   return OWC_OK;
 }
 
@@ -325,7 +332,7 @@ int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cac
                         const int32_t* q_start, const int32_t* o_start, const int32_t* q_len,
                         uint8_t* done, int32_t* out_tokens, int out_stride, int step, int32_t* step_state, int B,
                         int eos_id0, int eos_id1, int pad_id, const int32_t* out_row, const int32_t* forced_tok,
-                        void* logits_out, void* workspace, size_t ws_bytes, void* stream) {
+                        const owc_sampling* sampling, void* logits_out, void* workspace, size_t ws_bytes, void* stream) {
   if (!ctx || !w || !cache || !tok_io || !pos || !slot || !write_idx || !k_start || !k_len ||
       !q_start || !o_start || !q_len || !done || !out_tokens || !workspace)
     return OWC_ERR_ARG;
@@ -357,7 +364,10 @@ int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cac
   OWC_TRY(owc_launch_rmsnorm(x, d, w->final_norm_w, last, d, B, d, w->rms_eps, nullptr, st));
   OWC_TRY(owc_launch_gemm_bf16(last, d, w->lm_head_w, d, nullptr, nullptr, 0, logits, w->vocab, B,
                                w->vocab, d, OWC_EPI_NONE, ctx->zeros, st));
-  OWC_TRY(owc_launch_argmax(logits, w->vocab, B, w->vocab, tok_io, st));
+  if (sampling)
+    OWC_TRY(owc_launch_sample(logits, w->vocab, B, w->vocab, sampling, out_row, step, step_state, tok_io, st));
+  else
+    OWC_TRY(owc_launch_argmax(logits, w->vocab, B, w->vocab, tok_io, st));
   OWC_TRY(owc_launch_decode_update(tok_io, done, out_tokens, out_stride, step, step_state, B, eos_id0, eos_id1,
                                    pad_id, out_row, forced_tok, st));
   if (step_state) OWC_TRY(owc_launch_decode_advance(pos, write_idx, k_len, step_state, B, st));

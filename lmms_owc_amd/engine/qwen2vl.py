@@ -407,7 +407,7 @@ class Qwen2VLEngine:
     def generate(self, prompts: list, img_embeds: torch.Tensor | None, grids_per_prompt: list, max_new_tokens: int,
                  *, eos_token_id: int = -1, pad_token_id: int = 0, stop_check_every: int = 1, compact_rows: bool = True,
                  return_logits: bool = False, img_rows: list | None = None, forced_tokens=None,
-                 return_step_logits: bool = False, stats: dict | None = None):
+                 return_step_logits: bool = False, stats: dict | None = None, sampling: dict | None = None):
         """Greedy generation for a batch of prompts.
 
         prompts[b]: 1-D int array of token ids holding image_token_id placeholders;
@@ -425,6 +425,9 @@ class Qwen2VLEngine:
         DROPPED from the following steps (as soon as >= 1/64 of the live rows are done): GEMM M and the attention grid shrink,
         the KV cache stays in place (slot indirection), tokens land in their original rows.  Every kernel computes a row
         independently of its neighbours, so the tokens equal the uncompacted run bit for bit (tested).
+        `sampling` (optional): {"temperature": T > 0, "top_k": int (0 off), "top_p": float (None / >= 1 off), "seed": int,
+        "stream_ids": int per prompt (default: its index)} - HF's `do_sample` path (temperature -> top-k -> top-p -> multinomial) on
+        the library's documented Philox stream; a sequence's draws depend on (seed, its stream id, step) only.
         `stats` (optional dict) receives the live-row count of every step.
         Returns int32 [B, max_new_tokens] (pad after EOS) and, optionally, the first-step logits [B, vocab]
         (`return_logits`) or every step's logits [max_new_tokens, B, vocab] (`return_step_logits`).
@@ -483,6 +486,15 @@ class Qwen2VLEngine:
         forced = None
         if forced_tokens is not None:
             forced = self._i32(np.asarray(forced_tokens).reshape(B, max_new_tokens).T)   # [T, B]: one contiguous row per step
+        samp, samp_ref = None, None
+        if sampling is not None:
+            if not float(sampling["temperature"]) > 0:
+                raise ValueError("sampling needs temperature > 0 (temperature 0 is greedy: pass sampling=None)")
+            streams = self._i32(np.asarray(sampling.get("stream_ids", np.arange(B)), dtype=np.int64).reshape(B))
+            top_p = sampling.get("top_p")
+            samp = _lib.Sampling(float(sampling["temperature"]), int(sampling.get("top_k") or 0), float(top_p) if top_p else 0.0,
+                                 int(sampling.get("seed", 0)) & 0xFFFFFFFFFFFFFFFF, streams.data_ptr())
+            samp_ref = C.byref(samp)
 
         # ---- prefill in chunks of whole prompts (chunk size counted in packed ROWS: with a shared prefix every
         # prompt contributes len - P rows, so more prompts fit the same GEMM M)
@@ -493,7 +505,7 @@ class Qwen2VLEngine:
             while b1 < B and (b1 == b0 or rows + lens[b1] - p_all <= self.prefill_chunk_tokens):
                 rows += int(lens[b1]) - p_all
                 b1 += 1
-            self._prefill_chunk(prompts, pos_list, img_index, img_embeds, lens, b0, b1, cache, next_tok, first_logits)
+            self._prefill_chunk(prompts, pos_list, img_index, img_embeds, lens, b0, b1, cache, next_tok, first_logits, samp_ref)
             b0 = b1
 
         # ---- greedy decode: the live rows of the batch per step
@@ -523,7 +535,7 @@ class Qwen2VLEngine:
                     self._ctx, C.byref(self.w.llm), C.byref(cache), v[0].data_ptr(), v[1].data_ptr(), v[4].data_ptr(),
                     v[2].data_ptr(), v[5].data_ptr(), v[3].data_ptr(), q_start.data_ptr(), o_start.data_ptr(), q_len.data_ptr(),
                     dn.data_ptr(), out_tokens.data_ptr(), max_new_tokens, j, col.data_ptr(), n, eos_token_id, eos1, pad_token_id,
-                    v[6].data_ptr(), forced[j].data_ptr() if forced is not None else None,
+                    v[6].data_ptr(), forced[j].data_ptr() if forced is not None else None, samp_ref,
                     step_logits[j].data_ptr() if step_logits is not None else None, ws.data_ptr(), ws.numel(),
                     _lib.stream_ptr())
                 _lib.check(rc, self.dev_index)
@@ -619,7 +631,7 @@ class Qwen2VLEngine:
         rc = self._lib.owc_llm_prefill(
             self._ctx, C.byref(self.w.llm), C.byref(cache), t_ids.data_ptr(), t_iidx.data_ptr(), _lib.ptr(img_embeds),
             t_pos3.data_ptr(), t_slot.data_ptr(), t_idx.data_ptr(), t_start.data_ptr(), t_len.data_ptr(), t_len.data_ptr(),
-            t_kstart.data_ptr(), t_want.data_ptr(), 1, n_out, S, S, 0, 1, _lib.PREFILL_SCORE_ROWS, top.data_ptr(), logits.data_ptr(), ws.data_ptr(),
+            t_kstart.data_ptr(), t_want.data_ptr(), 1, n_out, S, S, 0, 1, _lib.PREFILL_SCORE_ROWS, None, 0, top.data_ptr(), logits.data_ptr(), ws.data_ptr(),
             ws.numel(), _lib.stream_ptr())
         _lib.check(rc, self.dev_index)
         if n_out == 1:      # only the last position was asked for: nothing to score
@@ -647,7 +659,7 @@ class Qwen2VLEngine:
                 p = int(neq[0])
         return p if p >= self.min_shared_prefix else 0
 
-    def _prefill_chunk(self, prompts, pos_list, img_index, img_embeds, lens, b0, b1, cache, next_tok, first_logits):
+    def _prefill_chunk(self, prompts, pos_list, img_index, img_embeds, lens, b0, b1, cache, next_tok, first_logits, sampling=None):
         d = self.d
         n = b1 - b0
         P = self._common_prefix(prompts, b0, b1)
@@ -683,6 +695,6 @@ class Qwen2VLEngine:
             self._ctx, C.byref(self.w.llm), C.byref(cache), t_ids.data_ptr(), t_iidx.data_ptr(),
             _lib.ptr(img_embeds), t_pos3.data_ptr(), t_slot.data_ptr(), t_idx.data_ptr(), t_start.data_ptr(),
             t_klen.data_ptr(), t_qlen.data_ptr(), t_kstart.data_ptr(), t_last.data_ptr(), n_seq, n, T,
-            int(q_len.max()), b0, n, _lib.PREFILL_LAST_TOKENS, next_tok[b0:b1].data_ptr(), logits_ptr, ws.data_ptr(), ws.numel(),
+            int(q_len.max()), b0, n, _lib.PREFILL_LAST_TOKENS, sampling, b0, next_tok[b0:b1].data_ptr(), logits_ptr, ws.data_ptr(), ws.numel(),
             _lib.stream_ptr())
         _lib.check(rc, self.dev_index)

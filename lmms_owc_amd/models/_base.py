@@ -158,3 +158,24 @@ class Model(ABC):
     @abstractmethod
     def generate_until_multi_round(self, requests: list) -> list[str]:
         raise NotImplementedError
+
+
+def sampling_from_gen_kwargs(gen_kwargs: dict, default_top_k: int = 50) -> dict | None:
+    """The reference's generation switches -> the engine's `sampling` argument (None = greedy).
+
+    Reference (src/models/_qwen2_vl.py:308-329, _llava_hf.py:355-376): `temperature` (default 0), `top_p` (default None),
+    `num_beams` (default 1) from the request's gen_kwargs, `do_sample = temperature > 0`.  HF then samples through
+    temperature -> top-k -> top-p with top_k from the checkpoint's generation_config.json (HF's own default is 50; Qwen2-VL's
+    ships `top_k: 1`, which makes its sampling the argmax) - `default_top_k` carries that value.  Beam search is not built:
+    num_beams != 1 raises (every task YAML of the reference is greedy, one beam).  The random stream is the library's documented
+    Philox stream keyed by torch's seed (the reference seeds torch with `--seed`, eval_model.py), one stream per DOCUMENT."""
+    if int(gen_kwargs.get("num_beams", 1) or 1) != 1:
+        raise NotImplementedError("beam search is not implemented by the HIP decoder (num_beams must be 1; the reference's task "
+                                  "configs are all greedy, one beam)")
+    t = gen_kwargs.get("temperature", 0) or 0
+    if not float(t) > 0:
+        return None
+    import torch
+
+    return {"temperature": float(t), "top_p": gen_kwargs.get("top_p"), "top_k": int(default_top_k), "seed": int(torch.initial_seed())}
+

@@ -22,7 +22,7 @@ from .. import _lib, utils
 from ..engine.llava import DIMS, NEXT_PINPOINTS, LlavaDims, LlavaEngine, LlavaWeights
 from . import imageproc
 from ._api import register_model
-from ._base import Model
+from ._base import Model, sampling_from_gen_kwargs
 from ._qwen2_vl import ByteTokenizer, LazyCheckpoint
 
 __all__ = ["LLaVA"]
@@ -190,8 +190,7 @@ class LLaVA(Model):
             for g in all_gen_kwargs:
                 g.pop("until", None)
             max_new = int(gen_kwargs.get("max_new_tokens", 1024))
-            if gen_kwargs.get("temperature", 0) not in (0, 0.0) or gen_kwargs.get("num_beams", 1) != 1:
-                raise NotImplementedError("the HIP decoder implements greedy decoding (temperature 0, 1 beam)")
+            sampling = sampling_from_gen_kwargs(gen_kwargs, getattr(self, "_default_top_k", 50))
             docs = [self.task_dict[task][split][did] for did in doc_ids]
             visuals_per_doc = [list(doc_to_visual[0](d)) for d in docs]
             contexts = list(contexts)
@@ -209,7 +208,8 @@ class LLaVA(Model):
                         break
                     visuals_per_doc = [list(o[0]) if o[0] is not None else [] for o in outs]
                     contexts = [o[1] for o in outs]
-                rows = self._generate_chunk(contexts, visuals_per_doc, max_new, feature_cache)
+                smp = None if sampling is None else {**sampling, "stream_ids": [int(d) * 64 + round_idx for d in doc_ids]}
+                rows = self._generate_chunk(contexts, visuals_per_doc, max_new, feature_cache, sampling=smp)
                 round_results.append(self.decode_tokens(rows))
                 round_idx += 1
             res.extend(zip(*round_results, strict=True))
@@ -293,7 +293,8 @@ class LLaVA(Model):
             rows = eng.feature_rows(views_per_image, sizes)
         return feats, rows
 
-    def _generate_chunk(self, contexts, visuals_per_doc, max_new: int, feature_cache: dict | None = None) -> list[np.ndarray]:
+    def _generate_chunk(self, contexts, visuals_per_doc, max_new: int, feature_cache: dict | None = None,
+                        sampling: dict | None = None) -> list[np.ndarray]:
         """One engine pass: single-turn prompts (context + that document's images) -> greedy token rows cut at EOS."""
         eng, tok = self._model, self._tokenizer
         feats, rows = self._encode_visuals([v for vs in visuals_per_doc for v in vs], feature_cache)
@@ -306,7 +307,8 @@ class LLaVA(Model):
             prompts.append(self._prompt_ids(ctx, [len(r) for r in mine]))
             rows_per_prompt.append(np.concatenate(mine) if mine else np.zeros(0, np.int64))
         eos = tok.eos_token_id
-        out = eng.generate_from_features(prompts, feats, rows_per_prompt, max_new, eos_token_id=eos, pad_token_id=eos).cpu().numpy()
+        out = eng.generate_from_features(prompts, feats, rows_per_prompt, max_new, eos_token_id=eos, pad_token_id=eos,
+                                         sampling=sampling).cpu().numpy()
         res = []
         for r in out:
             stop = np.flatnonzero(r == eos)
@@ -330,11 +332,12 @@ class LLaVA(Model):
             gen_kwargs = dict(all_gen_kwargs[0])
             gen_kwargs.pop("until", None)  # read and never applied by the reference (:310-320)
             max_new = int(gen_kwargs.get("max_new_tokens", 1024))
-            if gen_kwargs.get("temperature", 0) not in (0, 0.0) or gen_kwargs.get("num_beams", 1) != 1:
-                raise NotImplementedError("the HIP decoder implements greedy decoding (temperature 0, 1 beam)")
+            sampling = sampling_from_gen_kwargs(gen_kwargs, getattr(self, "_default_top_k", 50))
+            if sampling is not None:
+                sampling["stream_ids"] = [int(d) for d in doc_ids]   # one random stream per document
 
             visuals_per_doc = [doc_to_visual[0](self.task_dict[task][split][did]) for did in doc_ids]
-            res.extend(self._generate_chunk(contexts, visuals_per_doc, max_new))
+            res.extend(self._generate_chunk(contexts, visuals_per_doc, max_new, sampling=sampling))
         return reordered.get_original(res)
 
 

@@ -19,7 +19,7 @@ from .. import _lib, ops, utils
 from ..engine.qwen2vl import DIMS, Qwen2VLDims, Qwen2VLEngine, Qwen2VLWeights
 from . import imageproc
 from ._api import register_model
-from ._base import Model
+from ._base import Model, sampling_from_gen_kwargs
 
 __all__ = ["Qwen2VL"]
 
@@ -47,9 +47,9 @@ class ByteTokenizer:
     def chat_ids(self, question: str, n_image_tokens: list[int]) -> list[int]:
         return self.chat_ids_turns([("user", question, n_image_tokens)])
 
-    def chat_ids_turns(self, turns: list[tuple]) -> list[int]:
+    def chat_ids_turns(self, turns: list[tuple], system: str = SYSTEM_PROMPT) -> list[int]:
         """ChatML ids of a conversation: turns = [(role, text, n_image_tokens per image)], generation prompt appended."""
-        ids = [self.im_start] + self.encode("system\n" + SYSTEM_PROMPT) + [self.im_end] + self.encode("\n")
+        ids = [self.im_start] + self.encode("system\n" + system) + [self.im_end] + self.encode("\n")
         for role, text, n_image_tokens in turns:
             ids += [self.im_start] + self.encode(role + "\n")
             for n in n_image_tokens:
@@ -178,6 +178,9 @@ class Qwen2VL(Model):
 
             self._tokenizer = AutoTokenizer.from_pretrained(str(path))
             self.chat_template = getattr(self._tokenizer, "chat_template", None)
+            gc = path / "generation_config.json"   # HF merges it into every generate(): its top_k applies when a request samples
+            if gc.exists():
+                self._default_top_k = int(json.loads(gc.read_text()).get("top_k", 50) or 0)
         self._dims = dims
         self._start_workers()
         self._model = Qwen2VLEngine(weights)
@@ -187,11 +190,17 @@ class Qwen2VL(Model):
         raise NotImplementedError("Loglikelihood is not implemented for Qwen2_VL")  # as the reference (:141)
 
     def generate_until_multi_round(self, requests: list) -> list[tuple]:
-        """Multi-round dialogue (the `*_llamav_o1` tasks; reference :350-616): every round re-asks the task's
-        `doc_to_text(doc, round_idx=, previous_round_results=, last_round_info=)`, appends the user turn to the running
-        conversation (the image travels in round 0 only), generates greedily and cuts the answer at the `until` terms;
-        the result per request is the tuple of per-round answers.  Batched over documents; the image embeddings of
-        round 0 are kept on the GPU and reused by the later rounds (the reference re-encodes the image every round)."""
+        """Multi-round dialogue (the `*_llamav_o1` tasks; reference :350-616).  Per document and round r >= 1 the task's
+        `doc_to_text(doc, round_idx=r, previous_round_results=, last_round_info=)` is asked for the next user turn and returns
+        `(visuals, context, terminal, round_results, last_round_info)`; the reference (batch size 1) hands it
+        `last_round_info = {"messages": [conversation]}` - the running HF-style message list - and continues FROM THE MESSAGES THE
+        TASK RETURNS (`:479-480`; a task that returns no info restarts the conversation at the system prompt, and the per-round
+        results continue from the list the task returns, `:455-461`).  Restated here per document of a batch: the same protocol,
+        the same message structure (an image entry holds the PIL image where the reference stores a base64 JPEG data URL), the
+        user turn appended, greedy generation, the answer cut at the `until` terms and appended as the assistant turn; the
+        result per request is the tuple of per-round answers.  Batched over documents; the image embeddings of round 0 are kept
+        on the GPU and reused by the later rounds (the reference re-encodes the conversation's images every round), so a task
+        may edit the conversation's text but not its images."""
         res: list[tuple] = []
 
         def _collate(x):
@@ -208,10 +217,9 @@ class Qwen2VL(Model):
             if not isinstance(until, list):
                 raise ValueError(f"Expected `gen_kwargs['until']` to be of type Union[str,list] but got {type(until)}")
             max_new = int(gen_kwargs.get("max_new_tokens", 128))
-            if gen_kwargs.get("temperature", 0) not in (0, 0.0) or gen_kwargs.get("num_beams", 1) != 1:
-                raise NotImplementedError("the HIP decoder implements greedy decoding (temperature 0, 1 beam)")
+            sampling = sampling_from_gen_kwargs(gen_kwargs, getattr(self, "_default_top_k", 50))
             docs = [self.task_dict[task][split][did] for did in doc_ids]
-            visuals_per_doc = [doc_to_visual[0](d) for d in docs]
+            visuals_per_doc = [list(doc_to_visual[0](d)) for d in docs]
             prepared = list(self._pool.map(lambda v: imageproc.prepare_image(v, self._min_pixels, self._max_pixels),
                                            [v for vs in visuals_per_doc for v in vs]))
             it = iter(prepared)
@@ -220,27 +228,53 @@ class Qwen2VL(Model):
             emb = None
             if prepared:  # round 0's images, embedded once
                 emb = self._model.encode_images(self._pixel_values(prepared), [g for gs in grids_per_doc for g in gs])
-            turns = [[] for _ in docs]           # running conversations: (role, text, n_image_tokens)
-            round_results: list[list[str]] = []  # [round][doc]
+            image_slot = [{id(v): k for k, v in enumerate(vs)} for vs in visuals_per_doc]      # PIL object -> image index of its document
+            row_range, r0 = [], 0                       # [doc][image] -> (first, last + 1) row of `emb`
+            for gs in grids_per_doc:
+                row_range.append([])
+                for g in gs:
+                    row_range[-1].append((r0, r0 + g[1] * g[2] // 4))
+                    r0 += g[1] * g[2] // 4
+            messages: list[list] = [[] for _ in docs]   # the running conversation of every document (HF message dicts)
+            round_results: list[list[str]] = []         # [round][doc]
             round_idx, texts = 0, [c.replace("<image>", "") for c in contexts]
+            round_visuals = visuals_per_doc
             while True:
                 if round_idx:
                     outs = [doc_to_text[0](d, round_idx=round_idx, previous_round_results=[r[i] for r in round_results],
-                                           last_round_info=None) for i, d in enumerate(docs)]
+                                           last_round_info={"messages": [messages[i]]}) for i, d in enumerate(docs)]
                     # the per-round results continue from what the task RETURNS (item 3), as in the reference (:455-461): a task may
                     # rewrite or truncate earlier answers
                     round_results = [list(r) for r in zip(*[o[3] for o in outs], strict=True)]
                     if outs[0][2]:  # terminal signal (the reference looks at the first document of the batch, :462)
                         break
                     texts = [o[1].replace("<image>", "") for o in outs]
-                prompts = []
+                    round_visuals = [[] if o[0] is None else ([o[0]] if not isinstance(o[0], (list, tuple)) else list(o[0])) for o in outs]
+                    for i, o in enumerate(outs):   # the conversation continues from the messages the task hands back (:479-480)
+                        info = o[4]
+                        messages[i] = list(info["messages"][0]) if info and "messages" in info else []
+                prompts, round_grids, round_rows = [], [], []
                 for i, text in enumerate(texts):
-                    n_tok = [g[1] * g[2] // 4 for g in grids_per_doc[i]] if round_idx == 0 else []
-                    turns[i].append(("user", text, n_tok))
-                    prompts.append(self._conversation_ids(turns[i]))
+                    if not messages[i]:
+                        messages[i] = [{"role": "system", "content": SYSTEM_PROMPT}]
+                    content = [{"type": "image", "image": v} for v in round_visuals[i]] + [{"type": "text", "text": text}]
+                    messages[i].append({"role": "user", "content": content})
+                    # the conversation's images, in order, must be round-0 images of this document (identity): their embedding rows
+                    # are reused.  A conversation the task restarted holds none - its prompt then has no image tokens, as there.
+                    imgs = [c["image"] for m in messages[i] if isinstance(m["content"], list) for c in m["content"] if c.get("type") == "image"]
+                    try:
+                        ks = [image_slot[i][id(v)] for v in imgs]
+                    except KeyError:
+                        raise NotImplementedError("multi-round: the conversation's images must be the document's round-0 images "
+                                                  "(their embeddings are computed once and reused by the later rounds)") from None
+                    round_grids.append([grids_per_doc[i][k] for k in ks])
+                    round_rows.append(np.concatenate([np.arange(*row_range[i][k]) for k in ks]) if ks else np.zeros(0, np.int64))
+                    prompts.append(self._messages_ids(messages[i], [g[1] * g[2] // 4 for g in round_grids[-1]]))
                 pad = tok.pad_token_id if tok.pad_token_id is not None else 0
-                out = self._model.generate(prompts, emb, grids_per_doc, max_new, eos_token_id=tok.eos_token_id,
-                                           pad_token_id=pad).cpu().numpy()
+                # (sampling: one stream per document and ROUND - a round's draws must not repeat the previous round's)
+                smp = None if sampling is None else {**sampling, "stream_ids": [int(d) * 64 + round_idx for d in doc_ids]}
+                out = self._model.generate(prompts, emb, round_grids, max_new, eos_token_id=tok.eos_token_id, pad_token_id=pad,
+                                           img_rows=round_rows, sampling=smp).cpu().numpy()
                 rows = []
                 for r in out:
                     stop = np.flatnonzero(r == tok.eos_token_id)
@@ -251,24 +285,36 @@ class Qwen2VL(Model):
                         if len(term) > 0:
                             ans = ans.split(term)[0]
                     answers[i] = ans
-                    turns[i].append(("assistant", ans, []))
+                    messages[i].append({"role": "assistant", "content": [{"type": "text", "text": ans}]})
                 round_results.append(answers)
                 round_idx += 1
             res.extend(zip(*round_results, strict=True))
             self.cache_hook.add_partial("generate_until_multi_round", (contexts[0], gen_kwargs), round_results)
         return reordered.get_original(res)
 
-    def _conversation_ids(self, turns: list[tuple]) -> np.ndarray:
+    def _messages_ids(self, messages: list[dict], n_image_tokens: list[int]) -> np.ndarray:
+        """HF-style message list -> prompt ids with the generation prompt appended; image entry k expands to n_image_tokens[k]
+        placeholders.  A leading system message is taken as is, otherwise the default one is supplied (Qwen2-VL chat template)."""
         tok = self._tokenizer
         if isinstance(tok, ByteTokenizer):
-            return np.asarray(tok.chat_ids_turns(turns), dtype=np.int32)
-        messages = [{"role": "system", "content": SYSTEM_PROMPT}]
-        n_all = []
-        for role, text, n_image_tokens in turns:
-            messages.append({"role": role, "content": [{"type": "image"} for _ in n_image_tokens] + [{"type": "text", "text": text}]})
-            n_all += list(n_image_tokens)
-        ids = tok.encode(tok.apply_chat_template(messages, tokenize=False, add_generation_prompt=True))
-        out, it = [], iter(n_all)
+            it = iter(n_image_tokens)
+            msgs = list(messages)
+            system = SYSTEM_PROMPT
+            if msgs and msgs[0]["role"] == "system":
+                c = msgs.pop(0)["content"]
+                system = c if isinstance(c, str) else "".join(x.get("text", "") for x in c)
+            turns = []
+            for m in msgs:
+                c = m["content"]
+                if isinstance(c, str):
+                    turns.append((m["role"], c, []))
+                else:
+                    turns.append((m["role"], "".join(x["text"] for x in c if "text" in x), [next(it) for x in c if x.get("type") == "image"]))
+            return np.asarray(tok.chat_ids_turns(turns, system=system), dtype=np.int32)
+        plain = [{"role": m["role"], "content": m["content"] if isinstance(m["content"], str) else
+                  [{"type": "image"} if c.get("type") == "image" else c for c in m["content"]]} for m in messages]
+        ids = tok.encode(tok.apply_chat_template(plain, tokenize=False, add_generation_prompt=True))
+        out, it = [], iter(n_image_tokens)
         for t in ids:
             out.extend([t] * next(it) if t == self._dims.image_token_id else [t])
         return np.asarray(out, dtype=np.int32)
@@ -324,8 +370,7 @@ class Qwen2VL(Model):
             g.pop("until", None)   # samples file later records under `arguments` (_engine.py:262-266, _tracker.py:318-322)
         gen_kwargs = dict(all_gen_kwargs[0])   # popped and unused in the reference's single-round mode (:211-219)
         max_new = int(gen_kwargs.get("max_new_tokens", 128))
-        if gen_kwargs.get("temperature", 0) not in (0, 0.0) or gen_kwargs.get("num_beams", 1) != 1:
-            raise NotImplementedError("the HIP decoder implements greedy decoding (temperature 0, 1 beam)")
+        sampling = sampling_from_gen_kwargs(gen_kwargs, getattr(self, "_default_top_k", 50))
         docs = self.task_dict[task][split]
 
         def fetch(did):   # image fetch (file open + decode in the reference's tasks) AND preparation run on the pool workers
@@ -353,7 +398,9 @@ class Qwen2VL(Model):
             list(self._pool.map(lambda k, i=i, dst=dst: np.copyto(dst[k - i], images[k]), range(i, j)))
             groups.append(buf)
             i = j
-        return {"prompts": prompts, "grids": grids_per_prompt, "groups": groups, "max_new": max_new, "n": len(chunk)}
+        key = (max_new, None if sampling is None else (sampling["temperature"], sampling["top_p"], sampling["top_k"]))
+        return {"prompts": prompts, "grids": grids_per_prompt, "groups": groups, "max_new": max_new, "n": len(chunk),
+                "sampling": sampling, "doc_ids": [int(d) for d in doc_ids], "key": key}
 
     PINNED_POOL_BYTES = 4 << 30   # retained (idle) pinned staging per rank; buffers in flight are bounded by the look-ahead
 
@@ -434,7 +481,7 @@ class Qwen2VL(Model):
                     return n, False
                 if n + size > eb:
                     return n, True
-                mn = fut.result()["max_new"]
+                mn = fut.result()["key"]       # one pass = one generation length and one set of sampling switches
                 if first is None:
                     first = mn
                 elif mn != first:
@@ -473,7 +520,8 @@ class Qwen2VL(Model):
                 ahead_n -= size
             prep = preps[0] if len(preps) == 1 else {
                 "prompts": [x for p in preps for x in p["prompts"]], "grids": [x for p in preps for x in p["grids"]],
-                "groups": [x for p in preps for x in p["groups"]], "max_new": preps[0]["max_new"], "n": sum(p["n"] for p in preps)}
+                "groups": [x for p in preps for x in p["groups"]], "max_new": preps[0]["max_new"], "n": sum(p["n"] for p in preps),
+                "sampling": preps[0]["sampling"], "doc_ids": [x for p in preps for x in p["doc_ids"]]}
             top_up()
             host, ev = self._launch_chunk(prep, tok.eos_token_id, pad)
             inflight.append((host, ev, prep["groups"]))
@@ -496,7 +544,9 @@ class Qwen2VL(Model):
         emb = None
         if prep["groups"]:
             emb = self._model.encode_images(self._pixel_values(prep["groups"]), [g for gs in prep["grids"] for g in gs])
-        out = self._model.generate(prep["prompts"], emb, prep["grids"], prep["max_new"], eos_token_id=eos_token_id, pad_token_id=pad)
+        smp = None if prep.get("sampling") is None else {**prep["sampling"], "stream_ids": prep["doc_ids"]}   # one stream per document
+        out = self._model.generate(prep["prompts"], emb, prep["grids"], prep["max_new"], eos_token_id=eos_token_id, pad_token_id=pad,
+                                   sampling=smp)
         host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
         host.copy_(out, non_blocking=True)
         ev = torch.cuda.Event()

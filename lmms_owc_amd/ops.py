@@ -168,6 +168,20 @@ def argmax_bf16(logits):
     return out
 
 
+def sample_bf16(logits, temperature: float, top_k: int = 0, top_p: float | None = None, seed: int = 0, stream_ids=None, row_map=None,
+                step: int = 0):
+    """One draw per row of bf16 logits [rows, vocab] by owc_sampling (HF temperature -> top-k -> top-p -> multinomial; the library's
+    Philox stream: key = seed, counter = (stream id of the row's ORIGINAL row, step))."""
+    import ctypes as C
+
+    out = torch.empty((logits.shape[0],), dtype=I32, device=logits.device)
+    sp = _lib.Sampling(float(temperature), int(top_k or 0), float(top_p) if top_p else 0.0, int(seed) & 0xFFFFFFFFFFFFFFFF,
+                       _lib.ptr(stream_ids))
+    _call("owc_sample_bf16", _dev(logits), logits.data_ptr(), logits.stride(0), logits.shape[0], logits.shape[1], C.byref(sp),
+          _lib.ptr(row_map), int(step), out.data_ptr())
+    return out
+
+
 def token_logprob_bf16(logits, target):
     """log softmax(logits[r])[target[r]] (fp32; 0 where target[r] < 0) for bf16 logits [rows, vocab], int32 targets [rows]."""
     out = torch.empty((logits.shape[0],), dtype=torch.float32, device=logits.device)

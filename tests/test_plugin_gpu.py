@@ -50,6 +50,34 @@ def test_generate_until_batch_invariant_and_ordered(gpu):
         get_model("custom-model", model_type="qwen2-vl", model_name_or_path="synthetic:tiny", bogus=1)
 
 
+def test_sampled_generate_until_through_gen_kwargs(gpu):
+    """`--gen_kwargs temperature=0.8,top_p=0.9` (reference src/models/_qwen2_vl.py:308-329: do_sample = temperature > 0) reaches the
+    on-device sampler: the answers differ from the greedy ones, are reproducible under the same torch seed, do not depend on the
+    batch size (one random stream per document) and change with the seed; beams raise a clear error."""
+    import torch
+
+    from lmms_owc_amd.models import get_model
+    from lmms_owc_amd.tasks import load_task
+
+    outs = {}
+    for tag, bs, seed, gk in (("greedy", 4, 1234, {}), ("a", 1, 1234, {"temperature": 0.8, "top_p": 0.9}),
+                              ("b", 4, 1234, {"temperature": 0.8, "top_p": 0.9}), ("c", 4, 99, {"temperature": 0.8, "top_p": 0.9})):
+        torch.manual_seed(seed)
+        task = load_task("synthetic:9:56x84:3")
+        task.generation_kwargs.update(gk)
+        task.build_all_requests(limit=None, rank=0, world_size=1)
+        lm = get_model("custom-model", model_type="qwen2-vl", model_name_or_path="synthetic:tiny", batch_size=bs)
+        lm.task_dict[task.task_name] = task.dataset
+        outs[tag] = lm.generate_until(task.instances)
+    assert outs["a"] == outs["b"] and outs["a"] != outs["greedy"] and outs["c"] != outs["a"]
+    task = load_task("synthetic:3:56x84:3")
+    task.generation_kwargs.update({"num_beams": 4})
+    task.build_all_requests(limit=None, rank=0, world_size=1)
+    lm.task_dict[task.task_name] = task.dataset
+    with pytest.raises(NotImplementedError, match="beam search"):
+        lm.generate_until(task.instances)
+
+
 def test_evaluate_then_offline_metrics(gpu, scorer, tmp_path, capsys):
     import eval_metrics
     from lmms_owc_amd.engine.evaluate import simple_evaluate

@@ -240,6 +240,32 @@ def test_row_compaction_is_bit_identical(setup, gpu):
     assert min(s2["live_rows_per_step"]) < len(ps)
 
 
+def test_sampled_generation_is_a_function_of_seed_and_stream_only(setup, gpu):
+    """`generate(..., sampling=)` - HF's do_sample path (reference src/models/_qwen2_vl.py:319-329): a sequence's sampled tokens
+    depend on (weights, prompt, seed, its stream id) only: the same alone and inside a batch, with and without row compaction,
+    run after run; top_k = 1 reproduces the greedy tokens; another seed gives another continuation."""
+    cfg, w, eng, g = setup
+    r = np.random.default_rng(31)
+    prompts = [r.integers(10, 400, 7 + (i % 5)).astype(np.int64) for i in range(40)]
+    none = [[] for _ in prompts]
+    sp = {"temperature": 0.9, "top_k": 20, "top_p": 0.95, "seed": 77, "stream_ids": np.arange(100, 140)}
+    a = to_np(eng.generate(prompts, None, none, 12, sampling=sp))
+    assert np.array_equal(a, to_np(eng.generate(prompts, None, none, 12, sampling=sp)))
+    for i in (0, 17, 39):
+        solo = to_np(eng.generate([prompts[i]], None, [[]], 12, sampling={**sp, "stream_ids": [100 + i]}))
+        assert np.array_equal(solo[0], a[i]), i
+    greedy = to_np(eng.generate(prompts, None, none, 12))
+    assert np.array_equal(to_np(eng.generate(prompts, None, none, 12, sampling={"temperature": 1.3, "top_k": 1, "seed": 5})), greedy)
+    b = to_np(eng.generate(prompts, None, none, 12, sampling={**sp, "seed": 78}))
+    assert (a != b).mean() > 0.3 and (a != greedy).mean() > 0.3
+    vals, counts = np.unique(a[:, 1:8], return_counts=True)
+    eos = int(vals[np.argmax(counts)])
+    x = to_np(eng.generate(prompts, None, none, 12, sampling=sp, eos_token_id=eos, compact_rows=False))
+    st = {}
+    y = to_np(eng.generate(prompts, None, none, 12, sampling=sp, eos_token_id=eos, compact_rows=True, stats=st))
+    assert np.array_equal(x, y) and min(st["live_rows_per_step"]) < len(prompts)
+
+
 def test_rmsnorm_fused_into_the_skinny_gemm_is_bit_identical(setup, gpu):
     """Decode at 1-2 sequences (the kernel takes up to 4: the knob's maximum is exercised here): the qkv / gate-up projections
     normalise their own activations (gemm_bf16_skinny_norm_kernel, one launch less per RMSNorm).  Same bits as rmsnorm + GEMM - for
