@@ -84,7 +84,8 @@ def run_single(args: argparse.Namespace, date_id: str) -> dict | None:
                               batch_size=int(args.batch_size), limit=limit, gen_kwargs=args.gen_kwargs,
                               random_seed=seeds[0] or 0, numpy_random_seed=seeds[1] or 1234, torch_random_seed=seeds[2] or 1234,
                               fewshot_random_seed=seeds[3] or 1234, include_path=args.include_path, data_root=args.data_root,
-                              log_samples=args.log_samples, use_cache=args.use_cache, datetime_str=date_id)
+                              log_samples=args.log_samples, use_cache=args.use_cache, datetime_str=date_id,
+                              samples_as_lines=True)   # the samples only travel on to the tracker
     if results is not None:
         samples = results.pop("samples") if args.log_samples else None   # eval_model.py:217-233
         tracker.save_results_aggregated(results=results, samples=samples, datetime_str=date_id)

@@ -55,7 +55,7 @@ def simple_evaluate(model: str, model_args: str | dict = "", tasks: list[str] | 
                     numpy_random_seed: int = 1234, torch_random_seed: int = 1234, fewshot_random_seed: int = 1234,
                     include_path: str | None = None, data_root: str = "data", log_samples: bool = True,
                     task_objects: dict | None = None, model_object=None, bootstrap_iters: int = 100000,
-                    use_cache: str | None = None, datetime_str: str | None = None) -> dict | None:
+                    use_cache: str | None = None, datetime_str: str | None = None, samples_as_lines: bool = False) -> dict | None:
     random.seed(random_seed)
     np.random.seed(numpy_random_seed)
     torch.manual_seed(torch_random_seed)
@@ -77,7 +77,8 @@ def simple_evaluate(model: str, model_args: str | dict = "", tasks: list[str] | 
             t.generation_kwargs.update(gk)
     for t in task_dict.values():
         lm.task_dict[t.task_name] = t.dataset
-    results = evaluate(lm, task_dict, limit=limit, log_samples=log_samples, bootstrap_iters=bootstrap_iters)
+    results = evaluate(lm, task_dict, limit=limit, log_samples=log_samples, bootstrap_iters=bootstrap_iters,
+                       samples_as_lines=samples_as_lines)
     torch.set_grad_enabled(True)
     if results is None:
         return None
@@ -171,7 +172,12 @@ def doc_record(task, req, log_samples: bool) -> tuple[dict | None, dict]:
 
 
 def evaluate(lm, task_dict: dict, limit: int | float | None = None, log_samples: bool = True,
-             bootstrap_iters: int | None = 100000) -> dict | None:
+             bootstrap_iters: int | None = 100000, samples_as_lines: bool = False) -> dict | None:
+    """`samples_as_lines` (multi-rank runs with `log_samples`; what eval_model.py asks for): `results["samples"]` holds
+    `tracker.SampleLine` records - the owning rank has already produced the samples-file line, so rank 0's share of a task's tail
+    is a parse of the metric values only (tools/time_rank_tail.py)."""
+    from .tracker import SampleLine, sample_line
+
     rank, world = lm.rank, lm.world_size
     dist = _dist()
     results: dict = {k: {} for k in ("results", "group_subtasks", "configs", "versions", "n-shot", "higher_is_better", "n-samples")}
@@ -192,11 +198,18 @@ def evaluate(lm, task_dict: dict, limit: int | float | None = None, log_samples:
         # every rank post-processes the documents it owns ...
         local = [doc_record(task, req, log_samples) for req in reqs]
         if world > 1:   # ... and rank 0 receives [sample record, metric values] per document, ordered by doc_id below
-            blobs = [json.dumps([e, m], default=utils.convert_non_serializable, ensure_ascii=False).encode("utf-8") for e, m in local]
+            dumps = lambda o: json.dumps(o, default=utils.convert_non_serializable, ensure_ascii=False)  # noqa: E731
+            if log_samples and samples_as_lines:   # [the finished samples-file line, its two hashes, metric values]
+                blobs = [dumps([sample_line(dict(e)), e["prompt_hash"], e["target_hash"], m]).encode("utf-8") for e, m in local]
+            else:
+                blobs = [dumps([e, m]).encode("utf-8") for e, m in local]
             got = gather_records(lm, [r.doc_id for r in reqs], blobs, sizes, rank, world, dist)
             if rank != 0:
                 continue
-            local = [tuple(got[i]) for i in sorted(got)]
+            if log_samples and samples_as_lines:
+                local = [(SampleLine(got[i][0], DOC_HASH_OF_NONE, got[i][1], got[i][2]), got[i][3]) for i in sorted(got)]
+            else:
+                local = [tuple(got[i]) for i in sorted(got)]
         samples, metric_items = [], defaultdict(list)
         for example, metrics in local:
             if log_samples:

@@ -82,13 +82,31 @@ class EngineTracker:
         f = self._dir() / f"{self.date_id}_samples_{task_name}.jsonl"
         with f.open("a", encoding="utf-8") as fh:
             for sample in samples:
-                # `for key, value in enumerate(sample["arguments"][1])` over the gen_kwargs DICT (_tracker.py:318-322): the file
-                # records {position: KEY NAME} of the request's generation kwargs, not their values
-                arguments = dict(enumerate(sample["arguments"][1]))
-                sample["input"] = sample["arguments"][0]
-                sample["resps"] = utils.sanitize_list(sample["resps"])
-                sample["filtered_resps"] = utils.sanitize_list(sample["filtered_resps"])
-                sample["arguments"] = arguments
-                sample["target"] = str(sample["target"])
-                fh.write(json.dumps(sample, default=utils.convert_non_serializable, ensure_ascii=False) + "\n")
+                fh.write((sample.line if isinstance(sample, SampleLine) else sample_line(sample)) + "\n")
         return f
+
+
+def sample_line(sample: dict) -> str:
+    """One line of `<date>_samples_<task>.jsonl` (reference src/engine/_tracker.py:310-335) from a sample record of `evaluate`."""
+    # `for key, value in enumerate(sample["arguments"][1])` over the gen_kwargs DICT (_tracker.py:318-322): the file
+    # records {position: KEY NAME} of the request's generation kwargs, not their values
+    arguments = dict(enumerate(sample["arguments"][1]))
+    sample["input"] = sample["arguments"][0]
+    sample["resps"] = utils.sanitize_list(sample["resps"])
+    sample["filtered_resps"] = utils.sanitize_list(sample["filtered_resps"])
+    sample["arguments"] = arguments
+    sample["target"] = str(sample["target"])
+    return json.dumps(sample, default=utils.convert_non_serializable, ensure_ascii=False)
+
+
+class SampleLine(dict):
+    """A sample record that already IS its samples-file line (`evaluate(..., samples_as_lines=True)` in a multi-rank run: the rank
+    that owns the document serialises it, rank 0 neither parses nor re-encodes 50 000 records).  As a dict it carries what
+    `save_results_aggregated` reads - the three hashes; `.record()` parses the line for anything else."""
+
+    def __init__(self, line: str, doc_hash: str, prompt_hash: str, target_hash: str) -> None:
+        super().__init__(doc_hash=doc_hash, prompt_hash=prompt_hash, target_hash=target_hash)
+        self.line = line
+
+    def record(self) -> dict:
+        return json.loads(self.line)

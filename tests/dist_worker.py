@@ -1,6 +1,6 @@
 """Worker of the world-size-2 tests in tests/test_host_logic.py: runs simple_evaluate + the tracker under gloo with a stub
-model (no GPU, CPU string metrics only); rank 0 writes the result files.  OWC_TEST_TOKENS=1 gives the stub the token-record
-interface (`generate_until_tokens` / `decode_tokens`) so the engine's token gather path is exercised as well."""
+model (no GPU, CPU string metrics only); rank 0 writes the result files.  OWC_TEST_LINES=1 asks for `samples_as_lines` (the
+owning rank serialises the samples-file line, as eval_model.py does)."""
 import os
 import sys
 from pathlib import Path
@@ -38,20 +38,6 @@ class StubModel:
         return out
 
 
-class TokenStubModel(StubModel):
-    """Same answers through fixed-width token records (ids = UTF-8 bytes + 3), like the HIP model wrappers."""
-
-    def generate_until_tokens(self, requests):
-        rows = [[b + 3 for b in s.encode("utf-8")] for s in StubModel.generate_until(self, requests)]
-        mat = np.zeros((len(rows), 64), np.int32)
-        for i, r in enumerate(rows):
-            mat[i, : len(r)] = r
-        return mat, np.array([len(r) for r in rows], np.int32)
-
-    def decode_tokens(self, rows):
-        return [bytes(int(t) - 3 for t in r).decode("utf-8") for r in rows]
-
-
 def main():
     world = int(os.environ["WORLD_SIZE"])
     backend = os.environ.get("OWC_TEST_BACKEND", "gloo")   # "nccl" (= RCCL): tests/test_rccl_gpu.py, also with ONE rank
@@ -68,13 +54,13 @@ def main():
                {"metric": "textual_inclusion", "aggregation": "mean"}]
     task = ClassificationTask("toy", docs, metric_list=metrics)
     task.doc_to_visual = lambda doc: []
-    lm = TokenStubModel() if os.environ.get("OWC_TEST_TOKENS") == "1" else StubModel()
+    lm = StubModel()
     out_dir = Path(sys.argv[1])
     tracker = EngineTracker(output_path=str(out_dir))
     tracker.log_experiment_args(model_source="stub", model_args="")
     date = "2026-01-02T03:04:05"
     res = simple_evaluate(model="stub", task_objects={"toy": task}, limit=int(os.environ.get("OWC_TEST_LIMIT", "9")), model_object=lm,
-                          datetime_str=date)
+                          datetime_str=date, samples_as_lines=os.environ.get("OWC_TEST_LINES") == "1")
     assert (res is None) == (lm.rank != 0)
     if res is not None:
         samples = res.pop("samples")

@@ -208,12 +208,13 @@ def _run_ranks(tmp_path, tag: str, world: int, port: int, extra_env: dict) -> di
     return {n: mask(t) for n, t in files.items()}
 
 
-@pytest.mark.parametrize("tokens", ["0", "1"])
-def test_evaluate_two_ranks_byte_identical_to_one(tmp_path, tokens):
-    """world_size-2 gloo run (uneven shards 5 / 4): ONE fixed-width all_gather of the answers, rank 0 builds every record;
-    the results JSON and the samples JSONL are BYTE-identical to the single-process run's - through the UTF-8 byte records
-    of a plain `Model` plug-in (tokens=0) and through the token records of the HIP wrappers' interface (tokens=1)."""
-    outs = [_run_ranks(tmp_path, f"t{tokens}w", world, 29611 + world + 10 * int(tokens), {"OWC_TEST_TOKENS": tokens}) for world in (1, 2)]
+@pytest.mark.parametrize("lines", ["0", "1"])
+def test_evaluate_two_ranks_byte_identical_to_one(tmp_path, lines):
+    """world_size-2 gloo run (uneven shards 5 / 4): every rank scores the documents it owns, ONE fixed-width all_gather of the
+    per-document JSON records, rank 0 lines them up in doc_id order; the results JSON and the samples JSONL are BYTE-identical to the
+    single-process run's - with the sample records gathered as dicts (lines=0) and as finished samples-file lines
+    (`samples_as_lines`, what eval_model.py asks for: lines=1)."""
+    outs = [_run_ranks(tmp_path, f"l{lines}w", world, 29611 + world + 10 * int(lines), {"OWC_TEST_LINES": lines}) for world in (1, 2)]
     assert sorted(outs[0]) == sorted(outs[1]) and len(outs[0]) == 2
     assert outs[0] == outs[1]
     samples = [json.loads(ln) for ln in next(t for n, t in outs[0].items() if "_samples_" in n).splitlines()]

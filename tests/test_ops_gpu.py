@@ -302,14 +302,12 @@ def test_sampling_extremes_and_ties(gpu):
     g = torch.Generator(device=gpu).manual_seed(8)
     for V in (152064, 2048, 517):
         logits = (torch.randn((64, V), generator=g, device=gpu) * 3).to(torch.bfloat16)
-        am = ops.argmax_bf16(logits)
         vals = logits.float()
         top = vals.max(dim=1).values
         for kw in (dict(temperature=1.0, top_k=1), dict(temperature=1e-3), dict(temperature=0.7, top_k=1, top_p=0.5)):
             got = ops.sample_bf16(logits, seed=5, **kw)
             assert bool((vals.gather(1, got.long()[:, None])[:, 0] == top).all()), (V, kw)   # a maximal token (ties: any of them)
         assert torch.equal(ops.sample_bf16(logits, 1.0, top_k=1, seed=1), ops.sample_bf16(logits, 1.0, top_k=1, seed=1))
-        assert bool((ops.sample_bf16(logits, 1.0, top_p=1e-6, seed=3) == ops.sample_bf16(logits, 1.0, top_k=1, seed=3)).all()) or True
     tie = torch.tensor([[1.0, 3.0, 3.0, 2.0, 3.0, 0.0, -1.0, 0.5]], device=gpu).to(torch.bfloat16).expand(4000, 8).contiguous()
     drawn = set(to_np(ops.sample_bf16(tie, 1.0, top_k=2, seed=2)).tolist())
     assert drawn == {1, 2, 4}
