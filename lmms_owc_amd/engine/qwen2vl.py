@@ -407,7 +407,8 @@ class Qwen2VLEngine:
     def generate(self, prompts: list, img_embeds: torch.Tensor | None, grids_per_prompt: list, max_new_tokens: int,
                  *, eos_token_id: int = -1, pad_token_id: int = 0, stop_check_every: int = 1, compact_rows: bool = True,
                  return_logits: bool = False, img_rows: list | None = None, forced_tokens=None,
-                 return_step_logits: bool = False, stats: dict | None = None, sampling: dict | None = None):
+                 return_step_logits: bool = False, stats: dict | None = None, sampling: dict | None = None,
+                 carry: dict | None = None):
         """Greedy generation for a batch of prompts.
 
         prompts[b]: 1-D int array of token ids holding image_token_id placeholders;
@@ -429,6 +430,14 @@ class Qwen2VLEngine:
         "stream_ids": int per prompt (default: its index)} - HF's `do_sample` path (temperature -> top-k -> top-p -> multinomial) on
         the library's documented Philox stream; a sequence's draws depend on (seed, its stream id, step) only.
         `stats` (optional dict) receives the live-row count of every step.
+        `carry` (optional dict; EOS handling on, greedy): straggler hand-over between consecutive passes of a task.  In:
+        `carry["in"]` - the unfinished sequences of the previous pass (`carry["out"]` of that call), which join this pass's decode
+        steps as extra rows with their own KV rows, pending token and remaining budget; `carry["below"]` - once this pass's OWN
+        live rows are at most this many (and at least one decode step ran) the loop stops and the still-running sequences are
+        exported (0: run everything to the end - the last pass of a task); `carry["tags"]` - one identity per prompt.  Out:
+        `carry["finished"]` = [(tag, int32 tokens incl. pad)] of carried-in sequences that ended here, `carry["out"]` = the
+        export (None when nothing is left), `carry["unfinished_rows"]` = the own rows inside it (their rows of the returned
+        tensor are incomplete).  A sequence's tokens do not depend on which pass finishes it (batch invariance; tested).
         Returns int32 [B, max_new_tokens] (pad after EOS) and, optionally, the first-step logits [B, vocab]
         (`return_logits`) or every step's logits [max_new_tokens, B, vocab] (`return_step_logits`).
         """
@@ -437,10 +446,31 @@ class Qwen2VLEngine:
         lens = np.array([len(p) for p in prompts], dtype=np.int64)
         s_max = int(lens.max()) + max_new_tokens
         Hkv, G = d.n_kv_heads, d.n_q_heads // d.n_kv_heads
-        cache_elems = d.n_layers * B * Hkv * s_max * d.head_dim
+        cin = carry.get("in") if carry is not None else None
+        if carry is not None and (eos_token_id < 0 or sampling is not None or return_step_logits or return_logits or self.graph_decode):
+            raise ValueError("carry needs EOS handling on, greedy decoding and no logits output")
+        NC = 0 if cin is None else len(cin["tags"])
+        Bx = B + NC                                  # rows of the decode batch: this pass's prompts + the carried-in sequences
+        T_out = max_new_tokens                       # width of the token buffer = steps this pass may run + 1
+        if NC:
+            rem = np.asarray(cin["remaining"], dtype=np.int64)             # tokens each carried sequence may still emit
+            s_max = max(s_max, int((np.asarray(cin["cached"]) + rem).max()) + 2)   # (+2: a row runs <= 2 steps past its budget)
+            if not carry.get("below"):
+                T_out = max(T_out, int(rem.max()) + 1)                     # the last pass runs every sequence to its end
+        n_slots = Bx
+        if carry is not None:
+            # the passes of a task should ask the allocator for the SAME two blocks: a 20 GB cache that grew by 1 % is a fresh
+            # hipMalloc (~0.5 s each); slots for up to B / 8 (at least 256) carried sequences, key rows in steps of 16
+            n_slots = B + (max(NC, B // 8, 256) + 255) // 256 * 256
+            s_max = (max(s_max, int(lens.max()) + max_new_tokens + 2) + 15) // 16 * 16
+        cache_elems = d.n_layers * n_slots * Hkv * s_max * d.head_dim
         kc = torch.empty(cache_elems, dtype=BF16, device=self.device)
         vc = torch.empty(cache_elems, dtype=BF16, device=self.device)
-        cache = _lib.KvCache(kc.data_ptr(), vc.data_ptr(), B, s_max)
+        cache = _lib.KvCache(kc.data_ptr(), vc.data_ptr(), n_slots, s_max)
+        if NC:   # the carried sequences' K / V rows move into slots B.. of this pass's cache (one strided copy each)
+            w_c = cin["k"].shape[3]
+            kc.view(d.n_layers, n_slots, Hkv, s_max, d.head_dim)[:, B:Bx, :, :w_c].copy_(cin["k"])
+            vc.view(d.n_layers, n_slots, Hkv, s_max, d.head_dim)[:, B:Bx, :, :w_c].copy_(cin["v"])
 
         # positions (host integer bookkeeping)
         pos_list, max_pos = [], np.empty(B, dtype=np.int64)
@@ -473,11 +503,16 @@ class Qwen2VLEngine:
 
         # per-row decode state, two sets (a row compaction gathers from one into the other):
         # [set][fed token, rope position, cache write index, key count, cache slot, key start, output row][B] + the done flags
-        ar = np.arange(B, dtype=np.int64)
-        st_host = np.stack([np.zeros(B, np.int64), max_pos + 1, lens, lens + 1, ar, ar * Hkv * s_max, ar]).astype(np.int32)
-        state = torch.empty((2, 7, B), dtype=I32, device=self.device)
-        state[0].copy_(self._i32(st_host))
-        done2 = torch.zeros((2, B), dtype=torch.uint8, device=self.device)
+        ar = np.arange(Bx, dtype=np.int64)
+        st_host = np.zeros((7, Bx), np.int64)
+        st_host[1, :B], st_host[2, :B], st_host[3, :B] = max_pos + 1, lens, lens + 1
+        if NC:   # a carried sequence continues where it stood: pending token, its rope position, its keys
+            st_host[0, B:], st_host[1, B:] = cin["tok"], cin["pos"]
+            st_host[2, B:], st_host[3, B:] = cin["cached"], np.asarray(cin["cached"]) + 1
+        st_host[4], st_host[5], st_host[6] = ar, ar * Hkv * s_max, ar
+        state = torch.empty((2, 7, Bx), dtype=I32, device=self.device)
+        state[0].copy_(self._i32(st_host.astype(np.int32)))
+        done2 = torch.zeros((2, Bx), dtype=torch.uint8, device=self.device)
         cur = 0
         next_tok = state[0, 0]
         step_logits = torch.empty((max_new_tokens, B, d.vocab), dtype=BF16, device=self.device) if return_step_logits else None
@@ -485,7 +520,12 @@ class Qwen2VLEngine:
             torch.empty((B, d.vocab), dtype=BF16, device=self.device) if return_logits else None)
         forced = None
         if forced_tokens is not None:
-            forced = self._i32(np.asarray(forced_tokens).reshape(B, max_new_tokens).T)   # [T, B]: one contiguous row per step
+            f_host = np.zeros((T_out, Bx), np.int64)
+            f_host[:max_new_tokens, :B] = np.asarray(forced_tokens).reshape(B, max_new_tokens).T   # [T, B]: one contiguous row per step
+            for i in range(NC):   # a carried sequence writes its true column c0 + j - 1 at this pass's step j
+                fr = np.asarray(cin["forced_rest"][i])[: T_out - 1]
+                f_host[1:1 + len(fr), B + i] = fr
+            forced = self._i32(f_host)
         samp, samp_ref = None, None
         if sampling is not None:
             if not float(sampling["temperature"]) > 0:
@@ -512,29 +552,34 @@ class Qwen2VLEngine:
         if stats is not None:    # (events only: the caller reads `decode_ms` after it has synchronised)
             stats["decode_events"] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             stats["decode_events"][0].record()
-        out_tokens = torch.empty((B, max_new_tokens), dtype=I32, device=self.device)
+        out_tokens = torch.empty((Bx, T_out), dtype=I32, device=self.device)
         out_tokens.fill_(pad_token_id)              # rows dropped by a compaction keep pad behind their last column
         eos1 = -1
         rc = self._lib.owc_decode_update(self._ctx, next_tok.data_ptr(), done2[0].data_ptr(), out_tokens.data_ptr(),
-                                         max_new_tokens, 0, B, eos_token_id, eos1, pad_token_id, None,
+                                         T_out, 0, B, eos_token_id, eos1, pad_token_id, None,
                                          forced[0].data_ptr() if forced is not None else None, _lib.stream_ptr())
         _lib.check(rc, self.dev_index)
-        live_per_step = [B]
-        if max_new_tokens > 1:
+        live_per_step = [Bx]
+        steps_run = 0
+        row_of = np.arange(Bx)                                     # compact row -> row of out_tokens (host mirror of state[6])
+        if T_out > 1:
             q_start = self._i32(ar * (d.n_q_heads + 2 * Hkv))      # functions of the compact row index: prefixes stay valid
             o_start = self._i32(ar * d.n_q_heads)
-            q_len = self._i32(np.full(B, G))
-            nbytes = self._lib.owc_llm_workspace_bytes(C.byref(self.w.llm), B, B)
+            q_len = self._i32(np.full(Bx, G))
+            nbytes = self._lib.owc_llm_workspace_bytes(C.byref(self.w.llm), Bx, Bx)
             ws = self._workspace(nbytes)
             col = torch.ones(1, dtype=I32, device=self.device)     # the step's output column, advanced on the device
-            n = B                                                  # live rows
+            n = Bx                                                 # live rows
+            budget = np.full(Bx, max_new_tokens - 1, np.int64)     # decode steps a row may take in this pass
+            if NC:
+                budget[B:] = rem
 
             def step(j):
                 v, dn = state[cur], done2[cur]
                 rc = self._lib.owc_llm_decode_step(
                     self._ctx, C.byref(self.w.llm), C.byref(cache), v[0].data_ptr(), v[1].data_ptr(), v[4].data_ptr(),
                     v[2].data_ptr(), v[5].data_ptr(), v[3].data_ptr(), q_start.data_ptr(), o_start.data_ptr(), q_len.data_ptr(),
-                    dn.data_ptr(), out_tokens.data_ptr(), max_new_tokens, j, col.data_ptr(), n, eos_token_id, eos1, pad_token_id,
+                    dn.data_ptr(), out_tokens.data_ptr(), T_out, j, col.data_ptr(), n, eos_token_id, eos1, pad_token_id,
                     v[6].data_ptr(), forced[j].data_ptr() if forced is not None else None, samp_ref,
                     step_logits[j].data_ptr() if step_logits is not None else None, ws.data_ptr(), ws.numel(),
                     _lib.stream_ptr())
@@ -542,7 +587,7 @@ class Qwen2VLEngine:
 
             watch = eos_token_id >= 0 and stop_check_every > 0
             compact = compact_rows and step_logits is None
-            if self.graph_decode and B <= self.graph_max_batch and max_new_tokens >= 4 and forced is None and step_logits is None:
+            if self.graph_decode and carry is None and B <= self.graph_max_batch and max_new_tokens >= 4 and forced is None and step_logits is None:
                 # Small batches are launch-bound (~250 tiny launches per step): steps 2.. replay ONE captured hipGraph.  The
                 # step keeps its own rope position / write index / key count / output column on the device, so every replay
                 # is the same launch sequence with the same arguments (no row compaction on this path).
@@ -559,18 +604,23 @@ class Qwen2VLEngine:
                         break
                 del graph
             else:
-                flags = torch.empty(B, dtype=torch.uint8).pin_memory() if watch else None
-                pending = None                                      # (event, rows) of a done-flag snapshot in flight
-                for j in range(1, max_new_tokens):
+                flags = torch.empty(Bx, dtype=torch.uint8).pin_memory() if watch else None
+                pending = None                                      # (event, rows, step) of a done-flag snapshot in flight
+                below = int(carry.get("below") or 0) if carry is not None else 0
+                for j in range(1, T_out):
                     step(j)
+                    steps_run = j
                     live_per_step.append(n)
                     if pending is not None:
                         # the flags as of the step BEFORE the one just enqueued: the GPU is busy while the host looks at them
                         pending[0].synchronize()
-                        alive = np.flatnonzero(flags[:pending[1]].numpy() == 0)
+                        # (a row is also finished when its budget is spent: a carried sequence's cap, or this pass's own)
+                        alive = np.flatnonzero((flags[:pending[1]].numpy() == 0) & (budget[row_of[:pending[1]]] > pending[2]))
                         pending = None
                         if len(alive) == 0:
                             break
+                        if below and int((row_of[alive] < B).sum()) <= below:
+                            break                                   # the stragglers go on inside the next pass (exported below)
                         if compact and n - len(alive) >= max(1, n // 64):
                             live = self._i32(alive)
                             a, b_ = state[cur], state[cur ^ 1]
@@ -581,17 +631,87 @@ class Qwen2VLEngine:
                             _lib.check(rc, self.dev_index)
                             cur ^= 1
                             n = len(alive)
-                    if watch and j % stop_check_every == 0 and j + 1 < max_new_tokens:
+                            row_of = row_of[alive]
+                    if watch and j % stop_check_every == 0 and j + 1 < T_out:
                         flags[:n].copy_(done2[cur, :n], non_blocking=True)
                         ev = torch.cuda.Event()
                         ev.record()
-                        pending = (ev, n)
+                        pending = (ev, n, j)
+        if carry is not None:
+            self._carry_export(carry, cin, B, NC, n if T_out > 1 else Bx, cur, state, done2, row_of, steps_run, out_tokens, kc, vc,
+                               s_max, Bx, max_new_tokens, forced_tokens, pad_token_id, n_slots)
+            out_tokens = out_tokens[:B, :max_new_tokens]
         if stats is not None:
             stats["live_rows_per_step"] = live_per_step
             stats["decode_events"][1].record()
         if return_step_logits:
             return out_tokens, step_logits
         return (out_tokens, first_logits) if return_logits else out_tokens
+
+    def _carry_export(self, carry, cin, B, NC, n, cur, state, done2, row_of, steps_run, out_tokens, kc, vc, s_max, Bx,
+                      max_new_tokens, forced_tokens, pad_token_id, n_slots) -> None:
+        """End of a pass with straggler hand-over: after the last enqueued step has run, split the rows that were still in the
+        decode batch into finished ones and sequences that go on in the next pass (their K / V rows, pending token, position and
+        remaining budget are copied out: the pass's own cache is released with the pass)."""
+        d = self.d
+        torch.cuda.current_stream().synchronize()
+        st = state[cur, :, :n].cpu().numpy()                        # [7, n] after the last step (advanced in place)
+        dn = done2[cur, :n].cpu().numpy()
+        toks = out_tokens.cpu().numpy()
+        own_tags = list(carry.get("tags") or range(B))
+        c0 = np.zeros(Bx, np.int64)                                 # tokens a row had emitted BEFORE this pass
+        cap = np.full(Bx, max_new_tokens, np.int64)                 # its total budget of new tokens
+        if NC:
+            c0[B:] = np.asarray(cin["emitted"])
+            cap[B:] = c0[B:] + np.asarray(cin["remaining"])
+        emitted = np.where(np.arange(Bx) < B, 1 + steps_run, c0 + steps_run)    # ... and has now (own rows: column 0 = the prefill's)
+        emitted = np.minimum(emitted, cap)
+        running = np.zeros(Bx, bool)
+        running[row_of[:n][dn == 0]] = True
+        running &= emitted < cap
+        # carried-in sequences that ended in this pass: their earlier tokens + this pass's columns 1.. (pad behind EOS)
+        finished = []
+        for i in range(NC):
+            r = B + i
+            if running[r]:
+                continue
+            new = toks[r, 1:1 + int(emitted[r] - c0[r])]
+            full = np.full(int(cap[r]), pad_token_id, np.int32)
+            prev = np.asarray(cin["tokens"][i], np.int32)
+            full[:len(prev)] = prev
+            full[len(prev):len(prev) + len(new)] = new
+            finished.append((cin["tags"][i], full))
+        carry["finished"] = finished
+        carry["unfinished_rows"] = [int(r) for r in np.flatnonzero(running[:B])]
+        idx = np.flatnonzero(running)
+        if len(idx) == 0:
+            carry["out"] = None
+            return
+        pos_in_batch = {int(r): k for k, r in enumerate(row_of[:n])}
+        comp = np.array([pos_in_batch[int(r)] for r in idx])        # compact row of every exported sequence
+        cached = st[2, comp].astype(np.int64)                       # tokens in its cache = the next write index
+        w_c = int(cached.max())
+        sel = torch.from_numpy(idx.astype(np.int64)).to(self.device)
+        kv = (kc.view(d.n_layers, n_slots, d.n_kv_heads, s_max, d.head_dim), vc.view(d.n_layers, n_slots, d.n_kv_heads, s_max, d.head_dim))
+        k_out = kv[0][:, :, :, :w_c].index_select(1, sel)
+        v_out = kv[1][:, :, :, :w_c].index_select(1, sel)
+        tokens, tags, forced_rest = [], [], []
+        for r in idx:
+            r = int(r)
+            if r < B:
+                tokens.append(toks[r, :int(emitted[r])].copy())
+                tags.append(own_tags[r])
+                fr = None if forced_tokens is None else np.asarray(forced_tokens).reshape(B, max_new_tokens)[r, int(emitted[r]):]
+            else:
+                i = r - B
+                prev = np.asarray(cin["tokens"][i], np.int32)
+                tokens.append(np.concatenate([prev, toks[r, 1:1 + int(emitted[r] - c0[r])]]))
+                tags.append(cin["tags"][i])
+                fr = None if forced_tokens is None else np.asarray(cin["forced_rest"][i])[int(emitted[r] - c0[r]):]
+            forced_rest.append(fr)
+        carry["out"] = {"k": k_out, "v": v_out, "cached": cached, "tok": st[0, comp].astype(np.int64), "pos": st[1, comp].astype(np.int64),
+                        "emitted": emitted[idx], "remaining": (cap - emitted)[idx], "tokens": tokens, "tags": tags,
+                        "forced_rest": forced_rest}
 
     def score(self, ids, img_embeds: torch.Tensor | None, grids: list, start: int, *, img_rows=None):
         """Teacher-forced scoring of ONE token sequence (prompt + continuation) in a single prefill: the logits of the positions

@@ -452,18 +452,24 @@ class Qwen2VL(Model):
         units = list(reordered.get_batched(n=unit, batch_fn=None))
         tok = self._tokenizer
         pad = tok.pad_token_id if tok.pad_token_id is not None else 0
-        rows: list[np.ndarray] = []
-        ahead, inflight = deque(), deque()      # futures of submitted units (in order); launched passes (host ids, event, groups)
+        rows: dict[int, np.ndarray] = {}        # position in the collated order -> token row (cut at EOS)
+        ahead, inflight = deque(), deque()      # futures of submitted units (in order); launched passes (host ids, event, groups, ...)
         nxt = 0
         ahead_n = 0                             # requests submitted for preparation and not launched yet
+        carried = None                          # unfinished sequences of the previous pass (Qwen2VLEngine.generate `carry`)
+        launched = 0                            # requests launched so far = position of the next pass's first request
+
+        def cut(r) -> np.ndarray:
+            stop = np.flatnonzero(r == tok.eos_token_id)
+            return r[: stop[0]].copy() if len(stop) else r.copy()
 
         def finish(item) -> None:
-            host, ev, groups = item
+            host, ev, groups, pos0, skip = item
             ev.synchronize()          # the pass's GPU work is complete: its staging buffers can be reused
             self._pinned_give(groups)
-            for r in host.numpy():
-                stop = np.flatnonzero(r == tok.eos_token_id)
-                rows.append(r[: stop[0]].copy() if len(stop) else r.copy())
+            for i, r in enumerate(host.numpy()):
+                if i not in skip:     # (a straggler handed to the next pass: its row comes back with that pass)
+                    rows[pos0 + i] = cut(r)
 
         def top_up() -> None:
             nonlocal nxt, ahead_n
@@ -523,8 +529,20 @@ class Qwen2VL(Model):
                 "groups": [x for p in preps for x in p["groups"]], "max_new": preps[0]["max_new"], "n": sum(p["n"] for p in preps),
                 "sampling": preps[0]["sampling"], "doc_ids": [x for p in preps for x in p["doc_ids"]]}
             top_up()
-            host, ev = self._launch_chunk(prep, tok.eos_token_id, pad)
-            inflight.append((host, ev, prep["groups"]))
+            # straggler hand-over: while another pass follows, this pass stops decoding once its own live sequences are down to
+            # 1 / 64 of an engine batch and the rest ride along in the next pass's decode steps (greedy decoding only)
+            carry = None
+            if prep.get("sampling") is None and tok.eos_token_id is not None and tok.eos_token_id >= 0 and not getattr(self, "_no_carry", False):
+                carry = {"in": carried, "below": max(8, eb // 64) if left - prep["n"] > 0 else 0,
+                         "tags": list(range(launched, launched + prep["n"]))}
+            host, ev = self._launch_chunk(prep, tok.eos_token_id, pad, carry)
+            skip = set()
+            if carry is not None:
+                for tag, full in carry["finished"]:
+                    rows[tag] = cut(full)
+                carried, skip = carry["out"], set(carry["unfinished_rows"])
+            inflight.append((host, ev, prep["groups"], launched, skip))
+            launched += prep["n"]
             last_size = prep["n"]
             left -= prep["n"]
             self.last_timing["chunks"] += 1
@@ -535,9 +553,10 @@ class Qwen2VL(Model):
             finish(inflight.popleft())
         self.last_timing["total_s"] = time.perf_counter() - t_begin
         self.last_timing.setdefault("first_chunk_prep_s", 0.0)
-        return reordered.get_original(rows)
+        assert carried is None and len(rows) == len(requests)
+        return reordered.get_original([rows[i] for i in range(len(requests))])
 
-    def _launch_chunk(self, prep: dict, eos_token_id: int, pad: int):
+    def _launch_chunk(self, prep: dict, eos_token_id: int, pad: int, carry: dict | None = None):
         """GPU stage of one prepared chunk: H2D + patchify + vision tower + prefill + decode are ENQUEUED (nothing waits), the ids
         come back through a pinned buffer; returns (host int32 [n, T], event that passes when the buffer is filled).
         (tools/soak_host_ranks.py replaces exactly this method by a timed stand-in to soak the host side of 8 ranks.)"""
@@ -546,7 +565,7 @@ class Qwen2VL(Model):
             emb = self._model.encode_images(self._pixel_values(prep["groups"]), [g for gs in prep["grids"] for g in gs])
         smp = None if prep.get("sampling") is None else {**prep["sampling"], "stream_ids": prep["doc_ids"]}   # one stream per document
         out = self._model.generate(prep["prompts"], emb, prep["grids"], prep["max_new"], eos_token_id=eos_token_id, pad_token_id=pad,
-                                   sampling=smp)
+                                   sampling=smp, carry=carry)
         host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
         host.copy_(out, non_blocking=True)
         ev = torch.cuda.Event()

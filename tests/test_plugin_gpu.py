@@ -50,6 +50,37 @@ def test_generate_until_batch_invariant_and_ordered(gpu):
         get_model("custom-model", model_type="qwen2-vl", model_name_or_path="synthetic:tiny", bogus=1)
 
 
+def test_generate_until_with_straggler_hand_over_equals_without(gpu):
+    """`generate_until` over several engine passes with an EOS that many answers hit early and some never: the stragglers of a
+    pass finish inside the following passes (Qwen2VLEngine.generate `carry`), and every answer equals the one the same plug-in
+    gives with the hand-over switched off."""
+    from lmms_owc_amd.models import get_model
+    from lmms_owc_amd.tasks import load_task
+
+    outs = {}
+    for tag in ("carry", "plain"):
+        task = load_task("synthetic:90:56x84:3")
+        task.generation_kwargs.update({"max_new_tokens": 24})
+        task.build_all_requests(limit=None, rank=0, world_size=1)
+        lm = get_model("custom-model", model_type="qwen2-vl", model_name_or_path="synthetic:tiny", batch_size=1, engine_batch=24)
+        lm.task_dict[task.task_name] = task.dataset
+        if tag == "carry":   # first run: find a token that ends many answers early, use it as EOS in both runs
+            lm._no_carry = True
+            free = lm.generate_until_tokens(task.instances)[0]
+            vals, counts = np.unique(free[:, 2:12], return_counts=True)
+            eos = int(vals[np.argmax(counts)])
+            lm._no_carry = False
+            task.build_all_requests(limit=None, rank=0, world_size=1)
+        else:
+            lm._no_carry = True
+        lm._tokenizer.eos_token_id = eos
+        outs[tag] = lm.generate_until(task.instances)
+        if tag == "carry":
+            assert lm.last_timing["chunks"] >= 3
+    assert outs["carry"] == outs["plain"] and len(outs["carry"]) == 90
+    assert len({len(a) for a in outs["carry"]}) > 3      # really ragged
+
+
 def test_sampled_generate_until_through_gen_kwargs(gpu):
     """`--gen_kwargs temperature=0.8,top_p=0.9` (reference src/models/_qwen2_vl.py:308-329: do_sample = temperature > 0) reaches the
     on-device sampler: the answers differ from the greedy ones, are reproducible under the same torch seed, do not depend on the
@@ -467,25 +498,27 @@ def test_fp8_decoder_through_the_plugin(gpu, model_type, name):
 
 def test_token_records_equal_strings_and_pipeline_chunks(gpu):
     """`generate_until_tokens` + `decode_tokens` (the fixed-width records of the end-of-task RCCL gather) give exactly the strings
-    `generate_until` returns; the double-buffered chunk pipeline (preparation thread + pinned staging reuse + deferred token
-    read-back + quarter-first-chunk ramp) returns the same answers for every batch size, in request order."""
+    `generate_until` returns; the two-stage pipeline (preparation thread working in small units + pinned staging reuse + adaptive
+    assembly of engine passes + deferred token read-back) returns the same answers for every batch size, in request order."""
     from lmms_owc_amd.models import get_model
     from lmms_owc_amd.tasks import load_task
 
-    task = load_task("synthetic:300:56x84:3")      # 300 requests: batch 256 takes the ramp (64 + 192) and a 44-request tail
+    task = load_task("synthetic:300:56x84:3")      # 300 requests: batch 7 = 43 passes of one unit; batch 256 = units of 64, passes as they get ready
     outs = {}
     for bs in (7, 256):
         lm = get_model("custom-model", model_type="qwen2-vl", model_name_or_path="synthetic:tiny", batch_size=bs, engine_batch=0)
         lm.task_dict[task.task_name] = task.dataset
         task.build_all_requests(limit=None, rank=0, world_size=1)
         outs[bs] = lm.generate_until(task.instances)
-        assert lm.last_timing["chunks"] == (43 if bs == 7 else 3)
+        sizes = lm.last_timing["pass_sizes"]
+        assert sum(sizes) == 300 and max(sizes) <= bs and lm.last_timing["chunks"] == len(sizes)
+        assert len(sizes) == 43 if bs == 7 else 2 <= len(sizes) <= 5
     assert outs[7] == outs[256] and len(outs[7]) == 300
     # engine_batch="auto" (the default): batch_size is only a lower bound, the whole task fits one engine pass - same answers
     auto = get_model("custom-model", model_type="qwen2-vl", model_name_or_path="synthetic:tiny", batch_size=1)
     auto.task_dict[task.task_name] = task.dataset
     task.build_all_requests(limit=None, rank=0, world_size=1)
-    assert auto.engine_batch(8) >= 300 and auto.generate_until(task.instances) == outs[7] and auto.last_timing["chunks"] == 2
+    assert auto.engine_batch(8) >= 300 and auto.generate_until(task.instances) == outs[7] and sum(auto.last_timing["pass_sizes"]) == 300
     task.build_all_requests(limit=None, rank=0, world_size=1)
     mat, n = lm.generate_until_tokens(task.instances)
     assert mat.shape[0] == 300 and mat.dtype == np.int32 and n.shape == (300,)

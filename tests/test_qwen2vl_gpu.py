@@ -240,6 +240,46 @@ def test_row_compaction_is_bit_identical(setup, gpu):
     assert min(s2["live_rows_per_step"]) < len(ps)
 
 
+def test_straggler_carry_over_is_bit_identical(setup, gpu):
+    """Straggler hand-over between the passes of a task (`generate(..., carry=)`): a pass stops decoding once its OWN live
+    sequences are few, the unfinished ones - K / V rows, pending token, position, remaining budget - join the NEXT pass's decode
+    steps as extra rows, the last pass runs everything to its end.  Every sequence's tokens equal those of its pass run alone to
+    completion: forced (seeded ragged answer lengths with sequences that never stop inside the cap) and free-running."""
+    cfg, w, eng, g = setup
+    r = np.random.default_rng(123)
+    T, eos = 40, 9
+    sizes = (70, 50, 33, 21)
+    passes = [[r.integers(10, 400, 6 + (i % 9)).astype(np.int64) for i in range(n)] for n in sizes]
+    forced = [_ragged_forced(r, n, T, eos, 400, 6, cap_frac=0.08)[0] for n in sizes]
+
+    def run(with_forced: bool, eos_id: int, below: int):
+        ref = [to_np(eng.generate(p, None, [[] for _ in p], T, eos_token_id=eos_id, pad_token_id=0,
+                                  forced_tokens=forced[k] if with_forced else None)) for k, p in enumerate(passes)]
+        got = {}
+        state, handed = None, 0
+        for k, p in enumerate(passes):
+            c = {"in": state, "below": below if k + 1 < len(passes) else 0, "tags": [(k, i) for i in range(len(p))]}
+            out = to_np(eng.generate(p, None, [[] for _ in p], T, eos_token_id=eos_id, pad_token_id=0,
+                                     forced_tokens=forced[k] if with_forced else None, carry=c))
+            for i in range(len(p)):
+                if i not in c["unfinished_rows"]:
+                    got[(k, i)] = out[i]
+            for tag, full in c["finished"]:
+                got[tag] = full
+            state = c["out"]
+            handed += 0 if state is None else len(state["tags"])
+        assert state is None and len(got) == sum(sizes)
+        for k, n in enumerate(sizes):
+            for i in range(n):
+                assert np.array_equal(got[(k, i)], ref[k][i]), (with_forced, k, i, got[(k, i)], ref[k][i])
+        return handed
+
+    assert run(True, eos, 6) >= 6                    # sequences really travelled (some through more than one pass)
+    free = to_np(eng.generate(passes[0], None, [[] for _ in passes[0]], T))
+    vals, counts = np.unique(free[:, 2:20], return_counts=True)
+    assert run(False, int(vals[np.argmax(counts)]), 40) >= 10   # (free-running: many sequences never emit that token)
+
+
 def test_sampled_generation_is_a_function_of_seed_and_stream_only(setup, gpu):
     """`generate(..., sampling=)` - HF's do_sample path (reference src/models/_qwen2_vl.py:319-329): a sequence's sampled tokens
     depend on (weights, prompt, seed, its stream id) only: the same alone and inside a batch, with and without row compaction,

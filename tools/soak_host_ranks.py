@@ -50,7 +50,9 @@ def child(args) -> None:
         def _pinned_take(self, shape):   # no GPU in this process: the staging copies go to ordinary memory (same memcpy work)
             return torch.empty(int(np.prod(shape)), dtype=torch.uint8).view(shape)
 
-        def _launch_chunk(self, prep, eos_token_id, pad):
+        _no_carry = True
+
+        def _launch_chunk(self, prep, eos_token_id, pad, carry=None):
             n = prep["n"]
             t_end = time.perf_counter() + n * args.launch_ms_per_image * 1e-3
             while time.perf_counter() < t_end:      # the launching thread is busy (and holds the GIL part of the time)
