@@ -307,7 +307,7 @@ def ragged_leg(engine, dims, name: str, n: int, T: int, steps: int, device, sync
                     "ragged cu_seqlens vision launch groups + unequal prompts (shared 14-token prefix); uniform-noise pixels; never `value`"}
 
 
-def config2_leg(device, T: int, sync, profile, images: int = 512, passes: int = 3) -> dict:
+def config2_leg(device, T: int, sync, profile, images: int = 512, passes: int = 2) -> dict:
     """BASELINE.json configs[1] (never `value`): Qwen2-VL-2B bf16, 512 images (Caltech-101 --limit 512 at the synthetic 448x448 size),
     one GPU: its own weights and engine beside the headline model's, `passes` timed passes after one warm-up."""
     from lmms_owc_amd import ops as owc_ops
@@ -792,7 +792,7 @@ def main() -> None:
 
     ragged = None
     if args.image_sizes != "none" and not (args.no_extra_legs and args.image_sizes == "food101"):
-        ragged = ragged_leg(engine, dims, args.image_sizes, args.ragged_images, T, min(2, max(1, args.steps - 1)), device, sync, profile=profile)
+        ragged = ragged_leg(engine, dims, args.image_sizes, args.ragged_images, T, 1, device, sync, profile=profile)
         if dist is not None:
             t = torch.tensor([ragged["seconds_per_pass"]], device=cdev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -922,10 +922,10 @@ def main() -> None:
 
 
 def pil_leg(engine, dims, host_u8, B: int, T: int, device, sync, lm=None) -> dict:
-    """PIL images -> `Qwen2VL.generate_until` -> strings on the engine of the main leg (same weights): 3 x B images in chunks of B
-    (the engine's own batch; the wrapper cuts the first chunk 1/4 + 3/4), so that every later chunk's host preparation overlaps
-    the previous chunk's GPU work; the first piece's preparation has nothing to hide behind and is inside the timed region, as
-    are the one-time costs of a call (allocations for each new chunk size)."""
+    """PIL images -> `Qwen2VL.generate_until` -> strings on the engine of the main leg (same weights): 2 x B images; the wrapper
+    prepares them in units of B / 16 and assembles engine passes adaptively (the GPU starts after one unit's preparation, later
+    passes grow to B), so the host preparation overlaps GPU work; the first unit's preparation has nothing to hide behind and is
+    inside the timed region, as are the one-time costs of a call (allocations for each new pass size)."""
     from PIL import Image
 
     from lmms_owc_amd.models._qwen2_vl import ByteTokenizer, Qwen2VL
@@ -940,7 +940,7 @@ def pil_leg(engine, dims, host_u8, B: int, T: int, device, sync, lm=None) -> dic
             assert n_image_tokens == [S_IMG]
             return [int(t) for t in ids]
 
-    n, bs = 3 * B, B
+    n, bs = 2 * B, B
     arr = host_u8[:B].permute(0, 2, 3, 1).contiguous().numpy()            # HWC uint8 (uniform noise: the slowest JPEG case)
     docs = [{"visual": Image.fromarray(arr[i % len(arr)], "RGB"), "target": f"class_{i % 10}"} for i in range(n)]
     task = ClassificationTask("bench", docs, generation_kwargs={"max_new_tokens": T, "do_sample": False})
