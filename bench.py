@@ -431,6 +431,7 @@ def eos_terminated_leg(engine, pix, flat_grids, prompts, grids, B: int, sync, he
         # timed passes (a task pays this once, whatever its length; measured: up to 1 s of hipMalloc for 2 x 20 GB)
         warm = [torch.empty(kv_elems, dtype=torch.bfloat16, device=pix.device) for _ in range(2)]
         del warm
+
         forced, lens = ragged_answer_lengths(B, cap, mean_len, cap_frac, 4242 + rank)
         row = {"max_new_tokens": cap, "mean_answer_tokens": float(np.minimum(lens, cap).mean()), "sequences_at_cap": int((lens > cap).sum())}
         toks = {}
@@ -452,6 +453,11 @@ def eos_terminated_leg(engine, pix, flat_grids, prompts, grids, B: int, sync, he
         if len(toks) == 2:
             row["tokens_identical_with_and_without_compaction"] = bool(torch.equal(toks[True], toks[False]))
         if cap == max(caps) and hand_over_passes > 1:
+            torch.cuda.empty_cache()   # (the stand-alone passes' cache blocks go back to the driver; the hand-over passes' own, larger
+            slots = B + (max(B // 8, 256) + 255) // 256 * 256   # blocks - slots for carried sequences - are taken once, outside the timing)
+            rows_kv = (len(prompts[0]) + cap + 2 + 15) // 16 * 16
+            warm = [torch.empty(d.n_layers * slots * d.n_kv_heads * d.head_dim * rows_kv, dtype=torch.bfloat16, device=pix.device) for _ in range(2)]
+            del warm
             # a TASK is several passes: with straggler hand-over a pass stops once its own live sequences are few and the rest finish
             # inside the following passes (`generate(..., carry=)`), so the long tail is paid once per task, not once per pass
             ref = toks[True].numpy()
