@@ -6,6 +6,8 @@ supports batch size 1, `_base.py:103-104`): the round loop, what is handed to an
 entry in the user turn that carries it, the `until` cut and the assistant turn.  The model call itself is a callback
 (`generate_text(messages) -> str`), so the protocol is checked independently of the arithmetic (which has its own oracles).
 
+`reference_multi_round_llava` does the same for /root/reference/src/models/_llava_hf.py:440-584 (independent single-turn rounds).
+
 `render_qwen2vl_chat` renders a message list with the chat template PUBLISHED with the checkpoints the reference loads
 (Qwen/Qwen2-VL-*-Instruct `chat_template.json`; third-party data, restated here because no checkpoint file exists offline) - what
 `self.processor.apply_chat_template(msg, tokenize=False, add_generation_prompt=True)` returns at `_qwen2_vl.py:535-540`.
@@ -95,3 +97,37 @@ def reference_multi_round(doc: dict, context: str, doc_to_visual, doc_to_text, g
         batched_round_results.append([answer])                                    # :602
         batched_round_info.append([dict(messages=[message])])                     # :603
     return tuple(r[0] for r in batched_round_results)                             # :605
+
+
+def reference_multi_round_llava(doc: dict, context: str, doc_to_visual, doc_to_text, gen_kwargs: dict, generate_text, image_token: str = "<image>"):
+    """One request of LLaVA's `generate_until_multi_round` (reference src/models/_llava_hf.py:440-584, batch size 1).  Unlike the Qwen2-VL
+    wrapper it keeps NO conversation: every round is an independent single-turn prompt from the round's visuals and context
+    (`batched_round_info` is never appended to, so `last_round_info` is always None); `until` is popped and never applied.
+    `generate_text(context_with_image_tokens, visuals) -> str` stands for template + processor + generate + decode (:522-574)."""
+    visuals = [v for v in doc_to_visual(doc)]                                      # :451-452 (flattened over a batch of one)
+    gen_kwargs = dict(gen_kwargs)
+    if "until" in gen_kwargs:                                                     # :461-470 (validated, then unused)
+        until = gen_kwargs.pop("until")
+        if not isinstance(until, (str, list)):
+            raise ValueError(f"Expected `gen_kwargs['until']` to be of type Union[str,list] but got {type(until)}")
+    round_idx = 0
+    batched_round_results: list = []
+    contexts = (context,)
+    while True:
+        if round_idx != 0:                                                        # :478-497
+            previous_round_results = [round_results[0] for round_results in batched_round_results]
+            vis, ctx, terminal, rr, _info = doc_to_text(doc, round_idx=round_idx, previous_round_results=previous_round_results,
+                                                        last_round_info=None)
+            visuals, contexts = (vis,), (ctx,)
+            batched_round_results = [list(x) for x in zip(*[rr], strict=True)]
+            if terminal:
+                break
+        ctx = contexts[0]                                                         # :499
+        if isinstance(visuals, tuple):                                            # :501-502 (raises TypeError for a `None` visual, as there)
+            visuals = list(*visuals)
+        if image_token not in ctx:                                                # :506-509
+            ctx = f"{' '.join([image_token] * len(visuals))}\n{ctx}"
+        answer = generate_text(ctx, visuals)                                      # :511-574
+        round_idx += 1
+        batched_round_results.append([answer])                                    # :577
+    return tuple(r[0] for r in batched_round_results)                             # :579

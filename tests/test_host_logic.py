@@ -574,6 +574,88 @@ def test_multi_round_generation_follows_the_reference_protocol():
     lm._prep_thread.shutdown()
 
 
+def test_llava_multi_round_generation_follows_the_reference_protocol():
+    """`LLaVA.generate_until_multi_round` against oracle/multiround.reference_multi_round_llava (reference
+    src/models/_llava_hf.py:440-584): independent single-turn prompts per round, `<image>` tokens prepended when the round's context
+    has none, the task-returned round results carried on, `until` never applied.  Same method as the Qwen2-VL twin: the decoder is
+    one pure function of the prompt ids on both sides, the vision side a stand-in that keeps the host integer work (views, feature
+    rows).  The task returns a LIST of visuals in later rounds (the bundled tasks return None there, which the reference's
+    `list(*visuals)` cannot digest - models/_llava_hf.py's docstring)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+
+    from lmms_owc_amd.engine.llava import DIMS, LlavaDims, LlavaEngine
+    from lmms_owc_amd.models._base import CacheHook
+    from lmms_owc_amd.models._llava_hf import LLaVA, LlavaByteTokenizer, vicuna_prompt
+    from lmms_owc_amd.tasks import ClassificationTask
+    from oracle import multiround as MR
+
+    tok = LlavaByteTokenizer()
+    dims = LlavaDims(**{**DIMS["tiny"].__dict__, "image_token_id": tok.image_token_id})
+
+    class FakeEngine:
+        d, device = dims, torch.device("cpu")
+        feature_rows = LlavaEngine.feature_rows
+
+        def generate_from_features(self, prompts, feats, rows_per_prompt, max_new, eos_token_id=-1, pad_token_id=0, **_):
+            out = np.full((len(prompts), max_new), pad_token_id, np.int32)
+            for i, p in enumerate(prompts):
+                assert int((np.asarray(p) == dims.image_token_id).sum()) == len(rows_per_prompt[i])
+                t = _pseudo_answer_tokens(p, max_new, eos_token_id)
+                out[i, : len(t)] = t
+            return torch.from_numpy(out)
+
+    class HostOnly(LLaVA):
+        def _encode_visuals(self, flat, feature_cache=None):
+            prepared = [self._views(v) for v in flat]
+            return None, (self._model.feature_rows([p[0].shape[0] for p in prepared], [p[1] for p in prepared]) if prepared else [])
+
+    lm = HostOnly.__new__(HostOnly)
+    lm._engine_batch_arg, lm._decoder_dtype, lm._chat_template = 0, "bf16", None
+    lm._device, lm._rank, lm._world_size, lm.batch_size_per_gpu = torch.device("cpu"), 0, 1, 3
+    lm.cache_hook, lm.task_dict = CacheHook(None), {}
+    lm._tokenizer = lm._processor = tok
+    lm._dims, lm._model, lm._pool = dims, FakeEngine(), ThreadPoolExecutor(max_workers=2)
+    r = np.random.default_rng(4)
+    docs = [{"visual": Image.fromarray(r.integers(0, 256, (40 + 8 * i, 50, 3), dtype=np.uint8), "RGB"), "target": f"class_{i}", "i": i}
+            for i in range(5)]
+    task = ClassificationTask("mr", docs, output_type="generate_until_multi_round",
+                              prompts=["Describe the image.", "<image> What stands out?", "So what is it?"],
+                              generation_kwargs={"max_new_tokens": 40, "do_sample": False, "until": ["STOP"]})
+    base = task.doc_to_text_multi_round
+
+    def list_visuals(doc, round_idx=None, previous_round_results=None, last_round_info=None):
+        out = base(doc, round_idx=round_idx, previous_round_results=previous_round_results, last_round_info=last_round_info)
+        if round_idx is None or out[2]:
+            return out
+        v, text, stop, prev, info = out
+        vis = [doc["visual"].convert("RGB")] if round_idx == 1 else []     # round 1 shows the image again, round 2 is text only
+        if round_idx == 2:
+            prev = [prev[0][::-1]] + list(prev[1:])                         # the returned list replaces the carried one
+        return vis, text, stop, prev, info
+
+    task.doc_to_text_multi_round = list_visuals
+    lm.task_dict["mr"] = task.dataset
+    task.build_all_requests(limit=None, rank=0, world_size=1)
+    got = lm.generate_until_multi_round(task.instances)
+
+    def generate_text(ctx, visuals):
+        n_img = [len(rows) for rows in (lm._encode_visuals(visuals)[1])]
+        text = vicuna_prompt([{"role": "user", "content": ctx}], tok.eos_token, True)   # (pinned on the reference's template: test above)
+        ids, it = [tok.bos_token_id], iter(n_img)
+        for t in tok.encode(text):
+            ids += [t] * next(it) if t == tok.image_token_id else [t]
+        return tok.decode(_pseudo_answer_tokens(np.asarray(ids, np.int32), 40, tok.eos_token_id)[:-1])
+
+    want = [MR.reference_multi_round_llava(docs[inst.args[4]], inst.args[0], inst.args[2], inst.args[3],
+                                           {"max_new_tokens": 40, "do_sample": False, "until": ["STOP"]}, generate_text)
+            for inst in task.instances]
+    assert got == want and all(len(t) == 3 for t in got)
+    assert any("STOP" in a for t in got for a in t)                         # `until` is not applied by this wrapper (as there)
+    lm._pool.shutdown()
+
+
 def test_bench_flop_accounting():
     """bench.py prices utilisation on executed FLOPs: the nominal forward minus the last prefill layer's dead
     rows and the shared-prefix rows.  The subtraction must be the closed form of exactly those rows."""
