@@ -422,9 +422,10 @@ def eos_terminated_leg(engine, pix, flat_grids, prompts, grids, B: int, sync, he
     for cap in caps:
         kv_elems = d.n_layers * B * d.n_kv_heads * d.head_dim * (len(prompts[0]) + cap)
         kv_bytes = 4.0 * kv_elems
-        if kv_bytes + (8 << 30) > torch.cuda.mem_get_info()[0]:
+        need = 1.15 * kv_bytes + (24 << 30)      # the two cache blocks + embeddings, workspace, logits of the pass
+        if need > torch.cuda.mem_get_info()[0]:
             torch.cuda.empty_cache()
-        if kv_bytes + (8 << 30) > torch.cuda.mem_get_info()[0]:
+        if need > torch.cuda.mem_get_info()[0]:
             out["by_cap"].append({"max_new_tokens": cap, "skipped": f"KV cache of {kv_bytes / 2**30:.0f} GiB does not fit beside the weights at this batch"})
             continue
         # the K / V caches of this cap are new sizes for torch's caching allocator: take the blocks from the driver once, outside the
@@ -452,7 +453,7 @@ def eos_terminated_leg(engine, pix, flat_grids, prompts, grids, B: int, sync, he
             del emb
         if len(toks) == 2:
             row["tokens_identical_with_and_without_compaction"] = bool(torch.equal(toks[True], toks[False]))
-        if cap == max(caps) and hand_over_passes > 1:
+        if cap == max(caps) and hand_over_passes > 1 and 1.3 * kv_bytes + (24 << 30) <= torch.cuda.mem_get_info()[0] + torch.cuda.memory_reserved() - torch.cuda.memory_allocated():
             torch.cuda.empty_cache()   # (the stand-alone passes' cache blocks go back to the driver; the hand-over passes' own, larger
             slots = B + (max(B // 8, 256) + 255) // 256 * 256   # blocks - slots for carried sequences - are taken once, outside the timing)
             rows_kv = (len(prompts[0]) + cap + 2 + 15) // 16 * 16
@@ -740,7 +741,11 @@ def main() -> None:
     # ---- EOS-terminated leg (never `value`): seeded ragged answer lengths at the task configs' caps, with / without row compaction
     eos_leg = None
     if not args.no_eos_leg and T >= 2:
-        eos_leg = eos_terminated_leg(engine, pix, flat_grids, prompts, grids, B, sync, B * args.steps / dt_own, rank)
+        try:
+            eos_leg = eos_terminated_leg(engine, pix, flat_grids, prompts, grids, B, sync, B * args.steps / dt_own, rank)
+        except torch.OutOfMemoryError as e:   # (an extra leg must never sink the measurement: large models at the largest batch)
+            torch.cuda.empty_cache()
+            eos_leg = {"skipped": f"out of memory: {str(e)[:160]}", "by_cap": []}
         if dist is not None:   # whole-job rate of every pass = all ranks' images / the slowest rank's time
             for row in eos_leg["by_cap"]:
                 for k in ("compacted", "all_rows_every_step", "passes_with_straggler_hand_over"):
