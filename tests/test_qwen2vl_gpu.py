@@ -247,19 +247,20 @@ def test_straggler_carry_over_is_bit_identical(setup, gpu):
     completion: forced (seeded ragged answer lengths with sequences that never stop inside the cap) and free-running."""
     cfg, w, eng, g = setup
     r = np.random.default_rng(123)
-    T, eos = 40, 9
+    eos = 9
     sizes = (70, 50, 33, 21)
+    caps = (40, 24, 40, 32)      # passes of different generation lengths (requests grouped by gen_kwargs): a carried sequence keeps ITS cap
     passes = [[r.integers(10, 400, 6 + (i % 9)).astype(np.int64) for i in range(n)] for n in sizes]
-    forced = [_ragged_forced(r, n, T, eos, 400, 6, cap_frac=0.08)[0] for n in sizes]
+    forced = [_ragged_forced(r, n, T, eos, 400, 6, cap_frac=0.08)[0] for n, T in zip(sizes, caps)]
 
     def run(with_forced: bool, eos_id: int, below: int):
-        ref = [to_np(eng.generate(p, None, [[] for _ in p], T, eos_token_id=eos_id, pad_token_id=0,
+        ref = [to_np(eng.generate(p, None, [[] for _ in p], caps[k], eos_token_id=eos_id, pad_token_id=0,
                                   forced_tokens=forced[k] if with_forced else None)) for k, p in enumerate(passes)]
         got = {}
         state, handed = None, 0
         for k, p in enumerate(passes):
             c = {"in": state, "below": below if k + 1 < len(passes) else 0, "tags": [(k, i) for i in range(len(p))]}
-            out = to_np(eng.generate(p, None, [[] for _ in p], T, eos_token_id=eos_id, pad_token_id=0,
+            out = to_np(eng.generate(p, None, [[] for _ in p], caps[k], eos_token_id=eos_id, pad_token_id=0,
                                      forced_tokens=forced[k] if with_forced else None, carry=c))
             for i in range(len(p)):
                 if i not in c["unfinished_rows"]:
@@ -275,7 +276,7 @@ def test_straggler_carry_over_is_bit_identical(setup, gpu):
         return handed
 
     assert run(True, eos, 6) >= 6                    # sequences really travelled (some through more than one pass)
-    free = to_np(eng.generate(passes[0], None, [[] for _ in passes[0]], T))
+    free = to_np(eng.generate(passes[0], None, [[] for _ in passes[0]], caps[0]))
     vals, counts = np.unique(free[:, 2:20], return_counts=True)
     assert run(False, int(vals[np.argmax(counts)]), 40) >= 10   # (free-running: many sequences never emit that token)
 
