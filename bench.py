@@ -423,15 +423,15 @@ def eos_terminated_leg(engine, pix, flat_grids, prompts, grids, B: int, sync, he
         kv_elems = d.n_layers * B * d.n_kv_heads * d.head_dim * (len(prompts[0]) + cap)
         kv_bytes = 4.0 * kv_elems
         need = 1.15 * kv_bytes + (24 << 30)      # the two cache blocks + embeddings, workspace, logits of the pass
-        if need > torch.cuda.mem_get_info()[0]:
+        held = 4 * engine._kv[0].numel() if getattr(engine, "_kv", None) else 0   # (the engine's current pair is released when it grows)
+        if need > torch.cuda.mem_get_info()[0] + held:
             torch.cuda.empty_cache()
-        if need > torch.cuda.mem_get_info()[0]:
+        if need > torch.cuda.mem_get_info()[0] + held:
             out["by_cap"].append({"max_new_tokens": cap, "skipped": f"KV cache of {kv_bytes / 2**30:.0f} GiB does not fit beside the weights at this batch"})
             continue
-        # the K / V caches of this cap are new sizes for torch's caching allocator: take the blocks from the driver once, outside the
-        # timed passes (a task pays this once, whatever its length; measured: up to 1 s of hipMalloc for 2 x 20 GB)
-        warm = [torch.empty(kv_elems, dtype=torch.bfloat16, device=pix.device) for _ in range(2)]
-        del warm
+        # the K / V caches of this cap are larger than the main leg's: the engine's grow-only pair is grown once, outside the timed
+        # passes (a task pays this once, whatever its length; measured: up to 1 s of hipMalloc for 2 x 20 GB)
+        engine.reserve_kv(kv_elems)
 
         forced, lens = ragged_answer_lengths(B, cap, mean_len, cap_frac, 4242 + rank)
         row = {"max_new_tokens": cap, "mean_answer_tokens": float(np.minimum(lens, cap).mean()), "sequences_at_cap": int((lens > cap).sum())}
@@ -453,12 +453,11 @@ def eos_terminated_leg(engine, pix, flat_grids, prompts, grids, B: int, sync, he
             del emb
         if len(toks) == 2:
             row["tokens_identical_with_and_without_compaction"] = bool(torch.equal(toks[True], toks[False]))
-        if cap == max(caps) and hand_over_passes > 1 and 1.3 * kv_bytes + (24 << 30) <= torch.cuda.mem_get_info()[0] + torch.cuda.memory_reserved() - torch.cuda.memory_allocated():
-            torch.cuda.empty_cache()   # (the stand-alone passes' cache blocks go back to the driver; the hand-over passes' own, larger
-            slots = B + (max(B // 8, 256) + 255) // 256 * 256   # blocks - slots for carried sequences - are taken once, outside the timing)
-            rows_kv = (len(prompts[0]) + cap + 2 + 15) // 16 * 16
-            warm = [torch.empty(d.n_layers * slots * d.n_kv_heads * d.head_dim * rows_kv, dtype=torch.bfloat16, device=pix.device) for _ in range(2)]
-            del warm
+        if cap == max(caps) and hand_over_passes > 1 and 1.3 * kv_bytes + (24 << 30) <= (
+                torch.cuda.mem_get_info()[0] + torch.cuda.memory_reserved() - torch.cuda.memory_allocated() + 4 * engine._kv[0].numel()):
+            slots = B + (max(B // 8, 256) + 255) // 256 * 256   # (slots for carried sequences: the engine's cache pair grows once more,
+            rows_kv = (len(prompts[0]) + cap + 2 + 15) // 16 * 16   # outside the timing)
+            engine.reserve_kv(d.n_layers * slots * d.n_kv_heads * d.head_dim * rows_kv)
             # a TASK is several passes: with straggler hand-over a pass stops once its own live sequences are few and the rest finish
             # inside the following passes (`generate(..., carry=)`), so the long tail is paid once per task, not once per pass
             ref = toks[True].numpy()

@@ -353,6 +353,21 @@ class Qwen2VLEngine:
     def _i32(self, a) -> torch.Tensor:
         return _lib.h2d(a, self.device, np.int32)
 
+    def reserve_kv(self, elems: int) -> tuple[torch.Tensor, torch.Tensor]:
+        """The engine's K and V cache blocks (bf16, `elems` each): ONE grow-only pair per engine, handed out as views.
+        Passes of a task differ in size (the adaptive ramp of `generate_until`, carried sequences, generation lengths); a fresh
+        `torch.empty` per pass made every new size a fresh hipMalloc beside the cached blocks of the earlier sizes - seconds per
+        pass once the blocks are tens of GB, and out-of-memory retries for an MHA decoder (LLaVA-1.5: 0.5 MB of KV per token).
+        Work is stream-ordered, so the next pass may reuse the memory while the previous one is still queued.  On growth the
+        old pair goes back to the driver first (`empty_cache`), so the peak is the new pair, not the sum."""
+        kv = getattr(self, "_kv", None)
+        if kv is None or kv[0].numel() < elems:
+            self._kv = kv = None
+            if elems * 2 > (1 << 30):
+                torch.cuda.empty_cache()
+            self._kv = kv = (torch.empty(int(elems), dtype=BF16, device=self.device), torch.empty(int(elems), dtype=BF16, device=self.device))
+        return kv[0][:elems], kv[1][:elems]
+
     # -- vision tower ------------------------------------------------------------------
     def encode_images(self, pixel_values: torch.Tensor, grid_thw) -> torch.Tensor:
         """pixel_values [sum(t*h*w), 1176] bf16 (device) -> merged embeddings [sum/4, d_model] bf16."""
@@ -464,8 +479,7 @@ class Qwen2VLEngine:
             n_slots = B + (max(NC, B // 8, 256) + 255) // 256 * 256
             s_max = (max(s_max, int(lens.max()) + max_new_tokens + 2) + 15) // 16 * 16
         cache_elems = d.n_layers * n_slots * Hkv * s_max * d.head_dim
-        kc = torch.empty(cache_elems, dtype=BF16, device=self.device)
-        vc = torch.empty(cache_elems, dtype=BF16, device=self.device)
+        kc, vc = self.reserve_kv(cache_elems)
         cache = _lib.KvCache(kc.data_ptr(), vc.data_ptr(), n_slots, s_max)
         if NC:   # the carried sequences' K / V rows move into slots B.. of this pass's cache (one strided copy each)
             w_c = cin["k"].shape[3]

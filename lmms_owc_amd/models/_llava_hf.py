@@ -22,7 +22,7 @@ from .. import _lib, utils
 from ..engine.llava import DIMS, NEXT_PINPOINTS, LlavaDims, LlavaEngine, LlavaWeights
 from . import imageproc
 from ._api import register_model
-from ._base import Model, sampling_from_gen_kwargs
+from ._base import Model, PassPipeline, sampling_from_gen_kwargs
 from ._qwen2_vl import ByteTokenizer, LazyCheckpoint
 
 __all__ = ["LLaVA"]
@@ -67,7 +67,7 @@ class LlavaByteTokenizer(ByteTokenizer):
         return ids
 
 
-class LLaVA(Model):
+class LLaVA(PassPipeline, Model):
     def __init__(self, model_name_or_path: str = "llava-hf/llava-1.5-7b-hf", attn_implementation: str | None = None,
                  chat_template: str | None = None, use_cache: bool = True, batch_size: int = 1, device_map: str = "auto",
                  dtype: str | torch.dtype = "bfloat16", load_in_8bit: bool = False, load_in_4bit: bool = False,
@@ -110,9 +110,7 @@ class LLaVA(Model):
             self._tokenizer = AutoTokenizer.from_pretrained(str(path))
             self._tokenizer.padding_side = "left"  # as the reference (:163); prompts are packed, never padded, here
         self._dims = dims
-        from concurrent.futures import ThreadPoolExecutor
-
-        self._pool = ThreadPoolExecutor(max_workers=8)
+        self._start_workers()     # PIL worker pool + preparation thread + pinned staging (PassPipeline)
         self._model = LlavaEngine(weights)
         self._processor = self._tokenizer
 
@@ -316,29 +314,90 @@ class LLaVA(Model):
         return res
 
     def _generate_rows(self, requests: list) -> list[np.ndarray]:
-        res: list[np.ndarray] = []
-        tok = self._tokenizer
+        """Token rows (cut at EOS) per request, in request order, through the two-stage pass pipeline of `_base.PassPipeline`
+        (round 4: the host work of a chunk - CLIP resize / crop or anyres tiling, prompt ids - used to run in series with its
+        GPU work; LLaVA-1.5-7B from PIL images: 102 -> see tools/bench_llava_pil.py)."""
+        return self._run_passes(requests, default_max_new=1024)
 
-        def _collate(x):
-            return -len(tok.encode(x[0], add_special_tokens=False)), x[0]
+    def _collate_encode(self, text: str):
+        return self._tokenizer.encode(text, add_special_tokens=False)
 
-        reordered = utils.Collator([reg.args for reg in requests], _collate, grouping=True)
-        max_new_all = max([int(r.args[1].get("max_new_tokens", 1024)) for r in requests] + [1])
-        for chunk in reordered.get_batched(n=self.engine_batch(max_new_all), batch_fn=None):
-            contexts, all_gen_kwargs, doc_to_visual, doc_ids, tasks, splits = zip(*chunk, strict=True)
-            task, split = tasks[0], splits[0]
-            for g in all_gen_kwargs:   # the reference (batch size 1) pops it from EVERY request's own dict, which is what the
-                g.pop("until", None)   # samples file later records under `arguments` (_engine.py:262-266, _tracker.py:318-322)
-            gen_kwargs = dict(all_gen_kwargs[0])
-            gen_kwargs.pop("until", None)  # read and never applied by the reference (:310-320)
-            max_new = int(gen_kwargs.get("max_new_tokens", 1024))
-            sampling = sampling_from_gen_kwargs(gen_kwargs, getattr(self, "_default_top_k", 50))
-            if sampling is not None:
-                sampling["stream_ids"] = [int(d) for d in doc_ids]   # one random stream per document
+    def _prepare_chunk(self, chunk) -> dict:
+        """HOST stage of one unit (preparation thread; the views are cut on the PIL pool): per image its uint8 views and size, per
+        request its prompt ids with every `<image>` expanded to that image's feature count, all views stacked in pinned memory."""
+        contexts, all_gen_kwargs, doc_to_visual, doc_ids, tasks, splits = zip(*chunk, strict=True)
+        task, split = tasks[0], splits[0]
+        for g in all_gen_kwargs:   # the reference (batch size 1) pops it from EVERY request's own dict, which is what the
+            g.pop("until", None)   # samples file later records under `arguments` (_engine.py:262-266, _tracker.py:318-322)
+        gen_kwargs = dict(all_gen_kwargs[0])
+        gen_kwargs.pop("until", None)  # read and never applied by the reference (:310-320)
+        max_new = int(gen_kwargs.get("max_new_tokens", 1024))
+        sampling = sampling_from_gen_kwargs(gen_kwargs, getattr(self, "_default_top_k", 50))
+        docs = self.task_dict[task][split]
+        eng = self._model
 
-            visuals_per_doc = [doc_to_visual[0](self.task_dict[task][split][did]) for did in doc_ids]
-            res.extend(self._generate_chunk(contexts, visuals_per_doc, max_new, sampling=sampling))
-        return reordered.get_original(res)
+        def fetch(did):
+            return [self._views(v) for v in doc_to_visual[0](docs[did])]
+
+        per_doc = list(self._pool.map(fetch, doc_ids))
+        prompts, images_per_prompt, views, sizes = [], [], [], []
+        for ctx, imgs in zip(contexts, per_doc):
+            counts = []
+            for v, size in imgs:
+                counts.append(len(eng.feature_rows([v.shape[0]], [size])[0]))
+                views.append(v)
+                sizes.append(size)
+            if DEFAULT_IMAGE_TOKEN not in ctx:  # e.g. classification prompts carry no image token (:324-327, :506-509)
+                ctx = f"{' '.join([DEFAULT_IMAGE_TOKEN] * len(imgs))}\n{ctx}"
+            prompts.append(self._prompt_ids(ctx, counts))
+            images_per_prompt.append(len(imgs))
+        groups = []
+        if views:
+            n_v = sum(v.shape[0] for v in views)
+            buf = self._pinned_take((n_v, *views[0].shape[1:]))
+            dst, offs = buf.numpy(), np.cumsum([0] + [v.shape[0] for v in views])
+            list(self._pool.map(lambda k: np.copyto(dst[offs[k]:offs[k + 1]], views[k]), range(len(views))))
+            groups.append(buf)
+        key = (max_new, None if sampling is None else (sampling["temperature"], sampling["top_p"], sampling["top_k"]))
+        return {"prompts": prompts, "images_per_prompt": images_per_prompt, "views_per_image": [v.shape[0] for v in views], "sizes": sizes,
+                "groups": groups, "max_new": max_new, "n": len(chunk), "sampling": sampling, "doc_ids": [int(x) for x in doc_ids], "key": key}
+
+    @staticmethod
+    def _merge_preps(preps: list[dict]) -> dict:
+        cat = lambda k: [x for p in preps for x in p[k]]  # noqa: E731
+        return {"prompts": cat("prompts"), "images_per_prompt": cat("images_per_prompt"), "views_per_image": cat("views_per_image"),
+                "sizes": cat("sizes"), "groups": cat("groups"), "max_new": preps[0]["max_new"], "n": sum(p["n"] for p in preps),
+                "sampling": preps[0]["sampling"], "doc_ids": cat("doc_ids")}
+
+    def _launch_chunk(self, prep: dict, eos_token_id: int, pad: int, carry: dict | None = None):
+        """GPU stage of one pass (everything enqueued, nothing waits): H2D of the staged views + owc_clip_patchify_u8 + CLIP tower +
+        projector, the packed feature rows of every `<image>` token, prefill + decode; ids come back through a pinned buffer."""
+        eng = self._model
+        feats, rows_per_prompt = None, [np.zeros(0, np.int64)] * prep["n"]
+        if prep["groups"]:
+            n_v = sum(g.shape[0] for g in prep["groups"])
+            u8 = torch.empty((n_v, *prep["groups"][0].shape[1:]), dtype=torch.uint8, device=self._device)
+            o = 0
+            for g in prep["groups"]:
+                u8[o:o + g.shape[0]].copy_(g, non_blocking=True)
+                o += g.shape[0]
+            feats = eng.encode_views(eng.patchify(u8, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD))
+            rows = eng.feature_rows(prep["views_per_image"], prep["sizes"])
+            rows_per_prompt, cur = [], 0
+            for k in prep["images_per_prompt"]:
+                mine = rows[cur:cur + k]
+                cur += k
+                rows_per_prompt.append(np.concatenate(mine) if mine else np.zeros(0, np.int64))
+        smp = None if prep.get("sampling") is None else {**prep["sampling"], "stream_ids": prep["doc_ids"]}   # one stream per document
+        # (pad = EOS, as the reference passes pad_token_id=self.eot_token_id, :365-376)
+        out = eng.generate_from_features(prep["prompts"], feats, rows_per_prompt, prep["max_new"], eos_token_id=eos_token_id,
+                                         pad_token_id=eos_token_id if eos_token_id is not None and eos_token_id >= 0 else 0,
+                                         sampling=smp, carry=carry)
+        host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+        host.copy_(out, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return host, ev
 
 
 def dims_from_hf_config(cfg: dict) -> LlavaDims:

@@ -19,7 +19,7 @@ from .. import _lib, ops, utils
 from ..engine.qwen2vl import DIMS, Qwen2VLDims, Qwen2VLEngine, Qwen2VLWeights
 from . import imageproc
 from ._api import register_model
-from ._base import Model, sampling_from_gen_kwargs
+from ._base import Model, PassPipeline, sampling_from_gen_kwargs
 
 __all__ = ["Qwen2VL"]
 
@@ -58,7 +58,7 @@ class ByteTokenizer:
         return ids + [self.im_start] + self.encode("assistant\n")
 
 
-class Qwen2VL(Model):
+class Qwen2VL(PassPipeline, Model):
     def __init__(self, model_name_or_path: str = "Qwen/Qwen2-VL-7B-Instruct", use_cache: bool = True,
                  use_flash_attention_2: bool | None = False, max_pixels: int = 1024 * 28 * 28,
                  min_pixels: int = 4 * 28 * 28, batch_size: int = 1, device_map: str = "auto",
@@ -137,23 +137,6 @@ class Qwen2VL(Model):
             free += torch.cuda.memory_reserved(self._device) - torch.cuda.memory_allocated(self._device)
             cache[max_new_tokens] = max(self.batch_size, min(2048, int(0.25 * free / per_req)))
         return cache[max_new_tokens]
-
-    def _start_workers(self) -> None:
-        import os
-        from concurrent.futures import ThreadPoolExecutor
-
-        # host preparation: `OWC_PREP_THREADS` PIL workers (JPEG round trip + bicubic resize release the GIL) behind ONE
-        # preparation thread that runs up to two engine batches ahead of the GPU (`_generate_rows`)
-        # 8 workers prepare ~900 images/s per rank (JPEG round trip of a 448x448 image ~ 8 ms per worker), several times the GPU's
-        # rate; more workers only take the GIL away from the thread that launches the kernels (measured on the bench's PIL leg:
-        # 4-8 workers 0.89 of the engine rate, 32 workers 0.85, 64 workers 0.80)
-        ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
-        self._prep_threads = int(os.environ.get("OWC_PREP_THREADS", max(2, min(8, (os.cpu_count() or 8) // ranks_here))))
-        self._pool = ThreadPoolExecutor(max_workers=self._prep_threads)
-        self._prep_thread = ThreadPoolExecutor(max_workers=1)
-        import threading
-
-        self._pinned_free, self._pinned_lock = [], threading.Lock()
 
     # ------------------------------------------------------------------ loading
     def load_model(self) -> None:
@@ -402,161 +385,15 @@ class Qwen2VL(Model):
         return {"prompts": prompts, "grids": grids_per_prompt, "groups": groups, "max_new": max_new, "n": len(chunk),
                 "sampling": sampling, "doc_ids": [int(d) for d in doc_ids], "key": key}
 
-    PINNED_POOL_BYTES = 4 << 30   # retained (idle) pinned staging per rank; buffers in flight are bounded by the look-ahead
-
-    def _pinned_take(self, shape: tuple) -> torch.Tensor:
-        """Pinned staging buffer for one same-size image run: reused across chunks (page-locking a fresh GB per chunk costs
-        more than copying into it)."""
-        n = int(np.prod(shape))
-        with self._pinned_lock:
-            for i, t in enumerate(self._pinned_free):
-                if t.numel() >= n:
-                    return self._pinned_free.pop(i)[:n].view(shape)
-        return torch.empty(n, dtype=torch.uint8, pin_memory=True).view(shape)
-
-    def _pinned_give(self, bufs: list) -> None:
-        with self._pinned_lock:
-            for b in bufs:
-                base = b._base if b._base is not None else b
-                self._pinned_free.append(base.reshape(-1))
-            self._pinned_free.sort(key=lambda t: t.numel())
-            del self._pinned_free[:-6]   # keep the six largest ...
-            while len(self._pinned_free) > 1 and sum(t.numel() for t in self._pinned_free) > self.PINNED_POOL_BYTES:
-                del self._pinned_free[0]   # ... within a byte cap: page-locked host memory is per rank, eight ranks share a host
-
     def _generate_rows(self, requests: list) -> list[np.ndarray]:
-        """Token rows (cut at EOS) per request, in request order.
+        """Token rows (cut at EOS) per request, in request order: the two-stage pass pipeline of `_base.PassPipeline`."""
+        return self._run_passes(requests, default_max_new=128)
 
-        Two-stage pipeline.  A preparation thread readies the requests in small UNITS (engine_batch / 16, at least 64 requests:
-        image fetch + JPEG round trip + resize on the PIL pool, prompt ids, pinned staging) strictly in order and runs up to
-        two engine batches ahead.  This thread assembles the prepared units into engine passes ADAPTIVELY: the first pass takes
-        whatever is ready when the GPU is idle (so the GPU starts after one unit, not after a whole chunk's preparation), every
-        later pass waits until 1.5x the previous pass's requests are ready - or a full engine batch, or everything that is left -
-        unless the GPU runs dry first, in which case it takes what is there.  With a host that prepares faster than the GPU
-        consumes the passes grow geometrically to `engine_batch` and stay there; with a slower host the GPU is fed as the units
-        arrive.  (Round 3 cut the first chunk 1/4 + 3/4: on one rank with 448 x 448 images - 900 prepared images/s against 240 -
-        that hides everything, but eight ranks on real image sizes prepare 320 images/s per rank against 205, a task is 1.5-3
-        engine batches per rank, and the ramp was a fifth of the run: tools/soak_host_ranks.py.)  Tokens do not depend on how
-        the requests are grouped into passes (batch invariance, tested bit for bit).  A pass's ids come back through a pinned
-        buffer + event one pass later, so the stream always holds the next pass's work when the host waits."""
-        import time
-        from collections import deque
-
-        def _collate(x):
-            return -len(self._tokenizer.encode(x[0])), x[0]
-
-        reordered = utils.Collator([reg.args for reg in requests], _collate, grouping=True)
-        max_new = max([int(r.args[1].get("max_new_tokens", 128)) for r in requests] + [1])
-        eb = self.engine_batch(max_new)
-        unit = eb if eb < 256 else max(64, eb // 16)
-        units = list(reordered.get_batched(n=unit, batch_fn=None))
-        tok = self._tokenizer
-        pad = tok.pad_token_id if tok.pad_token_id is not None else 0
-        rows: dict[int, np.ndarray] = {}        # position in the collated order -> token row (cut at EOS)
-        ahead, inflight = deque(), deque()      # futures of submitted units (in order); launched passes (host ids, event, groups, ...)
-        nxt = 0
-        ahead_n = 0                             # requests submitted for preparation and not launched yet
-        carried = None                          # unfinished sequences of the previous pass (Qwen2VLEngine.generate `carry`)
-        launched = 0                            # requests launched so far = position of the next pass's first request
-
-        def cut(r) -> np.ndarray:
-            stop = np.flatnonzero(r == tok.eos_token_id)
-            return r[: stop[0]].copy() if len(stop) else r.copy()
-
-        def finish(item) -> None:
-            host, ev, groups, pos0, skip = item
-            ev.synchronize()          # the pass's GPU work is complete: its staging buffers can be reused
-            self._pinned_give(groups)
-            for i, r in enumerate(host.numpy()):
-                if i not in skip:     # (a straggler handed to the next pass: its row comes back with that pass)
-                    rows[pos0 + i] = cut(r)
-
-        def top_up() -> None:
-            nonlocal nxt, ahead_n
-            while nxt < len(units) and (ahead_n < 2 * eb or not ahead):
-                ahead.append((len(units[nxt]), self._prep_thread.submit(self._prepare_chunk, units[nxt])))
-                ahead_n += len(units[nxt])
-                nxt += 1
-
-        def ready_prefix() -> tuple[int, bool]:
-            """Requests in the leading run of prepared units that one pass can take (same generation length, <= engine_batch), and
-            whether the run ends at such a limit (then waiting for more units cannot make the pass larger)."""
-            n, first = 0, None
-            for size, fut in ahead:
-                if not fut.done():
-                    return n, False
-                if n + size > eb:
-                    return n, True
-                mn = fut.result()["key"]       # one pass = one generation length and one set of sampling switches
-                if first is None:
-                    first = mn
-                elif mn != first:
-                    return n, True
-                n += size
-            return n, nxt >= len(units)
-
-        t_begin = time.perf_counter()
-        self.last_timing = {"chunks": 0, "pass_sizes": []}
-        last_size, left = 0, len(requests)
-        while left:
-            top_up()
-            gpu_busy = bool(inflight) and not inflight[-1][1].query()
-            have, closed = ready_prefix()
-            if have == 0 and not gpu_busy:
-                t_wait = time.perf_counter()
-                ahead[0][1].result()            # nothing ready and the GPU is (about to be) idle: stand and wait for the next unit
-                key = "first_chunk_prep_s" if not self.last_timing["chunks"] else "prep_wait_s"
-                self.last_timing[key] = self.last_timing.get(key, 0.0) + time.perf_counter() - t_wait
-                continue
-            want = min(eb, left, max(unit, int(1.5 * last_size)))
-            if left <= eb and left - want < want // 2:
-                want = left                     # no small pass at the end of a task: it would run the decoder far below its rate
-            elif eb < left < eb + eb // 2:
-                want = min(want, (left + 1) // 2)   # ... nor a full pass followed by a sliver: two halves
-            if gpu_busy and have < want and not closed:
-                if len(inflight) > 1:           # use the wait: collect the pass before the one that is running
-                    finish(inflight.popleft())
-                else:
-                    time.sleep(0.002)
-                continue
-            preps = []
-            while ahead and sum(p["n"] for p in preps) < have:
-                size, fut = ahead.popleft()
-                preps.append(fut.result())
-                ahead_n -= size
-            prep = preps[0] if len(preps) == 1 else {
-                "prompts": [x for p in preps for x in p["prompts"]], "grids": [x for p in preps for x in p["grids"]],
+    @staticmethod
+    def _merge_preps(preps: list[dict]) -> dict:
+        return {"prompts": [x for p in preps for x in p["prompts"]], "grids": [x for p in preps for x in p["grids"]],
                 "groups": [x for p in preps for x in p["groups"]], "max_new": preps[0]["max_new"], "n": sum(p["n"] for p in preps),
                 "sampling": preps[0]["sampling"], "doc_ids": [x for p in preps for x in p["doc_ids"]]}
-            top_up()
-            # straggler hand-over: while another pass follows, this pass stops decoding once its own live sequences are down to
-            # 1 / 64 of an engine batch and the rest ride along in the next pass's decode steps (greedy decoding only)
-            carry = None
-            more = left - prep["n"] > 0
-            if (prep.get("sampling") is None and tok.eos_token_id is not None and tok.eos_token_id >= 0 and (more or carried is not None)
-                    and not getattr(self, "_no_carry", False)):
-                carry = {"in": carried, "below": max(8, eb // 64) if more else 0,
-                         "tags": list(range(launched, launched + prep["n"]))}
-            host, ev = self._launch_chunk(prep, tok.eos_token_id, pad, carry)
-            skip = set()
-            if carry is not None:
-                for tag, full in carry["finished"]:
-                    rows[tag] = cut(full)
-                carried, skip = carry["out"], set(carry["unfinished_rows"])
-            inflight.append((host, ev, prep["groups"], launched, skip))
-            launched += prep["n"]
-            last_size = prep["n"]
-            left -= prep["n"]
-            self.last_timing["chunks"] += 1
-            self.last_timing["pass_sizes"].append(prep["n"])
-            if len(inflight) > 2:
-                finish(inflight.popleft())
-        while inflight:
-            finish(inflight.popleft())
-        self.last_timing["total_s"] = time.perf_counter() - t_begin
-        self.last_timing.setdefault("first_chunk_prep_s", 0.0)
-        assert carried is None and len(rows) == len(requests)
-        return reordered.get_original([rows[i] for i in range(len(requests))])
 
     def _launch_chunk(self, prep: dict, eos_token_id: int, pad: int, carry: dict | None = None):
         """GPU stage of one prepared chunk: H2D + patchify + vision tower + prefill + decode are ENQUEUED (nothing waits), the ids
