@@ -172,6 +172,19 @@ class PassPipeline:
     def _collate_encode(self, text: str):
         return self._tokenizer.encode(text)
 
+    def _reserve_kv(self, first_prep: dict, slots: int, hand_over: bool) -> None:
+        """Before a task's first pass: grow the engine's K / V pair ONCE to what a full pass of this task needs (the ramp's passes
+        are views of it), instead of once per pass size of the ramp.  Prompt lengths are those of the first prepared unit plus a
+        tenth (requests are collated longest-first); a longer prompt later simply grows the pair again."""
+        d, eng = self._dims, self._model
+        if not hasattr(eng, "reserve_kv"):
+            return
+        longest = max([len(p) for p in first_prep["prompts"]] + [1])
+        rows = (int(longest * 1.1) + int(first_prep["max_new"]) + 2 + 15) // 16 * 16
+        if hand_over:
+            slots = slots + (max(slots // 8, 256) + 255) // 256 * 256
+        eng.reserve_kv(d.n_layers * slots * d.n_kv_heads * d.head_dim * rows)
+
     def _start_workers(self) -> None:
         import os
         from concurrent.futures import ThreadPoolExecutor
@@ -323,6 +336,8 @@ class PassPipeline:
                     and not getattr(self, "_no_carry", False)):
                 carry = {"in": carried, "below": max(8, eb // 64) if more else 0,
                          "tags": list(range(launched, launched + prep["n"]))}
+            if not self.last_timing["chunks"]:
+                self._reserve_kv(prep, min(eb, len(requests)), carry is not None and more)
             host, ev = self._launch_chunk(prep, tok.eos_token_id, pad, carry)
             skip = set()
             if carry is not None:
