@@ -1,6 +1,8 @@
 """EOS-aware row compaction must not change a token: `generate(..., compact_rows=True)` against `compact_rows=False` on seeded ragged
 answer lengths (forced continuations), with the first differing (row, step) and the live-row count of that step when they differ.
-usage: python tools/check_compaction.py [model] [B] [T] [prompt_len | img]   (img: the bench's 286-token image prompt, random embeddings)"""
+usage: python tools/check_compaction.py [model] [B] [T] [prompt_len | img] [compact | plain]
+(img: the bench's 286-token image prompt, random embeddings; a 5th argument runs ONE mode three times and exits - for
+`rocprofv3 --kernel-trace --stats`, profiles/r04_decode_loop_*_kernel_stats.csv)"""
 import sys
 from pathlib import Path
 
@@ -31,6 +33,16 @@ else:
     none = [[] for _ in prompts]
 forced, lens = ragged_answer_lengths(B, T, 8.0, 0.01, 7)
 kw = dict(eos_token_id=EOS_ID, pad_token_id=0, forced_tokens=forced)
+if len(sys.argv) > 5:
+    import time
+
+    mode = sys.argv[5] == "compact"
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.generate(prompts, emb, none, T, compact_rows=mode, **kw).cpu()
+        print(f"{sys.argv[5]}: {time.perf_counter() - t0:.3f} s per generate (prefill + {T - 1} decode steps)", flush=True)
+    sys.exit(0)
 sa, sb = {}, {}
 a = eng.generate(prompts, emb, none, T, compact_rows=False, stats=sa, **kw).cpu().numpy()
 a2 = eng.generate(prompts, emb, none, T, compact_rows=False, **kw).cpu().numpy()
