@@ -200,7 +200,8 @@ int owc_embed_tokens(owc_ctx* ctx, const int32_t* ids, const int32_t* img_index,
 /* Sampling parameters of a generation (NULL wherever one is taken: greedy argmax).  HF GenerationMixin._sample, reached from the
  * reference with do_sample = temperature > 0 (src/models/_qwen2_vl.py:319-329, _llava_hf.py:365-376): logits / temperature ->
  * top-k (0: off) -> top-p on the survivors (<= 0 or >= 1: off) -> softmax -> one multinomial draw.
- *   Random stream (documented, NOT torch's): Philox4x32-10, key = seed, counter = (stream id of the sequence, step, 0, 0);
+ *   Random stream (documented, NOT torch's): Philox4x32-10, key = seed, counter = (stream id of the sequence, step + its step
+ *   offset, 0, 0);
  *   stream_id (optional, int32 per ORIGINAL batch row; NULL: the row index): a sequence's draws depend on (seed, its stream id,
  *   step) only - not on the batch it runs in, not on row compaction, not on the rank count when the caller passes document ids.
  *   Weights are exact integers floor(2^40 exp((l - max) / T)); the kept set is cut by logit VALUE, so where HF's sort would split
@@ -211,6 +212,8 @@ typedef struct owc_sampling {
   float top_p;
   uint64_t seed;
   const int32_t* stream_id;
+  const int32_t* step_offset; /* optional, per ORIGINAL row: added to the step of the Philox counter (a sequence that continues in a
+                                 later pass keeps counting its own steps: owc_llm_decode_step's `step` is pass-local) */
 } owc_sampling;
 
 /* one token per row of bf16 logits by owc_sampling (row_map: optional ORIGINAL row of each row, see owc_llm_decode_step). */

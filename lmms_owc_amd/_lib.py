@@ -21,7 +21,7 @@ _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
 _timing_ok = False
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = range(6)
 
@@ -85,7 +85,7 @@ class KvCache(C.Structure):
 
 class Sampling(C.Structure):
     """owc_sampling: temperature / top-k / top-p + the Philox key and the per-sequence stream ids (include/owc.h)."""
-    _fields_ = [("temperature", f32), ("top_k", C.c_int32), ("top_p", f32), ("seed", C.c_uint64), ("stream_id", vp)]
+    _fields_ = [("temperature", f32), ("top_k", C.c_int32), ("top_p", f32), ("seed", C.c_uint64), ("stream_id", vp), ("step_offset", vp)]
 
 
 class BertLayer(C.Structure):

@@ -378,7 +378,8 @@ __device__ inline uint32_t sample_key(bf16_t v) {   // order-preserving 16-bit k
 __global__ __launch_bounds__(SAMPLE_T) void sample_kernel(const bf16_t* __restrict__ logits, long ld, int V, float inv_temp_log2e,
                                                           int top_k, float top_p, uint32_t seed_lo, uint32_t seed_hi,
                                                           const int* __restrict__ row_map, const int* __restrict__ stream_id,
-                                                          int step, const int* __restrict__ step_state, int* __restrict__ out) {
+                                                          const int* __restrict__ step_offset, int step,
+                                                          const int* __restrict__ step_state, int* __restrict__ out) {
   __shared__ unsigned int cnt[256];
   __shared__ unsigned long long mass[256];
   __shared__ float red[SAMPLE_T / 64];
@@ -481,7 +482,8 @@ __global__ __launch_bounds__(SAMPLE_T) void sample_kernel(const bf16_t* __restri
   // ---- the draw
   uint32_t rnd[4];
   const int orig = row_map ? row_map[row] : row;   // the sequence's ORIGINAL batch row (row compaction moves it)
-  philox4x32_10((uint32_t)(stream_id ? stream_id[orig] : orig), (uint32_t)step, 0u, 0u, seed_lo, seed_hi, rnd);
+  philox4x32_10((uint32_t)(stream_id ? stream_id[orig] : orig), (uint32_t)(step + (step_offset ? step_offset[orig] : 0)), 0u, 0u, seed_lo,
+                seed_hi, rnd);
   const unsigned long long r = ((unsigned long long)rnd[0] << 32) | rnd[1];
   const unsigned long long target = (unsigned long long)(((unsigned __int128)r * (unsigned __int128)Z) >> 64);   // < Z
   // ---- first token, in index order, whose running kept mass exceeds target: contiguous chunk per thread, block scan, rescan
@@ -841,7 +843,8 @@ int owc_launch_sample(const void* logits, long ld, int rows, int V, const owc_sa
                       const int* step_state, int* out, hipStream_t st) {
   if (rows <= 0 || V <= 0 || !sp || !(sp->temperature > 0.f)) return OWC_ERR_SHAPE;
   hipLaunchKernelGGL(sample_kernel, dim3(rows), dim3(SAMPLE_T), 0, st, (const bf16_t*)logits, ld, V, 1.4426950408889634f / sp->temperature,
-                     sp->top_k, sp->top_p, (uint32_t)sp->seed, (uint32_t)(sp->seed >> 32), row_map, sp->stream_id, step, step_state, out);
+                     sp->top_k, sp->top_p, (uint32_t)sp->seed, (uint32_t)(sp->seed >> 32), row_map, sp->stream_id, sp->step_offset, step, step_state,
+                     out);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 

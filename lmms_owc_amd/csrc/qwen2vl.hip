@@ -319,6 +319,7 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
     if (!sampling->stream_id && sampling_row0) OWC_FAIL(ctx, OWC_ERR_ARG, "owc_llm_prefill: sampling_row0 != 0 needs explicit stream ids");
     owc_sampling sp = *sampling;
     if (sp.stream_id) sp.stream_id += sampling_row0;
+    if (sp.step_offset) sp.step_offset += sampling_row0;
     OWC_TRY(owc_launch_sample(logits, w->vocab, n_out, w->vocab, &sp, nullptr, 0, nullptr, next_tok, st));
   } else {
     OWC_TRY(owc_launch_argmax(logits, w->vocab, n_out, w->vocab, next_tok, st));

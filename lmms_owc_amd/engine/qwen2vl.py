@@ -340,6 +340,7 @@ class Qwen2VLEngine:
         self.vit_chunk_tokens = vit_chunk_tokens
         self.prefill_chunk_tokens = prefill_chunk_tokens
         self._ws: torch.Tensor | None = None
+        self._kv: tuple | None = None      # the engine's grow-only K / V cache pair (reserve_kv)
         self._lib = _lib.load()
         self._ctx = _lib.ctx(self.dev_index)
 
@@ -360,7 +361,7 @@ class Qwen2VLEngine:
         pass once the blocks are tens of GB, and out-of-memory retries for an MHA decoder (LLaVA-1.5: 0.5 MB of KV per token).
         Work is stream-ordered, so the next pass may reuse the memory while the previous one is still queued.  On growth the
         old pair goes back to the driver first (`empty_cache`), so the peak is the new pair, not the sum."""
-        kv = getattr(self, "_kv", None)
+        kv = self._kv
         if kv is None or kv[0].numel() < elems:
             self._kv = kv = None
             if elems * 2 > (1 << 30):
@@ -445,7 +446,7 @@ class Qwen2VLEngine:
         "stream_ids": int per prompt (default: its index)} - HF's `do_sample` path (temperature -> top-k -> top-p -> multinomial) on
         the library's documented Philox stream; a sequence's draws depend on (seed, its stream id, step) only.
         `stats` (optional dict) receives the live-row count of every step.
-        `carry` (optional dict; EOS handling on, greedy): straggler hand-over between consecutive passes of a task.  In:
+        `carry` (optional dict; EOS handling on): straggler hand-over between consecutive passes of a task.  In:
         `carry["in"]` - the unfinished sequences of the previous pass (`carry["out"]` of that call), which join this pass's decode
         steps as extra rows with their own KV rows, pending token and remaining budget; `carry["below"]` - once this pass's OWN
         live rows are at most this many (and at least one decode step ran) the loop stops and the still-running sequences are
@@ -462,8 +463,8 @@ class Qwen2VLEngine:
         s_max = int(lens.max()) + max_new_tokens
         Hkv, G = d.n_kv_heads, d.n_q_heads // d.n_kv_heads
         cin = carry.get("in") if carry is not None else None
-        if carry is not None and (eos_token_id < 0 or sampling is not None or return_step_logits or return_logits or self.graph_decode):
-            raise ValueError("carry needs EOS handling on, greedy decoding and no logits output")
+        if carry is not None and (eos_token_id < 0 or return_step_logits or return_logits or self.graph_decode):
+            raise ValueError("carry needs EOS handling on and no logits output")
         NC = 0 if cin is None else len(cin["tags"])
         Bx = B + NC                                  # rows of the decode batch: this pass's prompts + the carried-in sequences
         T_out = max_new_tokens                       # width of the token buffer = steps this pass may run + 1
@@ -544,10 +545,15 @@ class Qwen2VLEngine:
         if sampling is not None:
             if not float(sampling["temperature"]) > 0:
                 raise ValueError("sampling needs temperature > 0 (temperature 0 is greedy: pass sampling=None)")
-            streams = self._i32(np.asarray(sampling.get("stream_ids", np.arange(B)), dtype=np.int64).reshape(B))
+            sid = np.zeros(Bx, np.int64)
+            sid[:B] = np.asarray(sampling.get("stream_ids", np.arange(B)), dtype=np.int64).reshape(B)
+            soff = np.zeros(Bx, np.int64)
+            if NC:   # a carried sequence keeps its stream and goes on counting ITS steps: pass-local step j is its step c0 + j - 1
+                sid[B:], soff[B:] = cin["stream"], np.asarray(cin["emitted"]) - 1
+            streams, step_off = self._i32(sid), self._i32(soff)
             top_p = sampling.get("top_p")
             samp = _lib.Sampling(float(sampling["temperature"]), int(sampling.get("top_k") or 0), float(top_p) if top_p else 0.0,
-                                 int(sampling.get("seed", 0)) & 0xFFFFFFFFFFFFFFFF, streams.data_ptr())
+                                 int(sampling.get("seed", 0)) & 0xFFFFFFFFFFFFFFFF, streams.data_ptr(), step_off.data_ptr())
             samp_ref = C.byref(samp)
 
         # ---- prefill in chunks of whole prompts (chunk size counted in packed ROWS: with a shared prefix every
@@ -653,7 +659,8 @@ class Qwen2VLEngine:
                         pending = (ev, n, j)
         if carry is not None:
             self._carry_export(carry, cin, B, NC, n if T_out > 1 else Bx, cur, state, done2, row_of, steps_run, out_tokens, kc, vc,
-                               s_max, Bx, max_new_tokens, forced_tokens, pad_token_id, n_slots)
+                               s_max, Bx, max_new_tokens, forced_tokens, pad_token_id, n_slots,
+                               None if sampling is None else sid)
             out_tokens = out_tokens[:B, :max_new_tokens]
         if stats is not None:
             stats["live_rows_per_step"] = live_per_step
@@ -663,7 +670,7 @@ class Qwen2VLEngine:
         return (out_tokens, first_logits) if return_logits else out_tokens
 
     def _carry_export(self, carry, cin, B, NC, n, cur, state, done2, row_of, steps_run, out_tokens, kc, vc, s_max, Bx,
-                      max_new_tokens, forced_tokens, pad_token_id, n_slots) -> None:
+                      max_new_tokens, forced_tokens, pad_token_id, n_slots, stream_of=None) -> None:
         """End of a pass with straggler hand-over: after the last enqueued step has run, split the rows that were still in the
         decode batch into finished ones and sequences that go on in the next pass (their K / V rows, pending token, position and
         remaining budget are copied out: the pass's own cache is released with the pass)."""
@@ -725,7 +732,7 @@ class Qwen2VLEngine:
             forced_rest.append(fr)
         carry["out"] = {"k": k_out, "v": v_out, "cached": cached, "tok": st[0, comp].astype(np.int64), "pos": st[1, comp].astype(np.int64),
                         "emitted": emitted[idx], "remaining": (cap - emitted)[idx], "tokens": tokens, "tags": tags,
-                        "forced_rest": forced_rest}
+                        "forced_rest": forced_rest, "stream": None if stream_of is None else np.asarray(stream_of)[idx]}
 
     def score(self, ids, img_embeds: torch.Tensor | None, grids: list, start: int, *, img_rows=None):
         """Teacher-forced scoring of ONE token sequence (prompt + continuation) in a single prefill: the logits of the positions

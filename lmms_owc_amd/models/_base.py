@@ -332,7 +332,7 @@ class PassPipeline:
             # 1 / 64 of an engine batch and the rest ride along in the next pass's decode steps (greedy decoding only)
             carry = None
             more = left - prep["n"] > 0
-            if (prep.get("sampling") is None and tok.eos_token_id is not None and tok.eos_token_id >= 0 and (more or carried is not None)
+            if (tok.eos_token_id is not None and tok.eos_token_id >= 0 and (more or carried is not None)
                     and not getattr(self, "_no_carry", False)):
                 carry = {"in": carried, "below": max(8, eb // 64) if more else 0,
                          "tags": list(range(launched, launched + prep["n"]))}

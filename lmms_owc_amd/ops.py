@@ -176,7 +176,7 @@ def sample_bf16(logits, temperature: float, top_k: int = 0, top_p: float | None 
 
     out = torch.empty((logits.shape[0],), dtype=I32, device=logits.device)
     sp = _lib.Sampling(float(temperature), int(top_k or 0), float(top_p) if top_p else 0.0, int(seed) & 0xFFFFFFFFFFFFFFFF,
-                       _lib.ptr(stream_ids))
+                       _lib.ptr(stream_ids), None)
     _call("owc_sample_bf16", _dev(logits), logits.data_ptr(), logits.stride(0), logits.shape[0], logits.shape[1], C.byref(sp),
           _lib.ptr(row_map), int(step), out.data_ptr())
     return out

@@ -244,7 +244,7 @@ def test_straggler_carry_over_is_bit_identical(setup, gpu):
     """Straggler hand-over between the passes of a task (`generate(..., carry=)`): a pass stops decoding once its OWN live
     sequences are few, the unfinished ones - K / V rows, pending token, position, remaining budget - join the NEXT pass's decode
     steps as extra rows, the last pass runs everything to its end.  Every sequence's tokens equal those of its pass run alone to
-    completion: forced (seeded ragged answer lengths with sequences that never stop inside the cap) and free-running."""
+    completion: forced (seeded ragged answer lengths with sequences that never stop inside the cap), free-running, and sampled."""
     cfg, w, eng, g = setup
     r = np.random.default_rng(123)
     eos = 9
@@ -253,14 +253,16 @@ def test_straggler_carry_over_is_bit_identical(setup, gpu):
     passes = [[r.integers(10, 400, 6 + (i % 9)).astype(np.int64) for i in range(n)] for n in sizes]
     forced = [_ragged_forced(r, n, T, eos, 400, 6, cap_frac=0.08)[0] for n, T in zip(sizes, caps)]
 
-    def run(with_forced: bool, eos_id: int, below: int):
-        ref = [to_np(eng.generate(p, None, [[] for _ in p], caps[k], eos_token_id=eos_id, pad_token_id=0,
+    def run(with_forced: bool, eos_id: int, below: int, sampled: bool = False):
+        smp = [None if not sampled else {"temperature": 0.9, "top_k": 30, "seed": 11, "stream_ids": 1000 * k + np.arange(len(p))}
+               for k, p in enumerate(passes)]
+        ref = [to_np(eng.generate(p, None, [[] for _ in p], caps[k], eos_token_id=eos_id, pad_token_id=0, sampling=smp[k],
                                   forced_tokens=forced[k] if with_forced else None)) for k, p in enumerate(passes)]
         got = {}
         state, handed = None, 0
         for k, p in enumerate(passes):
             c = {"in": state, "below": below if k + 1 < len(passes) else 0, "tags": [(k, i) for i in range(len(p))]}
-            out = to_np(eng.generate(p, None, [[] for _ in p], caps[k], eos_token_id=eos_id, pad_token_id=0,
+            out = to_np(eng.generate(p, None, [[] for _ in p], caps[k], eos_token_id=eos_id, pad_token_id=0, sampling=smp[k],
                                      forced_tokens=forced[k] if with_forced else None, carry=c))
             for i in range(len(p)):
                 if i not in c["unfinished_rows"]:
@@ -279,6 +281,8 @@ def test_straggler_carry_over_is_bit_identical(setup, gpu):
     free = to_np(eng.generate(passes[0], None, [[] for _ in passes[0]], caps[0]))
     vals, counts = np.unique(free[:, 2:20], return_counts=True)
     assert run(False, int(vals[np.argmax(counts)]), 40) >= 10   # (free-running: many sequences never emit that token)
+    # sampled: a carried sequence keeps its random stream and goes on counting its own steps
+    assert run(False, int(vals[np.argmax(counts)]), 40, sampled=True) >= 10
 
 
 def test_sampled_generation_is_a_function_of_seed_and_stream_only(setup, gpu):
