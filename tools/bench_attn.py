@@ -22,6 +22,7 @@ def i32(a, dev):
 
 def main():
     dev = torch.device("cuda:0")
+    torch.manual_seed(0)     # (seeded inputs: the output hashes printed at the end are comparable between builds - tools/ab_libs.sh)
     # vision: 64 images x 1024 tokens, 16 heads x 80
     n, L, H, hd = 64, 1024, 16, 80
     T, E = n * L, H * hd
@@ -67,6 +68,11 @@ def main():
         _lib.load().owc_tuning_set(b"attn_dbg", v)
         print(f"-- attn_dbg = {v:#x}")
         bench_all(vit, prefill, prefill_long, n, H, L, hd, nb, Hq, S, nb3, Hq3, S3)
+    import hashlib
+
+    torch.cuda.synchronize()
+    for name, t in (("vit", out), ("prefill", o2), ("prefill_long", o3)):
+        print(f"sha256 {name:13s} {hashlib.sha256(t.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16]}")
 
 
 def bench_all(vit, prefill, prefill_long, n, H, L, hd, nb, Hq, S, nb3, Hq3, S3):
