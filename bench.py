@@ -590,6 +590,8 @@ def main() -> None:
     ap.add_argument("--no-pil-leg", action="store_true", help="skip the PIL -> generate_until -> strings leg")
     ap.add_argument("--no-decode-leg", action="store_true", help="skip the HBM-regime decode leg (decode step at batch 1 / 32 / 128)")
     ap.add_argument("--no-eos-leg", action="store_true", help="skip the EOS-terminated ragged-answer-length leg (max_new_tokens 64 / 256)")
+    ap.add_argument("--eos-mean-len", type=float, default=8.0,
+                    help="mean answer length (tokens incl. EOS, geometric) of the EOS-terminated leg: 8 = classification answers; ~100 = chain-of-thought answers")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the other configs' short legs (Food-101 image sizes, Qwen2-VL-2B / 512 images, label-cosine at C = 10 000)")
     ap.add_argument("--image-sizes", default="food101", choices=sorted(DATASET_SIZES) + ["none"],
@@ -741,7 +743,8 @@ def main() -> None:
     eos_leg = None
     if not args.no_eos_leg and T >= 2:
         try:
-            eos_leg = eos_terminated_leg(engine, pix, flat_grids, prompts, grids, B, sync, B * args.steps / dt_own, rank)
+            eos_leg = eos_terminated_leg(engine, pix, flat_grids, prompts, grids, B, sync, B * args.steps / dt_own, rank,
+                                         mean_len=args.eos_mean_len)
         except torch.OutOfMemoryError as e:   # (an extra leg must never sink the measurement: large models at the largest batch)
             torch.cuda.empty_cache()
             eos_leg = {"skipped": f"out of memory: {str(e)[:160]}", "by_cap": []}
