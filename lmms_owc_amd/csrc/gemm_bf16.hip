@@ -49,6 +49,8 @@ int g_skinny_max_m = 24;   // M at and below which the weight-streaming skinny k
 int g_mid_max_tiles = 256;  // fewer 128x128 tiles than this -> 64x64 tiles (0 disables: A-B knob "gemm_mid_max_tiles")
 int g_big_min_tiles = 144;  // fewer 256x256 tiles than this -> use the 128x128 kernel (measured: 160-162 tiles 256x256 +24...40 %, 126 tiles -3...8 %; knob "gemm_big_min_tiles")
 int g_small_tiles = 1;    // 64x64-tile kernel: also 32x64 / 64x32 / 32x32 tiles where they shorten the launch (knob "gemm_small_tiles": 0 off, 2 / 3 / 4 force 64x64 / 64x32 / 32x32)
+int g_ring_128 = 1;       // 128x64 tiles of the ring kernel where 64x64 tiles need more than one round of 256 CUs (knob "gemm_ring_128", round 4:
+                          // the 7B down projection at M = 512 / 640 / 1024 160 -> 138 / 199 -> 157 / 278 -> 225 us, o 33 -> 31 / 41 -> 33 / 59 -> 46)
 int g_tall_tiles = 1;     // 64x160 / 128x160 tiles of the ring kernel for launches of <= 128 rows x many columns (knob "gemm_wide_tiles")
 int g_k_pairs = 1;        // ring kernel, long K: four (knob value 2: two) K-tiles per stage (knob "gemm_k_pairs"; 0 off)
 int g_k_pairs_min_k = 1024;   // (knob "gemm_k_pairs_min_k"; 2B widths, K = 1536: step at batch 32 / 64 2.35 / 2.43 -> 2.27 / 2.35 ms)
@@ -1171,7 +1173,20 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
         if (g_small_tiles > 1) shape = (g_small_tiles - 2) % 3;   // A-B: force a shape
       }
     }
-    if (shape == 0) {
+    bool done128 = false;
+    if constexpr (EPI == OWC_EPI_NONE || EPI == OWC_EPI_RESIDUAL) {
+      // more than one round of 64x64 tiles (M >= 257 on the N = 3584 projections; where a long-answer task's decode loop lives): 128x64
+      // tiles halve the blocks and cut the L2 -> LDS bytes by a quarter (A 128 + W 64 rows per K-tile for twice the output); up to 256
+      // blocks one per CU with two K-tiles per stage, above that 72 KiB of LDS per block so that two share a CU (one round to 512)
+      if (g_ring_128 && shape == 0 && !ktail && tm64 * tn64 > 384 && M >= 129) {   // (at 257-384 blocks of 64x64 it is +-2 %: they stay)
+        const long nb128 = (long)((M + 127) / 128) * tn64;
+        if (nb128 > 256) OWC_L64(3, false, 128, 64);          // 72 KiB of LDS: two blocks per CU, one round up to 512 blocks
+        else if (g_k_pairs && K >= g_k_pairs_min_k) OWC_L64(3, false, 128, 64, 2);
+        else OWC_L64(4, false, 128, 64);
+        done128 = true;
+      }
+    }
+    if (shape == 0 && !done128) {
       if (g_k_pairs && !ktail && K >= g_k_pairs_min_k && tm64 * tn64 <= 512) OWC_L64(2, false, 64, 64, 2);   // (qkv at M = 300-400: 33 -> 29 us)
       else if (tm64 * tn64 > 512 && tm64 * tn64 <= 768) { if (ktail) OWC_L64(3, true, 64, 64); else OWC_L64(3, false, 64, 64); }
       else { if (ktail) OWC_L64(4, true, 64, 64); else OWC_L64(4, false, 64, 64); }
@@ -1410,3 +1425,4 @@ void owc_gemm_set_k_pairs(int v) { g_k_pairs = v; }
 void owc_gemm_set_k_pairs_min_k(int v) { g_k_pairs_min_k = v < 0 ? 1024 : v; }
 void owc_gemm_set_tall_tiles(int v) { g_tall_tiles = v != 0; g_wide_min_blocks = v > 1 ? v : 128; }
 void owc_gemm_set_small_tiles(int v) { g_small_tiles = v < 0 ? 1 : v; }
+void owc_gemm_set_ring_128(int v) { g_ring_128 = v < 0 ? 1 : v != 0; }

@@ -272,6 +272,38 @@ def test_gemm_small_tile_shapes_race_screen(gpu, m, n, k, epi):
         lib.owc_tuning_set(b"gemm_skinny_max_m", SKINNY_MAX_M)
 
 
+@pytest.mark.parametrize("m,n,k,epi", [(512, 3584, 18944, "residual"), (1100, 3584, 3584, "residual"), (700, 4608, 3584, "none"), (300, 3584, 128, "none"),
+                                       (513, 3600, 64, "residual")])
+def test_gemm_ring_128_race_screen(gpu, m, n, k, epi):
+    """The ring kernel's 128x64 tiles (round 4: 257-1169 rows x few thousand columns - the narrow projections of a mid-batch decode
+    step; one block per CU with two K-tiles per stage up to 256 blocks, two per CU above) against the 64x64 tiles and the
+    128x128 kernel, 8 times each: bit-identical; ragged M / N, one and two K-tiles (fewer than ring stages), K = 18944."""
+    from lmms_owc_amd import _lib, ops
+
+    lib = _lib.load()
+    a = bf16_randn((m, k), 70 + (m % 97), device=gpu)
+    w = bf16_randn((n, k), 71, 0.05, device=gpu)
+    b = bf16_randn((n,), 72, device=gpu)
+    r = bf16_randn((m, n), 73, device=gpu)
+    E = {"none": _lib.EPI_NONE, "residual": _lib.EPI_RESIDUAL}[epi]
+
+    def run():
+        return ops.gemm_bf16(a, w, b, epilogue=E, residual=r if epi == "residual" else None)
+
+    try:
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 0)          # the 128x128 kernel
+        want = run()
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 1 << 30)
+        for knob in (0, 1):                                  # 64x64 ring tiles, then 128x64
+            assert lib.owc_tuning_set(b"gemm_ring_128", knob) == 0
+            for i in range(8):
+                got = run()
+                assert torch.equal(got, want), (knob, i, (got != want).sum().item())
+    finally:
+        lib.owc_tuning_set(b"gemm_ring_128", -1)
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 256)
+
+
 @pytest.mark.parametrize("m,n,k,epi", [(128, 37888, 3584, "swiglu"), (100, 33000, 1024, "none"), (40, 37888, 128, "swiglu"),
                                        (64, 40960, 64, "none"), (65, 20512, 3584, "swiglu")])
 def test_gemm_wide_tiles_race_screen(gpu, m, n, k, epi):
