@@ -25,6 +25,8 @@ import sys
 import time
 from pathlib import Path
 
+T_PROCESS_START = time.perf_counter()   # `leg_seconds` / `--leg-budget-s` count from here (torch import included)
+
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -96,7 +98,12 @@ def cpu_baseline_lmm(dims, device, seed: int, new_tokens: int, pix_dev, hip_toke
     cfg._attn_implementation = "sdpa"
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.bfloat16)
-    ctx = getattr(__import__("transformers.modeling_utils", fromlist=["no_init_weights"]), "no_init_weights", None)
+    ctx = None    # skip HF's own random init of 7.6 B parameters (minutes of host time): every parameter is overwritten below
+    for mod in ("transformers.initialization", "transformers.modeling_utils"):   # (transformers 5.x / 4.x)
+        try:
+            ctx = ctx or getattr(__import__(mod, fromlist=["no_init_weights"]), "no_init_weights", None)
+        except ImportError:
+            pass
     try:
         if ctx is not None:
             with ctx():
@@ -592,6 +599,10 @@ def main() -> None:
     ap.add_argument("--no-eos-leg", action="store_true", help="skip the EOS-terminated ragged-answer-length leg (max_new_tokens 64 / 256)")
     ap.add_argument("--eos-mean-len", type=float, default=8.0,
                     help="mean answer length (tokens incl. EOS, geometric) of the EOS-terminated leg: 8 = classification answers; ~100 = chain-of-thought answers")
+    ap.add_argument("--leg-budget-s", type=float, default=420.0,
+                    help="seconds since process start after which the remaining OPTIONAL legs (PIL, HBM-regime decode) are skipped with a "
+                         "note, so that a long --steps run still ends within minutes; the timed region, the EOS / image-size / other-config "
+                         "legs and the CPU baseline always run")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the other configs' short legs (Food-101 image sizes, Qwen2-VL-2B / 512 images, label-cosine at C = 10 000)")
     ap.add_argument("--image-sizes", default="food101", choices=sorted(DATASET_SIZES) + ["none"],
@@ -704,6 +715,21 @@ def main() -> None:
 
     lib, ctx = _lib.load(), _lib.ctx(local)
     NK = len(_lib.PROF_KINDS)
+    leg_seconds, lap_t = {}, [time.perf_counter()]
+    leg_seconds["setup_weights_inputs"] = round(lap_t[0] - T_PROCESS_START, 1)
+
+    def lap(name: str) -> None:
+        """Wall seconds of every part of this run (rank 0's clock), reported as `leg_seconds`."""
+        now = time.perf_counter()
+        leg_seconds[name] = round(now - lap_t[0], 1)
+        lap_t[0] = now
+
+    def over_budget() -> bool:
+        """Rank 0 decides for all ranks (the legs hold collectives)."""
+        flag = torch.tensor([1.0 if time.perf_counter() - T_PROCESS_START > args.leg_budget_s else 0.0], device=cdev, dtype=torch.float64)
+        if dist is not None:
+            dist.broadcast(flag, 0)
+        return bool(flag.item() > 0)
 
     def read_profile() -> dict:
         ms, wk, n = (C.c_double * NK)(), (C.c_double * NK)(), (C.c_int64 * NK)()
@@ -722,6 +748,7 @@ def main() -> None:
     dt_own = t_own - t0                          # without the wait for the other ranks: the per-rank rates
     prof = read_profile() if rank == 0 else None
     lib.owc_gemm_profile_enable(ctx, 0)
+    lap("warmup_and_timed_steps")
     fp8_run = args.decoder_dtype == "fp8"
     assert out.shape == (B, T)
     tall = torch.tensor([dt_local, dt_own], device=cdev, dtype=torch.float64)
@@ -759,40 +786,7 @@ def main() -> None:
                         row[k]["vs_headline"] = row[k]["images_per_s"] / images_per_s
             eos_leg["headline_images_per_s_forced_16"] = images_per_s
 
-    # ---- PCIe-inclusive leg (never `value`): the same step fed from host uint8 images (what the boundary hands over in a
-    # real run): pinned H2D copy + GPU rescale/normalise/patchify + the step above
-    host_u8 = torch.randint(0, 256, (B, 3, 448, 448), dtype=torch.uint8).pin_memory()
-    sync()
-    p0 = time.perf_counter()
-    dev_u8 = host_u8.to(device, non_blocking=True)
-    pix_h = owc_ops.patchify_u8(dev_u8, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD)
-    emb_h = engine.encode_images(pix_h, flat_grids)
-    engine.generate(prompts, emb_h, grids, T, eos_token_id=-1, pad_token_id=0).cpu()
-    sync()
-    pcie_dt = torch.tensor([time.perf_counter() - p0], device=cdev, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(pcie_dt, op=dist.ReduceOp.MAX)
-    pcie_images_per_s = world * B / float(pcie_dt.item())
-    del dev_u8, pix_h, emb_h
-
-    # ---- real-boundary leg (never `value`): PIL images -> Qwen2VL.generate_until -> strings, i.e. the reference's plug-in
-    # contract end to end (JPEG round trip + bicubic resize + tokenise on the host worker pool, double-buffered against the GPU)
-    pil = None
-    if not args.no_pil_leg:
-        pil = pil_leg(engine, dims, host_u8, B, T, device, sync)
-        if dist is not None:
-            t = torch.tensor([pil["seconds"]], device=cdev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            pil["seconds"] = float(t.item())
-        pil["images_per_s"] = world * pil["images"] / pil["seconds"]
-    del host_u8
-
-    # ---- HBM-regime decode leg (never `value`): ms per decode step at the reference's batch size and mid batches
-    decode_leg = None
-    if rank == 0 and not args.no_decode_leg:
-        decode_leg = decode_regime_leg(engine, dims)
-    if dist is not None:
-        dist.barrier()
+    lap("eos_terminated")
 
     def profile(on: bool):
         """Leg-level kernel profile: start (True) / stop and read (False) the library's per-launch-class HIP-event recording."""
@@ -811,6 +805,50 @@ def main() -> None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ragged["seconds_per_pass"] = float(t.item())
             ragged["images_per_s"] = world * ragged["images"] / ragged["seconds_per_pass"]
+
+    lap("real_image_sizes")
+
+    # ---- PCIe-inclusive leg (never `value`): the same step fed from host uint8 images (what the boundary hands over in a
+    # real run): pinned H2D copy + GPU rescale/normalise/patchify + the step above
+    host_u8 = torch.randint(0, 256, (B, 3, 448, 448), dtype=torch.uint8).pin_memory()
+    sync()
+    p0 = time.perf_counter()
+    dev_u8 = host_u8.to(device, non_blocking=True)
+    pix_h = owc_ops.patchify_u8(dev_u8, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD)
+    emb_h = engine.encode_images(pix_h, flat_grids)
+    engine.generate(prompts, emb_h, grids, T, eos_token_id=-1, pad_token_id=0).cpu()
+    sync()
+    pcie_dt = torch.tensor([time.perf_counter() - p0], device=cdev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(pcie_dt, op=dist.ReduceOp.MAX)
+    pcie_images_per_s = world * B / float(pcie_dt.item())
+    del dev_u8, pix_h, emb_h
+    lap("from_host_uint8")
+
+    # ---- real-boundary leg (never `value`): PIL images -> Qwen2VL.generate_until -> strings, i.e. the reference's plug-in
+    # contract end to end (JPEG round trip + bicubic resize + tokenise on the host worker pool, double-buffered against the GPU)
+    pil = None
+    if not args.no_pil_leg and over_budget():
+        pil = {"skipped": f"--leg-budget-s {args.leg_budget_s:.0f} s reached before this leg (long --steps run); run it with --steps 3"}
+    elif not args.no_pil_leg:
+        pil = pil_leg(engine, dims, host_u8, B, T, device, sync)
+        if dist is not None:
+            t = torch.tensor([pil["seconds"]], device=cdev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            pil["seconds"] = float(t.item())
+        pil["images_per_s"] = world * pil["images"] / pil["seconds"]
+    del host_u8
+    lap("from_pil")
+
+    # ---- HBM-regime decode leg (never `value`): ms per decode step at the reference's batch size and mid batches
+    decode_leg = None
+    if not args.no_decode_leg and over_budget():
+        decode_leg = {"skipped": f"--leg-budget-s {args.leg_budget_s:.0f} s reached before this leg (long --steps run); run it with --steps 3"}
+    elif rank == 0 and not args.no_decode_leg:
+        decode_leg = decode_regime_leg(engine, dims)
+    if dist is not None:
+        dist.barrier()
+    lap("roofline_decode")
 
     # ---- scorer leg: label-cosine/s (embed predictions + cosine top-5 against resident class embeddings)
     n_lab, L = args.scorer_labels, 16
@@ -840,6 +878,7 @@ def main() -> None:
     if dist is not None:
         dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
     labels_per_s = world * n_lab * args.steps / float(sdt.item())
+    lap("label_cosine")
     label_tokens = int(lens.sum())
 
     # ---- the other BASELINE configs in front of the driver (never `value`): configs[1] and the scorer side of configs[4]
@@ -850,6 +889,7 @@ def main() -> None:
             cfg2 = config2_leg(device, T, sync if dist is None else torch.cuda.synchronize, profile)
     if dist is not None:
         dist.barrier()
+    lap("config2_and_cosine_10k")
 
     parity_failure = None
     if rank == 0:
@@ -922,6 +962,9 @@ def main() -> None:
                 if bad and not parity_failure:
                     parity_failure = f"full-size token parity failed: {len(bad)} teacher-forced flip(s) on a decisive margin: {bad[:2]}"
                 result["cpu_baseline"]["parity_gate"] = {"logit_bound": FULLSIZE_LOGIT_BOUND, "passed": parity_failure is None}
+        lap("cpu_baseline")
+        leg_seconds["total_since_process_start"] = round(time.perf_counter() - T_PROCESS_START, 1)
+        result["leg_seconds"] = leg_seconds
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

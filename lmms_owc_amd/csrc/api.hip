@@ -55,7 +55,10 @@ int owc_tuning_set(const char* name, int value) {
     owc_gemm_set_small_tiles(value);
     owc_gemm_fp8_set_shapes(value != 0 && value != 2);   // (2 forces 64x64 for both dtypes)
   }   // 0: 64x64 tiles only; 1 (default): by block count; 2..4: force 64x64 / 64x32 / 32x32
-  else if (!strcmp(name, "gemm_ring_128")) owc_gemm_set_ring_128(value);   // 128x64 ring tiles for 257+ rows x few columns
+  else if (!strcmp(name, "gemm_ring_128")) {   // 128x64 ring tiles for several hundred rows x few thousand columns (bf16 and fp8)
+    owc_gemm_set_ring_128(value);
+    owc_gemm_fp8_set_ring_128(value);
+  }
   else if (!strcmp(name, "decode_fuse")) owc_llm_set_decode_fuse(value);
   else if (!strcmp(name, "decode_norm_fuse")) owc_gemm_set_norm_fuse_max_m(value);   // max rows (<= 4) for the RMSNorm-fused skinny GEMM; 0 = off
   else if (!strcmp(name, "decode_attn_nbuf1")) owc_attn_set_decode_nbuf1(value);   // block count above which the fused decode attention single-buffers V

@@ -27,6 +27,7 @@ int g_fp8_pingpong = 1;       // "gemm_pingpong" knob: 2 / default = on, 0 or 1 
                               // bf16 kernel's two-set W layout: 7b.down 2573 -> 3001, 72b.gateup 2658 -> 3008, sq8192 2736 -> 3059 TFLOP/s
 int g_fp8_skinny_max_m = 0;   // follows the "gemm_skinny_max_m" knob.  Off by default since round 3: the ring kernel's narrow / wide tiles beat it at every M (72B fp8 decode step at batch 1 / 8 / 16 / 32 / 64: 20.8 / 21.9 / 23.7 / 28.0 / 41.2 -> 19.9 / 20.1 / 20.0 / 20.9 / 22.9 ms)
 int g_fp8_shapes = 1;          // the ring kernel's other tile shapes / K grouping (follows "gemm_small_tiles")
+int g_fp8_ring_128 = 1;        // 128x64 tiles of the ring kernel where 64x64 tiles need more than one round of two blocks per CU (follows "gemm_ring_128")
 int g_fp8_mid_max_tiles = 128;  // fewer 256x256 tiles than this -> 64x64 tiles (follows "gemm_mid_max_tiles": 0 disables)
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;
 
@@ -773,6 +774,8 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
       if (longk) OWC_L8(4, 32, 32, 4); else OWC_L8(8, 32, 32, 1);
     } else if (g_fp8_shapes && EPI != OWC_EPI_SWIGLU && blocks(64, 64) <= 256 && blocks(64, 32) <= 256) {
       if (longk) OWC_L8(3, 64, 32, 4); else OWC_L8(6, 64, 32, 1);
+    } else if (g_fp8_ring_128 && g_fp8_shapes && EPI != OWC_EPI_SWIGLU && blocks(64, 64) > 512 && M >= 129) {
+      OWC_L8(3, 128, 64, 1);   // (round 4: 72 KiB of LDS, two blocks per CU: 512 blocks in one round)
     } else if (longk && blocks(64, 64) <= 512) {
       OWC_L8(3, 64, 64, 2);
     } else {
@@ -799,6 +802,7 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
 void owc_gemm_fp8_set_skinny_max_m(int v) { g_fp8_skinny_max_m = v < 0 ? 0 : v; }  // negative: back to the default
 void owc_gemm_fp8_set_pingpong(int v) { g_fp8_pingpong = v; }
 void owc_gemm_fp8_set_shapes(int v) { g_fp8_shapes = v; }
+void owc_gemm_fp8_set_ring_128(int v) { g_fp8_ring_128 = v < 0 ? 1 : v != 0; }
 void owc_gemm_fp8_set_mid_max_tiles(int v) { g_fp8_mid_max_tiles = v ? 128 : 0; }
 
 int owc_launch_quant_rows_fp8(const void* X, long ldx, void* Q, long ldq, float* S, int rows, int cols, hipStream_t st) {

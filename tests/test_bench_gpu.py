@@ -56,3 +56,7 @@ def test_two_ranks_share_one_gpu(gpu):
     cos = out["label_cosine_10k_classes"]
     assert cos["classes"] == 10000 and cos["top1_matches_dense_matmul_on_256_rows"] and 0 < cos["roofline"]["frac"] < 1
     assert out["config2_qwen2vl_2b"] is None and len(out["builder_run_configs"]) == 2     # (this run IS the 2B model)
+    # where the run's wall time went (rank 0's clock); the optional legs are skipped beyond --leg-budget-s - not here
+    ls = out["leg_seconds"]
+    assert {"setup_weights_inputs", "warmup_and_timed_steps", "eos_terminated", "real_image_sizes", "roofline_decode"} <= set(ls)
+    assert abs(sum(v for k, v in ls.items() if k != "total_since_process_start") - ls["total_since_process_start"]) < 2.0

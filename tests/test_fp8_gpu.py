@@ -184,11 +184,13 @@ def test_gemm_fp8_mid_kernel_race_screen(gpu, m, n, k, epi):
 
 
 @pytest.mark.parametrize("m,n,k,epi", [(64, 8192, 29696, "res"), (40, 1096, 128, "bias"), (130, 8192, 8192, "res"), (100, 10240, 8192, "bias"),
-                                       (128, 59392, 8192, "swiglu"), (24, 40000, 256, "bias"), (70, 33024, 3584, "swiglu"), (300, 2048, 8192, "res")])
+                                       (128, 59392, 8192, "swiglu"), (24, 40000, 256, "bias"), (70, 33024, 3584, "swiglu"), (300, 2048, 8192, "res"),
+                                       (520, 4160, 512, "bias"), (700, 8192, 1024, "res"), (513, 10240, 256, "bias")])
 def test_gemm_fp8_ring_shapes_race_screen(gpu, m, n, k, epi):
     """The fp8 ring kernel's round-3 forms - 32x32 / 64x32 tiles and several K-tiles per stage for the narrow projections (72B o / down /
     qkv at decode batch 17-256), 32/64/128 x 256 tiles for <= 128 rows x tens of thousands of columns (gate/up), 64x64 with two K-tiles
-    per stage - against the 256x256 kernel, 8 times per shape: ragged M / N, 1 and 2 K-tiles (fewer than stages), SwiGLU.  Bit-identical."""
+    per stage, round 4's 128x64 tiles for several hundred rows (the last three cases: 72B o / qkv at decode batch 257-768) - against the
+    256x256 kernel, 8 times per shape: ragged M / N, 1 and 2 K-tiles (fewer than stages), SwiGLU.  Bit-identical."""
     from lmms_owc_amd import _lib, ops
 
     lib = _lib.load()
