@@ -460,19 +460,27 @@ def eos_terminated_leg(engine, pix, flat_grids, prompts, grids, B: int, sync, he
             del emb
         if len(toks) == 2:
             row["tokens_identical_with_and_without_compaction"] = bool(torch.equal(toks[True], toks[False]))
-        if cap == max(caps) and hand_over_passes > 1 and 1.3 * kv_bytes + (24 << 30) <= (
-                torch.cuda.mem_get_info()[0] + torch.cuda.memory_reserved() - torch.cuda.memory_allocated() + 4 * engine._kv[0].numel()):
-            slots = B + (max(B // 8, 256) + 255) // 256 * 256   # (slots for carried sequences: the engine's cache pair grows once more,
-            rows_kv = (len(prompts[0]) + cap + 2 + 15) // 16 * 16   # outside the timing)
+        avail = torch.cuda.mem_get_info()[0] + torch.cuda.memory_reserved() - torch.cuda.memory_allocated() + 4 * engine._kv[0].numel()
+        # slots for carried sequences, as `PassPipeline._reserve_kv` sizes them: half a pass if the cache with them plus their export
+        # copy fits with room to spare, else an eighth
+        capacity = next((c for c in (B // 2, B // 8) if (1.0 + 2.0 * c / B) * 1.05 * kv_bytes + (24 << 30) <= avail), None)
+        if cap == max(caps) and hand_over_passes > 1 and capacity is not None:
+            from lmms_owc_amd.models._base import hand_over_below
+
+            capacity = (max(capacity, 256) + 255) // 256 * 256
+            slots = B + capacity                                    # (the engine's cache pair grows once more, outside the timing)
+            rows_kv = (len(prompts[0]) + cap + 2 + 15) // 16 * 16
             engine.reserve_kv(d.n_layers * slots * d.n_kv_heads * d.head_dim * rows_kv)
             # a TASK is several passes: with straggler hand-over a pass stops once its own live sequences are few and the rest finish
             # inside the following passes (`generate(..., carry=)`), so the long tail is paid once per task, not once per pass
             ref = toks[True].numpy()
-            state, got, handed = None, {}, []
+            state, got, handed, below = None, {}, [], []
             sync()
             t0 = time.perf_counter()
             for k in range(hand_over_passes):
-                c = {"in": state, "below": max(8, B // 64) if k + 1 < hand_over_passes else 0, "tags": [(k, i) for i in range(B)]}
+                n_in = 0 if state is None else len(state["tags"])
+                c = {"in": state, "below": hand_over_below(B, n_in, capacity) if k + 1 < hand_over_passes else 0, "tags": [(k, i) for i in range(B)]}
+                below.append(c["below"])
                 emb = engine.encode_images(pix, flat_grids)
                 out_k = engine.generate(prompts, emb, grids, cap, eos_token_id=EOS_ID, pad_token_id=0, forced_tokens=forced, carry=c).cpu().numpy()
                 skip = set(c["unfinished_rows"])
@@ -487,6 +495,7 @@ def eos_terminated_leg(engine, pix, flat_grids, prompts, grids, B: int, sync, he
             row["passes_with_straggler_hand_over"] = {
                 "passes": hand_over_passes, "seconds": dt, "images_per_s": hand_over_passes * B / dt,
                 "vs_headline": hand_over_passes * B / dt / headline_images_per_s, "sequences_handed_to_the_next_pass": handed,
+                "hand_over_when_own_live_sequences_at_most": below, "slots_for_carried_sequences": capacity,
                 "tokens_identical_to_a_pass_run_alone": bool(same)}
         pad_ok = all(bool((toks[True][b, min(int(lens[b]), cap):] == 0).all()) for b in range(0, B, max(1, B // 64)))
         row["pad_behind_stop_column"] = pad_ok
@@ -741,8 +750,10 @@ def main() -> None:
     sync()
     lib.owc_gemm_profile_enable(ctx, 1 if rank == 0 else 0)
     t0 = time.perf_counter()
+    step_end = []
     for _ in range(args.steps):
         out = step()
+        step_end.append(time.perf_counter())   # (a step ends with its token ids on the host: no extra synchronisation)
     t_own = sync()
     dt_local = time.perf_counter() - t0          # barrier-bracketed: what `value` is computed from (max over ranks)
     dt_own = t_own - t0                          # without the wait for the other ranks: the per-rank rates
@@ -912,6 +923,7 @@ def main() -> None:
                                    "weights of the real architecture; images strided across ranks, no data-path collective",
                        "images_per_gpu_per_step": B, "prompt_tokens": 286, "new_tokens": T, "parallelism": f"dp{world}",
                        **({"tuning": args.tune} if args.tune else {})},
+            "ms_of_each_step": [round((b - a) * 1e3, 1) for a, b in zip([t0] + step_end[:-1], step_end)],   # rank 0: drift under sustained load shows here
             "per_rank_images_per_s": [B * args.steps / t for t in per_rank_own],   # each rank's own clock, before the closing barrier
             "rccl_world_size": dist.get_world_size() if dist is not None else 1,
             "batch_invariance_check": "ok: image 0's tokens inside the batch == the same image run alone" if invariant else

@@ -181,8 +181,17 @@ class PassPipeline:
             return
         longest = max([len(p) for p in first_prep["prompts"]] + [1])
         rows = (int(longest * 1.1) + int(first_prep["max_new"]) + 2 + 15) // 16 * 16
+        self._carry_capacity = 0
         if hand_over:
-            slots = slots + (max(slots // 8, 256) + 255) // 256 * 256
+            # slots for sequences handed over between passes: as many as a pass has, if 40 % of the memory left beside one pass's
+            # cache holds them twice (a carried sequence's rows exist in the export AND in the next pass's cache for a moment);
+            # never fewer than an eighth of a pass (round 4's first rule, which every model / batch so far has run with)
+            slot_bytes = 4 * d.n_layers * d.n_kv_heads * d.head_dim * rows                    # K and V, bf16
+            free = torch.cuda.mem_get_info(self._device)[0] + torch.cuda.memory_reserved(self._device) - torch.cuda.memory_allocated(self._device)
+            held = 4 * eng._kv[0].numel() if getattr(eng, "_kv", None) else 0                 # (the current pair is released when it grows)
+            fit = int(0.4 * (free + held - slots * slot_bytes) / (2 * slot_bytes))
+            self._carry_capacity = (max(min(slots, fit), slots // 8, 256) + 255) // 256 * 256
+            slots = slots + self._carry_capacity
         eng.reserve_kv(d.n_layers * slots * d.n_kv_heads * d.head_dim * rows)
 
     def _start_workers(self) -> None:
@@ -328,16 +337,19 @@ class PassPipeline:
                 ahead_n -= size
             prep = preps[0] if len(preps) == 1 else self._merge_preps(preps)
             top_up()
-            # straggler hand-over: while another pass follows, this pass stops decoding once its own live sequences are down to
-            # 1 / 64 of an engine batch and the rest ride along in the next pass's decode steps (greedy decoding only)
+            # straggler hand-over: while another pass follows, this pass stops decoding once its own live sequences are few enough
+            # (`hand_over_below`) and the rest ride along in the next pass's decode steps
             carry = None
             more = left - prep["n"] > 0
-            if (tok.eos_token_id is not None and tok.eos_token_id >= 0 and (more or carried is not None)
-                    and not getattr(self, "_no_carry", False)):
-                carry = {"in": carried, "below": max(8, eb // 64) if more else 0,
-                         "tags": list(range(launched, launched + prep["n"]))}
+            hand_over = (tok.eos_token_id is not None and tok.eos_token_id >= 0 and (more or carried is not None)
+                         and not getattr(self, "_no_carry", False))
             if not self.last_timing["chunks"]:
-                self._reserve_kv(prep, min(eb, len(requests)), carry is not None and more)
+                self._reserve_kv(prep, min(eb, len(requests)), hand_over and more)
+            if hand_over:
+                n_in = 0 if carried is None else len(carried["tags"])
+                capacity = getattr(self, "_carry_capacity", 0) or max(eb // 8, 256)
+                carry = {"in": carried, "below": hand_over_below(prep["n"], n_in, capacity) if more else 0,
+                         "tags": list(range(launched, launched + prep["n"]))}
             host, ev = self._launch_chunk(prep, tok.eos_token_id, pad, carry)
             skip = set()
             if carry is not None:
@@ -359,6 +371,19 @@ class PassPipeline:
         assert carried is None and len(rows) == len(requests)
         return reordered.get_original([rows[i] for i in range(len(requests))])
 
+
+
+def hand_over_below(n_own: int, n_carried_in: int, capacity: int) -> int:
+    """The straggler hand-over threshold of one pass (`Qwen2VLEngine.generate(carry={"below": ...})`): the pass stops decoding
+    once at most this many of its OWN sequences are unfinished; they go on inside the next pass's decode steps.
+
+    A decode step costs about t0 + c * rows (7B on MI355X: ~5 ms + ~12.5 us per row): every step a pass does NOT run with a
+    shrinking batch saves t0, the tokens themselves cost c wherever they are decoded - so hand over as early as the slots allow:
+    half of the pass, or what is left of the `capacity` (slots reserved for carried sequences, `PassPipeline._reserve_kv`) beside
+    the sequences that came in with this pass.  Round 4 first handed over at 1/64 of a pass (32 of 2048): with classification
+    answers (mean 8 tokens) a pass then ran ~35 decode steps instead of ~6, with chain-of-thought answers (mean 100, cap 256) all
+    255 - DESIGN.md section 8.  The tokens do not depend on the threshold (tests/test_qwen2vl_gpu.py, test_plugin_gpu.py)."""
+    return max(8, min(n_own // 2, capacity - n_carried_in))
 
 
 def sampling_from_gen_kwargs(gen_kwargs: dict, default_top_k: int = 50) -> dict | None:

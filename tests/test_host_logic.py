@@ -696,3 +696,14 @@ def test_bench_launches_its_own_ranks(tmp_path):
     bad = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
                          env={**env, "OWC_BENCH_DRYRUN_FAIL_RANK": "1"}, timeout=300)
     assert bad.returncode == 7 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_hand_over_threshold_policy():
+    """`hand_over_below`: half of the pass, capped by the slots left for carried sequences, never below 8."""
+    from lmms_owc_amd.models._base import hand_over_below
+
+    assert hand_over_below(2048, 0, 1024) == 1024
+    assert hand_over_below(2048, 1000, 1024) == 24
+    assert hand_over_below(2048, 2000, 1024) == 8       # more came in than the slots reserved: (nearly) everything finishes here
+    assert hand_over_below(128, 0, 1024) == 64          # a small pass of the adaptive ramp
+    assert hand_over_below(10, 0, 256) == 8
