@@ -479,7 +479,7 @@ def eos_terminated_leg(engine, pix, flat_grids, prompts, grids, B: int, sync, he
             t0 = time.perf_counter()
             for k in range(hand_over_passes):
                 n_in = 0 if state is None else len(state["tags"])
-                c = {"in": state, "below": hand_over_below(B, n_in, capacity) if k + 1 < hand_over_passes else 0, "tags": [(k, i) for i in range(B)]}
+                c = {"in": state, "below": hand_over_below(B, n_in, capacity) if k + 1 < hand_over_passes else 0, "slots": capacity, "tags": [(k, i) for i in range(B)]}
                 below.append(c["below"])
                 emb = engine.encode_images(pix, flat_grids)
                 out_k = engine.generate(prompts, emb, grids, cap, eos_token_id=EOS_ID, pad_token_id=0, forced_tokens=forced, carry=c).cpu().numpy()

@@ -450,7 +450,8 @@ class Qwen2VLEngine:
         `carry["in"]` - the unfinished sequences of the previous pass (`carry["out"]` of that call), which join this pass's decode
         steps as extra rows with their own KV rows, pending token and remaining budget; `carry["below"]` - once this pass's OWN
         live rows are at most this many (and at least one decode step ran) the loop stops and the still-running sequences are
-        exported (0: run everything to the end - the last pass of a task); `carry["tags"]` - one identity per prompt.  Out:
+        exported (0: run everything to the end - the last pass of a task); `carry["tags"]` - one identity per prompt;
+        `carry["slots"]` (optional) - cache slots kept for carried sequences beside this pass's own.  Out:
         `carry["finished"]` = [(tag, int32 tokens incl. pad)] of carried-in sequences that ended here, `carry["out"]` = the
         export (None when nothing is left), `carry["unfinished_rows"]` = the own rows inside it (their rows of the returned
         tensor are incomplete).  A sequence's tokens do not depend on which pass finishes it (batch invariance; tested).
@@ -476,8 +477,9 @@ class Qwen2VLEngine:
         n_slots = Bx
         if carry is not None:
             # the passes of a task should ask the allocator for the SAME two blocks: a 20 GB cache that grew by 1 % is a fresh
-            # hipMalloc (~0.5 s each); slots for up to B / 8 (at least 256) carried sequences, key rows in steps of 16
-            n_slots = B + (max(NC, B // 8, 256) + 255) // 256 * 256
+            # hipMalloc (~0.5 s each); slots for carried sequences = what the caller reserved (`carry["slots"]`), else up to
+            # B / 8 (at least 256); key rows in steps of 16
+            n_slots = B + (max(NC, int(carry["slots"])) if carry.get("slots") else (max(NC, B // 8, 256) + 255) // 256 * 256)
             s_max = (max(s_max, int(lens.max()) + max_new_tokens + 2) + 15) // 16 * 16
         cache_elems = d.n_layers * n_slots * Hkv * s_max * d.head_dim
         kc, vc = self.reserve_kv(cache_elems)

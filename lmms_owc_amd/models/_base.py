@@ -181,16 +181,15 @@ class PassPipeline:
             return
         longest = max([len(p) for p in first_prep["prompts"]] + [1])
         rows = (int(longest * 1.1) + int(first_prep["max_new"]) + 2 + 15) // 16 * 16
-        self._carry_capacity = 0
         if hand_over:
             # slots for sequences handed over between passes: as many as a pass has, if 40 % of the memory left beside one pass's
             # cache holds them twice (a carried sequence's rows exist in the export AND in the next pass's cache for a moment);
-            # never fewer than an eighth of a pass (round 4's first rule, which every model / batch so far has run with)
+            # none - no hand-over in this task - when not even 64 fit (an MHA decoder at a batch that fills the memory)
             slot_bytes = 4 * d.n_layers * d.n_kv_heads * d.head_dim * rows                    # K and V, bf16
             free = torch.cuda.mem_get_info(self._device)[0] + torch.cuda.memory_reserved(self._device) - torch.cuda.memory_allocated(self._device)
             held = 4 * eng._kv[0].numel() if getattr(eng, "_kv", None) else 0                 # (the current pair is released when it grows)
             fit = int(0.4 * (free + held - slots * slot_bytes) / (2 * slot_bytes))
-            self._carry_capacity = (max(min(slots, fit), slots // 8, 256) + 255) // 256 * 256
+            self._carry_capacity = max(0, min((slots + 63) // 64 * 64, fit // 64 * 64))
             slots = slots + self._carry_capacity
         eng.reserve_kv(d.n_layers * slots * d.n_kv_heads * d.head_dim * rows)
 
@@ -344,12 +343,12 @@ class PassPipeline:
             hand_over = (tok.eos_token_id is not None and tok.eos_token_id >= 0 and (more or carried is not None)
                          and not getattr(self, "_no_carry", False))
             if not self.last_timing["chunks"]:
+                self._carry_capacity = (max(eb // 8, 256) + 255) // 256 * 256 if hand_over and more else 0   # (an engine without `reserve_kv`)
                 self._reserve_kv(prep, min(eb, len(requests)), hand_over and more)
-            if hand_over:
+            if hand_over and self._carry_capacity > 0:
                 n_in = 0 if carried is None else len(carried["tags"])
-                capacity = getattr(self, "_carry_capacity", 0) or max(eb // 8, 256)
-                carry = {"in": carried, "below": hand_over_below(prep["n"], n_in, capacity) if more else 0,
-                         "tags": list(range(launched, launched + prep["n"]))}
+                carry = {"in": carried, "below": hand_over_below(prep["n"], n_in, self._carry_capacity) if more else 0,
+                         "slots": self._carry_capacity, "tags": list(range(launched, launched + prep["n"]))}
             host, ev = self._launch_chunk(prep, tok.eos_token_id, pad, carry)
             skip = set()
             if carry is not None:
