@@ -621,7 +621,8 @@ def main() -> None:
     ap.add_argument("--nominal-forward", action="store_true",
                     help="run the model's nominal forward: full last prefill layer on every row and no shared-prefix segment "
                          "(same tokens bit for bit; shows what the two dead-work eliminations are worth)")
-    ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--cpu-images", type=int, default=3,
+                    help="images of the CPU baseline (HF generate on the host cores, ~25-40 s each for 7B); the first is the warm-up, `value` = mean of the rest")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
                     help="owc_tuning_set(KNOB, VALUE) before anything runs (A-B experiments; recorded in config.tuning)")
     ap.add_argument("--dry-run", action="store_true", help="launcher + rendezvous check on CPU (gloo); stops before HIP init")
