@@ -362,3 +362,47 @@ def toy_concept_items() -> list:
             ("airplane", ["ignored first round", "an image of the airplane with two wings"]), ("sea lion", "The sea lion and its ball"),
             ("grand piano", "piano"), ("golden retriever", "A dog, the Golden Retriever of Scotland and a stick"),
             (["airplane"], ["Boeing"]), ("tabby cat", "what type of object, some cat")]
+
+
+# ---------------------------------------------------------------------------------- multi-round protocol (tools/gen_golden_multiround.py)
+def mr_answer_of(prompt_text: str) -> str:
+    """The stand-in checkpoint of the multi-round protocol golden: a deterministic function of the rendered prompt.  Some answers
+    carry the stop string and a tail that the `until` cut must remove."""
+    import hashlib
+
+    h = hashlib.sha1(prompt_text.encode()).hexdigest()
+    words = ["maple", "otter", "quartz", "lantern", "violet", "harbor", "falcon", "cedar"]
+    body = " ".join(words[int(c, 16) % 8] for c in h[:3])
+    if int(h[3], 16) % 3 == 0:
+        body += " STOP trailing words " + h[4:8]
+    return body
+
+
+def mr_image_of(seed: int, size=(40, 56)):
+    from PIL import Image
+
+    r = np.random.default_rng(seed)
+    return Image.fromarray(r.integers(0, 256, (size[1], size[0], 3), dtype=np.uint8), "RGB")
+
+
+def mr_docs_and_task():
+    """Three docs and a multi-round `doc_to_text` (test input, the 5-tuple protocol of the reference's tasks): at most three rounds
+    (two for doc 2), doc 1's second round brings a second image, a doc ends early when its last answer contains 'cedar'."""
+    docs = [{"id": i, "label": f"class{i}", "seed": 100 + i} for i in range(3)]
+
+    def doc_to_visual(doc):
+        return [mr_image_of(doc["seed"])]
+
+    def doc_to_text(doc, round_idx=0, previous_round_results=None, last_round_info=None):
+        prev = list(previous_round_results or [])
+        n_rounds = 3 if doc["id"] != 2 else 2
+        terminal = round_idx >= n_rounds or any("cedar" in p for p in prev[-1:])
+        visuals = [mr_image_of(doc["seed"] + 50)] if (doc["id"] == 1 and round_idx == 1) else []
+        text = f"Round {round_idx} for {doc['label']}: given {' | '.join(prev) if prev else 'nothing'}, refine the answer."
+        return visuals, text, terminal, prev, last_round_info
+
+    return docs, doc_to_visual, doc_to_text
+
+
+def mr_context(doc: dict) -> str:
+    return f"<image>What type of object is in this photo? ({doc['label']})" if doc["id"] != 2 else "Describe the photo."
