@@ -164,8 +164,8 @@ class LLaVA(PassPipeline, Model):
         reference warns, this wrapper keeps NO history: every round is an independent single-turn prompt built from what the
         task's `doc_to_text(doc, round_idx=, previous_round_results=, last_round_info=)` returns for that round - its visuals
         and its context (`<image>` tokens prepended when the context has none, the same chat template as `generate_until`),
-        greedy, EOS only (`until` is read and never applied, :455-466); the rounds stop at the terminal signal of the FIRST
-        document of a batch (:496); the result per request is the tuple of per-round answers.  Batched over documents; an
+        greedy, EOS only (`until` is read and never applied, :455-466); a document's rounds stop at ITS terminal signal (the
+        reference's batch is one document, :496); the result per request is the tuple of per-round answers.  Batched over documents; an
         image that appears in several rounds goes through the host-side resize / anyres tiling once.
         One deliberate difference: the classification tasks' `doc_to_text_multi_round` returns `visual = None` after round 0
         (`_caltech101_utils.py:66-72`); the reference then evaluates `list(*visuals)` on `(None,)` and raises TypeError (:500-501),
@@ -193,24 +193,35 @@ class LLaVA(PassPipeline, Model):
             visuals_per_doc = [list(doc_to_visual[0](d)) for d in docs]
             contexts = list(contexts)
             feature_cache: dict = {}            # id(PIL image) -> (views uint8, original size): a round's repeat is not re-encoded
-            round_results: list[list[str]] = []  # [round][doc]
-            round_idx = 0
+            results: list[list[str]] = [[] for _ in docs]   # [doc] -> its per-round answers so far
+            active, round_idx = list(range(len(docs))), 0
             while True:
                 if round_idx:
-                    outs = [doc_to_text[0](d, round_idx=round_idx, previous_round_results=[r[i] for r in round_results],
-                                           last_round_info=None) for i, d in enumerate(docs)]
-                    # the per-round results continue from what the task RETURNS (item 3), as in the reference (:496-506): a task may
-                    # rewrite or truncate earlier answers
-                    round_results = [list(r) for r in zip(*[o[3] for o in outs], strict=True)]
-                    if outs[0][2]:   # terminal signal of the first document of the batch (:496)
-                        break
-                    visuals_per_doc = [list(o[0]) if o[0] is not None else [] for o in outs]
-                    contexts = [o[1] for o in outs]
-                smp = None if sampling is None else {**sampling, "stream_ids": [int(d) * 64 + round_idx for d in doc_ids]}
-                rows = self._generate_chunk(contexts, visuals_per_doc, max_new, feature_cache, sampling=smp)
-                round_results.append(self.decode_tokens(rows))
+                    # every document follows ITS OWN terminal signal (the reference runs one document per batch, :496): a finished
+                    # document leaves the following rounds, its result is the list its task returned last
+                    still = []
+                    for i in active:
+                        vis, ctx, terminal, rr, _info = doc_to_text[0](docs[i], round_idx=round_idx, previous_round_results=list(results[i]),
+                                                                       last_round_info=None)
+                        # the per-round results continue from what the task RETURNS, as in the reference (:496-506): a task may
+                        # rewrite or truncate earlier answers
+                        results[i] = list(rr)
+                        if terminal:
+                            continue
+                        visuals_per_doc[i] = list(vis) if vis is not None else []
+                        contexts[i] = ctx
+                        still.append(i)
+                    active = still
+                if not active:
+                    break
+                smp = None if sampling is None else {**sampling, "stream_ids": [int(doc_ids[i]) * 64 + round_idx for i in active]}
+                rows = self._generate_chunk([contexts[i] for i in active], [visuals_per_doc[i] for i in active], max_new, feature_cache,
+                                            sampling=smp)
+                for i, ans in zip(active, self.decode_tokens(rows)):
+                    results[i].append(ans)
                 round_idx += 1
-            res.extend(zip(*round_results, strict=True))
+            res.extend(tuple(r) for r in results)
+            round_results = [list(r) for r in results]
             self.cache_hook.add_partial("generate_until_multi_round", (contexts[0], gen_kwargs), round_results)
         return reordered.get_original(res)
 

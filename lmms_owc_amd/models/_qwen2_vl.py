@@ -181,9 +181,9 @@ class Qwen2VL(PassPipeline, Model):
         results continue from the list the task returns, `:455-461`).  Restated here per document of a batch: the same protocol,
         the same message structure (an image entry holds the PIL image where the reference stores a base64 JPEG data URL), the
         user turn appended, greedy generation, the answer cut at the `until` terms and appended as the assistant turn; the
-        result per request is the tuple of per-round answers.  Batched over documents; the image embeddings of round 0 are kept
-        on the GPU and reused by the later rounds (the reference re-encodes the conversation's images every round), so a task
-        may edit the conversation's text but not its images."""
+        result per request is the tuple of per-round answers.  Batched over documents; an image's embedding is computed in the
+        round that first shows it and reused by the later rounds (the reference re-encodes the conversation's images every
+        round); a later round's visuals - or images a task puts into the messages it hands back - are encoded when they appear."""
         res: list[tuple] = []
 
         def _collate(x):
@@ -202,60 +202,77 @@ class Qwen2VL(PassPipeline, Model):
             max_new = int(gen_kwargs.get("max_new_tokens", 128))
             sampling = sampling_from_gen_kwargs(gen_kwargs, getattr(self, "_default_top_k", 50))
             docs = [self.task_dict[task][split][did] for did in doc_ids]
-            visuals_per_doc = [list(doc_to_visual[0](d)) for d in docs]
-            prepared = list(self._pool.map(lambda v: imageproc.prepare_image(v, self._min_pixels, self._max_pixels),
-                                           [v for vs in visuals_per_doc for v in vs]))
-            it = iter(prepared)
-            arrs_per_doc = [[next(it) for _ in vs] for vs in visuals_per_doc]
-            grids_per_doc = [[(1, a.shape[1] // 14, a.shape[2] // 14) for a in arrs] for arrs in arrs_per_doc]
-            emb = None
-            if prepared:  # round 0's images, embedded once
-                emb = self._model.encode_images(self._pixel_values(prepared), [g for gs in grids_per_doc for g in gs])
-            image_slot = [{id(v): k for k, v in enumerate(vs)} for vs in visuals_per_doc]      # PIL object -> image index of its document
-            row_range, r0 = [], 0                       # [doc][image] -> (first, last + 1) row of `emb`
-            for gs in grids_per_doc:
-                row_range.append([])
-                for g in gs:
-                    row_range[-1].append((r0, r0 + g[1] * g[2] // 4))
-                    r0 += g[1] * g[2] // 4
+            # round 0: the reference flattens the batch's visuals and hands message i the i-th entry (:409-413, :482-483) - at its
+            # batch size of one that is the document's FIRST image; later rounds get the list the task returns, whole
+            visuals_per_doc = [list(doc_to_visual[0](d))[:1] for d in docs]
+            emb = None                                  # embeddings of every image seen so far in this batch, in arrival order
+            image_slot = [{} for _ in docs]             # [doc] PIL object (identity) -> image index of its document
+            grids_per_doc = [[] for _ in docs]          # [doc][image] -> (t, h, w) patch grid
+            row_range, n_rows = [[] for _ in docs], 0   # [doc][image] -> (first, last + 1) row of `emb`
+
+            def embed_new(per_doc: list[list]) -> None:
+                """Prepare + encode the images not seen before (any round may bring new ones) and register their rows."""
+                nonlocal emb, n_rows
+                new = [(i, v) for i, vs in enumerate(per_doc) for v in vs if id(v) not in image_slot[i]]
+                new = [(i, v) for k, (i, v) in enumerate(new) if all(id(v) != id(w) or i != j for j, w in new[:k])]
+                if not new:
+                    return
+                arrs = list(self._pool.map(lambda v: imageproc.prepare_image(v, self._min_pixels, self._max_pixels), [v for _, v in new]))
+                grids = [(1, a.shape[1] // 14, a.shape[2] // 14) for a in arrs]
+                e = self._model.encode_images(self._pixel_values(arrs), grids)
+                emb = e if emb is None or e is None else torch.cat([emb, e])
+                for (i, v), g in zip(new, grids):
+                    image_slot[i][id(v)] = len(grids_per_doc[i])
+                    grids_per_doc[i].append(g)
+                    row_range[i].append((n_rows, n_rows + g[1] * g[2] // 4))
+                    n_rows += g[1] * g[2] // 4
+
             messages: list[list] = [[] for _ in docs]   # the running conversation of every document (HF message dicts)
-            round_results: list[list[str]] = []         # [round][doc]
-            round_idx, texts = 0, [c.replace("<image>", "") for c in contexts]
+            results: list[list[str]] = [[] for _ in docs]   # [doc] -> its per-round answers so far
+            texts = [c.replace("<image>", "") for c in contexts]
             round_visuals = visuals_per_doc
+            active, round_idx = list(range(len(docs))), 0
+            pad = tok.pad_token_id if tok.pad_token_id is not None else 0
             while True:
                 if round_idx:
-                    outs = [doc_to_text[0](d, round_idx=round_idx, previous_round_results=[r[i] for r in round_results],
-                                           last_round_info={"messages": [messages[i]]}) for i, d in enumerate(docs)]
-                    # the per-round results continue from what the task RETURNS (item 3), as in the reference (:455-461): a task may
-                    # rewrite or truncate earlier answers
-                    round_results = [list(r) for r in zip(*[o[3] for o in outs], strict=True)]
-                    if outs[0][2]:  # terminal signal (the reference looks at the first document of the batch, :462)
-                        break
-                    texts = [o[1].replace("<image>", "") for o in outs]
-                    round_visuals = [[] if o[0] is None else ([o[0]] if not isinstance(o[0], (list, tuple)) else list(o[0])) for o in outs]
-                    for i, o in enumerate(outs):   # the conversation continues from the messages the task hands back (:479-480)
-                        info = o[4]
+                    # every document follows ITS OWN terminal signal (the reference runs one document per batch, :462): a finished
+                    # document leaves the following rounds, its result is the list its task returned last
+                    still = []
+                    for i in active:
+                        vis, text, terminal, rr, info = doc_to_text[0](docs[i], round_idx=round_idx, previous_round_results=list(results[i]),
+                                                                       last_round_info={"messages": [messages[i]]})
+                        # the per-round results continue from what the task RETURNS, as in the reference (:455-461): a task may
+                        # rewrite or truncate earlier answers
+                        results[i] = list(rr)
+                        if terminal:
+                            continue
+                        texts[i] = text.replace("<image>", "")
+                        round_visuals[i] = [] if vis is None else ([vis] if not isinstance(vis, (list, tuple)) else list(vis))
+                        # the conversation continues from the messages the task hands back (:479-480)
                         messages[i] = list(info["messages"][0]) if info and "messages" in info else []
-                prompts, round_grids, round_rows = [], [], []
-                for i, text in enumerate(texts):
+                        still.append(i)
+                    active = still
+                if not active:
+                    break
+                for i in active:
                     if not messages[i]:
                         messages[i] = [{"role": "system", "content": SYSTEM_PROMPT}]
-                    content = [{"type": "image", "image": v} for v in round_visuals[i]] + [{"type": "text", "text": text}]
+                    content = [{"type": "image", "image": v} for v in round_visuals[i]] + [{"type": "text", "text": texts[i]}]
                     messages[i].append({"role": "user", "content": content})
-                    # the conversation's images, in order, must be round-0 images of this document (identity): their embedding rows
-                    # are reused.  A conversation the task restarted holds none - its prompt then has no image tokens, as there.
-                    imgs = [c["image"] for m in messages[i] if isinstance(m["content"], list) for c in m["content"] if c.get("type") == "image"]
-                    try:
-                        ks = [image_slot[i][id(v)] for v in imgs]
-                    except KeyError:
-                        raise NotImplementedError("multi-round: the conversation's images must be the document's round-0 images "
-                                                  "(their embeddings are computed once and reused by the later rounds)") from None
+                # the conversation's images, in order (the reference re-reads them from the messages every round, :541): an image
+                # seen in an earlier round (identity) reuses its embedding rows, a new one - a later round's visual, or one a task put
+                # into the messages it handed back - is encoded now.  A conversation the task restarted holds none.
+                conv_imgs = [[c["image"] for m in messages[i] if isinstance(m["content"], list) for c in m["content"] if c.get("type") == "image"]
+                             if i in active else [] for i in range(len(docs))]
+                embed_new(conv_imgs)
+                prompts, round_grids, round_rows = [], [], []
+                for i in active:
+                    ks = [image_slot[i][id(v)] for v in conv_imgs[i]]
                     round_grids.append([grids_per_doc[i][k] for k in ks])
                     round_rows.append(np.concatenate([np.arange(*row_range[i][k]) for k in ks]) if ks else np.zeros(0, np.int64))
                     prompts.append(self._messages_ids(messages[i], [g[1] * g[2] // 4 for g in round_grids[-1]]))
-                pad = tok.pad_token_id if tok.pad_token_id is not None else 0
                 # (sampling: one stream per document and ROUND - a round's draws must not repeat the previous round's)
-                smp = None if sampling is None else {**sampling, "stream_ids": [int(d) * 64 + round_idx for d in doc_ids]}
+                smp = None if sampling is None else {**sampling, "stream_ids": [int(doc_ids[i]) * 64 + round_idx for i in active]}
                 out = self._model.generate(prompts, emb, round_grids, max_new, eos_token_id=tok.eos_token_id, pad_token_id=pad,
                                            img_rows=round_rows, sampling=smp).cpu().numpy()
                 rows = []
@@ -263,15 +280,15 @@ class Qwen2VL(PassPipeline, Model):
                     stop = np.flatnonzero(r == tok.eos_token_id)
                     rows.append(r[: stop[0]] if len(stop) else r)
                 answers = tok.batch_decode(rows, skip_special_tokens=True, clean_up_tokenization_spaces=False)
-                for i, ans in enumerate(answers):
+                for i, ans in zip(active, answers):
                     for term in until:
                         if len(term) > 0:
                             ans = ans.split(term)[0]
-                    answers[i] = ans
                     messages[i].append({"role": "assistant", "content": [{"type": "text", "text": ans}]})
-                round_results.append(answers)
+                    results[i].append(ans)
                 round_idx += 1
-            res.extend(zip(*round_results, strict=True))
+            res.extend(tuple(r) for r in results)
+            round_results = [list(r) for r in results]
             self.cache_hook.add_partial("generate_until_multi_round", (contexts[0], gen_kwargs), round_results)
         return reordered.get_original(res)
 

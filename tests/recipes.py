@@ -387,11 +387,12 @@ def mr_image_of(seed: int, size=(40, 56)):
 
 def mr_docs_and_task():
     """Three docs and a multi-round `doc_to_text` (test input, the 5-tuple protocol of the reference's tasks): at most three rounds
-    (two for doc 2), doc 1's second round brings a second image, a doc ends early when its last answer contains 'cedar'."""
+    (two for doc 2), doc 1's second round brings a second image, doc 2 has two round-0 images, a doc ends early when its last
+    answer contains 'cedar'."""
     docs = [{"id": i, "label": f"class{i}", "seed": 100 + i} for i in range(3)]
 
-    def doc_to_visual(doc):
-        return [mr_image_of(doc["seed"])]
+    def doc_to_visual(doc):   # (doc 2 has two images: the reference's round 0 shows the model only the first, _qwen2_vl.py:409-413 / :482-483)
+        return [mr_image_of(doc["seed"])] + ([mr_image_of(doc["seed"] + 7, (56, 84))] if doc["id"] == 2 else [])
 
     def doc_to_text(doc, round_idx=0, previous_round_results=None, last_round_info=None):
         prev = list(previous_round_results or [])

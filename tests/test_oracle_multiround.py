@@ -77,3 +77,149 @@ def test_llava_multi_round_oracle_equals_the_reference_run(case):
     assert all(t["generate_kwargs"]["max_new_tokens"] == want_new and t["generate_kwargs"]["do_sample"] is False for t in gold["trace"])
     # LLaVA's wrapper pops `until` and never applies it (:461-470): the stop string and its tail stay in the answers
     assert any("STOP trailing" in a for r in gold["results"] for a in r)
+
+
+def _text_of_ids(tok, ids) -> str:
+    """Prompt ids of the byte tokenizer -> the rendered chat string (a run of image placeholders = one `<|image_pad|>`)."""
+    names = {tok.im_start: "<|im_start|>", tok.im_end: "<|im_end|>", tok.vision_start: "<|vision_start|>", tok.vision_end: "<|vision_end|>"}
+    out, buf, prev = [], [], None
+    for t in (int(x) for x in ids):
+        if 3 <= t < 259:
+            buf.append(t - 3)
+        else:
+            if buf:
+                out.append(bytes(buf).decode())
+                buf = []
+            if t == tok.image_pad:
+                if prev != tok.image_pad:
+                    out.append("<|image_pad|>")
+            else:
+                out.append(names[t])
+        prev = t
+    if buf:
+        out.append(bytes(buf).decode())
+    return "".join(out)
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_product_multi_round_equals_the_reference_run(case):
+    """The PRODUCT's host path against the reference's own run, no oracle in between: `Qwen2VL.generate_until_multi_round` (batched,
+    three requests per engine pass) around a stand-in engine that decodes the prompt ids it is handed back into text and answers
+    with the golden's stand-in function of that text.  Every answer is a hash of the rendered conversation, so equal result tuples
+    mean equal prompts in every round: system turn, image placeholders in the turns that carry images, `until`-cut assistant turns
+    (trailing space and all), round order, early terminal signal, original request order."""
+    import numpy as np
+    import torch
+
+    from lmms_owc_amd.models._qwen2_vl import ByteTokenizer, Qwen2VL
+    from lmms_owc_amd.tasks import TaskInstance
+
+    gold = json.loads(GOLD.read_text())["qwen2vl"][case]
+    tok = ByteTokenizer()
+    seen = []
+
+    class Dims:
+        image_token_id, decoder_dtype = tok.image_pad, "bf16"
+
+    class FakeEngine:
+        d, device = Dims(), torch.device("cpu")
+
+        def encode_images(self, pix, grids):
+            return None
+
+        def generate(self, prompts, emb, grids, max_new, eos_token_id=-1, pad_token_id=0, **_):
+            out = np.full((len(prompts), max_new), pad_token_id, np.int32)
+            for i, p in enumerate(prompts):
+                text = _text_of_ids(tok, p)
+                seen.append((text, max_new))
+                t = (tok.encode(recipes.mr_answer_of(text)) + [eos_token_id])[:max_new]
+                out[i, : len(t)] = t
+            return torch.from_numpy(out)
+
+    class HostOnly(Qwen2VL):
+        def _pixel_values(self, images):
+            return None
+
+    docs, d2v, d2t = recipes.mr_docs_and_task()
+    lm = HostOnly.from_engine(FakeEngine(), tok, batch_size=3)
+    lm.task_dict["mr"] = {"test": docs}
+    reqs = [TaskInstance(request_type="generate_until_multi_round", idx=0, metadata={"task": "mr", "doc_id": d["id"], "repeats": 1},
+                         arguments=(recipes.mr_context(d), dict(gold["gen_kwargs"]), d2v, d2t, d["id"], "mr", "test")) for d in docs]
+    try:
+        got = lm.generate_until_multi_round(reqs)
+    finally:
+        lm._pool.shutdown()
+        lm._prep_thread.shutdown()
+    ref_texts = sorted(t["texts"][0] for t in gold["trace"])
+    if case != 2:     # (case 2: 16 new tokens cut the stand-in's answers short of what the reference's stand-in returned whole)
+        assert [list(t) for t in got] == gold["results"]
+        assert sorted(t for t, _ in seen) == ref_texts                       # the same rendered prompts, call for call
+    assert {m for _, m in seen} == {gold["trace"][0]["generate_kwargs"]["max_new_tokens"]}     # 48 / the default 128 / 16
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_product_llava_multi_round_equals_the_reference_run(case):
+    """`LLaVA.generate_until_multi_round` (batched, three requests per pass) against the reference's own run: the stand-in engine
+    collapses every image's placeholder run back to one `<image>`, decodes the prompt and answers with the golden's function of it -
+    equal tuples mean equal single-turn prompts in every round (image tokens prepended when the context has none, none for a round
+    without visuals, `until` never applied, every document on its own terminal signal)."""
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+
+    from lmms_owc_amd.engine.llava import DIMS, LlavaDims, LlavaEngine
+    from lmms_owc_amd.models._base import CacheHook
+    from lmms_owc_amd.models._llava_hf import LLaVA, LlavaByteTokenizer
+    from lmms_owc_amd.tasks import TaskInstance
+
+    gold = json.loads(GOLD.read_text())["llava"][case]
+    tok = LlavaByteTokenizer()
+    dims = LlavaDims(**{**DIMS["tiny"].__dict__, "image_token_id": tok.image_token_id})
+    seen = []
+
+    class FakeEngine:
+        d, device = dims, torch.device("cpu")
+        feature_rows = LlavaEngine.feature_rows
+
+        def generate_from_features(self, prompts, feats, rows_per_prompt, max_new, eos_token_id=-1, pad_token_id=0, **_):
+            out = np.full((len(prompts), max_new), pad_token_id, np.int32)
+            for i, p in enumerate(prompts):
+                p = [int(t) for t in p]
+                ids = [t for k, t in enumerate(p) if not (t == dims.image_token_id and k and p[k - 1] == dims.image_token_id)]
+                # consecutive images are separated by a space in the prompt (`<image> <image>`), so runs never merge
+                text, buf = "", []
+                for t in ids + [None]:
+                    if t is not None and 3 <= t < 259:
+                        buf.append(t - 3)
+                        continue
+                    text += bytes(buf).decode()
+                    buf = []
+                    if t == dims.image_token_id:
+                        text += "<image>"
+                seen.append((text, max_new))
+                t = (tok.encode(recipes.mr_answer_of(text)) + [eos_token_id])[:max_new]
+                out[i, : len(t)] = t
+            return torch.from_numpy(out)
+
+    class HostOnly(LLaVA):
+        def _encode_visuals(self, flat, feature_cache=None):
+            prepared = [self._views(v) for v in flat]
+            return None, (self._model.feature_rows([p[0].shape[0] for p in prepared], [p[1] for p in prepared]) if prepared else [])
+
+    lm = HostOnly.__new__(HostOnly)
+    lm._engine_batch_arg, lm._decoder_dtype, lm._chat_template = 0, "bf16", None
+    lm._device, lm._rank, lm._world_size, lm.batch_size_per_gpu = torch.device("cpu"), 0, 1, 3
+    lm.cache_hook, lm.task_dict = CacheHook(None), {}
+    lm._tokenizer = lm._processor = tok
+    lm._dims, lm._model, lm._pool = dims, FakeEngine(), ThreadPoolExecutor(max_workers=2)
+    docs, d2v, d2t = recipes.mr_docs_and_task()
+    lm.task_dict["mr"] = {"test": docs}
+    reqs = [TaskInstance(request_type="generate_until_multi_round", idx=0, metadata={"task": "mr", "doc_id": d["id"], "repeats": 1},
+                         arguments=(recipes.mr_context(d), dict(gold["gen_kwargs"]), d2v, d2t, d["id"], "mr", "test")) for d in docs]
+    try:
+        got = lm.generate_until_multi_round(reqs)
+    finally:
+        lm._pool.shutdown()
+    assert [list(t) for t in got] == gold["results"]
+    assert sorted(t for t, _ in seen) == sorted(t["texts"][0] for t in gold["trace"])
+    assert {m for _, m in seen} == {gold["trace"][0]["generate_kwargs"]["max_new_tokens"]}     # 48 / the default 1024
