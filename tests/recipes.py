@@ -407,3 +407,23 @@ def mr_docs_and_task():
 
 def mr_context(doc: dict) -> str:
     return f"<image>What type of object is in this photo? ({doc['label']})" if doc["id"] != 2 else "Describe the photo."
+
+
+def su_docs_and_task():
+    """Single-round protocol golden: six docs - one image each, except doc 3 (two images) and doc 4 (none); contexts with and
+    without an `<image>` marker, of different lengths (the Collator sorts by them), one with surrounding blanks."""
+    docs = [{"id": i, "label": f"class{i}", "seed": 200 + i} for i in range(6)]
+
+    def doc_to_visual(doc):
+        if doc["id"] == 4:
+            return []
+        return [mr_image_of(doc["seed"])] + ([mr_image_of(doc["seed"] + 9, (84, 56))] if doc["id"] == 3 else [])
+
+    return docs, doc_to_visual
+
+
+def su_context(doc: dict) -> str:
+    i = doc["id"]
+    return ["What type of object is in this photo?", "<image>What is this? Answer with one word.", "Name the object.  ",
+            "<image> <image>\nWhat do the two photos have in common?", "No picture here: say hello.",
+            "What type of object is in this photo? Let's think step by step."][i] + (f" ({doc['label']})" if i in (0, 5) else "")

@@ -223,3 +223,144 @@ def test_product_llava_multi_round_equals_the_reference_run(case):
     assert [list(t) for t in got] == gold["results"]
     assert sorted(t for t, _ in seen) == sorted(t["texts"][0] for t in gold["trace"])
     assert {m for _, m in seen} == {gold["trace"][0]["generate_kwargs"]["max_new_tokens"]}     # 48 / the default 1024
+
+
+class _DoneEvent:
+    def query(self):
+        return True
+
+    def synchronize(self):
+        pass
+
+
+def _llava_text(tok, image_token_id, p) -> str:
+    """Prompt ids of the LLaVA byte tokenizer -> the rendered prompt (every image's placeholder run = one `<image>`)."""
+    p = [int(t) for t in p]
+    ids = [t for k, t in enumerate(p) if not (t == image_token_id and k and p[k - 1] == image_token_id)]
+    text, buf = "", []
+    for t in ids + [None]:
+        if t is not None and 3 <= t < 259:
+            buf.append(t - 3)
+            continue
+        text += bytes(buf).decode()
+        buf = []
+        if t == image_token_id:
+            text += "<image>"
+    return text
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_product_generate_until_equals_the_reference_run(case):
+    """The HOT PATH's host loop against the reference's own run (`Qwen2VL.generate_until`, /root/reference/src/models/_qwen2_vl.py:
+    143-348, executed by tools/gen_golden_multiround.py on the stand-in checkpoint): six requests - with / without an `<image>`
+    marker, two images, no image, trailing blanks - through the product's pass pipeline (units of three, merged passes) around a
+    stand-in engine.  Equal strings in request order mean equal rendered prompts (the answer is a hash of the prompt), the same
+    default `max_new_tokens`, `until` popped and NOT applied, nothing stripped."""
+    import numpy as np
+    import torch
+
+    from lmms_owc_amd.models._qwen2_vl import ByteTokenizer, Qwen2VL
+    from lmms_owc_amd.tasks import TaskInstance
+
+    gold = json.loads(GOLD.read_text())["qwen2vl_single"][case]
+    tok = ByteTokenizer()
+    seen = []
+
+    class Dims:
+        image_token_id, decoder_dtype = tok.image_pad, "bf16"
+
+    class FakeEngine:
+        d, device = Dims(), torch.device("cpu")
+
+        def generate(self, prompts, emb, grids, max_new, eos_token_id=-1, pad_token_id=0, **_):
+            out = np.full((len(prompts), max_new), pad_token_id, np.int32)
+            for i, p in enumerate(prompts):
+                text = _text_of_ids(tok, p)
+                seen.append((text, max_new, sum(len(g) for g in [grids[i]])))
+                t = (tok.encode(recipes.mr_answer_of(text)) + [eos_token_id])[:max_new]
+                out[i, : len(t)] = t
+            return torch.from_numpy(out)
+
+    class HostOnly(Qwen2VL):
+        def _pinned_take(self, shape):
+            return torch.empty(shape, dtype=torch.uint8)
+
+        def _pinned_give(self, groups):
+            pass
+
+        def _launch_chunk(self, prep, eos_token_id, pad, carry=None):
+            return self._model.generate(prep["prompts"], None, prep["grids"], prep["max_new"], eos_token_id=eos_token_id, pad_token_id=pad), _DoneEvent()
+
+    docs, d2v = recipes.su_docs_and_task()
+    lm = HostOnly.from_engine(FakeEngine(), tok, batch_size=3)
+    lm._no_carry = True
+    lm.task_dict["su"] = {"test": docs}
+    reqs = [TaskInstance(request_type="generate_until", idx=0, metadata={"task": "su", "doc_id": d["id"], "repeats": 1},
+                         arguments=(recipes.su_context(d), dict(gold["gen_kwargs"]), d2v, d["id"], "su", "test")) for d in docs]
+    try:
+        got = lm.generate_until(reqs)
+    finally:
+        lm._pool.shutdown()
+        lm._prep_thread.shutdown()
+    assert got == gold["results"]
+    assert sorted((t, n) for t, _, n in seen) == sorted((t["texts"][0], t["images"]) for t in gold["trace"])     # prompts AND image counts
+    assert {m for _, m, _ in seen} == {gold["trace"][0]["generate_kwargs"]["max_new_tokens"]}                    # 64 / the default 128
+    assert all("until" not in r.args[1] for r in reqs)             # popped from the request's own dict, as the reference does (:211-219)
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_product_llava_generate_until_equals_the_reference_run(case):
+    """`LLaVA.generate_until` (/root/reference/src/models/_llava_hf.py:260-392) the same way."""
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+
+    from lmms_owc_amd.engine.llava import DIMS, LlavaDims, LlavaEngine
+    from lmms_owc_amd.models._base import CacheHook
+    from lmms_owc_amd.models._llava_hf import LLaVA, LlavaByteTokenizer
+    from lmms_owc_amd.tasks import TaskInstance
+
+    gold = json.loads(GOLD.read_text())["llava_single"][case]
+    tok = LlavaByteTokenizer()
+    dims = LlavaDims(**{**DIMS["tiny"].__dict__, "image_token_id": tok.image_token_id})
+    seen = []
+
+    class FakeEngine:
+        d, device = dims, torch.device("cpu")
+        feature_rows = LlavaEngine.feature_rows
+
+    class HostOnly(LLaVA):
+        def _pinned_take(self, shape):
+            return torch.empty(shape, dtype=torch.uint8)
+
+        def _pinned_give(self, groups):
+            pass
+
+        def _launch_chunk(self, prep, eos_token_id, pad, carry=None):
+            out = np.full((prep["n"], prep["max_new"]), eos_token_id, np.int32)
+            for i, p in enumerate(prep["prompts"]):
+                text = _llava_text(tok, dims.image_token_id, p)
+                seen.append((text, prep["max_new"], prep["images_per_prompt"][i]))
+                t = (tok.encode(recipes.mr_answer_of(text)) + [eos_token_id])[: prep["max_new"]]
+                out[i, : len(t)] = t
+            return torch.from_numpy(out), _DoneEvent()
+
+    lm = HostOnly.__new__(HostOnly)
+    lm._engine_batch_arg, lm._decoder_dtype, lm._chat_template = 0, "bf16", None
+    lm._device, lm._rank, lm._world_size, lm.batch_size_per_gpu = torch.device("cpu"), 0, 1, 3
+    lm.cache_hook, lm.task_dict, lm._no_carry = CacheHook(None), {}, True
+    lm._tokenizer = lm._processor = tok
+    lm._dims, lm._model = dims, FakeEngine()
+    lm._pool, lm._prep_thread = ThreadPoolExecutor(max_workers=2), ThreadPoolExecutor(max_workers=1)
+    docs, d2v = recipes.su_docs_and_task()
+    lm.task_dict["su"] = {"test": docs}
+    reqs = [TaskInstance(request_type="generate_until", idx=0, metadata={"task": "su", "doc_id": d["id"], "repeats": 1},
+                         arguments=(recipes.su_context(d), dict(gold["gen_kwargs"]), d2v, d["id"], "su", "test")) for d in docs]
+    try:
+        got = lm.generate_until(reqs)
+    finally:
+        lm._pool.shutdown()
+        lm._prep_thread.shutdown()
+    assert got == gold["results"]
+    assert sorted((t, n) for t, _, n in seen) == sorted((t["texts"][0], t["images"]) for t in gold["trace"])
+    assert {m for _, m, _ in seen} == {gold["trace"][0]["generate_kwargs"]["max_new_tokens"]}                    # 64 / the default 1024

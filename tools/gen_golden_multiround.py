@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Golden vectors for the multi-round generation PROTOCOL, produced by RUNNING THE REFERENCE's own
-`Qwen2VL.generate_until_multi_round` (/root/reference/src/models/_qwen2_vl.py:350-616) and
-`LLaVA.generate_until_multi_round` (/root/reference/src/models/_llava_hf.py) in this container.  Writes
+"""Golden vectors for the generation PROTOCOL of the two model wrappers - what the host loop hands the model and what it returns -
+produced by RUNNING THE REFERENCE's own `Qwen2VL.generate_until_multi_round` (/root/reference/src/models/_qwen2_vl.py:350-616),
+`LLaVA.generate_until_multi_round` (/root/reference/src/models/_llava_hf.py:394-584) and the single-round `generate_until` of both
+(`_qwen2_vl.py:143-348`, `_llava_hf.py:260-392`: the hot path's host loop) in this container.  Writes
 
   tests/golden/multiround_protocol.json
 
@@ -208,6 +209,38 @@ def run_llava(lm, TaskInstance, gen_kwargs):
             "contexts": [r.args[0] for r in make_requests(TaskInstance, docs, d2v, d2t, gen_kwargs)]}
 
 
+def make_single_requests(TaskInstance, docs, doc_to_visual, gen_kwargs):
+    reqs = []
+    for d in docs:
+        args = (recipes.su_context(d), dict(gen_kwargs), doc_to_visual, d["id"], "su", "test")
+        reqs.append(TaskInstance(request_type="generate_until", arguments=args, idx=0, metadata={"task": "su", "doc_id": d["id"], "repeats": 1}))
+    return reqs
+
+
+def run_single(module, which: str, TaskInstance, gen_kwargs):
+    """The reference's single-round `generate_until` (the hot path's host loop: _qwen2_vl.py:143-348 / _llava_hf.py:260-392) on the
+    stand-in checkpoint: six requests, the trace of generate calls and the returned strings in request order."""
+    box = {}
+    # (the wrapper object and its stand-ins are built by run_qwen / run_llava; the method they call is swapped for `generate_until`)
+    runner = run_qwen if which == "qwen" else run_llava
+    cls = module.Qwen2VL if which == "qwen" else module.LLaVA
+    docs, d2v = recipes.su_docs_and_task()
+    orig = cls.generate_until_multi_round
+
+    def call_single(self, _requests):
+        self.task_dict = {"su": {"test": docs}}
+        box["res"] = self.generate_until(make_single_requests(TaskInstance, docs, d2v, gen_kwargs))
+        return [(r,) for r in box["res"]]
+
+    cls.generate_until_multi_round = call_single
+    try:
+        out = runner(module, TaskInstance, gen_kwargs)
+    finally:
+        cls.generate_until_multi_round = orig
+    return {"results": list(box["res"]), "trace": out["trace"], "gen_kwargs": gen_kwargs,
+            "contexts": [recipes.su_context(d) for d in docs]}
+
+
 def main():
     qm, lm, TaskInstance = import_wrappers()
     out = {"versions": G.versions(),
@@ -218,7 +251,9 @@ def main():
                {"max_new_tokens": 48, "do_sample": False, "until": ["STOP"]},
                {"until": "STOP"},
                {"max_new_tokens": 16, "temperature": 0})],
-           "llava": [run_llava(lm, TaskInstance, gk) for gk in ({"max_new_tokens": 48, "do_sample": False, "until": ["STOP"]}, {})]}
+           "llava": [run_llava(lm, TaskInstance, gk) for gk in ({"max_new_tokens": 48, "do_sample": False, "until": ["STOP"]}, {})],
+           "qwen2vl_single": [run_single(qm, "qwen", TaskInstance, gk) for gk in ({"max_new_tokens": 64, "do_sample": False, "until": ["STOP"]}, {})],
+           "llava_single": [run_single(lm, "llava", TaskInstance, gk) for gk in ({"max_new_tokens": 64, "do_sample": False, "until": ["STOP"]}, {})]}
     GOLD.mkdir(parents=True, exist_ok=True)
     (GOLD / "multiround_protocol.json").write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
     print("wrote", GOLD / "multiround_protocol.json", {k: len(v) if isinstance(v, list) else "-" for k, v in out.items()})
