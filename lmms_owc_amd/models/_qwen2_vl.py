@@ -375,7 +375,7 @@ class Qwen2VL(PassPipeline, Model):
 
         def fetch(did):   # image fetch (file open + decode in the reference's tasks) AND preparation run on the pool workers
             # (a document's FIRST image only: the reference flattens the batch's visuals and hands message i the i-th entry, :196-200 /
-            # :232-233 - at its batch size of one that is image 0; pinned on its own run, tests/test_oracle_multiround.py)
+            # :232-233 - at its batch size of one that is image 0; pinned on its own run, tests/test_wrapper_protocol.py)
             return [imageproc.prepare_image(v, self._min_pixels, self._max_pixels) for v in list(doc_to_visual[0](docs[did]))[:1]]
 
         arrs_per_doc = list(self._pool.map(fetch, doc_ids))

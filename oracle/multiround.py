@@ -12,10 +12,10 @@ entry in the user turn that carries it, the `until` cut and the assistant turn. 
 (Qwen/Qwen2-VL-*-Instruct `chat_template.json`; third-party data, restated here because no checkpoint file exists offline) - what
 `self.processor.apply_chat_template(msg, tokenize=False, add_generation_prompt=True)` returns at `_qwen2_vl.py:535-540`.
 parity: the template text is restated from the published checkpoint, not read from it ("parity unpinned" for that string);
-the PROTOCOL is pinned on the reference's own run: tools/gen_golden_multiround.py executes the reference's two
+the PROTOCOL is pinned on the reference's own run: tools/gen_golden_wrappers.py executes the reference's two
 `generate_until_multi_round` methods in the build container on a stand-in checkpoint (answer = a function of the rendered
 prompt) and records every generate call (rendered prompt, image count, generation arguments) and the returned tuples in
-tests/golden/multiround_protocol.json; tests/test_oracle_multiround.py drives the two functions below with the same stand-in
+tests/golden/wrapper_protocol.json; tests/test_wrapper_protocol.py drives the two functions below with the same stand-in
 and requires the same calls and the same results.
 """
 

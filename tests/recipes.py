@@ -364,7 +364,7 @@ def toy_concept_items() -> list:
             (["airplane"], ["Boeing"]), ("tabby cat", "what type of object, some cat")]
 
 
-# ---------------------------------------------------------------------------------- multi-round protocol (tools/gen_golden_multiround.py)
+# ---------------------------------------------------------------------------------- multi-round protocol (tools/gen_golden_wrappers.py)
 def mr_answer_of(prompt_text: str) -> str:
     """The stand-in checkpoint of the multi-round protocol golden: a deterministic function of the rendered prompt.  Some answers
     carry the stop string and a tail that the `until` cut must remove."""
@@ -427,3 +427,27 @@ def su_context(doc: dict) -> str:
     return ["What type of object is in this photo?", "<image>What is this? Answer with one word.", "Name the object.  ",
             "<image> <image>\nWhat do the two photos have in common?", "No picture here: say hello.",
             "What type of object is in this photo? Let's think step by step."][i] + (f" ({doc['label']})" if i in (0, 5) else "")
+
+
+def ll_logits(ids, vocab: int = 272) -> np.ndarray:
+    """Stand-in decoder of the loglikelihood protocol golden: logits [S, vocab] as a deterministic function of the id prefix; for
+    sequences with an even id sum position t prefers ids[t] (so the reference's UNSHIFTED greedy comparison is true for some requests)."""
+    import zlib
+
+    ids = np.asarray(ids, np.int32)
+    out = np.empty((len(ids), vocab), np.float64)
+    boost = int(ids.sum()) % 2 == 0
+    for t in range(len(ids)):
+        out[t] = np.random.default_rng(zlib.crc32(ids[: t + 1].tobytes())).normal(size=vocab) * 2.0
+        if boost:
+            out[t, ids[t]] += 12.0
+    return out
+
+
+def ll_continuation(doc: dict) -> str:
+    return f" a {doc['label']} thing"
+
+
+def ll_context(doc: dict) -> str:
+    """(loglikelihood contexts carry no `<image>` marker: the reference prepends one per image unconditionally, _llava_hf.py:204-206)"""
+    return su_context(doc).replace("<image>", "").lstrip()

@@ -1,5 +1,5 @@
-"""oracle/multiround.py pinned on the REFERENCE's own run (tests/golden/multiround_protocol.json, written by
-tools/gen_golden_multiround.py: /root/reference/src/models/_qwen2_vl.py:350-616 and _llava_hf.py:440-584 executed in the build
+"""oracle/multiround.py pinned on the REFERENCE's own run (tests/golden/wrapper_protocol.json, written by
+tools/gen_golden_wrappers.py: /root/reference/src/models/_qwen2_vl.py:350-616 and _llava_hf.py:440-584 executed in the build
 container on a stand-in checkpoint whose answer is a function of the rendered prompt).  The restated protocol, driven with the same
 stand-in, must hand the model the same prompts with the same number of images, round by round, and return the same tuples - then
 tests/test_host_logic.py's comparison of the product with this oracle is a comparison with the reference's behaviour."""
@@ -10,7 +10,7 @@ import pytest
 
 from tests import recipes
 
-GOLD = Path(__file__).parent / "golden" / "multiround_protocol.json"
+GOLD = Path(__file__).parent / "golden" / "wrapper_protocol.json"
 
 
 def _in_order(sub: list, full: list) -> bool:
@@ -252,7 +252,7 @@ def _llava_text(tok, image_token_id, p) -> str:
 @pytest.mark.parametrize("case", [0, 1])
 def test_product_generate_until_equals_the_reference_run(case):
     """The HOT PATH's host loop against the reference's own run (`Qwen2VL.generate_until`, /root/reference/src/models/_qwen2_vl.py:
-    143-348, executed by tools/gen_golden_multiround.py on the stand-in checkpoint): six requests - with / without an `<image>`
+    143-348, executed by tools/gen_golden_wrappers.py on the stand-in checkpoint): six requests - with / without an `<image>`
     marker, two images, no image, trailing blanks - through the product's pass pipeline (units of three, merged passes) around a
     stand-in engine.  Equal strings in request order mean equal rendered prompts (the answer is a hash of the prompt), the same
     default `max_new_tokens`, `until` popped and NOT applied, nothing stripped."""
@@ -364,3 +364,63 @@ def test_product_llava_generate_until_equals_the_reference_run(case):
     assert got == gold["results"]
     assert sorted((t, n) for t, _, n in seen) == sorted((t["texts"][0], t["images"]) for t in gold["trace"])
     assert {m for _, m, _ in seen} == {gold["trace"][0]["generate_kwargs"]["max_new_tokens"]}                    # 64 / the default 1024
+
+
+def test_product_llava_loglikelihood_equals_the_reference_run():
+    """`LLaVA.loglikelihood` against the reference's own run (/root/reference/src/models/_llava_hf.py:169-258 on a stand-in decoder whose
+    logits are `recipes.ll_logits(ids)`): six requests (one / two / no image, string and callable targets).  The product hands its
+    engine's scoring call the same ids - image tokens always prepended, the Vicuna prompt and prompt + continuation renderings, every
+    `<image>` expanded to the image's feature count - and the same `start` (the prompt's length tokenised WITHOUT expansion, the
+    reference's label mask), and returns the same (mean shifted cross-entropy, unshifted greedy flag)."""
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+
+    from lmms_owc_amd.engine.llava import DIMS, LlavaDims, LlavaEngine
+    from lmms_owc_amd.models._base import CacheHook
+    from lmms_owc_amd.models._llava_hf import LLaVA, LlavaByteTokenizer
+    from lmms_owc_amd.tasks import TaskInstance
+
+    gold = json.loads(GOLD.read_text())["llava_loglikelihood"]
+    tok = LlavaByteTokenizer()
+    dims = LlavaDims(**{**DIMS["tiny"].__dict__, "image_token_id": tok.image_token_id})
+    assert dims.grid ** 2 == gold["tokens_per_image"]
+    calls = []
+
+    class FakeEngine:
+        d, device = dims, torch.device("cpu")
+        feature_rows = LlavaEngine.feature_rows
+
+        def score(self, ids, feats, grids, start, img_rows=None):
+            ids = np.asarray(ids)
+            assert int((ids == dims.image_token_id).sum()) == len(img_rows)
+            calls.append({"sequence_length": len(ids), "masked_leading_positions": int(start)})
+            z = recipes.ll_logits(ids)
+            lsm = z - np.log(np.exp(z - z.max(1, keepdims=True)).sum(1, keepdims=True)) - z.max(1, keepdims=True)
+            lp = np.array([lsm[i - 1, ids[i]] for i in range(start, len(ids))])
+            return lp.astype(np.float32), z[start:].argmax(1).astype(np.int32)
+
+    class HostOnly(LLaVA):
+        def _encode_visuals(self, flat, feature_cache=None):
+            prepared = [self._views(v) for v in flat]
+            return None, (self._model.feature_rows([p[0].shape[0] for p in prepared], [p[1] for p in prepared]) if prepared else [])
+
+    lm = HostOnly.__new__(HostOnly)
+    lm._engine_batch_arg, lm._decoder_dtype, lm._chat_template = 0, "bf16", None
+    lm._device, lm._rank, lm._world_size, lm.batch_size_per_gpu = torch.device("cpu"), 0, 1, 1
+    lm.cache_hook, lm.task_dict = CacheHook(None), {}
+    lm._tokenizer = lm._processor = tok
+    lm._dims, lm._model, lm._pool = dims, FakeEngine(), ThreadPoolExecutor(max_workers=2)
+    docs, d2v = recipes.su_docs_and_task()
+    lm.task_dict["su"] = {"test": docs}
+    reqs = [TaskInstance(request_type="loglikelihood", idx=0, metadata={"task": "su", "doc_id": d["id"], "repeats": 1},
+                         arguments=(recipes.ll_context(d), recipes.ll_continuation(d) if d["id"] % 2 else (lambda doc: recipes.ll_continuation(doc)),
+                                    d2v, d["id"], "su", "test")) for d in docs]
+    try:
+        got = lm.loglikelihood(reqs)
+    finally:
+        lm._pool.shutdown()
+    assert [c["sequence_length"] for c in calls] == [t["sequence_length"] for t in gold["trace"]]
+    assert [c["masked_leading_positions"] for c in calls] == [t["masked_leading_positions"] for t in gold["trace"]]
+    assert [m for _, m in got] == [m for _, m in gold["results"]] and any(m for _, m in got) and not all(m for _, m in got)
+    np.testing.assert_allclose([l for l, _ in got], [l for l, _ in gold["results"]], rtol=2e-6)

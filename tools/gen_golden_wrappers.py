@@ -4,7 +4,7 @@ produced by RUNNING THE REFERENCE's own `Qwen2VL.generate_until_multi_round` (/r
 `LLaVA.generate_until_multi_round` (/root/reference/src/models/_llava_hf.py:394-584) and the single-round `generate_until` of both
 (`_qwen2_vl.py:143-348`, `_llava_hf.py:260-392`: the hot path's host loop) in this container.  Writes
 
-  tests/golden/multiround_protocol.json
+  tests/golden/wrapper_protocol.json
 
 What runs is the reference's code: its Collator, its round loop, what it hands to / takes back from the task's `doc_to_text`
 (`previous_round_results`, `last_round_info`), its message lists, the `until` cut, the result tuples and their order.  What is
@@ -14,7 +14,7 @@ character) and `qwen_vl_utils.process_vision_info` (collects the image entries o
 executed (it imports every wrapper: torchvision, llava, ...): the two wrapper modules are imported as submodules of a bare
 package.  The task side (docs, `doc_to_visual`, `doc_to_text`) is test INPUT written here, not reference code.
 
-    python tools/gen_golden_multiround.py      # needs /root/reference; the fixture travels, the reference does not
+    python tools/gen_golden_wrappers.py      # needs /root/reference; the fixture travels, the reference does not
 
 The recorded trace per request and round - rendered prompt text, number of images handed to the processor, generation
 arguments - and the returned tuples are what tests/test_host_logic.py checks oracle/multiround.py against (and through it the
@@ -241,6 +241,77 @@ def run_single(module, which: str, TaskInstance, gen_kwargs):
             "contexts": [recipes.su_context(d) for d in docs]}
 
 
+def run_llava_loglik(lm, TaskInstance):
+    """The reference's LLaVA.loglikelihood (src/models/_llava_hf.py:169-258) on a stand-in decoder (logits = recipes.ll_logits of the
+    ids, loss = HF's mean shifted cross-entropy over the unmasked labels): per request the two rendered texts, the image count, how
+    many leading positions the labels mask covers, the sequence length the model saw, and the returned (loss, greedy flag)."""
+    from jinja2.sandbox import ImmutableSandboxedEnvironment
+
+    from lmms_owc_amd.engine.llava import DIMS
+    from lmms_owc_amd.models._llava_hf import LlavaByteTokenizer
+
+    btok, n_per_image = LlavaByteTokenizer(), DIMS["tiny"].grid ** 2
+    trace = []
+    docs, d2v = recipes.su_docs_and_task()
+
+    class Tok(CharTokenizer):
+        chat_template = None
+
+        def apply_chat_template(self, messages, tokenize=False, add_generation_prompt=True):
+            env = ImmutableSandboxedEnvironment(trim_blocks=True, lstrip_blocks=True)
+            return env.from_string(self.chat_template).render(messages=messages, add_generation_prompt=add_generation_prompt,
+                                                              bos_token="<s>", eos_token="</s>")
+
+    class Processor:
+        def __call__(self, text=None, images=None, return_tensors="pt"):
+            ids = btok.encode(text[0], add_special_tokens=True)
+            if images:   # (HF's LlavaProcessor expands every <image> to the image's feature count only when images are given)
+                ids = [t for i in ids for t in ([i] * n_per_image if i == btok.image_token_id else [i])]
+            self.last = {"text": text[0], "images": 0 if images is None else len(images)}
+            return FakeInputs(input_ids=torch.tensor([ids]))
+
+    proc = Processor()
+
+    class Net:
+        device, dtype = torch.device("cpu"), torch.float32
+
+        def __call__(self, input_ids=None, labels=None, **kw):
+            logits = torch.from_numpy(recipes.ll_logits(input_ids[0].numpy()))[None]
+            shift_logits, shift_labels = logits[0, :-1], labels[0, 1:]
+            loss = torch.nn.functional.cross_entropy(shift_logits, shift_labels.long(), ignore_index=-100)
+            trace[-1].update({"masked_leading_positions": int((labels[0] == -100).sum()), "sequence_length": int(input_ids.shape[1])})
+            return {"loss": loss, "logits": logits}
+
+    obj = object.__new__(lm.LLaVA)
+    fields = {"_tokenizer": Tok(), "_processor": proc, "processor": proc, "_model": Net(), "batch_size_per_gpu": 1, "_rank": 0,
+              "_world_size": 1, "_device_map": "cpu", "_use_cache": True, "_chat_template": None, "task_dict": {"su": {"test": docs}},
+              "accelerator": types.SimpleNamespace(is_main_process=False, unwrap_model=lambda m: m)}
+    for k, v in fields.items():
+        try:
+            object.__setattr__(obj, k, v)
+        except AttributeError:
+            pass
+    reqs = []
+    for d in docs:
+        target = recipes.ll_continuation(d) if d["id"] % 2 else (lambda doc: recipes.ll_continuation(doc))   # str and callable targets
+        reqs.append(TaskInstance(request_type="loglikelihood", arguments=(recipes.ll_context(d), target, d2v, d["id"], "su", "test"), idx=0,
+                                 metadata={"task": "su", "doc_id": d["id"], "repeats": 1}))
+    orig_call = proc.__class__.__call__
+
+    def spy(self, text=None, images=None, return_tensors="pt"):
+        out = orig_call(self, text=text, images=images, return_tensors=return_tensors)
+        if images is not None:
+            trace.append({"prompt_and_continuation": text[0], "images": len(images)})
+        else:
+            trace[-1]["prompt"] = text[0]
+        return out
+
+    proc.__class__.__call__ = spy
+    res = obj.loglikelihood(reqs)
+    return {"results": [[float(a), bool(b)] for a, b in res], "trace": trace, "contexts": [recipes.ll_context(d) for d in docs],
+            "continuations": [recipes.ll_continuation(d) for d in docs], "tokens_per_image": n_per_image}
+
+
 def main():
     qm, lm, TaskInstance = import_wrappers()
     out = {"versions": G.versions(),
@@ -253,10 +324,11 @@ def main():
                {"max_new_tokens": 16, "temperature": 0})],
            "llava": [run_llava(lm, TaskInstance, gk) for gk in ({"max_new_tokens": 48, "do_sample": False, "until": ["STOP"]}, {})],
            "qwen2vl_single": [run_single(qm, "qwen", TaskInstance, gk) for gk in ({"max_new_tokens": 64, "do_sample": False, "until": ["STOP"]}, {})],
-           "llava_single": [run_single(lm, "llava", TaskInstance, gk) for gk in ({"max_new_tokens": 64, "do_sample": False, "until": ["STOP"]}, {})]}
+           "llava_single": [run_single(lm, "llava", TaskInstance, gk) for gk in ({"max_new_tokens": 64, "do_sample": False, "until": ["STOP"]}, {})],
+           "llava_loglikelihood": run_llava_loglik(lm, TaskInstance)}
     GOLD.mkdir(parents=True, exist_ok=True)
-    (GOLD / "multiround_protocol.json").write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
-    print("wrote", GOLD / "multiround_protocol.json", {k: len(v) if isinstance(v, list) else "-" for k, v in out.items()})
+    (GOLD / "wrapper_protocol.json").write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
+    print("wrote", GOLD / "wrapper_protocol.json", {k: len(v) if isinstance(v, list) else "-" for k, v in out.items()})
 
 
 if __name__ == "__main__":
