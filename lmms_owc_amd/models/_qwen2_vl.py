@@ -217,7 +217,22 @@ class Qwen2VL(PassPipeline, Model):
                 new = [(i, v) for k, (i, v) in enumerate(new) if all(id(v) != id(w) or i != j for j, w in new[:k])]
                 if not new:
                     return
-                arrs = list(self._pool.map(lambda v: imageproc.prepare_image(v, self._min_pixels, self._max_pixels), [v for _, v in new]))
+                def prep(v):
+                    # a PIL image goes through the JPEG round trip the reference applies when it builds the message (:485-490); a task
+                    # that hands back a message in the reference's own format - a base64 JPEG data URL - is decoded as it is
+                    if isinstance(v, str):
+                        import base64
+                        from io import BytesIO
+
+                        from PIL import Image
+
+                        if not v.startswith("data:image") or ";base64," not in v:
+                            raise ValueError("multi-round: an image entry of a message must be a PIL image or a base64 data URL")
+                        return imageproc.prepare_image(Image.open(BytesIO(base64.b64decode(v.split(";base64,", 1)[1]))),
+                                                       self._min_pixels, self._max_pixels, jpeg=False)
+                    return imageproc.prepare_image(v, self._min_pixels, self._max_pixels)
+
+                arrs = list(self._pool.map(prep, [v for _, v in new]))
                 grids = [(1, a.shape[1] // 14, a.shape[2] // 14) for a in arrs]
                 e = self._model.encode_images(self._pixel_values(arrs), grids)
                 emb = e if emb is None or e is None else torch.cat([emb, e])

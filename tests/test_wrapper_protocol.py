@@ -101,8 +101,8 @@ def _text_of_ids(tok, ids) -> str:
     return "".join(out)
 
 
-@pytest.mark.parametrize("case", [0, 1, 2])
-def test_product_multi_round_equals_the_reference_run(case):
+@pytest.mark.parametrize("case,data_urls", [(0, False), (1, False), (2, False), (0, True)])
+def test_product_multi_round_equals_the_reference_run(case, data_urls):
     """The PRODUCT's host path against the reference's own run, no oracle in between: `Qwen2VL.generate_until_multi_round` (batched,
     three requests per engine pass) around a stand-in engine that decodes the prompt ids it is handed back into text and answers
     with the golden's stand-in function of that text.  Every answer is a hash of the rendered conversation, so equal result tuples
@@ -141,6 +141,24 @@ def test_product_multi_round_equals_the_reference_run(case):
             return None
 
     docs, d2v, d2t = recipes.mr_docs_and_task()
+    if data_urls:   # a task that hands the conversation back in the REFERENCE's message format: images as base64 JPEG data URLs (:485-500)
+        import base64
+        from io import BytesIO
+
+        base = d2t
+
+        def d2t(doc, round_idx=0, previous_round_results=None, last_round_info=None):   # noqa: F811
+            vis, text, terminal, prev, info = base(doc, round_idx=round_idx, previous_round_results=previous_round_results,
+                                                   last_round_info=last_round_info)
+            for msg in (info or {}).get("messages", []):
+                for turn in msg:
+                    for c in turn["content"] if isinstance(turn["content"], list) else []:
+                        if c.get("type") == "image" and not isinstance(c["image"], str):
+                            buf = BytesIO()
+                            c["image"].convert("RGB").save(buf, format="JPEG")
+                            c["image"] = "data:image/jpeg;base64," + base64.b64encode(buf.getvalue()).decode()
+            return vis, text, terminal, prev, info
+
     lm = HostOnly.from_engine(FakeEngine(), tok, batch_size=3)
     lm.task_dict["mr"] = {"test": docs}
     reqs = [TaskInstance(request_type="generate_until_multi_round", idx=0, metadata={"task": "mr", "doc_id": d["id"], "repeats": 1},
