@@ -173,9 +173,14 @@ class ClassificationTask:
     def dump_config(self) -> dict:
         """`configs[task]` of the results file: the keys `TaskConfig.to_dict` writes for a classification task
         (src/data/tasks/_config.py; key set and order pinned in tests/golden/engine_formats.json)."""
-        msk = {"pre_prompt": self.pre_prompt, "prompt": self.prompt, "post_prompt": self.post_prompt}
-        if self.prompts is not None:
-            msk["prompts"] = list(self.prompts)
+        # the YAML's own `model_specific_kwargs.default` when the task came from one (key order included); else the keys the
+        # reference's task YAMLs of that type carry: pre_prompt / prompt / post_prompt, a multi-round task `prompts` in place of `prompt`
+        msk = getattr(self, "_msk_yaml", None)
+        if msk is None:
+            msk = {"pre_prompt": self.pre_prompt, "prompt": self.prompt, "post_prompt": self.post_prompt}
+            if self.prompts is not None:
+                msk = {"pre_prompt": self.pre_prompt, "prompts": list(self.prompts), "post_prompt": self.post_prompt}
+        msk = copy.deepcopy(msk)
         return {
             "task": self.task_name, "dataset_path": self.dataset_path, "dataset_kwargs": {}, "test_split": self.split,
             "full_docs": False, "process_results_use_image": False, "doc_to_visual": repr(self.doc_to_visual),
@@ -210,6 +215,8 @@ def load_task(name: str, *, data_root: str | Path = "data", include_path: str | 
                               generation_kwargs=cfg.get("generation_kwargs"), metric_list=cfg.get("metric_list"),
                               split=cfg.get("test_split", "test"), output_type=output_type,
                               prompts=msk.get("prompts") if output_type == "generate_until_multi_round" else None)
+    if msk:
+        task._msk_yaml = dict(msk)
     task.dataset_path = dataset_path
     return task
 

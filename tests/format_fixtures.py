@@ -42,6 +42,29 @@ class StandInModel:
         return out
 
 
+    def generate_until_multi_round(self, requests):
+        out = []
+        for r in requests:
+            ctx, gen_kwargs, d2v, d2t, doc_id, task, split = r.args
+            gen_kwargs.pop("until", None)
+            doc = self.task_dict[task][split][doc_id]
+            out.append(recipes.toy_multi_round_answers(doc_id, doc["target"], d2t, doc))
+        return out
+
+
+TOY_MR_PROMPTS = ["What type of object is in this photo? Summarise.", "Caption the image.", "Reason about the caption.", "Give the final answer."]
+
+
+def toy_task_mr():
+    from lmms_owc_amd.tasks import ClassificationTask
+
+    t = ClassificationTask("toymr", recipes.toy_docs(), output_type="generate_until_multi_round", prompts=list(TOY_MR_PROMPTS),
+                           generation_kwargs={"max_new_tokens": 64, "do_sample": False}, metric_list=[dict(m) for m in TOY_METRICS])
+    t.dataset_path = "data/toy"
+    t.doc_to_visual = lambda doc: []
+    return t
+
+
 def toy_task():
     from lmms_owc_amd.tasks import ClassificationTask
 
@@ -61,7 +84,7 @@ def install_text_pipeline(scorer) -> None:
     text.set_concept_nlp(lambda texts: [recipes.toy_nlp(t) for t in texts])
 
 
-def run_engine(out_dir: Path) -> tuple[dict, dict]:
+def run_engine(out_dir: Path, multi_round: bool = False) -> tuple[dict, dict]:
     """simple_evaluate + tracker exactly as eval_model.py drives them; returns (results, {file name: text})."""
     from lmms_owc_amd.engine.evaluate import simple_evaluate
     from lmms_owc_amd.engine.tracker import EngineTracker
@@ -69,7 +92,8 @@ def run_engine(out_dir: Path) -> tuple[dict, dict]:
     tracker = EngineTracker(output_path=str(out_dir))
     tracker.log_experiment_args(model_source="stand-in", model_args="", system_instruction=None, chat_template=None,
                                 fewshot_as_multiturn=False)
-    res = simple_evaluate(model="stand-in", model_args="", task_objects={"toytask": toy_task()}, batch_size=1, limit=7,
+    tasks = {"toymr": toy_task_mr()} if multi_round else {"toytask": toy_task()}
+    res = simple_evaluate(model="stand-in", model_args="", task_objects=tasks, batch_size=1, limit=7,
                           model_object=StandInModel(), datetime_str=DATE)
     samples = res.pop("samples")
     tracker.save_results_aggregated(results=res, samples=samples, datetime_str=DATE)
@@ -94,8 +118,9 @@ def assert_same_json(got, want, tol: float, path: str = "") -> None:
         assert type(got) is type(want) and got == want, f"{path}: {got!r} != {want!r}"
 
 
-def check_engine_files(files: dict, tol: float) -> None:
-    gold = json.loads((GOLD / "engine_formats.json").read_text())["files"]
+def check_engine_files(files: dict, tol: float, multi_round: bool = False) -> None:
+    gold = json.loads((GOLD / "engine_formats.json").read_text())
+    gold, task = (gold["multi_round"]["files"], "toymr") if multi_round else (gold["files"], "toytask")
     assert sorted(files) == sorted(gold)
     sname = next(n for n in gold if "_samples_" in n)
     got_lines, want_lines = files[sname].splitlines(), gold[sname].splitlines()
@@ -107,7 +132,7 @@ def check_engine_files(files: dict, tol: float) -> None:
     assert list(got) == list(want), (list(got), list(want))
     for k in VOLATILE_RESULT_KEYS:
         got.pop(k), want.pop(k)
-    for cfg in (got["configs"]["toytask"], want["configs"]["toytask"]):
+    for cfg in (got["configs"][task], want["configs"][task]):
         for k in VOLATILE_CONFIG_KEYS:
             cfg.pop(k)
     assert_same_json(got, want, tol, "results.json")
@@ -115,7 +140,7 @@ def check_engine_files(files: dict, tol: float) -> None:
     assert files[rname].count("\n") == gold[rname].count("\n") and files[rname].startswith('{\n  "results": {')
 
 
-def check_eval_metrics(root: Path, capsys, tol: float) -> None:
+def check_eval_metrics(root: Path, capsys, tol: float, multi_round: bool = False) -> None:
     """Runs THIS repo's eval_metrics.main on the reference's `before` file; the rewritten JSONL and the printed table must
     equal the reference's `after` / stdout (columns, order, int-vs-float formatting; floats within tol)."""
     import os
@@ -124,9 +149,12 @@ def check_eval_metrics(root: Path, capsys, tol: float) -> None:
     import eval_metrics
 
     gold = json.loads((GOLD / "eval_metrics.json").read_text())
-    d = root / "logs" / "schedule" / "toytask" / "stand-in"
+    task = "toymr" if multi_round else "toytask"
+    if multi_round:
+        gold = gold["multi_round"]
+    d = root / "logs" / "schedule" / task / "stand-in"
     d.mkdir(parents=True)
-    f = d / "2026-01-02T03-04-05_samples_toytask.jsonl"
+    f = d / f"2026-01-02T03-04-05_samples_{task}.jsonl"
     f.write_text(gold["before"])
     cwd = os.getcwd()
     os.chdir(root)

@@ -355,6 +355,21 @@ def toy_answer(doc_id: int, target: str) -> str:
             f"this photo shows the {t} in a garden", f"{t}."][doc_id % 7]
 
 
+def toy_multi_round_answers(doc_id: int, target: str, doc_to_text, doc) -> tuple:
+    """Stand-in for a wrapper's `generate_until_multi_round` on one request: rounds until the task's terminal signal; the last
+    round answers like `toy_answer`, the earlier ones carry a round tag."""
+    answers, r = [f"{toy_answer(doc_id, target)} [round 0]"], 1
+    while True:
+        out = doc_to_text(doc, round_idx=r, previous_round_results=list(answers), last_round_info=None)
+        answers = list(out[3])
+        if out[2]:
+            break
+        answers.append(f"{toy_answer(doc_id, target)} [round {r}]")
+        r += 1
+    answers[-1] = toy_answer(doc_id, target)
+    return tuple(answers)
+
+
 def toy_concept_items() -> list:
     """(ref, pred) pairs for concept_semantic_similarity: str / [str] refs, str / [.., str] preds, duplicates, prefix words
     ('the', 'a', 'its'), skip words ('this photo', 'image', 'it'), capitalised entities, a one-concept prediction."""

@@ -46,6 +46,19 @@ def test_eval_metrics_cli_matches_reference(pipeline, tmp_path, capsys):
     F.check_eval_metrics(tmp_path, capsys, tol=2e-6)
 
 
+def test_multi_round_task_files_match_reference_tracker(pipeline, tmp_path):
+    """The same through a `generate_until_multi_round` task (the `*_llamav_o1` configs' type): 7-tuple requests, the tuple of round
+    answers nested in `resps`, scoring on the LAST round (`_manager.py:1033-1036`) - results dict and samples file of the reference's
+    own engine + tracker run (tools/gen_golden_formats.py)."""
+    _, files = F.run_engine(tmp_path / "out", multi_round=True)
+    F.check_engine_files(files, tol=2e-6, multi_round=True)
+
+
+def test_eval_metrics_cli_on_a_multi_round_samples_file_matches_reference(pipeline, tmp_path, capsys):
+    """eval_metrics.py:67-68 unwraps the nested multi-round responses before scoring."""
+    F.check_eval_metrics(tmp_path, capsys, tol=2e-6, multi_round=True)
+
+
 def test_concept_semantic_similarity_matches_reference(pipeline):
     F.check_concept_similarity(tol=2e-6)
 

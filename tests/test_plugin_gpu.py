@@ -223,6 +223,14 @@ def test_eval_metrics_cli_matches_reference_gpu(ref_pipeline, tmp_path, capsys):
     ref_pipeline.check_eval_metrics(tmp_path, capsys, tol=2e-5)
 
 
+def test_multi_round_engine_files_and_eval_metrics_match_reference_gpu(ref_pipeline, tmp_path, capsys):
+    """The `generate_until_multi_round` task type through the same two checks (nested round answers, last-round scoring,
+    eval_metrics.py's unwrap), on the HIP scorer."""
+    _, files = ref_pipeline.run_engine(tmp_path / "out", multi_round=True)
+    ref_pipeline.check_engine_files(files, tol=2e-5, multi_round=True)
+    ref_pipeline.check_eval_metrics(tmp_path / "em", capsys, tol=2e-5, multi_round=True)
+
+
 def test_concept_semantic_similarity_matches_reference_gpu(ref_pipeline):
     """The reference's concept_semantic_similarity with the injected parser: same concept lists, similarities and the four
     reductions within 2e-5 (tests/golden/concept_similarity.json)."""

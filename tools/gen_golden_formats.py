@@ -83,9 +83,25 @@ metadata:
   - version: 0.0
 """
 
+TOY_MR_PROMPTS = ["What type of object is in this photo? Summarise.", "Caption the image.", "Reason about the caption.", "Give the final answer."]
+TOY_MR_YAML = TOY_YAML.replace('task: "toytask"', 'task: "toymr"').replace(
+    '    prompt: "What type of object is in this photo?"\n', "    prompts:\n" + "".join(f'      - "{q}"\n' for q in TOY_MR_PROMPTS)).replace(
+    "doc_to_text: !function toy_utils.doc_to_text\n", "doc_to_text: !function toy_utils.doc_to_text_multi_round\n").replace(
+    "output_type: generate_until\n", "output_type: generate_until_multi_round\n")
+
 TOY_UTILS = '''
 def doc_to_visual(doc):
     return []
+
+
+def doc_to_text_multi_round(doc, model_specific_kwargs=None, round_idx=None, previous_round_results=None, last_round_info=None):
+    k = model_specific_kwargs or {}
+    prompts = k["prompts"]
+    if round_idx is None:
+        return k.get("pre_prompt", "") + prompts[0] + k.get("post_prompt", "")
+    if round_idx < len(prompts):
+        return None, k.get("pre_prompt", "") + prompts[round_idx] + k.get("post_prompt", ""), False, previous_round_results or [], last_round_info
+    return None, None, True, previous_round_results or [], last_round_info
 
 
 def doc_to_text(doc, model_specific_kwargs=None):
@@ -149,6 +165,17 @@ def setup_reference():
                 out.append(recipes.toy_answer(doc_id, doc["target"]))
             return out
 
+        def generate_until_multi_round(self, requests):
+            """The wrapper's side of the protocol (_qwen2_vl.py:434-603) without a model: rounds until the task's terminal signal, the
+            last round answers like `generate_until`, the earlier ones with a round tag."""
+            out = []
+            for r in requests:
+                ctx, gen_kwargs, d2v, d2t, doc_id, task, split = r.args
+                gen_kwargs.pop("until", None)
+                doc = self.task_dict[task][split][doc_id]
+                out.append(recipes.toy_multi_round_answers(doc_id, doc["target"], d2t, doc))
+            return out
+
     m.Model, m.get_model = Model, (lambda name, **kw: StandInModel(**kw))
     sys.modules["src.models"] = m
     c = recipes.bert_cfg("tiny")
@@ -158,23 +185,24 @@ def setup_reference():
     return metrics, text_mod, utils
 
 
-def run_engine(tmp: Path) -> dict:
+def run_engine(tmp: Path, task: str = "toytask", yaml_text: str = TOY_YAML) -> dict:
     import datasets
 
     import src.engine as E
     from src.data.tasks import TaskManager
 
     docs = recipes.toy_docs()
-    datasets.DatasetDict({"test": datasets.Dataset.from_list(docs)}).save_to_disk(str(tmp / "data" / "toy"))
-    tdir = tmp / "tasks" / "toytask"
+    if not (tmp / "data" / "toy").exists():
+        datasets.DatasetDict({"test": datasets.Dataset.from_list(docs)}).save_to_disk(str(tmp / "data" / "toy"))
+    tdir = tmp / "tasks" / task
     tdir.mkdir(parents=True)
-    (tdir / "toytask.yaml").write_text(TOY_YAML)
+    (tdir / f"{task}.yaml").write_text(yaml_text)
     (tdir / "toy_utils.py").write_text(TOY_UTILS)
-    out_dir = tmp / "logs" / "schedule" / "toytask" / "stand-in"
+    out_dir = tmp / "logs" / "schedule" / task / "stand-in"
     tracker = E.EngineTracker(output_path=str(out_dir))
-    tm = TaskManager(include_path=str(tmp / "tasks"), include_defaults=False, model_name="stand-in")
+    tm = TaskManager(include_path=str(tmp / "tasks" / task), include_defaults=False, model_name="stand-in")
     date = "2026-01-02T03:04:05"
-    res = E.simple_evaluate(model_name="stand-in", model_args="", tasks=["toytask"], batch_size=1, limit=7, bootstrap_iters=100000,
+    res = E.simple_evaluate(model_name="stand-in", model_args="", tasks=[task], batch_size=1, limit=7, bootstrap_iters=100000,
                             log_samples=True, engine_tracker=tracker, task_manager=tm, datetime_str=date,
                             cli_args=Namespace(process_with_media=False, output_path=str(out_dir)))
     samples = res.pop("samples")
@@ -185,16 +213,16 @@ def run_engine(tmp: Path) -> dict:
     return {"results": json.loads(json.dumps(res, default=str)), "files": files, "out_dir_rel": str(out_dir.relative_to(tmp))}
 
 
-def run_eval_metrics(tmp: Path, samples_name: str) -> dict:
+def run_eval_metrics(tmp: Path, samples_name: str, task: str = "toytask") -> dict:
     spec = importlib.util.spec_from_file_location("ref_eval_metrics", REF / "eval_metrics.py")
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    f = tmp / "logs" / "schedule" / "toytask" / "stand-in" / samples_name
+    f = tmp / "logs" / "schedule" / task / "stand-in" / samples_name
     before = f.read_text()
     buf = io.StringIO()
     metrics = "semantic_similarity,textual_inclusion,mean_average_semantic_similarity,concept_semantic_similarity"
     with contextlib.redirect_stdout(buf):
-        mod.main(Namespace(input="logs/schedule", metrics=metrics, seed=1234, log_level="WARNING"))
+        mod.main(Namespace(input=f"logs/schedule/{task}", metrics=metrics, seed=1234, log_level="WARNING"))
     return {"metrics": metrics, "before": before, "after": f.read_text(), "stdout": buf.getvalue()}
 
 
@@ -222,6 +250,10 @@ def main():
             eng = run_engine(tmp)
             sname = next(n for n in eng["files"] if "_samples_" in n)
             em = run_eval_metrics(tmp, sname)
+            # the same through a MULTI-ROUND task (output_type generate_until_multi_round: 7-tuple requests, last-round scoring
+            # _manager.py:1033-1036, nested `resps`, eval_metrics.py:67-68's unwrap)
+            eng["multi_round"] = run_engine(tmp, "toymr", TOY_MR_YAML)
+            em["multi_round"] = run_eval_metrics(tmp, next(n for n in eng["multi_round"]["files"] if "_samples_" in n), "toymr")
         conc = run_concept(metrics)
     finally:
         os.chdir(cwd)
