@@ -442,6 +442,54 @@ def test_multi_round_generation(gpu, scorer):
     assert len(smp) == 4 and len(smp[0]["filtered_resps"][0]) == 3 and "semantic_similarity,none" in res["results"]["synthetic"]
 
 
+def test_multi_round_new_image_in_a_later_round_and_per_document_termination(gpu):
+    """Round 4 (found by running the reference's wrapper, tests/test_wrapper_protocol.py): a later round may bring a NEW image - it is
+    encoded when it appears and its rows are scattered behind the round-0 image's - and every document of a batch ends on its OWN
+    terminal signal.  Real engine: document 1's second round (two images in the conversation) equals the hand-built conversation fed
+    to the engine directly; the answers do not depend on the batch size; documents have 1 / 2 / 3 rounds."""
+    import torch
+    from PIL import Image
+
+    from lmms_owc_amd import ops
+    from lmms_owc_amd.models import get_model, imageproc
+    from lmms_owc_amd.tasks import TaskInstance
+
+    r = np.random.default_rng(5)
+    docs = [{"i": i, "img": Image.fromarray(r.integers(0, 256, (56 + 28 * i, 84, 3), dtype=np.uint8), "RGB"),
+             "extra": Image.fromarray(r.integers(0, 256, (84, 56, 3), dtype=np.uint8), "RGB")} for i in range(3)]
+    qs = ["What is in the photo?", "And in this second one?", "So what do they share?"]
+
+    def d2v(doc):
+        return [doc["img"]]
+
+    def d2t(doc, round_idx=0, previous_round_results=None, last_round_info=None):
+        prev = list(previous_round_results or [])
+        if round_idx > doc["i"]:                       # document i runs i + 1 rounds
+            return None, None, True, prev, last_round_info
+        return ([doc["extra"]] if round_idx == 1 else None), qs[round_idx], False, prev, last_round_info
+
+    outs = []
+    for bs in (1, 3):
+        lm = get_model("custom-model", model_type="qwen2-vl", model_name_or_path="synthetic:tiny", batch_size=bs)
+        lm.task_dict["mr"] = {"test": docs}
+        reqs = [TaskInstance(request_type="generate_until_multi_round", idx=0, metadata={"task": "mr", "doc_id": d["i"], "repeats": 1},
+                             arguments=("<image>" + qs[0], {"max_new_tokens": 6, "do_sample": False}, d2v, d2t, d["i"], "mr", "test")) for d in docs]
+        outs.append(lm.generate_until_multi_round(reqs))
+    assert outs[0] == outs[1] and [len(t) for t in outs[0]] == [1, 2, 3]
+    # document 2, round 1, by hand: system + (user: image A + q0) + (assistant: a0) + (user: image B + q1)
+    tok, eng = lm.tokenizer, lm.model
+    arrs = [imageproc.prepare_image(v, lm._min_pixels, lm._max_pixels) for v in (docs[2]["img"], docs[2]["extra"])]
+    grids = [(1, a.shape[1] // 14, a.shape[2] // 14) for a in arrs]
+    emb = torch.cat([eng.encode_images(ops.patchify_u8(torch.from_numpy(a[None]).to(gpu), imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD), [g])
+                     for a, g in zip(arrs, grids)])
+    a0, a1, _ = outs[0][2]
+    n = [g[1] * g[2] // 4 for g in grids]
+    ids = tok.chat_ids_turns([("user", qs[0], [n[0]]), ("assistant", a0, []), ("user", qs[1], [n[1]])])
+    toks = eng.generate([np.asarray(ids, np.int32)], emb, [grids], 6, eos_token_id=tok.eos_token_id, pad_token_id=0).cpu().numpy()[0]
+    stop = np.flatnonzero(toks == tok.eos_token_id)
+    assert tok.decode(toks[: stop[0]] if len(stop) else toks) == a1
+
+
 @pytest.mark.parametrize("name", ["tiny", "tiny-next"])
 def test_llava_multi_round_generation(gpu, scorer, name):
     """LLaVA.generate_until_multi_round (/root/reference/src/models/_llava_hf.py:394-584): NO history - every round is an
