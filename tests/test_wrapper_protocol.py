@@ -267,7 +267,7 @@ def _llava_text(tok, image_token_id, p) -> str:
     return text
 
 
-@pytest.mark.parametrize("case", [0, 1])
+@pytest.mark.parametrize("case", [0, 1, 2])
 def test_product_generate_until_equals_the_reference_run(case):
     """The HOT PATH's host loop against the reference's own run (`Qwen2VL.generate_until`, /root/reference/src/models/_qwen2_vl.py:
     143-348, executed by tools/gen_golden_wrappers.py on the stand-in checkpoint): six requests - with / without an `<image>`
@@ -307,9 +307,11 @@ def test_product_generate_until_equals_the_reference_run(case):
             pass
 
         def _launch_chunk(self, prep, eos_token_id, pad, carry=None):
+            sampled.append(prep["sampling"])
             return self._model.generate(prep["prompts"], None, prep["grids"], prep["max_new"], eos_token_id=eos_token_id, pad_token_id=pad), _DoneEvent()
 
     docs, d2v = recipes.su_docs_and_task()
+    sampled = []
     lm = HostOnly.from_engine(FakeEngine(), tok, batch_size=3)
     lm._no_carry = True
     lm.task_dict["su"] = {"test": docs}
@@ -324,9 +326,16 @@ def test_product_generate_until_equals_the_reference_run(case):
     assert sorted((t, n) for t, _, n in seen) == sorted((t["texts"][0], t["images"]) for t in gold["trace"])     # prompts AND image counts
     assert {m for _, m, _ in seen} == {gold["trace"][0]["generate_kwargs"]["max_new_tokens"]}                    # 64 / the default 128
     assert all("until" not in r.args[1] for r in reqs)             # popped from the request's own dict, as the reference does (:211-219)
+    # `do_sample = temperature > 0` (:308-329): what the reference hands HF generate is what the on-device sampler is given
+    kw = gold["trace"][0]["generate_kwargs"]
+    assert kw["num_beams"] == 1 and kw["do_sample"] is (case == 2)
+    if case == 2:
+        assert all(s_ is not None and abs(s_["temperature"] - kw["temperature"]) < 1e-6 and abs(s_["top_p"] - kw["top_p"]) < 1e-6 for s_ in sampled)
+    else:
+        assert all(s_ is None for s_ in sampled) and kw["temperature"] == 0
 
 
-@pytest.mark.parametrize("case", [0, 1])
+@pytest.mark.parametrize("case", [0, 1, 2])
 def test_product_llava_generate_until_equals_the_reference_run(case):
     """`LLaVA.generate_until` (/root/reference/src/models/_llava_hf.py:260-392) the same way."""
     import numpy as np
@@ -355,6 +364,7 @@ def test_product_llava_generate_until_equals_the_reference_run(case):
             pass
 
         def _launch_chunk(self, prep, eos_token_id, pad, carry=None):
+            sampled.append(prep["sampling"])
             out = np.full((prep["n"], prep["max_new"]), eos_token_id, np.int32)
             for i, p in enumerate(prep["prompts"]):
                 text = _llava_text(tok, dims.image_token_id, p)
@@ -370,6 +380,7 @@ def test_product_llava_generate_until_equals_the_reference_run(case):
     lm._tokenizer = lm._processor = tok
     lm._dims, lm._model = dims, FakeEngine()
     lm._pool, lm._prep_thread = ThreadPoolExecutor(max_workers=2), ThreadPoolExecutor(max_workers=1)
+    sampled = []
     docs, d2v = recipes.su_docs_and_task()
     lm.task_dict["su"] = {"test": docs}
     reqs = [TaskInstance(request_type="generate_until", idx=0, metadata={"task": "su", "doc_id": d["id"], "repeats": 1},
@@ -382,6 +393,12 @@ def test_product_llava_generate_until_equals_the_reference_run(case):
     assert got == gold["results"]
     assert sorted((t, n) for t, _, n in seen) == sorted((t["texts"][0], t["images"]) for t in gold["trace"])
     assert {m for _, m, _ in seen} == {gold["trace"][0]["generate_kwargs"]["max_new_tokens"]}                    # 64 / the default 1024
+    kw = gold["trace"][0]["generate_kwargs"]
+    assert kw["num_beams"] == 1 and kw["do_sample"] is (case == 2)
+    if case == 2:
+        assert all(s_ is not None and abs(s_["temperature"] - kw["temperature"]) < 1e-6 and abs(s_["top_p"] - kw["top_p"]) < 1e-6 for s_ in sampled)
+    else:
+        assert all(s_ is None for s_ in sampled)
 
 
 def test_product_llava_loglikelihood_equals_the_reference_run():

@@ -323,8 +323,10 @@ def main():
                {"until": "STOP"},
                {"max_new_tokens": 16, "temperature": 0})],
            "llava": [run_llava(lm, TaskInstance, gk) for gk in ({"max_new_tokens": 48, "do_sample": False, "until": ["STOP"]}, {})],
-           "qwen2vl_single": [run_single(qm, "qwen", TaskInstance, gk) for gk in ({"max_new_tokens": 64, "do_sample": False, "until": ["STOP"]}, {})],
-           "llava_single": [run_single(lm, "llava", TaskInstance, gk) for gk in ({"max_new_tokens": 64, "do_sample": False, "until": ["STOP"]}, {})],
+           "qwen2vl_single": [run_single(qm, "qwen", TaskInstance, gk) for gk in (
+               {"max_new_tokens": 64, "do_sample": False, "until": ["STOP"]}, {}, {"max_new_tokens": 64, "temperature": 0.8, "top_p": 0.9})],
+           "llava_single": [run_single(lm, "llava", TaskInstance, gk) for gk in (
+               {"max_new_tokens": 64, "do_sample": False, "until": ["STOP"]}, {}, {"max_new_tokens": 64, "temperature": 0.8, "top_p": 0.9})],
            "llava_loglikelihood": run_llava_loglik(lm, TaskInstance)}
     GOLD.mkdir(parents=True, exist_ok=True)
     (GOLD / "wrapper_protocol.json").write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
