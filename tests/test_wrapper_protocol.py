@@ -459,3 +459,125 @@ def test_product_llava_loglikelihood_equals_the_reference_run():
     assert [c["masked_leading_positions"] for c in calls] == [t["masked_leading_positions"] for t in gold["trace"]]
     assert [m for _, m in got] == [m for _, m in gold["results"]] and any(m for _, m in got) and not all(m for _, m in got)
     np.testing.assert_allclose([l for l, _ in got], [l for l, _ in gold["results"]], rtol=2e-6)
+
+
+def test_prompt_ids_with_a_real_tokenizer_equal_hf_processor(tmp_path):
+    """The checkpoint path of the prompt builder (`Qwen2VL._prompt_ids` / `_messages_ids` with an HF tokenizer: chat template through
+    the tokenizer, every `<|image_pad|>` expanded to its image's token count) against HF's own `Qwen2VLProcessor.__call__` - what the
+    reference runs at `_qwen2_vl.py:289-305` - on the tiny on-disk tokenizer of tests/ckpt_util.py: one, two and no images, a
+    two-turn conversation.  (The processor object is assembled without its video processor: transformers 5.x wants torchvision
+    for that class; the image / text path is HF's code.)"""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from transformers import AutoTokenizer, Qwen2VLImageProcessor, Qwen2VLProcessor
+
+    from lmms_owc_amd.models import imageproc
+    from lmms_owc_amd.models._qwen2_vl import SYSTEM_PROMPT, Qwen2VL
+    from tests import ckpt_util
+
+    cfg = recipes.tiny_cfg()
+    specials = {"<|endoftext|>": 490, "<|im_start|>": 491, "<|im_end|>": 492, "<|vision_start|>": 493, "<|vision_end|>": 494,
+                "<|image_pad|>": cfg.image_token_id}
+    ckpt_util.write_tokenizer(tmp_path, cfg.text.vocab_size, specials)
+    tok = AutoTokenizer.from_pretrained(str(tmp_path))
+    proc = object.__new__(Qwen2VLProcessor)
+    proc.image_processor, proc.tokenizer = Qwen2VLImageProcessor(min_pixels=4 * 784, max_pixels=1024 * 784), tok
+    proc.video_processor, proc.chat_template = None, tok.chat_template
+    proc.image_token, proc.video_token = "<|image_pad|>", "<|video_pad|>"
+    proc.image_token_id, proc.video_token_id = cfg.image_token_id, None
+
+    class Dims:
+        image_token_id, decoder_dtype = cfg.image_token_id, "bf16"
+
+    class FakeEngine:
+        d, device = Dims(), torch.device("cpu")
+
+    lm = Qwen2VL.from_engine(FakeEngine(), tok)
+    try:
+        r = np.random.default_rng(2)
+        imgs = [Image.fromarray(r.integers(0, 256, (h, w, 3), dtype=np.uint8), "RGB") for h, w in ((56, 84), (112, 56))]
+        n_tok = []
+        for im in imgs:
+            a = imageproc.prepare_image(im, 4 * 784, 1024 * 784, jpeg=False)
+            n_tok.append(a.shape[1] * a.shape[2] // (14 * 14 * 4))
+        q = "what type of object is in this photo ?"
+
+        def hf_ids(messages, images):
+            text = tok.apply_chat_template(messages, tokenize=False, add_generation_prompt=True)
+            out = proc(text=[text], images=images or None, padding=True, return_tensors="pt")
+            return out["input_ids"][0].tolist()
+
+        system = {"role": "system", "content": SYSTEM_PROMPT}
+        # single round, as the reference builds the message (:223-282): one image / none
+        for k in (1, 0):
+            content = [{"type": "image", "image": imgs[0]}] * k + [{"type": "text", "text": q}]
+            want = hf_ids([system, {"role": "user", "content": content}], imgs[:k])
+            assert lm._prompt_ids(q, n_tok[:k]).tolist() == want
+            assert int((np.asarray(want) == cfg.image_token_id).sum()) == sum(n_tok[:k])
+        # a two-turn conversation with an image in each user turn (multi-round, :477-533)
+        msgs = [system, {"role": "user", "content": [{"type": "image", "image": imgs[0]}, {"type": "text", "text": q}]},
+                {"role": "assistant", "content": [{"type": "text", "text": "a sea lion"}]},
+                {"role": "user", "content": [{"type": "image", "image": imgs[1]}, {"type": "text", "text": "is this a dog ?"}]}]
+        assert lm._messages_ids(msgs, n_tok).tolist() == hf_ids(msgs, imgs)
+    finally:
+        lm._pool.shutdown()
+        lm._prep_thread.shutdown()
+
+
+@pytest.mark.parametrize("next_", [False, True])
+def test_llava_prompt_ids_with_a_real_tokenizer_equal_hf_processor(tmp_path, next_):
+    """`LLaVA._prompt_ids` on a checkpoint's own tokenizer against HF's `LlavaProcessor` / `LlavaNextProcessor` (what the reference calls
+    at `_llava_hf.py:347`): BOS, tokenisation of the rendered prompt, and every `<image>` expanded to the image's feature count - for
+    LLaVA-NeXT the anyres count (best resolution, un-padded tile grid + one newline per row + the base view) that HF's processor
+    computes from the image size, for landscape / portrait / extreme / square images; two images in one prompt."""
+    import json as _json
+
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    from transformers import AutoTokenizer, CLIPImageProcessor, LlavaNextImageProcessor, LlavaNextProcessor, LlavaProcessor
+
+    from lmms_owc_amd.engine.llava import LlavaEngine
+    from lmms_owc_amd.models._base import CacheHook
+    from lmms_owc_amd.models._llava_hf import LLaVA, dims_from_hf_config
+    from tests import ckpt_util
+
+    info = ckpt_util.write_llava_checkpoint(tmp_path, next_=next_)
+    cfg = info["cfg"]
+    tok = AutoTokenizer.from_pretrained(str(tmp_path))
+    size = cfg.vision.image_size
+    kw = dict(tokenizer=tok, patch_size=14, vision_feature_select_strategy="default", num_additional_image_tokens=1)
+    if next_:
+        ip = LlavaNextImageProcessor(size={"shortest_edge": size}, crop_size={"height": size, "width": size},
+                                     image_grid_pinpoints=[list(p) for p in cfg.image_grid_pinpoints])
+        proc = LlavaNextProcessor(image_processor=ip, **kw)
+    else:
+        proc = LlavaProcessor(image_processor=CLIPImageProcessor(size={"shortest_edge": size}, crop_size={"height": size, "width": size}), **kw)
+    dims = dims_from_hf_config(_json.loads((tmp_path / "config.json").read_text()))
+
+    class FakeEngine:
+        d, device = dims, torch.device("cpu")
+        feature_rows = LlavaEngine.feature_rows
+
+    lm = LLaVA.__new__(LLaVA)
+    lm._engine_batch_arg, lm._decoder_dtype, lm._chat_template = 0, "bf16", None
+    lm._device, lm._rank, lm._world_size, lm.batch_size_per_gpu = torch.device("cpu"), 0, 1, 1
+    lm.cache_hook, lm.task_dict = CacheHook(None), {}
+    lm._tokenizer = lm._processor = tok
+    lm._dims, lm._model, lm._pool = dims, FakeEngine(), ThreadPoolExecutor(max_workers=1)
+    r = np.random.default_rng(3)
+    try:
+        for sizes in ([(60, 90)], [(90, 60)], [(40, 120)], [(33, 33)], [(60, 90), (50, 50)]):
+            imgs = [Image.fromarray(r.integers(0, 256, (h, w, 3), dtype=np.uint8), "RGB") for h, w in sizes]
+            ctx = " ".join(["<image>"] * len(imgs)) + "\nwhat type of object is in this photo ?"
+            counts = []
+            for im in imgs:
+                views, size_hw = lm._views(im)
+                counts.append(len(lm._model.feature_rows([views.shape[0]], [size_hw])[0]))
+            want = proc(images=imgs, text=lm._render(ctx), return_tensors="pt")["input_ids"][0].tolist()
+            got = lm._prompt_ids(ctx, counts).tolist()
+            assert got == want, (sizes, counts, sum(1 for t in want if t == dims.image_token_id))
+    finally:
+        lm._pool.shutdown()
