@@ -243,6 +243,12 @@ def test_product_llava_multi_round_equals_the_reference_run(case):
     assert {m for _, m in seen} == {gold["trace"][0]["generate_kwargs"]["max_new_tokens"]}     # 48 / the default 1024
 
 
+def _gk(gold: dict, doc: dict) -> dict:
+    """The request's own gen_kwargs (case 3 of the single-round goldens mixes two settings by document)."""
+    g = gold["gen_kwargs"]
+    return dict(g[doc["id"] % len(g)] if isinstance(g, list) else g)
+
+
 class _DoneEvent:
     def query(self):
         return True
@@ -267,7 +273,7 @@ def _llava_text(tok, image_token_id, p) -> str:
     return text
 
 
-@pytest.mark.parametrize("case", [0, 1, 2])
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
 def test_product_generate_until_equals_the_reference_run(case):
     """The HOT PATH's host loop against the reference's own run (`Qwen2VL.generate_until`, /root/reference/src/models/_qwen2_vl.py:
     143-348, executed by tools/gen_golden_wrappers.py on the stand-in checkpoint): six requests - with / without an `<image>`
@@ -316,7 +322,7 @@ def test_product_generate_until_equals_the_reference_run(case):
     lm._no_carry = True
     lm.task_dict["su"] = {"test": docs}
     reqs = [TaskInstance(request_type="generate_until", idx=0, metadata={"task": "su", "doc_id": d["id"], "repeats": 1},
-                         arguments=(recipes.su_context(d), dict(gold["gen_kwargs"]), d2v, d["id"], "su", "test")) for d in docs]
+                         arguments=(recipes.su_context(d), _gk(gold, d), d2v, d["id"], "su", "test")) for d in docs]
     try:
         got = lm.generate_until(reqs)
     finally:
@@ -324,7 +330,9 @@ def test_product_generate_until_equals_the_reference_run(case):
         lm._prep_thread.shutdown()
     assert got == gold["results"]
     assert sorted((t, n) for t, _, n in seen) == sorted((t["texts"][0], t["images"]) for t in gold["trace"])     # prompts AND image counts
-    assert {m for _, m, _ in seen} == {gold["trace"][0]["generate_kwargs"]["max_new_tokens"]}                    # 64 / the default 128
+    # per prompt the generation length the reference asked HF for: 64 / the default 128 / (case 3) 64 or 96 by the request's own
+    # gen_kwargs - requests with different settings never share a pass (the Collator groups by them)
+    assert sorted((t, m) for t, m, _ in seen) == sorted((t["texts"][0], t["generate_kwargs"]["max_new_tokens"]) for t in gold["trace"])
     assert all("until" not in r.args[1] for r in reqs)             # popped from the request's own dict, as the reference does (:211-219)
     # `do_sample = temperature > 0` (:308-329): what the reference hands HF generate is what the on-device sampler is given
     kw = gold["trace"][0]["generate_kwargs"]
@@ -335,7 +343,7 @@ def test_product_generate_until_equals_the_reference_run(case):
         assert all(s_ is None for s_ in sampled) and kw["temperature"] == 0
 
 
-@pytest.mark.parametrize("case", [0, 1, 2])
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
 def test_product_llava_generate_until_equals_the_reference_run(case):
     """`LLaVA.generate_until` (/root/reference/src/models/_llava_hf.py:260-392) the same way."""
     import numpy as np
@@ -384,7 +392,7 @@ def test_product_llava_generate_until_equals_the_reference_run(case):
     docs, d2v = recipes.su_docs_and_task()
     lm.task_dict["su"] = {"test": docs}
     reqs = [TaskInstance(request_type="generate_until", idx=0, metadata={"task": "su", "doc_id": d["id"], "repeats": 1},
-                         arguments=(recipes.su_context(d), dict(gold["gen_kwargs"]), d2v, d["id"], "su", "test")) for d in docs]
+                         arguments=(recipes.su_context(d), _gk(gold, d), d2v, d["id"], "su", "test")) for d in docs]
     try:
         got = lm.generate_until(reqs)
     finally:
@@ -392,7 +400,7 @@ def test_product_llava_generate_until_equals_the_reference_run(case):
         lm._prep_thread.shutdown()
     assert got == gold["results"]
     assert sorted((t, n) for t, _, n in seen) == sorted((t["texts"][0], t["images"]) for t in gold["trace"])
-    assert {m for _, m, _ in seen} == {gold["trace"][0]["generate_kwargs"]["max_new_tokens"]}                    # 64 / the default 1024
+    assert sorted((t, m) for t, m, _ in seen) == sorted((t["texts"][0], t["generate_kwargs"]["max_new_tokens"]) for t in gold["trace"])
     kw = gold["trace"][0]["generate_kwargs"]
     assert kw["num_beams"] == 1 and kw["do_sample"] is (case == 2)
     if case == 2:

@@ -212,7 +212,8 @@ def run_llava(lm, TaskInstance, gen_kwargs):
 def make_single_requests(TaskInstance, docs, doc_to_visual, gen_kwargs):
     reqs = []
     for d in docs:
-        args = (recipes.su_context(d), dict(gen_kwargs), doc_to_visual, d["id"], "su", "test")
+        gk = gen_kwargs[d["id"] % len(gen_kwargs)] if isinstance(gen_kwargs, list) else gen_kwargs   # a list: mixed generation settings
+        args = (recipes.su_context(d), dict(gk), doc_to_visual, d["id"], "su", "test")
         reqs.append(TaskInstance(request_type="generate_until", arguments=args, idx=0, metadata={"task": "su", "doc_id": d["id"], "repeats": 1}))
     return reqs
 
@@ -234,7 +235,7 @@ def run_single(module, which: str, TaskInstance, gen_kwargs):
 
     cls.generate_until_multi_round = call_single
     try:
-        out = runner(module, TaskInstance, gen_kwargs)
+        out = runner(module, TaskInstance, gen_kwargs[0] if isinstance(gen_kwargs, list) else gen_kwargs)
     finally:
         cls.generate_until_multi_round = orig
     return {"results": list(box["res"]), "trace": out["trace"], "gen_kwargs": gen_kwargs,
@@ -324,9 +325,11 @@ def main():
                {"max_new_tokens": 16, "temperature": 0})],
            "llava": [run_llava(lm, TaskInstance, gk) for gk in ({"max_new_tokens": 48, "do_sample": False, "until": ["STOP"]}, {})],
            "qwen2vl_single": [run_single(qm, "qwen", TaskInstance, gk) for gk in (
-               {"max_new_tokens": 64, "do_sample": False, "until": ["STOP"]}, {}, {"max_new_tokens": 64, "temperature": 0.8, "top_p": 0.9})],
+               {"max_new_tokens": 64, "do_sample": False, "until": ["STOP"]}, {}, {"max_new_tokens": 64, "temperature": 0.8, "top_p": 0.9},
+               [{"max_new_tokens": 64, "do_sample": False}, {"max_new_tokens": 96, "do_sample": False, "until": ["STOP"]}])],
            "llava_single": [run_single(lm, "llava", TaskInstance, gk) for gk in (
-               {"max_new_tokens": 64, "do_sample": False, "until": ["STOP"]}, {}, {"max_new_tokens": 64, "temperature": 0.8, "top_p": 0.9})],
+               {"max_new_tokens": 64, "do_sample": False, "until": ["STOP"]}, {}, {"max_new_tokens": 64, "temperature": 0.8, "top_p": 0.9},
+               [{"max_new_tokens": 64, "do_sample": False}, {"max_new_tokens": 96, "do_sample": False, "until": ["STOP"]}])],
            "llava_loglikelihood": run_llava_loglik(lm, TaskInstance)}
     GOLD.mkdir(parents=True, exist_ok=True)
     (GOLD / "wrapper_protocol.json").write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
