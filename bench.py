@@ -61,13 +61,13 @@ def flops_per_image(d, new_tokens: int, patches: int = 1024) -> float:
     return float(f_vit + f_pre + f_dec)
 
 
-def pruned_flops_per_image(d, prompts_per_chunk: int) -> float:
+def pruned_flops_per_image(d, prompts_per_chunk: int, S: int | None = None) -> float:
     """FLOPs of the model's nominal forward that the path does NOT execute, subtracted before any utilisation figure:
     * owc_llm_prefill runs the last decoder layer's attention, o-proj and MLP for the last token of each prompt only (the
       other rows' outputs feed nothing; logits bit-identical, tests/test_qwen2vl_gpu.py);
     * the S_TEXT_BEFORE leading text tokens are identical in every prompt of the task and are prefilled once per launch group
       (shared-prefix segment, bit-identical, same test file), so each prompt contributes S - 14 (1 - 1/n) rows."""
-    S = S_TEXT_BEFORE + S_IMG + S_TEXT_AFTER
+    S = S if S is not None else S_TEXT_BEFORE + S_IMG + S_TEXT_AFTER
     H, KV, hd, dm, ff, L = d.n_q_heads, d.n_kv_heads, d.head_dim, d.d_model, d.d_ff, d.n_layers
     last_layer = (S - 1) * (2 * H * hd * dm + 6 * dm * ff) + 2 * S * S * H * hd - 4 * S * H * hd
     shared_rows = S_TEXT_BEFORE * (1.0 - 1.0 / max(prompts_per_chunk, 1))
@@ -237,7 +237,31 @@ def _sizes_flowers102(r, n):
     return out
 
 
+# BASELINE.json configs[2] evaluates the three datasets together: their test splits hold 30 300 : 1 692 : 2 463 images
+CONFIG3_MIX = (("food101", 30300), ("dtd", 1692), ("flowers102", 2463))
+
+
+def _sizes_config3(r, n):
+    total = sum(c for _, c in CONFIG3_MIX)
+    counts = [int(round(n * c / total)) for _, c in CONFIG3_MIX]
+    counts[0] += n - sum(counts)
+    out = []
+    for (name, _), c in zip(CONFIG3_MIX, counts):
+        out += DATASET_SIZES[name](r, c)
+    order = r.permutation(len(out))      # a task's documents arrive interleaved, not dataset by dataset
+    return [out[i] for i in order]
+
+
+def _sizes_max_pixels(r, n):
+    """Every image lands on the reference's `max_pixels` cap (1024 x 28 x 28, `_qwen2_vl.py:64-65`): SUN397 / Stanford-Cars-like
+    sources of >= 0.8 Mpx - half of them square (-> 896 x 896 = a 64 x 64 patch grid = 1024 image tokens), half 4:3 landscape
+    (1024 x 768 -> 756 x 1036 = a 54 x 74 grid = 999 image tokens)."""
+    return [(1024, 1024) if i % 2 == 0 else (768, 1024) for i in range(n)]
+
+
 DATASET_SIZES = {"food101": _sizes_food101, "dtd": _sizes_dtd, "flowers102": _sizes_flowers102}
+DATASET_SIZES["config3"] = _sizes_config3
+DATASET_SIZES["max_pixels"] = _sizes_max_pixels
 
 
 def gemm_roofline(p: dict, dt_total: float, what: str) -> dict:
@@ -304,14 +328,83 @@ def ragged_leg(engine, dims, name: str, n: int, T: int, steps: int, device, sync
         solo = engine.generate([prompts[i]], emb1, [gpp[i]], T, eos_token_id=-1, pad_token_id=0).cpu()
         inv = inv and bool(torch.equal(solo[0], out[i]))
     flops = float(sum(flops_per_image(dims, T, g[1] * g[2]) for g in grids))
+    # executed FLOPs (what `mfma_frac_end_to_end` is priced on, as in the headline): minus the last prefill layer's dead rows and
+    # the shared 14-token prefix, per image at ITS prompt length
+    mean_rows = float(np.mean(n_tok)) + S_TEXT_AFTER
+    per_chunk = max(1, min(n, int((engine.prefill_chunk_tokens - S_TEXT_BEFORE) // mean_rows))) if engine.share_prefix else 1
+    f_exec = flops - float(sum(pruned_flops_per_image(dims, per_chunk, S_TEXT_BEFORE + t + S_TEXT_AFTER) for t in n_tok))
+    att = None
+    if prof:
+        P2 = float(sum((g[1] * g[2]) ** 2 for g in grids))
+        a_fl = steps * dims.v_depth * 4.0 * P2 * dims.v_embed               # QK^T + PV, non-causal, every layer, every image
+        pa = prof["attn_vision"]
+        a_tf = a_fl / (pa["ms"] * 1e-3) / 1e12 if pa["ms"] > 0 else 0.0
+        att = {"bound": "mfma", "kernel": "attn_fwd_kernel<80,false>", "achieved": a_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+               "frac": a_tf / PEAK_BF16_TFLOPS, "traffic": None, "launches": pa["launches"], "kernel_ms_total": pa["ms"],
+               "share_of_leg_time": pa["ms"] * 1e-3 / time_or(dt * steps),
+               "patches_per_image": {"min": min(g[1] * g[2] for g in grids), "mean": float(np.mean([g[1] * g[2] for g in grids])),
+                                     "max": max(g[1] * g[2] for g in grids)}}
     return {"dataset_size_model": name, "images": n, "seconds_per_pass": dt, "images_per_s": n / dt, "image_tokens_per_s": sum(n_tok) / dt,
             "image_tokens_per_image": {"min": min(n_tok), "mean": float(np.mean(n_tok)), "max": max(n_tok)},
             "distinct_grids": len(by_size), "prompt_tokens": {"min": 30 + min(n_tok), "max": 30 + max(n_tok)},
-            "model_flops_per_image_mean": flops / n, "mfma_frac_end_to_end_nominal": flops / dt / (PEAK_BF16_TFLOPS * 1e12),
+            "model_flops_per_image_mean": flops / n, "executed_flops_per_image_mean": f_exec / n,
+            "mfma_frac_end_to_end": f_exec / dt / (PEAK_BF16_TFLOPS * 1e12),
+            "mfma_frac_end_to_end_nominal": flops / dt / (PEAK_BF16_TFLOPS * 1e12),
             "deterministic_and_batch_invariant": inv,
             "roofline": gemm_roofline(prof["gemm_bf16"], dt * steps, "of the ragged launch groups") if prof else None,
+            "roofline_attention_vision": att,
             "what": "seeded (height, width) model of the dataset's published sizing rule -> smart_resize within [3136, 802816] px -> "
                     "ragged cu_seqlens vision launch groups + unequal prompts (shared 14-token prefix); uniform-noise pixels; never `value`"}
+
+
+class BoxCalibration:
+    """How fast is THIS box?  MI355X devices differ by up to ~12 % on MFMA-dense loops (MI355X_MICROARCH.md, DVFS give-back item 5:
+    the clock a device holds under matrix load), and the driver's headline moves with it.  The yardstick is the step's own largest
+    launch class - the 7B gate/up projection with the SwiGLU epilogue at M = 65536 (`gemm_bf16_nt_256pp_kernel`, 17.8 TFLOP per
+    launch) on random operands - run back to back for ~2 s BEFORE and AFTER the timed region, TFLOP/s from HIP events on the
+    launch stream.  `value_per_calibration_tflops` = images/s per calibration TFLOP/s should be the same on every box."""
+
+    M, N, K = 65536, 37888, 3584
+
+    def __init__(self, device, seconds: float = 2.0):
+        from lmms_owc_amd import ops as owc_ops
+
+        self.ops, self.seconds = owc_ops, seconds
+        g = torch.Generator(device=device).manual_seed(4242)
+        self.a = torch.randn((self.M, self.K), generator=g, device=device, dtype=torch.bfloat16)
+        self.w = torch.randn((self.N, self.K), generator=g, device=device, dtype=torch.bfloat16) * (self.K ** -0.5)
+        self.c = torch.empty((self.M, self.N // 2), device=device, dtype=torch.bfloat16)
+        self.runs = []
+
+    def run(self) -> float:
+        from lmms_owc_amd import ops as owc_ops
+
+        flop = 2.0 * self.M * self.N * self.K
+
+        def burst(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                owc_ops.gemm_bf16(self.a, self.w, epilogue=owc_ops.EPI_SWIGLU, out=self.c)
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) * 1e-3
+
+        burst(8)                                           # the clock settles under load within the first launches
+        n = max(16, int(self.seconds / (burst(8) / 8)))
+        t = burst(n)
+        self.runs.append({"launches": n, "seconds": t, "tflops": n * flop / t / 1e12})
+        return self.runs[-1]["tflops"]
+
+    def report(self, images_per_s_per_gpu: float) -> dict:
+        tf = [r["tflops"] for r in self.runs]
+        mean = float(np.mean(tf)) if tf else 0.0
+        return {"kernel": f"7B gate/up projection + SwiGLU epilogue, M = {self.M}, N = {self.N}, K = {self.K}, random operands, back to back",
+                "tflops_before_timed_region": tf[0] if tf else None, "tflops_after_timed_region": tf[1] if len(tf) > 1 else None,
+                "tflops": mean, "frac_of_peak": mean / PEAK_BF16_TFLOPS, "runs": self.runs,
+                "value_per_calibration_tflops": images_per_s_per_gpu / mean if mean > 0 else None,
+                "what": "images/s per GPU divided by the box's own GEMM rate: constant across boxes when a headline difference is the "
+                        "box (DESIGN.md section 5 lists the pairs measured so far)"}
 
 
 def config2_leg(device, T: int, sync, profile, images: int = 512, passes: int = 2) -> dict:
@@ -353,6 +446,67 @@ def config2_leg(device, T: int, sync, profile, images: int = 512, passes: int = 
             "roofline": gemm_roofline(prof["gemm_bf16"], dt * passes, "of the 2B pass")}
 
 
+def qwen72b_fp8_leg(device, T: int, profile, images: int = 256) -> dict:
+    """BASELINE.json configs[4], LMM side (never `value`): Qwen2-VL-72B with the fp8 (e4m3fn, per-token x per-channel scales) decoder,
+    `images` synthetic 448x448 images, one warm-up + one timed pass, 73 GB of weights initialised on the device."""
+    import dataclasses
+
+    from lmms_owc_amd import ops as owc_ops
+    from lmms_owc_amd.engine.qwen2vl import DIMS, Qwen2VLEngine, Qwen2VLWeights
+    from lmms_owc_amd.models import imageproc
+
+    t_w = time.perf_counter()
+    d = dataclasses.replace(DIMS["qwen2-vl-72b"], decoder_dtype="fp8")
+    eng = Qwen2VLEngine(Qwen2VLWeights.random(d, device, seed=1234))
+    torch.cuda.synchronize()
+    t_w = time.perf_counter() - t_w
+    gen = torch.Generator(device=device).manual_seed(78)
+    u8 = torch.randint(0, 256, (images, 3, 448, 448), generator=gen, device=device, dtype=torch.uint8)
+    pix = owc_ops.patchify_u8(u8, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD)
+    del u8
+    ids = prompt_ids(d.image_token_id)
+    prompts, grids, flat = [ids] * images, [[(1, 32, 32)]] * images, [(1, 32, 32)] * images
+
+    def step():
+        return eng.generate(prompts, eng.encode_images(pix, flat), grids, T, eos_token_id=-1, pad_token_id=0).cpu()
+
+    step()
+    torch.cuda.synchronize()
+    profile(True)
+    t0 = time.perf_counter()
+    out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = profile(False)
+    solo = eng.generate(prompts[:1], eng.encode_images(pix[:1024], flat[:1]), grids[:1], T, eos_token_id=-1, pad_token_id=0).cpu()
+    f = flops_per_image(d, T)
+    per_chunk = max(1, min(images, (eng.prefill_chunk_tokens - S_TEXT_BEFORE) // (S_IMG + S_TEXT_AFTER)))
+    f_exec = f - pruned_flops_per_image(d, per_chunk)
+    g8, g16 = prof["gemm_fp8"], prof["gemm_bf16"]
+    tf8 = g8["work"] / (g8["ms"] * 1e-3) / 1e12 if g8["ms"] > 0 else 0.0
+    tf16 = g16["work"] / (g16["ms"] * 1e-3) / 1e12 if g16["ms"] > 0 else 0.0
+    return {"config": "BASELINE.json configs[4], LMM side: Qwen2-VL-72B, fp8-e4m3 decoder projections (bf16 elsewhere), synthetic 448x448 images, 1 GPU",
+            "images": images, "new_tokens": T, "seconds_per_pass": dt, "images_per_s": images / dt, "weights_gb": eng.w.nbytes() / 1e9,
+            "weight_init_seconds": t_w, "model_flops_per_image": f, "executed_flops_per_image": f_exec,
+            "mfma_frac_end_to_end_vs_bf16_peak": images / dt * f_exec / (PEAK_BF16_TFLOPS * 1e12),
+            "batch_invariance_check": bool(torch.equal(solo[0], out[0])),
+            "roofline": {"bound": "mfma", "kernel": "gemm_fp8_nt_* (decoder projections, scaled f8f6f4 MFMA)", "achieved": tf8, "peak": PEAK_FP8_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tf8 / PEAK_FP8_TFLOPS, "traffic": None, "launches": g8["launches"],
+                         "kernel_ms_total": g8["ms"], "share_of_leg_time": g8["ms"] * 1e-3 / time_or(dt)},
+            "bf16_gemm_in_same_leg": {"achieved": tf16, "frac": tf16 / PEAK_BF16_TFLOPS, "kernel_ms_total": g16["ms"],
+                                      "share_of_leg_time": g16["ms"] * 1e-3 / time_or(dt)}}
+
+
+def llava_next_34b_leg(batch: int = 16) -> dict:
+    """BASELINE.json configs[3] (never `value`): LLaVA-NeXT-34B (CLIP ViT-L/14-336 anyres + Yi-34B dims, 69.5 GB of bf16 weights
+    initialised on the device), `batch` synthetic 480x640 images, one warm-up + one timed pass (tools/bench_llava.py)."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import bench_llava
+
+    return bench_llava.run("llava-next-34b", batch, steps=1, warmup=1, new_tokens=16, image_size="480x640", text_tokens=48,
+                           decoder_dtype="bf16")
+
+
 def cosine_10k_leg(scorer, device, sync, profile, n_pred: int = 65536, n_cls: int = 10000, k: int = 5, passes: int = 5) -> dict:
     """BASELINE.json configs[4]'s scorer side (never `value`): class-name embedding of a ~10k-class vocabulary on the GPU + cosine
     top-k of `n_pred` predictions against it (the N x C similarity matrix is never materialised)."""
@@ -392,13 +546,6 @@ def cosine_10k_leg(scorer, device, sync, profile, n_pred: int = 65536, n_cls: in
                          "hbm_gbs_on_algorithmic_bytes": byt / (ck["ms"] * 1e-3) / 1e9 if ck["ms"] > 0 else 0.0,
                          "note": "2 N C D on the f32-input MFMA (157 TF dense f32 matrix peak); algorithmic bytes 4 D (N + C) + 8 k N"}}
 
-
-BUILDER_RUN_CONFIGS = {
-    "configs[3] LLaVA-NeXT-34B (CLIP-L/336 + Yi-34B dims, 69.5 GB of weights: load time keeps it out of the default run)":
-        "python tools/bench_llava.py --model llava-next-34b --batch 48 --image-size 480x640",
-    "configs[4] Qwen2-VL-72B fp8 decoder (73 GB of fp8 + bf16 weights)":
-        "python bench.py --model 72b --decoder-dtype fp8 --batch 1024 --no-cpu-baseline --no-pil-leg --no-extra-legs",
-}
 
 EOS_ID = 151645   # <|im_end|>: Qwen2-VL's EOS token id
 
@@ -614,14 +761,23 @@ def main() -> None:
                          "legs and the CPU baseline always run")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the other configs' short legs (Food-101 image sizes, Qwen2-VL-2B / 512 images, label-cosine at C = 10 000)")
-    ap.add_argument("--image-sizes", default="food101", choices=sorted(DATASET_SIZES) + ["none"],
+    ap.add_argument("--image-sizes", default="config3", choices=sorted(DATASET_SIZES) + ["none"],
                     help="extra leg (never `value`): images of the dataset's real size distribution through smart_resize "
-                         "(64...1024 image tokens per image, ragged vision / prefill launch groups); reports images/s and image-tokens/s")
+                         "(64...1024 image tokens per image, ragged vision / prefill launch groups); reports images/s and image-tokens/s; "
+                         "config3 = BASELINE.json configs[2]'s mixture Food-101 : DTD : Flowers-102 = 30300 : 1692 : 2463")
     ap.add_argument("--ragged-images", type=int, default=1024, help="images of the --image-sizes leg")
+    ap.add_argument("--cap-images", type=int, default=256,
+                    help="images of the `max_pixels_images` leg (every image on the reference's max_pixels cap: ~1024 image tokens, "
+                         "4096 patches - the SUN397 / Stanford-Cars regime); 0 skips it")
+    ap.add_argument("--no-big-legs", action="store_true",
+                    help="skip the Qwen2-VL-72B fp8 (256 images) and LLaVA-NeXT-34B (16 images) legs that run after the CPU baseline on one GPU")
+    ap.add_argument("--big-leg-budget-s", type=float, default=540.0,
+                    help="seconds since process start after which a big-model leg is not started any more")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the box calibration GEMM bursts around the timed region")
     ap.add_argument("--nominal-forward", action="store_true",
                     help="run the model's nominal forward: full last prefill layer on every row and no shared-prefix segment "
                          "(same tokens bit for bit; shows what the two dead-work eliminations are worth)")
-    ap.add_argument("--cpu-images", type=int, default=3,
+    ap.add_argument("--cpu-images", type=int, default=2,
                     help="images of the CPU baseline (HF generate on the host cores, ~25-40 s each for 7B); the first is the warm-up, `value` = mean of the rest")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
                     help="owc_tuning_set(KNOB, VALUE) before anything runs (A-B experiments; recorded in config.tuning)")
@@ -749,6 +905,14 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     sync()
+    calib = None
+    if not args.no_calibration and args.model == "7b":   # (the yardstick is a 7B shape; every rank runs it: the ranks stay in step)
+        try:
+            calib = BoxCalibration(device)
+            calib.run()
+        except torch.OutOfMemoryError:
+            calib = None
+        sync()
     lib.owc_gemm_profile_enable(ctx, 1 if rank == 0 else 0)
     t0 = time.perf_counter()
     step_end = []
@@ -760,6 +924,10 @@ def main() -> None:
     dt_own = t_own - t0                          # without the wait for the other ranks: the per-rank rates
     prof = read_profile() if rank == 0 else None
     lib.owc_gemm_profile_enable(ctx, 0)
+    if calib is not None:
+        calib.run()
+        sync()
+        calib.a = calib.w = calib.c = None     # 3.2 GB back to the allocator
     lap("warmup_and_timed_steps")
     fp8_run = args.decoder_dtype == "fp8"
     assert out.shape == (B, T)
@@ -819,6 +987,21 @@ def main() -> None:
             ragged["images_per_s"] = world * ragged["images"] / ragged["seconds_per_pass"]
 
     lap("real_image_sizes")
+
+    # ---- every image on the max_pixels cap (never `value`): P = 4096 patches, ~1024 image tokens, S ~ 1054 - vision attention is O(P^2)
+    cap_leg = None
+    if args.cap_images > 0 and not args.no_extra_legs:
+        try:
+            cap_leg = ragged_leg(engine, dims, "max_pixels", args.cap_images, T, 1, device, sync, profile=profile)
+        except torch.OutOfMemoryError as e:
+            torch.cuda.empty_cache()
+            cap_leg = {"skipped": f"out of memory: {str(e)[:160]}", "deterministic_and_batch_invariant": True}
+        if dist is not None and "seconds_per_pass" in cap_leg:
+            t = torch.tensor([cap_leg["seconds_per_pass"]], device=cdev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            cap_leg["seconds_per_pass"] = float(t.item())
+            cap_leg["images_per_s"] = world * cap_leg["images"] / cap_leg["seconds_per_pass"]
+    lap("max_pixels_images")
 
     # ---- PCIe-inclusive leg (never `value`): the same step fed from host uint8 images (what the boundary hands over in a
     # real run): pinned H2D copy + GPU rescale/normalise/patchify + the step above
@@ -919,10 +1102,15 @@ def main() -> None:
             "value": images_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if not fp8_run else "fp8-e4m3 decoder projections (per-token / per-channel scales), bf16 elsewhere", "data": "synthetic",
-            "config": {"workload": f"Qwen2-VL-{args.model.upper()}{' (fp8 decoder)' if fp8_run else ''} open-world classify: {B} synthetic 448x448 images per GPU per step "
-                                   f"(1024 patches -> 256 image tokens), prompt S=286, {T} forced greedy tokens, seeded random "
-                                   "weights of the real architecture; images strided across ranks, no data-path collective",
+            # (the driver's record keeps the scalars of `config` and `roofline` and the first 120 characters of a string)
+            "config": {"workload": f"Qwen2-VL-{args.model.upper()}{' (fp8 decoder)' if fp8_run else ''}: {B} synthetic 448x448 images/GPU/step, timed from pixel_values "
+                                   f"RESIDENT IN HBM, S=286, {T} forced greedy tokens; (1024 patches -> 256 image tokens per image, seeded random "
+                                   "weights of the real architecture; images strided across ranks, no data-path collective; the same step fed "
+                                   "from host uint8 / PIL images: images_per_s_from_host_uint8 / images_per_s_from_pil below)",
                        "images_per_gpu_per_step": B, "prompt_tokens": 286, "new_tokens": T, "parallelism": f"dp{world}",
+                       "timed_region_starts_from": "pixel_values resident in HBM",
+                       "images_per_s_from_host_uint8": pcie_images_per_s,
+                       "images_per_s_from_pil": pil.get("images_per_s") if pil else None,
                        **({"tuning": args.tune} if args.tune else {})},
             "ms_of_each_step": [round((b - a) * 1e3, 1) for a, b in zip([t0] + step_end[:-1], step_end)],   # rank 0: drift under sustained load shows here
             "per_rank_images_per_s": [B * args.steps / t for t in per_rank_own],   # each rank's own clock, before the closing barrier
@@ -946,12 +1134,15 @@ def main() -> None:
             "roofline_attention": attention_rooflines(prof, dims, B, T, args.steps, dt),
             "roofline_decode": decode_leg,
             "eos_terminated": eos_leg,
-            "real_image_sizes": ragged,
             "config2_qwen2vl_2b": cfg2,
             "label_cosine_10k_classes": cos10k,
-            "builder_run_configs": BUILDER_RUN_CONFIGS,
             "roofline_label_cosine": scorer_rooflines(sprof, n_lab, args.scorer_classes, 5, args.steps, float(sdt.item())),
         }
+        if calib is not None and calib.runs:
+            cal = calib.report(images_per_s / world)
+            result["roofline"]["box_calibration_tflops"] = cal["tflops"]
+            result["config"]["box_calibration_tflops"] = cal["tflops"]
+            result["config"]["value_per_calibration_tflops"] = cal["value_per_calibration_tflops"]
         if args.one_gpu_value:
             result["scaling_efficiency"] = images_per_s / (world * args.one_gpu_value)
         if fp8_run:
@@ -976,14 +1167,53 @@ def main() -> None:
                     parity_failure = f"full-size token parity failed: {len(bad)} teacher-forced flip(s) on a decisive margin: {bad[:2]}"
                 result["cpu_baseline"]["parity_gate"] = {"logit_bound": FULLSIZE_LOGIT_BOUND, "passed": parity_failure is None}
         lap("cpu_baseline")
+        # ---- BASELINE.json configs[3] / configs[4]'s LMM side on this GPU (never `value`): the headline model's weights, inputs and
+        # caches go back to the driver first (73 GB of fp8 + bf16 weights, then 69.5 GB of bf16 weights)
+        big = {"config5_qwen2vl_72b_fp8": None, "config4_llava_next_34b": None}
+        if world == 1 and not args.no_big_legs and not args.no_extra_legs:
+            engine = weights = pix = scorer = cls_z = emb0 = None
+            import gc
+
+            for name, fn in (("config5_qwen2vl_72b_fp8", lambda: qwen72b_fp8_leg(device, T, profile)),
+                             ("config4_llava_next_34b", lambda: llava_next_34b_leg())):
+                if time.perf_counter() - T_PROCESS_START > args.big_leg_budget_s:
+                    big[name] = {"skipped": f"--big-leg-budget-s {args.big_leg_budget_s:.0f} s reached before this leg"}
+                    continue
+                gc.collect()
+                torch.cuda.empty_cache()
+                try:
+                    big[name] = fn()
+                except Exception as e:   # an extra leg must never sink the measurement
+                    big[name] = {"skipped": f"{type(e).__name__}: {str(e)[:200]}"}
+                lap(name)
+            gc.collect()
+            torch.cuda.empty_cache()
+        # ---- the line ends with what round 5 added (the driver's record keeps the END of the line)
+        result["images_per_s_from_host_uint8"] = result.pop("images_per_s_from_host_uint8")
+        result["images_per_s_from_pil"] = result.pop("images_per_s_from_pil")
+        result.update(big)
+        result["real_image_sizes"] = ragged
+        result["max_pixels_images"] = cap_leg
+        if calib is not None and calib.runs:
+            result["box_calibration"] = cal
+        cfgd = result["config"]
+        for k, leg in (("config3_mix", ragged), ("max_pixels", cap_leg)):
+            if leg and "images_per_s" in leg:
+                cfgd[k + "_images_per_s"], cfgd[k + "_mfma_frac_end_to_end"] = leg["images_per_s"], leg.get("mfma_frac_end_to_end")
+                if leg.get("roofline_attention_vision"):
+                    cfgd[k + "_vision_attn_tflops"] = leg["roofline_attention_vision"]["achieved"]
+                    cfgd[k + "_vision_attn_share"] = leg["roofline_attention_vision"]["share_of_leg_time"]
+        cfgd["qwen2vl_72b_fp8_images_per_s"] = (big["config5_qwen2vl_72b_fp8"] or {}).get("images_per_s")
+        cfgd["llava_next_34b_images_per_s"] = (big["config4_llava_next_34b"] or {}).get("value")
         leg_seconds["total_since_process_start"] = round(time.perf_counter() - T_PROCESS_START, 1)
         result["leg_seconds"] = leg_seconds
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if ragged is not None and not ragged["deterministic_and_batch_invariant"]:
-        raise SystemExit("ragged leg: determinism / batch invariance failed (the JSON line above carries the measurement)")
+    for leg in (ragged, cap_leg):
+        if leg is not None and not leg["deterministic_and_batch_invariant"]:
+            raise SystemExit("ragged leg: determinism / batch invariance failed (the JSON line above carries the measurement)")
     if not invariant:
         raise SystemExit("batch invariance check failed (the JSON line above carries the measurement)")
     if parity_failure:

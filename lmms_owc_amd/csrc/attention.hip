@@ -423,7 +423,9 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
   const long trow = (long)pos[b] * 64;          // rope table row of the fed token
 
   // ---- the owner of the last tile: rope(k), cache write of k and v (lanes 0-7: one rotary pair of 8-dim chunks each; lanes 8-23: v)
-  if (w == ((ntiles - 1) & 3)) {
+  // (widx < s_max: a finished row that the caller has not dropped yet keeps advancing its write index; it must never write into
+  //  the next slot - the host compacts such rows away before that, this is the second line of defence)
+  if (w == ((ntiles - 1) & 3) && widx < s_max) {
     if (l < 8) {
       const bf16_t* kp = tok + (long)(n_q + hk) * 128;
       const bf16x8 a = *(const bf16x8*)(kp + l * 8), bb = *(const bf16x8*)(kp + l * 8 + 64);

@@ -471,9 +471,11 @@ class Qwen2VLEngine:
         T_out = max_new_tokens                       # width of the token buffer = steps this pass may run + 1
         if NC:
             rem = np.asarray(cin["remaining"], dtype=np.int64)             # tokens each carried sequence may still emit
-            s_max = max(s_max, int((np.asarray(cin["cached"]) + rem).max()) + 2)   # (+2: a row runs <= 2 steps past its budget)
-            if not carry.get("below"):
+            s_max = max(s_max, int((np.asarray(cin["cached"]) + rem).max()) + 2)   # (+2: a row runs <= 2 steps past its budget -
+            if not carry.get("below"):                                     #  the decode loop below compacts it away in time)
                 T_out = max(T_out, int(rem.max()) + 1)                     # the last pass runs every sequence to its end
+            if not compact_rows:   # nothing drops a finished row: every row takes all T_out - 1 steps and writes a K / V row each
+                s_max = max(s_max, int(max(lens.max(), np.asarray(cin["cached"]).max())) + T_out)
         n_slots = Bx
         if carry is not None:
             # the passes of a task should ask the allocator for the SAME two blocks: a 20 GB cache that grew by 1 % is a fresh
@@ -637,13 +639,24 @@ class Qwen2VLEngine:
                         # the flags as of the step BEFORE the one just enqueued: the GPU is busy while the host looks at them
                         pending[0].synchronize()
                         # (a row is also finished when its budget is spent: a carried sequence's cap, or this pass's own)
-                        alive = np.flatnonzero((flags[:pending[1]].numpy() == 0) & (budget[row_of[:pending[1]]] > pending[2]))
+                        seen = pending[1]                           # rows of the batch when the flags were taken (= n: only this block compacts)
+                        alive = np.flatnonzero((flags[:seen].numpy() == 0) & (budget[row_of[:seen]] > pending[2]))
                         pending = None
                         if len(alive) == 0:
                             break
                         if below and int((row_of[alive] < B).sum()) <= below:
                             break                                   # the stragglers go on inside the next pass (exported below)
-                        if compact and n - len(alive) >= max(1, n // 64):
+                        # A finished row stays in the batch until enough of them make a compaction worth its launch, and every
+                        # step advances its cache write index and rope position like a live row's.  Its slot holds `s_max` rows
+                        # (sized for the LIVE rows' budgets), so a finished row must leave before it writes past its slot into
+                        # the next one - with passes of different generation lengths or carried-in sequences T_out exceeds what
+                        # an own row's slot was sized for.  The next step (j + 1) writes at w0 + j; the flags are one step old.
+                        crowded = False
+                        if compact and len(alive) < seen:
+                            gone = np.setdiff1d(row_of[:seen], row_of[alive], assume_unique=True)
+                            ahead_ = j + 1 + max(1, stop_check_every)             # rows linger until the next look at the flags
+                            crowded = bool((st_host[2, gone] + ahead_ >= s_max).any() or (st_host[1, gone] + ahead_ >= d.max_positions).any())
+                        if compact and (crowded or n - len(alive) >= max(1, n // 64)):
                             live = self._i32(alive)
                             a, b_ = state[cur], state[cur ^ 1]
                             rc = self._lib.owc_decode_compact(

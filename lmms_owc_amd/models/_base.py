@@ -260,6 +260,17 @@ class PassPipeline:
         eb = self.engine_batch(max_new)
         unit = eb if eb < 256 else max(64, eb // 16)
         units = list(reordered.get_batched(n=unit, batch_fn=None))
+
+        def unit_key(u) -> tuple:
+            """What `_prepare_chunk` will put in prep["key"] for this unit: its first request's generation length and sampling
+            switches (one pass = one key; a straggler is only ever handed to a pass of ITS key)."""
+            gk = u[0][1]
+            smp = sampling_from_gen_kwargs(gk, getattr(self, "_default_top_k", 50))
+            return (int(gk.get("max_new_tokens", default_max_new)),
+                    None if smp is None else (smp["temperature"], smp["top_p"], smp["top_k"]))
+
+        unit_keys = [unit_key(u) for u in units]
+        taken = 0                               # units launched so far = index of the next pass's first unit
         tok = self._tokenizer
         pad = tok.pad_token_id if tok.pad_token_id is not None else 0
         rows: dict[int, np.ndarray] = {}        # position in the collated order -> token row (cut at EOS)
@@ -334,17 +345,24 @@ class PassPipeline:
                 size, fut = ahead.popleft()
                 preps.append(fut.result())
                 ahead_n -= size
+                taken += 1
             prep = preps[0] if len(preps) == 1 else self._merge_preps(preps)
             top_up()
             # straggler hand-over: while another pass follows, this pass stops decoding once its own live sequences are few enough
             # (`hand_over_below`) and the rest ride along in the next pass's decode steps
+            # A pass applies ONE generation length and ONE set of sampling switches to every row of its decode batch, carried-in rows
+            # included: the hand-over is only between passes of the same key.  A pass whose successor has another key (requests
+            # are grouped by gen_kwargs) runs its own stragglers to the end, like the last pass of a task.
             carry = None
-            more = left - prep["n"] > 0
+            more = left - prep["n"] > 0 and unit_keys[taken] == preps[0]["key"]
             hand_over = (tok.eos_token_id is not None and tok.eos_token_id >= 0 and (more or carried is not None)
                          and not getattr(self, "_no_carry", False))
             if not self.last_timing["chunks"]:
-                self._carry_capacity = (max(eb // 8, 256) + 255) // 256 * 256 if hand_over and more else 0   # (an engine without `reserve_kv`)
-                self._reserve_kv(prep, min(eb, len(requests)), hand_over and more)
+                # slots for carried sequences are reserved once per task: when ANY pass of it can hand over to a successor of its key
+                some = more or any(a == b for a, b in zip(unit_keys[taken:], unit_keys[taken + 1:]))
+                can = tok.eos_token_id is not None and tok.eos_token_id >= 0 and some and not getattr(self, "_no_carry", False)
+                self._carry_capacity = (max(eb // 8, 256) + 255) // 256 * 256 if can else 0   # (an engine without `reserve_kv`)
+                self._reserve_kv(prep, min(eb, len(requests)), can)
             if hand_over and self._carry_capacity > 0:
                 n_in = 0 if carried is None else len(carried["tags"])
                 carry = {"in": carried, "below": hand_over_below(prep["n"], n_in, self._carry_capacity) if more else 0,

@@ -677,6 +677,28 @@ def test_bench_flop_accounting():
     want = P * (1 - 1 / 240) * ((L - 1) * row_full + 2 * dm * (H + 2 * KV) * hd)
     assert abs(shared - want) <= 1e-6 * want
     assert 0.05 < many / f_model < 0.06                           # 5.5 % of the nominal forward
+    # round 5: the same closed form at another prompt length (the max_pixels leg: 14 + 1024 + 16 tokens), and the size models of
+    # the two large-image legs
+    S2 = 14 + 1024 + 16
+    assert bench.pruned_flops_per_image(d, 1, S2) == (S2 - 1) * row_tail + 2 * S2 * S2 * H * hd - 4 * S2 * H * hd
+    f_cap = bench.flops_per_image(d, 16, 4096)
+    assert 21e12 < f_cap < 24e12                                  # ~4.2 x the 448 x 448 image
+    vis_attn = d.v_depth * 4.0 * 4096 * 4096 * d.v_embed
+    assert 0.11 < vis_attn / f_cap < 0.14                         # vision attention: 12.6 % of a cap-size image's FLOPs (448 x 448: 3.1 %)
+    import numpy as np
+
+    from lmms_owc_amd.models import imageproc
+
+    def tokens(hw):
+        h1, w1 = imageproc.smart_resize(*hw, 28, 4 * 784, 16384 * 784)
+        h2, w2 = imageproc.smart_resize(h1, w1, 28, 4 * 784, 1024 * 784)
+        return h2 * w2 // 784
+
+    cap = [tokens(hw) for hw in bench.DATASET_SIZES["max_pixels"](np.random.default_rng(0), 8)]
+    assert cap == [1024, 999] * 4
+    mix = bench.DATASET_SIZES["config3"](np.random.default_rng(4321), 1024)
+    assert len(mix) == 1024 and sum(1 for hw in mix if max(hw) <= 512) >= 880        # Food-101 dominates the mixture (~900 of 1024)
+    assert sum(1 for hw in mix if min(hw) == 500) == 73                               # Flowers-102's share
 
 
 def test_bench_launches_its_own_ranks(tmp_path):

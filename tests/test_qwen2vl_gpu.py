@@ -285,6 +285,42 @@ def test_straggler_carry_over_is_bit_identical(setup, gpu):
     assert run(False, int(vals[np.argmax(counts)]), 40, sampled=True) >= 10
 
 
+def test_finished_rows_never_write_past_their_cache_slot(setup, gpu):
+    """Round 4's ADVICE: a finished row stays in the decode batch until >= n / 64 rows are finished, and every step advances its
+    cache write index.  The last pass of a task with 130 carried-in sequences (38 tokens still to go each) and ONE own long prompt
+    with a short generation length: the own row's budget ends at step 3, one finished row of 131 is below the compaction
+    threshold (2), so it used to ride along for 35 more steps and write K / V rows past its slot - into slot 1, the first carried
+    sequence's first keys.  Now the host drops such a row before it reaches the end of its slot (and the kernel refuses the
+    write): every carried sequence's tokens equal those of its own pass run alone; also with no spare slot at all
+    (`slots` = the carried sequences) and with `stop_check_every` > 1."""
+    cfg, w, eng, g = setup
+    r = np.random.default_rng(5)
+    first = [r.integers(10, 400, 10).astype(np.int64) for _ in range(130)]      # identical prompt lengths
+    last = [r.integers(10, 400, 60).astype(np.int64)]
+    none = [[] for _ in first]
+    free = to_np(eng.generate(first, None, none, 40))
+    eos = int(np.setdiff1d(np.arange(10, 400), np.concatenate([free.ravel(), to_np(eng.generate(last, None, [[]], 4)).ravel()]))[0])
+    ref0 = to_np(eng.generate(first, None, none, 40, eos_token_id=eos, pad_token_id=0))   # nobody emits `eos`: 40 tokens each
+    ref1 = to_np(eng.generate(last, None, [[]], 4, eos_token_id=eos, pad_token_id=0))
+    assert np.array_equal(ref0, free)
+    for slots, every in ((None, 1), (130, 1), (130, 3)):
+        c0 = {"in": None, "below": 130, "tags": [(0, i) for i in range(130)]}
+        if slots:
+            c0["slots"] = slots
+        eng.generate(first, None, none, 40, eos_token_id=eos, pad_token_id=0, carry=c0)
+        assert c0["out"] is not None and len(c0["out"]["tags"]) == 130 and int(np.min(c0["out"]["remaining"])) >= 30
+        c1 = {"in": c0["out"], "below": 0, "tags": [(1, 0)]}
+        if slots:
+            c1["slots"] = slots
+        st = {}
+        out1 = to_np(eng.generate(last, None, [[]], 4, eos_token_id=eos, pad_token_id=0, carry=c1, stop_check_every=every, stats=st))
+        assert c1["out"] is None and np.array_equal(out1, ref1)
+        assert min(st["live_rows_per_step"]) == 130            # the own row did leave the batch although 1 < 131 // 64
+        got = dict(c1["finished"])
+        for i in range(130):
+            assert np.array_equal(got[(0, i)], ref0[i]), (slots, every, i, got[(0, i)], ref0[i])
+
+
 def test_sampled_generation_is_a_function_of_seed_and_stream_only(setup, gpu):
     """`generate(..., sampling=)` - HF's do_sample path (reference src/models/_qwen2_vl.py:319-329): a sequence's sampled tokens
     depend on (weights, prompt, seed, its stream id) only: the same alone and inside a batch, with and without row compaction,

@@ -589,3 +589,84 @@ def test_llava_prompt_ids_with_a_real_tokenizer_equal_hf_processor(tmp_path, nex
             assert got == want, (sizes, counts, sum(1 for t in want if t == dims.image_token_id))
     finally:
         lm._pool.shutdown()
+
+
+def test_stragglers_are_only_handed_to_a_pass_of_their_own_generation_settings():
+    """Straggler hand-over with MIXED gen_kwargs in one request list (round 4's ADVICE): a pass applies one generation length and
+    one set of sampling switches to every row of its decode batch, so an unfinished sequence may only travel to a pass of ITS key.
+    Four settings (greedy 64, greedy 96, sampled t = 0.7, sampled t = 0.3), five text-only requests each, passes of two: a
+    stand-in `_launch_chunk` hands over its last own row whenever the pipeline allows it (`below` > 0) and checks that every
+    carried-in sequence was exported under this pass's key; the last pass of every key must be told to drain (`below` == 0)."""
+    import numpy as np
+    import torch
+
+    from lmms_owc_amd.models._qwen2_vl import ByteTokenizer, Qwen2VL
+    from lmms_owc_amd.tasks import TaskInstance
+
+    tok = ByteTokenizer()
+
+    class Dims:
+        image_token_id, decoder_dtype = tok.image_pad, "bf16"
+
+    class FakeEngine:
+        d, device = Dims(), torch.device("cpu")
+
+    log = []
+
+    def answer(prompt) -> list:
+        return tok.encode(recipes.mr_answer_of(_text_of_ids(tok, prompt)))
+
+    class HostOnly(Qwen2VL):
+        def _pinned_take(self, shape):
+            return torch.empty(shape, dtype=torch.uint8)
+
+        def _pinned_give(self, groups):
+            pass
+
+        def _launch_chunk(self, prep, eos_token_id, pad, carry=None):
+            key = prep["key"] if "key" in prep else (prep["max_new"], None if prep["sampling"] is None else
+                                                     (prep["sampling"]["temperature"], prep["sampling"]["top_p"], prep["sampling"]["top_k"]))
+            out = np.full((prep["n"], prep["max_new"]), pad, np.int32)
+            rows = []
+            for i, p in enumerate(prep["prompts"]):
+                t = (answer(p) + [eos_token_id])[: prep["max_new"]]
+                out[i, : len(t)] = t
+                rows.append(out[i].copy())
+            log.append({"key": key, "n": prep["n"], "below": None if carry is None else carry["below"],
+                        "in": 0 if carry is None or carry["in"] is None else len(carry["in"]["tags"])})
+            if carry is not None:
+                cin = carry["in"]
+                carry["finished"] = []
+                if cin is not None:
+                    assert all(k == key for k in cin["key"]), (cin["key"], key)   # a carried sequence arrives in a pass of its own key
+                    carry["finished"] = list(zip(cin["tags"], cin["rows"]))
+                carry["out"], carry["unfinished_rows"] = None, []
+                if carry["below"]:      # the pipeline allows a hand-over: the last own row travels
+                    r = prep["n"] - 1
+                    carry["out"] = {"tags": [carry["tags"][r]], "rows": [rows[r]], "key": [key]}
+                    carry["unfinished_rows"] = [r]
+                    out[r] = pad          # (its row of this pass's buffer is incomplete: the pipeline must not read it)
+            return torch.from_numpy(out), _DoneEvent()
+
+    settings = [{"max_new_tokens": 64}, {"max_new_tokens": 96}, {"max_new_tokens": 64, "temperature": 0.7, "top_p": 0.9},
+                {"max_new_tokens": 64, "temperature": 0.3, "top_p": 0.9}]
+    docs = [{"id": i, "label": f"class{i}"} for i in range(20)]
+    lm = HostOnly.from_engine(FakeEngine(), tok, batch_size=2)
+    lm.task_dict["mix"] = {"test": docs}
+    reqs = [TaskInstance(request_type="generate_until", idx=0, metadata={"task": "mix", "doc_id": d["id"], "repeats": 1},
+                         arguments=(f"Say something about item {d['id']}.", dict(settings[d["id"] % 4], until=["\n\n"]),
+                                    lambda doc: [], d["id"], "mix", "test")) for d in docs]
+    try:
+        got = lm.generate_until(reqs)
+    finally:
+        lm._pool.shutdown()
+        lm._prep_thread.shutdown()
+    want = [tok.decode(answer(lm._prompt_ids(r.args[0], []))[: r.args[1].get("max_new_tokens", 128)]) for r in reqs]
+    assert got == want
+    assert len({e["key"] for e in log}) == 4 and sum(e["n"] for e in log) == 20
+    assert sum(1 for e in log if e["below"]) >= 4                       # hand-overs did happen ...
+    for a, b in zip(log, log[1:] + [None]):
+        if b is None or b["key"] != a["key"]:
+            assert not a["below"], (a, b)                               # ... but the last pass of a key drains its stragglers
+        if b is not None and b["key"] != a["key"]:
+            assert b["in"] == 0, (a, b)                                 # and nothing crosses into a pass of another key

@@ -34,6 +34,20 @@ def main():
         ops.attention(qkv, 3 * E, hd, qkv[:, E:], 3 * E, hd, qkv[:, 2 * E:], 3 * E, hd, out, E, hd, starts, starts, lens,
                       n_seq=n, n_heads=H, kv_group=1, head_dim=hd, max_q_len=L, causal=False, scale=hd ** -0.5)
 
+    # the same tokens cut into fewer, longer images: 32 x 2048 and 16 x 4096 patches (4096 = the reference's max_pixels cap,
+    # /root/reference/src/models/_qwen2_vl.py:64-65), and the cap leg's other grid, 54 x 74 = 3996 patches (not a multiple of 64)
+    big = {}
+    for n_b, L_b in ((32, 2048), (16, 4096), (16, 3996)):
+        big[(n_b, L_b)] = (i32(np.arange(n_b) * L_b, dev), i32(np.full(n_b, L_b), dev))
+
+    def vit_at(n_b, L_b):
+        st_b, ln_b = big[(n_b, L_b)]
+
+        def fn():
+            ops.attention(qkv, 3 * E, hd, qkv[:, E:], 3 * E, hd, qkv[:, 2 * E:], 3 * E, hd, out, E, hd, st_b, st_b, ln_b,
+                          n_seq=n_b, n_heads=H, kv_group=1, head_dim=hd, max_q_len=L_b, causal=False, scale=hd ** -0.5)
+        return fn
+
     # decoder prefill: 114 prompts x 286, 28 q heads / 4 kv heads x 128
     nb, S, Hq, Hkv, smax = 114, 286, 28, 4, 302
     q = torch.randn(nb * S, (Hq + 2 * Hkv) * 128, device=dev).to(torch.bfloat16)
@@ -67,7 +81,8 @@ def main():
       for v in vals:
         _lib.load().owc_tuning_set(b"attn_dbg", v)
         print(f"-- attn_dbg = {v:#x}")
-        bench_all(vit, prefill, prefill_long, n, H, L, hd, nb, Hq, S, nb3, Hq3, S3)
+        bench_all(vit, prefill, prefill_long, n, H, L, hd, nb, Hq, S, nb3, Hq3, S3,
+                  extra=[(f"vit hd80 {n_b}x{L_b}", vit_at(n_b, L_b), 4.0 * n_b * H * L_b * L_b * hd) for n_b, L_b in big])
     import hashlib
 
     torch.cuda.synchronize()
@@ -75,9 +90,9 @@ def main():
         print(f"sha256 {name:13s} {hashlib.sha256(t.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16]}")
 
 
-def bench_all(vit, prefill, prefill_long, n, H, L, hd, nb, Hq, S, nb3, Hq3, S3):
-    for name, fn, flops in (("vit hd80 64x1024", vit, 4.0 * n * H * L * L * hd), ("prefill hd128 114x286 causal", prefill, 2.0 * nb * Hq * S * S * 128),
-                            ("prefill hd128 24x2388 causal (llava-34b)", prefill_long, 2.0 * nb3 * Hq3 * S3 * S3 * 128)):
+def bench_all(vit, prefill, prefill_long, n, H, L, hd, nb, Hq, S, nb3, Hq3, S3, extra=()):
+    for name, fn, flops in [("vit hd80 64x1024", vit, 4.0 * n * H * L * L * hd), *extra, ("prefill hd128 114x286 causal", prefill, 2.0 * nb * Hq * S * S * 128),
+                            ("prefill hd128 24x2388 causal (llava-34b)", prefill_long, 2.0 * nb3 * Hq3 * S3 * S3 * 128)]:
         for _ in range(3):
             fn()
         torch.cuda.synchronize()

@@ -43,6 +43,70 @@ def not_executed(d, S: int, shared_rows: float) -> float:
     return float(last_layer + shared_rows * per_row)
 
 
+def run(model: str, batch: int, steps: int = 2, warmup: int = 1, new_tokens: int = 16, image_size: str = "480x640",
+        text_tokens: int = 48, decoder_dtype: str = "bf16") -> dict:
+    """One measurement (also a leg of bench.py's default run: `llava_next_34b_leg`)."""
+    from lmms_owc_amd import _lib
+    from lmms_owc_amd.engine import anyres
+    from lmms_owc_amd.engine.llava import DIMS, LlavaEngine, LlavaWeights
+    from lmms_owc_amd.models import imageproc
+
+    device = torch.device("cuda", torch.cuda.current_device())
+    d = DIMS[model]
+    if decoder_dtype != "bf16":
+        import dataclasses
+
+        d = dataclasses.replace(d, decoder_dtype=decoder_dtype)
+    t_w = time.perf_counter()
+    eng = LlavaEngine(LlavaWeights.random(d, device, seed=1234))
+    torch.cuda.synchronize()
+    t_w = time.perf_counter() - t_w
+    h, w = (int(x) for x in image_size.split("x"))
+    nv = anyres.num_views((h, w), d.grid_pinpoints, d.image_size) if d.grid_pinpoints else 1
+    B, T = batch, new_tokens
+    u8 = torch.randint(0, 256, (B * nv, 3, d.image_size, d.image_size), dtype=torch.uint8, device=device)
+    rows = eng.feature_rows([nv] * B, [(h, w)] * B)
+    r = np.random.default_rng(0)
+    head, tail = r.integers(1000, 30000, text_tokens // 2), r.integers(1000, 30000, text_tokens - text_tokens // 2)
+    prompts = [np.concatenate([head, np.full(len(rows[b]), d.image_token_id), tail]).astype(np.int32) for b in range(B)]
+    S = len(prompts[0])
+
+    def step():
+        feats = eng.encode_views(eng.patchify(u8, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD))
+        return eng.generate_from_features(prompts, feats, rows, T, eos_token_id=-1, pad_token_id=0).cpu()
+
+    lib, ctx = _lib.load(), _lib.ctx(device.index or 0)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    lib.owc_gemm_profile_enable(ctx, 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms2, fl2, n2 = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int64 * 2)()
+    _lib.check(lib.owc_gemm_profile_read(ctx, ms2, fl2, n2), 0)
+    ms, fl, n = C.c_double(ms2[0] + ms2[1]), C.c_double(fl2[0] + fl2[1]), C.c_int64(n2[0] + n2[1])
+    fp8_tf = fl2[1] / (ms2[1] * 1e-3) / 1e12 if ms2[1] > 0 else None
+    lib.owc_gemm_profile_enable(ctx, 0)
+    assert out.shape == (B, T)
+    ips = B * steps / dt
+    f_model = flops(d, nv, S, T)
+    per_group = max(1, min(B, 65536 // S))  # prompts per prefill launch group (engine default prefill_chunk_tokens)
+    f = f_model - not_executed(d, S, len(head) * (1.0 - 1.0 / per_group))  # executed FLOPs: what the utilisation is priced on
+    return {"metric": f"images/s {model} open-world classify (1 GPU)", "value": ips, "unit": "images/s", "dtype": "bf16" if decoder_dtype == "bf16" else "fp8-e4m3 decoder projections, bf16 elsewhere",
+            "data": "synthetic", "ms_per_step": dt / steps * 1e3,
+            "config": {"workload": f"{model}: {B} synthetic {h}x{w} images per step, {nv} CLIP view(s) of {d.image_size}px each, "
+                                   f"prompt S={S} ({len(rows[0])} image tokens), {T} forced greedy tokens, random weights",
+                       "views_per_image": nv, "prompt_tokens": S, "new_tokens": T},
+            "model_flops_per_image": f_model, "executed_flops_per_image": f, "mfma_frac_end_to_end": ips * f / PEAK,
+            "roofline": {"bound": "mfma", "achieved": fl.value / (ms.value * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": fl.value / (ms.value * 1e-3) / PEAK, "share_of_step_time": ms.value * 1e-3 / dt,
+                         "launches": int(n.value)},
+            "decoder_dtype": decoder_dtype, "fp8_gemm_tflops": fp8_tf, "weights_gb": eng.w.nbytes() / 1e9, "weight_init_seconds": t_w}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="llava-1.5-7b")
@@ -54,63 +118,9 @@ def main() -> None:
     ap.add_argument("--text-tokens", type=int, default=48)
     ap.add_argument("--decoder-dtype", default="bf16", choices=["bf16", "fp8"])
     args = ap.parse_args()
-    from lmms_owc_amd import _lib
-    from lmms_owc_amd.engine import anyres
-    from lmms_owc_amd.engine.llava import DIMS, LlavaEngine, LlavaWeights
-    from lmms_owc_amd.models import imageproc
-
-    device = torch.device("cuda", 0)
-    torch.cuda.set_device(device)
-    d = DIMS[args.model]
-    if args.decoder_dtype != "bf16":
-        import dataclasses
-
-        d = dataclasses.replace(d, decoder_dtype=args.decoder_dtype)
-    eng = LlavaEngine(LlavaWeights.random(d, device, seed=1234))
-    h, w = (int(x) for x in args.image_size.split("x"))
-    nv = anyres.num_views((h, w), d.grid_pinpoints, d.image_size) if d.grid_pinpoints else 1
-    B, T = args.batch, args.new_tokens
-    u8 = torch.randint(0, 256, (B * nv, 3, d.image_size, d.image_size), dtype=torch.uint8, device=device)
-    rows = eng.feature_rows([nv] * B, [(h, w)] * B)
-    r = np.random.default_rng(0)
-    head, tail = r.integers(1000, 30000, args.text_tokens // 2), r.integers(1000, 30000, args.text_tokens - args.text_tokens // 2)
-    prompts = [np.concatenate([head, np.full(len(rows[b]), d.image_token_id), tail]).astype(np.int32) for b in range(B)]
-    S = len(prompts[0])
-
-    def step():
-        feats = eng.encode_views(eng.patchify(u8, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD))
-        return eng.generate_from_features(prompts, feats, rows, T, eos_token_id=-1, pad_token_id=0).cpu()
-
-    lib, ctx = _lib.load(), _lib.ctx(0)
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    lib.owc_gemm_profile_enable(ctx, 1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ms2, fl2, n2 = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int64 * 2)()
-    _lib.check(lib.owc_gemm_profile_read(ctx, ms2, fl2, n2), 0)
-    ms, fl, n = C.c_double(ms2[0] + ms2[1]), C.c_double(fl2[0] + fl2[1]), C.c_int64(n2[0] + n2[1])
-    fp8_tf = fl2[1] / (ms2[1] * 1e-3) / 1e12 if ms2[1] > 0 else None
-    lib.owc_gemm_profile_enable(ctx, 0)
-    assert out.shape == (B, T)
-    ips = B * args.steps / dt
-    f_model = flops(d, nv, S, T)
-    per_group = max(1, min(B, 65536 // S))  # prompts per prefill launch group (engine default prefill_chunk_tokens)
-    f = f_model - not_executed(d, S, len(head) * (1.0 - 1.0 / per_group))  # executed FLOPs: what the utilisation is priced on
-    print(json.dumps({"metric": f"images/s {args.model} open-world classify (1 GPU)", "value": ips, "unit": "images/s", "dtype": "bf16" if args.decoder_dtype == "bf16" else "fp8-e4m3 decoder projections, bf16 elsewhere",
-                      "data": "synthetic", "ms_per_step": dt / args.steps * 1e3,
-                      "config": {"workload": f"{args.model}: {B} synthetic {h}x{w} images per step, {nv} CLIP view(s) of {d.image_size}px each, "
-                                             f"prompt S={S} ({len(rows[0])} image tokens), {T} forced greedy tokens, random weights",
-                                 "views_per_image": nv, "prompt_tokens": S, "new_tokens": T},
-                      "model_flops_per_image": f_model, "executed_flops_per_image": f, "mfma_frac_end_to_end": ips * f / PEAK,
-                      "roofline": {"bound": "mfma", "achieved": fl.value / (ms.value * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                                   "frac": fl.value / (ms.value * 1e-3) / PEAK, "share_of_step_time": ms.value * 1e-3 / dt,
-                                   "launches": int(n.value)},
-                      "decoder_dtype": args.decoder_dtype, "fp8_gemm_tflops": fp8_tf, "weights_gb": eng.w.nbytes() / 1e9}), flush=True)
+    torch.cuda.set_device(0)
+    print(json.dumps(run(args.model, args.batch, args.steps, args.warmup, args.new_tokens, args.image_size, args.text_tokens,
+                         args.decoder_dtype)), flush=True)
 
 
 if __name__ == "__main__":
