@@ -70,7 +70,9 @@ const char* owc_last_error(const owc_ctx* ctx);
  * folds the decoder's RMSNorm into the qkv / gate-up projection; 0 off), "gemm_k_pairs" / "gemm_k_pairs_min_k" (K-tiles per ring stage: 0 one,
  * default four from K >= 1024), "gemm_wide_tiles" (0: no 64x160 / 128x160 tiles of that
  * kernel for launches of at most 128 rows x tens of thousands of columns), "gemm_ring_128" (0: no 128x64 tiles of that kernel - bf16
- * and fp8 - for a few hundred rows x a few thousand columns, where 64x64 tiles need more than a round and a half of the chip).
+ * and fp8 - for a few hundred rows x a few thousand columns, where 64x64 tiles need more than a round and a half of the chip),
+ * "gemm_pp128" (the 256x128-tile ping-pong kernel for launches with too few 256x256 tiles to fill the chip - the o / down projections
+ * of a decode step at 1024-2048 rows: 0 off, n > 0: from n tiles of 256x128, negative: the default).
  * Every knob above selects between kernels that return the SAME results.  The timing-only experiment knobs "gemm_dbg" /
  * "attn_dbg" (parts of a kernel switched off to price them; outputs are garbage) exist only in libowc_hip_timing.so, which
  * `python -m lmms_owc_amd.build --timing` builds with -DOWC_TIMING_KNOBS for tools/; the product library does not know them.

@@ -61,6 +61,7 @@ int g_norm_fuse_max_m = 2; // rows up to which the decoder's RMSNorm is fused in
                            // Measured, 7B decode step in ms, separate / fused: 1 row 3.78 / 3.44, 2 rows 3.78 / 3.65, 4 rows 3.88 / 4.11 - every wave
                            // normalises every row itself, so beyond 2 rows the redundant work outweighs the launch it saves
 int g_pingpong = 1;       // 256x256 launches with K % 128 == 0 use the ping-pong kernel (A-B knob "gemm_pingpong", 0 = lock-step kernel)
+int g_pp128_min_tiles = 128;  // the 256x128 ping-pong kernel runs from this many of its tiles, up to 256 = one round (knob "gemm_pp128"; 0 off)
 int g_big_min_m = 129;   // M at and above which the 256x256 kernels may run (knob "gemm_big_min_m"; round 1: 1024)
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -811,6 +812,229 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Ping-pong kernel on a 256 x 128 tile (round 5): the role-alternating schedule of gemm_bf16_nt_256pp_kernel for launches whose
+// 256 x 256 tiles would leave more than half of the CUs idle - the o / down projections (N = 3584) of a decode step at
+// 1024-2048 rows (a full pass's decode batch: 8 x 14 = 112 tiles of 256^2, 224 of 256 x 128), which ran on the 128 x 128
+// lock-step kernel at 0.36 of the MFMA peak.  8 waves = 4 (rows) x 2 (columns) wave tiles of 64 x 64 (64 accumulator VGPRs);
+// waves 0-3 (rows 0-127) and waves 4-7 (rows 128-255) are the two role groups, one barrier interval apart.  A K-tile is TWO
+// phases - the wave tile's column half 0, then half 1, each 4 m tiles x 2 n tiles x 2 k-steps = 16 MFMAs - and a phase is
+// [load section] s_barrier [MFMA section] s_barrier as there.  A K-tile lasts half as long as a 256 x 256 one, so the DMA
+// runs TWO K-tiles ahead through a ring of three 48-KiB stages (A 256 rows + W 128 rows of 128 B; 144 KiB):
+//   L0(u)  read A(u) [8 ds_read_b128]                                 issue W(u+2), A rows 0-127 of u+2    wait: W(u+1) landed
+//   L1(u)  read W(cols half 1, u) [4], W(cols half 0, u+1) [4]        issue A rows 128-255 of u+2          wait: A(u+1) landed
+// with counted vmcnt(8) / vmcnt(6) (four / three half-tiles stay in flight), the wait at the END of a load section and the
+// read one phase later (RAW), a stage restaged a whole K-tile after its last read (WAR; every load section ends with
+// lgkmcnt(0) before its barrier).  The column-half-0 fragments are dead after the first MFMA section, so the next tile's
+// go into the same registers (the 256 x 256 kernel needs two sets).  The loop walks three K-tiles per iteration, so every
+// ring slot is a compile-time constant (no vector instruction in the loop but the MFMAs); the 2-4 last K-tiles are peeled
+// with exact counts.  Requires K % 64 == 0, K >= 128.  Every output element is ONE ascending K chain (k-step 0 then 1 of
+// every K-tile): bit-identical to every other bf16 GEMM kernel here.
+// ------------------------------------------------------------------------------------------------
+constexpr int P128_A_BYTES = 256 * BK * 2;                 // 32 KiB
+constexpr int P128_STAGE = P128_A_BYTES + 128 * BK * 2;    // 48 KiB
+constexpr int P128_LDS = 3 * P128_STAGE;                   // 144 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_nt_256x128pp_kernel(
+    const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
+    const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv, long ldc, int M, int N, int K,
+    int tiles_m, int tiles_n, int dbg, owc_gemm_aux aux) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int nblk = tiles_m * tiles_n;
+  const int nk = K / BK;
+
+  int m0, n0;
+  {
+    const int bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int width = GROUP_M2 * tiles_n;
+    const int group = lid / width;
+    const int first_m = group * GROUP_M2;
+    const int gsize = min(tiles_m - first_m, GROUP_M2);
+    m0 = (first_m + (lid % width) % gsize) * 256;
+    n0 = ((lid % width) / gsize) * 128;
+  }
+  const char* abase = (const char*)(A + (long)m0 * lda);
+  const char* wbase = (const char*)(W + (long)n0 * ldw);
+  // DMA sources of this wave: A half h, piece j -> rows 128h + 16w + 8j .. +8; W piece j -> rows 16w + 8j .. +8
+  unsigned aoff[2][2], woff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = 128 * h + 16 * w + 8 * j + (l >> 3);
+      aoff[h][j] = (unsigned)((long)min(row, M - 1 - m0) * lda * 2 + ((l & 7) ^ ((row >> 1) & 7)) * 16);
+    }
+    const int row = 16 * w + 8 * j + (l >> 3);
+    woff[j] = (unsigned)((long)min(row, N - 1 - n0) * ldw * 2 + ((l & 7) ^ ((row >> 1) & 7)) * 16);
+  }
+  // (kt: the K-tile, sl: its ring slot = kt % 3, a compile-time constant at every call)
+  auto issue_a = [&](int kt, int sl, int h) {   // scalar base + 32-bit lane offset form (see the 256 x 256 kernel)
+    char* dst = lds + sl * P128_STAGE + (128 * h + 16 * w) * 128;
+    const char* ab = abase + (long)kt * (BK * 2);
+    asm volatile("" : "+s"(ab), "+v"(aoff[h][0]), "+v"(aoff[h][1]));
+    glds16(ab + aoff[h][0], dst);
+    glds16(ab + aoff[h][1], dst + 1024);
+  };
+  auto issue_w = [&](int kt, int sl) {
+    char* dst = lds + sl * P128_STAGE + P128_A_BYTES + 16 * w * 128;
+    const char* wb = wbase + (long)kt * (BK * 2);
+    asm volatile("" : "+s"(wb), "+v"(woff[0]), "+v"(woff[1]));
+    glds16(wb + woff[0], dst);
+    glds16(wb + woff[1], dst + 1024);
+  };
+
+  const int grp = w >> 2, wr = 2 * grp + ((w >> 1) & 1), wc = w & 1;   // wave tile: rows 64 wr .., columns 64 wc ..
+  const int fr = l & 15, fq = l >> 4;
+  const int swz = (fr >> 1) & 7;
+  const int rowA = (wr * 64 + fr) * 128;
+  const int rowW = P128_A_BYTES + (wc * 64 + fr) * 128;
+  const int ch0 = ((0 + fq) ^ swz) << 4, ch1 = ((4 + fq) ^ swz) << 4;
+
+  f32x4 acc[4][4];  // [nt][mt]
+  bf16x8 fa[2][4], wx[2][2], wy[2][2];   // A (4 m tiles x 2 k-steps), W column half 0, W column half 1
+
+  auto read_a = [&](const char* sbase) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      fa[0][t] = *(const bf16x8*)(sbase + rowA + t * 2048 + ch0);
+      fa[1][t] = *(const bf16x8*)(sbase + rowA + t * 2048 + ch1);
+    }
+  };
+  auto read_w = [&](bf16x8 (&dst)[2][2], const char* sbase, int nh) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      dst[0][t] = *(const bf16x8*)(sbase + rowW + (nh * 2 + t) * 2048 + ch0);
+      dst[1][t] = *(const bf16x8*)(sbase + rowW + (nh * 2 + t) * 2048 + ch1);
+    }
+  };
+#define OWC_PP_SYNC_L(VM)                                                                         \
+  do {                                                                                            \
+    if constexpr ((VM) >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((VM) < 0 ? 0 : (VM)) : "memory"); \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                               \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+  } while (0)
+  auto half = [&](const bf16x8 (&wf)[2][2], int nh) {   // MFMA section: the wave tile's column half nh over the whole K-tile
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[nh * 2 + n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][n], fa[ks][m], acc[nh * 2 + n][m], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // one K-tile u in ring slot SL; MODE 0 steady (u + 2 < nk), 1 second to last, 2 last
+  auto ktile = [&](auto mode_c, auto slot_c, int u) {
+    constexpr int MODE = decltype(mode_c)::value, SL = decltype(slot_c)::value;
+    constexpr int SL1 = (SL + 1) % 3, SL2 = (SL + 2) % 3;
+    const char* cur = lds + SL * P128_STAGE;
+    // L0
+    read_a(cur);
+    if constexpr (MODE == 0) {
+      issue_w(u + 2, SL2);
+      issue_a(u + 2, SL2, 0);
+      OWC_PP_SYNC_L(8);   // W(u+1) landed; in flight: A0(u+1), A1(u+1), W(u+2), A0(u+2)
+    } else if constexpr (MODE == 1) {
+      OWC_PP_SYNC_L(4);   // in flight: A0(u+1), A1(u+1)
+    } else {
+      OWC_PP_SYNC_L(-1);
+    }
+    half(wx, 0);
+    // L1
+    read_w(wy, cur, 1);
+    if constexpr (MODE <= 1) read_w(wx, lds + SL1 * P128_STAGE, 0);
+    if constexpr (MODE == 0) {
+      issue_a(u + 2, SL2, 1);
+      OWC_PP_SYNC_L(6);   // A(u+1) landed; in flight: W(u+2), A0(u+2), A1(u+2)
+    } else if constexpr (MODE == 1) {
+      OWC_PP_SYNC_L(0);
+    } else {
+      OWC_PP_SYNC_L(-1);
+    }
+    half(wy, 1);
+  };
+
+  // ---- prologue: K-tiles 0 and 1 entirely (issue order = the steady state's)
+  issue_a(0, 0, 0);
+  issue_a(0, 0, 1);
+  issue_w(0, 0);
+  issue_w(1, 1);
+  issue_a(1, 1, 0);
+  issue_a(1, 1, 1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");   // K-tile 0 landed and published
+  __builtin_amdgcn_sched_barrier(0);
+  read_w(wx, lds, 0);
+  if (grp) {   // group 1 runs one barrier interval behind group 0
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  using M0_ = std::integral_constant<int, 0>;
+  using M1_ = std::integral_constant<int, 1>;
+  using M2_ = std::integral_constant<int, 2>;
+  using S0_ = std::integral_constant<int, 0>;
+  using S1_ = std::integral_constant<int, 1>;
+  using S2_ = std::integral_constant<int, 2>;
+  int u = 0;
+  for (; u + 4 < nk; u += 3) {   // u % 3 == 0 throughout: the slots are constants
+    ktile(M0_{}, S0_{}, u);
+    ktile(M0_{}, S1_{}, u + 1);
+    ktile(M0_{}, S2_{}, u + 2);
+  }
+  const int left = nk - u;   // 2, 3 or 4
+  if (left == 4) {
+    ktile(M0_{}, S0_{}, u);
+    ktile(M0_{}, S1_{}, u + 1);
+    ktile(M1_{}, S2_{}, u + 2);
+    ktile(M2_{}, S0_{}, u + 3);
+  } else if (left == 3) {
+    ktile(M0_{}, S0_{}, u);
+    ktile(M1_{}, S1_{}, u + 1);
+    ktile(M2_{}, S2_{}, u + 2);
+  } else {
+    ktile(M1_{}, S0_{}, u);
+    ktile(M2_{}, S1_{}, u + 1);
+  }
+  if (!grp) {  // group 0 waits for group 1's last MFMA section: every wave has executed the same number of barriers
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef OWC_PP_SYNC_L
+  // (the accumulators are pinned here: MFMAs have no side effect an s_barrier orders, and LLVM's sinking pass otherwise moves the
+  // last K-tile's MFMAs next to their only use, into the epilogue's conditional store blocks - round 3, fp8 kernel)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
+
+  if (OWC_TK(dbg & 4)) {  // timing experiment: no epilogue
+    if (acc[0][0][0] == 123.456f) ((float*)Cv)[0] = 1.f;
+    return;
+  }
+  if constexpr (EPI == OWC_EPI_F32) {
+    gemm_epilogue<EPI, 4>(acc, m0 + wr * 64, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux);
+  } else {
+    // LDS is quiescent: every wave has passed the final barrier with its reads retired and no DMA pending
+    constexpr int CCOLS = EPI == OWC_EPI_SWIGLU ? 64 : 128;
+    gemm_epilogue<EPI, 4>(acc, m0 + wr * 64, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux, lds, CCOLS * 2, wr * 64, wc * 64);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    store_ctile<8>(lds, 256, CCOLS, (bf16_t*)Cv, ldc, m0, EPI == OWC_EPI_SWIGLU ? (n0 >> 1) : n0, M,
+                   EPI == OWC_EPI_SWIGLU ? (N >> 1) : N, w, l);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Skinny-M variant (M <= 64: greedy decode at the reference's own batch sizes, 1 ... a few dozen sequences).  There the
 // GEMM is a weight STREAM: every byte of W is read once per step, the arithmetic is nothing, and the tiled kernels above
 // leave most CUs idle (the o / down projections of the 7B decoder are 28 tiles wide).  Here ONE WAVE owns 16 rows of W
@@ -1115,7 +1339,9 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
         hipFuncSetAttribute((const void*)gemm_bf16_nt_256_kernel<EPI>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_kernel<EPI>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_bf16_nt_256x128pp_kernel<EPI>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, P128_LDS) != hipSuccess)
       return OWC_ERR_HIP;
     attr_set = true;
   }
@@ -1127,7 +1353,15 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
     owc_gemm_profile_end(prof, s);
     return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
   }
-  if (big && g_pingpong && (K % (2 * BK)) == 0) {
+  // too few 256x256 tiles to fill the chip, but one round of 256x128 tiles does (decode o / down projections at 1024-2048 rows)
+  const long t128 = (long)((M + 255) / 256) * ((N + 127) / 128);
+  const bool pp128 = !big && !wide && g_pp128_min_tiles > 0 && g_pingpong && M >= g_big_min_m && N >= 128 && (K % BK) == 0 && K >= 2 * BK &&
+                     t128 >= g_pp128_min_tiles && t128 <= 256;
+  if (pp128) {
+    hipLaunchKernelGGL(gemm_bf16_nt_256x128pp_kernel<EPI>, dim3((int)t128), dim3(512), P128_LDS, s, (const bf16_t*)A, lda, (const bf16_t*)W,
+                       ldw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C, ldc, M, N, K, (M + 255) / 256, (N + 127) / 128, g_gemm_dbg, aux);
+  }
+  else if (big && g_pingpong && (K % (2 * BK)) == 0) {
     // C far larger than L2 + Infinity Cache (256 MB): stream it out (`global_store ... nt`) instead of evicting the operand panels the
     // XCD's L2 is sharing: +0.3...3 % per launch on the path's shapes (vit.proj 1154 -> 1192 TFLOP/s, gate/up 1459 -> 1480), never
     // slower; a small C (decode steps) stays cacheable for the kernel that reads it next
@@ -1426,3 +1660,4 @@ void owc_gemm_set_k_pairs_min_k(int v) { g_k_pairs_min_k = v < 0 ? 1024 : v; }
 void owc_gemm_set_tall_tiles(int v) { g_tall_tiles = v != 0; g_wide_min_blocks = v > 1 ? v : 128; }
 void owc_gemm_set_small_tiles(int v) { g_small_tiles = v < 0 ? 1 : v; }
 void owc_gemm_set_ring_128(int v) { g_ring_128 = v < 0 ? 1 : v != 0; }
+void owc_gemm_set_pp128(int v) { g_pp128_min_tiles = v < 0 ? 128 : v; }

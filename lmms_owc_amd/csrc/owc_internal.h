@@ -90,6 +90,7 @@ int owc_launch_gemm_bf16_rmsnorm(const void* X, long ldx, const void* gamma, flo
 void owc_gemm_set_skinny_deep(int v);
 void owc_gemm_set_small_tiles(int v);
 void owc_gemm_set_ring_128(int v);
+void owc_gemm_set_pp128(int v);
 void owc_gemm_fp8_set_ring_128(int v);
 void owc_gemm_fp8_set_shapes(int v);
 void owc_gemm_set_k_pairs(int v);

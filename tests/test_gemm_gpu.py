@@ -304,6 +304,46 @@ def test_gemm_ring_128_race_screen(gpu, m, n, k, epi):
         lib.owc_tuning_set(b"gemm_mid_max_tiles", 256)
 
 
+@pytest.mark.parametrize("m,n,k,epi", [(2048, 3584, 18944, "residual"), (2048, 3584, 3584, "residual"), (1300, 3584, 3584, "none"),
+                                       (1500, 3000, 128, "residual"),    # two K-tiles: prologue + the peeled tail only
+                                       (1100, 3520, 192, "none"),         # three K-tiles, ragged N (a 64-column last tile)
+                                       (1281, 2600, 256, "residual"),     # four K-tiles (the 4-tile tail), one row into the sixth row tile
+                                       (1900, 3584, 320, "none"),         # five K-tiles: one loop iteration + a 2-tile tail
+                                       (2048, 4096, 448, "swiglu"), (1792, 3584, 1280, "quick_gelu")])
+def test_gemm_256x128_pingpong_race_screen(gpu, m, n, k, epi):
+    """Round 5: `gemm_bf16_nt_256x128pp_kernel` (role-alternating waves on a 256 x 128 tile behind a three-stage LDS-DMA ring, two
+    K-tiles ahead, counted vmcnt(8) / vmcnt(6)) - the o / down projections of a decode step at 1024-2048 rows, where 256 x 256 tiles
+    would leave more than half of the chip idle.  Against the 128 x 128 kernel (knob off), 10 launches per shape: bit-identical
+    (one ascending K chain per output whatever the tile), for every length of the peeled tail (2-4 K-tiles), ragged M / N, every
+    epilogue family the LDS-staged store takes."""
+    from lmms_owc_amd import _lib, ops
+
+    lib = _lib.load()
+    a = bf16_randn((m, k), 50 + (m % 97), device=gpu)
+    w = bf16_randn((n, k), 51, 0.05, device=gpu)
+    b = bf16_randn((n,), 52, device=gpu)
+    r = bf16_randn((m, n), 53, device=gpu)
+    E = {"none": _lib.EPI_NONE, "residual": _lib.EPI_RESIDUAL, "swiglu": _lib.EPI_SWIGLU, "quick_gelu": _lib.EPI_QUICK_GELU}[epi]
+
+    def run():
+        if epi == "swiglu":
+            return ops.gemm_bf16(a, w, None, epilogue=E)
+        return ops.gemm_bf16(a, w, b, epilogue=E, residual=r if epi == "residual" else None)
+
+    try:
+        assert lib.owc_tuning_set(b"gemm_pp128", 0) == 0
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 0)          # the 128x128 kernel whatever the tile count
+        want = run()
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 256)
+        assert lib.owc_tuning_set(b"gemm_pp128", 1) == 0      # from one tile of 256 x 128 (every shape here has <= 256 of them)
+        for i in range(10):
+            got = run()
+            assert torch.equal(got, want), (i, (got != want).sum().item())
+    finally:
+        lib.owc_tuning_set(b"gemm_pp128", -1)
+        lib.owc_tuning_set(b"gemm_mid_max_tiles", 256)
+
+
 @pytest.mark.parametrize("m,n,k,epi", [(128, 37888, 3584, "swiglu"), (100, 33000, 1024, "none"), (40, 37888, 128, "swiglu"),
                                        (64, 40960, 64, "none"), (65, 20512, 3584, "swiglu")])
 def test_gemm_wide_tiles_race_screen(gpu, m, n, k, epi):
