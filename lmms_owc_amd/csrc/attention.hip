@@ -15,6 +15,19 @@
 //  * LDS images: head_dim 80 -> natural 160-B rows (conflict-free for both read kinds);
 //    head_dim 128 -> 256-B rows with chunk ^= (key & 7) << 1 applied on the DMA source and on both reads.
 //  * softmax in fp32 with exp2; masked/ragged keys handled on the last tile only.
+//  * round 5 (the loop was vector-ALU bound: 37 % matrix pipe, 56 % VALU, and the two do not overlap on this SIMD): the
+//    per-score vector work is down to fma + exp2 + add + half a pack - p = exp2(s * c - m_ref * c) with c = scale * log2(e), as
+//    before, but m_ref is a LAZY reference maximum: the row's running maximum as of the last time it was updated.  A tile
+//    computes its exponentials straight away (no row maximum, no cross-lane exchange, no rescale); only when a lane's sum of 16
+//    fresh exponentials exceeds 2^10 - some score of the row beat m_ref by more than 6 in log2 units - does the wave enter the
+//    slow path, where every such row (the decision is per ROW: OR over its four lanes, a function of the row's own scores, so
+//    a row's bits do not depend on which rows share its wave) takes the tile's true maximum, rescales O and l and recomputes
+//    its exponentials; rows that did not ask recompute the same bits.  P is a bf16 FLOATING-point operand and O / l are fp32,
+//    so a reference up to 2^10 below the true maximum costs no precision (values <= 2^10 instead of <= 1; tools/attn_accuracy.py:
+//    error against a float64 attention unchanged).  The first tile always takes the slow path (m_ref starts at 0).
+//    Measured and NOT kept: Q pre-multiplied by c in bf16 with the score chains started from -m_ref (the accumulators are then
+//    the exp2 arguments: another 8 VALU per 16 scores gone, +5 % over this form) - the extra rounding of Q costs 2-10 x the
+//    error at logit std 3-12 (rms 0.0018 -> 0.004-0.006 of rms |O|, profiles/r05_attn_lazy_max_ab3.txt).
 #include "owc_internal.h"
 
 namespace {
@@ -170,8 +183,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     o[d][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     o[d][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  float mrun[2] = {-1e30f, -1e30f};
+  float nmc[2] = {0.f, 0.f};       // -m_ref * c of the lane's two query rows (log2 units), uniform over a row's four lanes
   float lrun[2] = {0.f, 0.f};
+  constexpr float LAZY_BIG = 1024.f;   // a lane's 16 exponentials sum to <= 16 while no score exceeds m_ref
 
   // fragment byte offsets inside a tile
   // K (A operand of S^T): row key = 16*kt + fr, chunk ks*4+g
@@ -206,8 +220,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
         if (C::CPR % 4 == 0 || ks < C::KS - 1) {
           kf = *(const bf16x8*)(krow + ((c ^ kswz) << 4));
         } else {
-          // head_dim 80: chunks 10, 11 of the last k-step do not exist; the Q fragment is zero there, so any
-          // finite K data (the row's last real chunk) contributes exactly 0
+          // head_dim 80: chunks 10, 11 of the last k-step do not exist; the Q fragment is zero there, so any finite K data (the
+          // row's last real chunk) contributes exactly 0.  (Round 5 measured ONE v_mfma_f32_16x16x16_bf16 on dims 64-79 for that
+          // half step instead: the same bits and the same time - the 16-deep MFMA takes as long as the 32-deep one on gfx950.)
           const int cc = min(c, C::CPR - 1);
           kf = *(const bf16x8*)(krow + ((cc ^ kswz) << 4));
         }
@@ -236,23 +251,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
             if (key >= L || (CAUSAL && key > qrow[qt] + coff)) s[kt][qt][r] = -1e30f;
           }
     }
+    // per 16-query tile: fast path p = exp2(s c - m_ref c), one add per value for the row sum; slow path (wave-uniform branch:
+    // the first tile, and whenever some row of the wave outgrew its reference maximum) as described on top
     bf16x8 pf[2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      // raw scores; the softmax scale (and log2 e) is folded into the exp2 argument by one (packed) fma per pair
-      float mx = -1e30f;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
-      mx = max_over_groups(mx);
-      const float mnew = fmaxf(mrun[qt], mx);
-      const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * scale_log2e);
-      const float neg = -mnew * scale_log2e;
-      mrun[qt] = mnew;
-      const f32x2 sc2 = (f32x2){scale_log2e, scale_log2e}, ng2 = (f32x2){neg, neg};
-      f32x2 sum2 = (f32x2){0.f, 0.f};
       float x[4][4];
+      float s0 = 0.f, s1 = 0.f;   // two chains: half the dependent-add latency
+      const f32x2 sc2 = (f32x2){scale_log2e, scale_log2e};
+      f32x2 ng2 = (f32x2){nmc[qt], nmc[qt]};
+      asm volatile("" : "+v"(ng2));   // a real register pair holding the value twice: the packed fma must not pick src2's high half for its low
+                                      // result (`op_sel:[0,0,1]`, the form build.py refuses)
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -261,20 +270,55 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
           const f32x2 p = OWC_TK(dbg & 2) ? a : (f32x2){__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};   // (timing build: no exp)
           x[kt][r] = p[0];
           x[kt][r + 1] = p[1];
-          sum2 += p;  // v_pk_add_f32
+          s0 += p[0];
+          s1 += p[1];
         }
-      const float sum = sum2[0] + sum2[1];
-      lrun[qt] = lrun[qt] * alpha + sum;
-      // the running max rarely moves after the first tiles: skip the O rescale when no lane needs it
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+      // (the two halves are pinned in registers of their own before they are added: the SLP vectoriser keeps (s0, s1) as one packed
+      // pair, and its horizontal add is `v_pk_add_f32 ... op_sel:[0,1]`, the form build.py refuses - gemm_epilogue.h has the story)
+      asm volatile("" : "+v"(s0), "+v"(s1));
+      float sum = s0 + s1;
+      if (t == 0 || __builtin_amdgcn_ballot_w64(sum > LAZY_BIG) != 0) {
+        asm volatile("" ::: "memory");
+        float mx = -1e30f;
 #pragma unroll
-        for (int d = 0; d < C::DT; ++d) {
-          o[d][qt][0] *= alpha;
-          o[d][qt][1] *= alpha;
-          o[d][qt][2] *= alpha;
-          o[d][qt][3] *= alpha;
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
+        mx = max_over_groups(mx);                                          // the tile's row maximum (raw score units)
+        const float ask = max_over_groups(sum > LAZY_BIG ? 1.f : 0.f);   // the ROW asks (any of its four lanes)
+        const float over = __builtin_fmaf(mx, scale_log2e, nmc[qt]);       // by how much it exceeds m_ref, in log2 units
+        const float d = (t == 0) ? over : (ask > 0.f ? over : 0.f);        // rows that did not ask keep m_ref: same bits below
+        if (t != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(-d);
+          lrun[qt] *= alpha;
+#pragma unroll
+          for (int dd = 0; dd < C::DT; ++dd) {
+            o[dd][qt][0] *= alpha;
+            o[dd][qt][1] *= alpha;
+            o[dd][qt][2] *= alpha;
+            o[dd][qt][3] *= alpha;
+          }
         }
+        nmc[qt] -= d;
+        ng2 = (f32x2){nmc[qt], nmc[qt]};
+        asm volatile("" : "+v"(ng2));
+        s0 = 0.f;
+        s1 = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            const f32x2 a = (f32x2){s[kt][qt][r], s[kt][qt][r + 1]} * sc2 + ng2;
+            const float pa = __builtin_amdgcn_exp2f(a[0]), pb = __builtin_amdgcn_exp2f(a[1]);
+            x[kt][r] = pa;
+            x[kt][r + 1] = pb;
+            s0 += pa;
+            s1 += pb;
+          }
+        asm volatile("" : "+v"(s0), "+v"(s1));
+        sum = s0 + s1;
       }
+      lrun[qt] += sum;
 #pragma unroll
       for (int sx = 0; sx < 2; ++sx) {
         bf16x8 f;

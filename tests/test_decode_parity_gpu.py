@@ -193,6 +193,7 @@ WIDTHS = {
     "7b": (3584, 28, 4, 18944, True),       # BASELINE config #3
     "yi34b": (7168, 56, 8, 20480, False),   # BASELINE config #4 (LLaVA-1.6-34B decoder: Llama-style, no biases)
     "72b": (8192, 64, 8, 29568, True),      # BASELINE config #5
+    "q25_3b": (2048, 16, 2, 11008, True),   # Qwen2.5-VL-3B's decoder (registry name qwen2.5-vl-3b; the -7b decoder has the "7b" widths)
 }
 
 
@@ -354,9 +355,11 @@ def test_2b_width_decode_steps_all_gemm_kernels(gpu, B):
     _run_slice("2b", gpu, B, 8)
 
 
-@pytest.mark.parametrize("name,B", [("7b", 8), ("7b", 300), ("yi34b", 8), ("yi34b", 130), ("72b", 8), ("72b", 130)])
+@pytest.mark.parametrize("name,B", [("7b", 8), ("7b", 300), ("yi34b", 8), ("yi34b", 130), ("72b", 8), ("72b", 130), ("q25_3b", 8),
+                                    ("q25_3b", 300)])
 def test_config_width_decode_steps(gpu, name, B):
-    """BASELINE configs #3 / #4 / #5 at their own decoder widths (2-layer slices), prefill + 5 decode steps."""
+    """BASELINE configs #3 / #4 / #5 at their own decoder widths (2-layer slices), prefill + 5 decode steps; round 5: the
+    Qwen2.5-VL-3B decoder's widths (/root/reference/src/models/_qwen2_vl.py:635-648: `qwen2.5-vl-3b`; d = 2048, 16 / 2 heads, 11008)."""
     _run_slice(name, gpu, B, 6)
 
 

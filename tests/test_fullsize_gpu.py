@@ -47,6 +47,38 @@ def test_vision_slice_full_width(slice_model, gpu):
         assert np.abs(got - ref).mean() <= 0.004 * np.abs(ref).max()
 
 
+def test_qwen25_vision_slice_full_width(gpu):
+    """Qwen2.5-VL's vision tower at its real widths (registry names qwen2.5-vl-7b / -3b, /root/reference/src/models/_qwen2_vl.py:
+    106-115, 635-648): hidden 1280 x 16 heads, gated MLP of 3420 (zero-padded to 3456 = 27 x 128 at load, so its down projection
+    runs the ping-pong GEMM), 112-pixel windows, a 3-block slice whose MIDDLE block is a full-attention block, merger 5120 -> 2048
+    (the 3B decoder's width).  18 300 patch rows in one launch group: twelve 448 x 448 images, two 36 x 28-patch images (504 x 392:
+    both sides end in HALF windows) and one cap-size non-square image (54 x 74 patches = 756 x 1036 pixels: 6 3/4 x 9 1/4 windows, 3996
+    keys in the full-attention block) - against oracle/qwen25vl_np.py (pinned on HF's Qwen2_5_VLForConditionalGeneration) under the
+    2 % bound of the Qwen2-VL slice."""
+    from lmms_owc_amd.engine.qwen2vl import Qwen2VLDims, Qwen2VLEngine, Qwen2VLWeights
+    from oracle import qwen25vl_np as Q25
+
+    cfg = Q25.Cfg25(vision=Q25.Vision25Cfg(depth=3, embed_dim=1280, num_heads=16, intermediate_size=3420, hidden_size=2048,
+                                           window_size=112, fullatt_block_indexes=(1,)),
+                    text=Q.TextCfg(hidden_size=2048, num_hidden_layers=1, num_attention_heads=16, num_key_value_heads=2,
+                                   intermediate_size=256, vocab_size=512, tie_word_embeddings=False), image_token_id=500)
+    w = recipes.qwen25vl_weights(cfg, 97)
+    dims = Qwen2VLDims(v_variant=1, v_depth=3, v_embed=1280, v_heads=16, v_mlp=3420, v_fullatt=(1,), n_layers=1, d_model=2048, n_q_heads=16,
+                       n_kv_heads=2, d_ff=256, vocab=512, tie_embeddings=False, image_token_id=500, max_positions=512, max_grid=128)
+    eng = Qwen2VLEngine(Qwen2VLWeights.from_state_dict(dims, w, gpu))
+    assert eng.w.vit.mlp_hidden == 3456
+    grid = [(1, 32, 32)] * 6 + [(1, 36, 28)] + [(1, 32, 32)] * 6 + [(1, 54, 74), (1, 36, 28)]
+    pix = recipes.pixel_values(grid, 8)
+    out = to_np(eng.encode_images(torch.from_numpy(pix).to(torch.bfloat16).to(gpu), grid))
+    starts = np.concatenate([[0], np.cumsum([g[1] * g[2] for g in grid])])
+    assert starts[-1] == 18300 and out.shape == (18300 // 4, 2048)
+    for i in (0, 6, 13, 14):   # a 448 x 448 image, both half-window images (mid-batch and last), the cap-size image
+        ref = Q25.vit_forward(w, cfg, pix[starts[i]:starts[i + 1]], grid[i:i + 1], bf16=True)
+        got = out[starts[i] // 4:starts[i + 1] // 4]
+        assert np.abs(got - ref).max() <= 0.02 * np.abs(ref).max(), (i, grid[i], np.abs(got - ref).max(), np.abs(ref).max())
+        assert np.abs(got - ref).mean() <= 0.004 * np.abs(ref).max(), (i, grid[i])
+
+
 def test_decoder_slice_full_width(slice_model, gpu):
     cfg, w, eng = slice_model
     grid = [(1, 32, 32)]

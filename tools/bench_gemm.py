@@ -26,6 +26,8 @@ SHAPES = [
     ("7b.down", 18304, 3584, 18944),
     ("vit.qkv.x8", 32768, 4096, 1280),
     ("vit.qkv.k5120", 32768, 4096, 5120),
+    ("vit25.gateup", 32768, 6912, 1280),     # Qwen2.5-VL vision MLP: gate / up of 3420 -> 3456 rows each (zero-padded at load), SwiGLU pairs
+    ("vit25.down", 32768, 1280, 3456),       # ... and its down projection: K = 3420 padded to 3456 = 27 x 128 (the ping-pong kernel's K % 128)
     ("sq4096", 4096, 4096, 4096),
     ("sq8192", 8192, 8192, 8192),
     ("7b.dec2k.qkv", 2048, 4608, 3584),

@@ -13,7 +13,7 @@ from tests import test_decode_parity_gpu as T  # noqa: E402
 CASES = [("2b", 8, 8, "bf16"), ("2b", 200, 8, "bf16"), ("2b", 1280, 8, "bf16"), ("7b", 8, 6, "bf16"), ("7b", 300, 6, "bf16"),
          ("yi34b", 8, 6, "bf16"), ("yi34b", 130, 6, "bf16"), ("72b", 8, 6, "bf16"), ("72b", 130, 6, "bf16"),
          ("72b", 8, T.FP8_STEPS, "fp8"), ("72b", 130, T.FP8_STEPS, "fp8"), ("72b", 8, T.FP8_STEPS, "fp8", 128.0),
-         ("72b", 130, T.FP8_STEPS, "fp8", 128.0), ("72b", 130, T.FP8_STEPS, "fp8", 1024.0)]
+         ("72b", 130, T.FP8_STEPS, "fp8", 128.0), ("72b", 130, T.FP8_STEPS, "fp8", 1024.0), ("q25_3b", 8, 6, "bf16"), ("q25_3b", 300, 6, "bf16")]
 only = set(sys.argv[1:])
 for name, B, steps, dt, *ch in CASES:
     if only and name not in only and dt not in only:
