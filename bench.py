@@ -1257,7 +1257,10 @@ def pil_leg(engine, dims, host_u8, B: int, T: int, device, sync, lm=None) -> dic
     dtp = time.perf_counter() - t0
     assert len(answers) == n and all(isinstance(a, str) for a in answers)
     first = lm.last_timing.get("first_chunk_prep_s", 0.0)
+    pinned_to = lm._cpu_affinity
+    lm.release_host_resources()     # the CPU baseline below runs in this process: its threads must see every core again
     return {"seconds": dtp, "images": n, "batch_size": bs, "prep_threads": lm._prep_threads, "host_cores": os.cpu_count(),
+            "cpu_affinity": None if not pinned_to else f"{len(pinned_to)} CPUs of the GPU's NUMA node ({pinned_to[0]}..{pinned_to[-1]})",
             "chunks": lm.last_timing.get("chunks"),
             "first_chunk_prep_s": first,   # exposed once per generate_until call (a task), whatever its length
             "images_per_s_after_first_prep": n / max(dtp - first, 1e-9),   # what a long task converges to (per rank)

@@ -148,6 +148,43 @@ def gather_records(lm, doc_ids: list[int], blobs: list[bytes], sizes: list[int],
     return out
 
 
+def _json_native(v) -> bool:
+    """True when `json.loads(json.dumps(v))` gives back an equal object of the same types (tuples, non-str keys and anything
+    `convert_non_serializable` would stringify do not)."""
+    if v is None or isinstance(v, (str, bool, int)):
+        return True
+    if isinstance(v, float):
+        return v == v and v not in (float("inf"), float("-inf"))
+    if type(v) is list:
+        return all(_json_native(x) for x in v)
+    if type(v) is dict:
+        return all(type(k) is str and _json_native(x) for k, x in v.items())
+    return False
+
+
+_PICKLED = "__owc_pickled_metrics__"
+
+
+def _wire_metrics(m: dict) -> dict:
+    """Metric values as they cross to rank 0: themselves when JSON carries them unchanged, else pickled (the reference moves
+    pickles: `gather_object`, `_engine.py:298-315`) - rank 0 must aggregate the SAME objects a 1-rank run aggregates."""
+    if _json_native(m):
+        return m
+    import base64
+    import pickle
+
+    return {_PICKLED: base64.b64encode(pickle.dumps(m)).decode("ascii")}
+
+
+def _unwire_metrics(m: dict) -> dict:
+    if len(m) == 1 and _PICKLED in m:
+        import base64
+        import pickle
+
+        return pickle.loads(base64.b64decode(m[_PICKLED]))
+    return m
+
+
 def doc_record(task, req, log_samples: bool) -> tuple[dict | None, dict]:
     """One document's share of the post-processing (`_engine.py:244-292`): metric values and, with `log_samples`, the sample record."""
     doc = req.doc
@@ -200,16 +237,16 @@ def evaluate(lm, task_dict: dict, limit: int | float | None = None, log_samples:
         if world > 1:   # ... and rank 0 receives [sample record, metric values] per document, ordered by doc_id below
             dumps = lambda o: json.dumps(o, default=utils.convert_non_serializable, ensure_ascii=False)  # noqa: E731
             if log_samples and samples_as_lines:   # [the finished samples-file line, its two hashes, metric values]
-                blobs = [dumps([sample_line(dict(e)), e["prompt_hash"], e["target_hash"], m]).encode("utf-8") for e, m in local]
+                blobs = [dumps([sample_line(dict(e)), e["prompt_hash"], e["target_hash"], _wire_metrics(m)]).encode("utf-8") for e, m in local]
             else:
-                blobs = [dumps([e, m]).encode("utf-8") for e, m in local]
+                blobs = [dumps([e, _wire_metrics(m)]).encode("utf-8") for e, m in local]
             got = gather_records(lm, [r.doc_id for r in reqs], blobs, sizes, rank, world, dist)
             if rank != 0:
                 continue
             if log_samples and samples_as_lines:
-                local = [(SampleLine(got[i][0], DOC_HASH_OF_NONE, got[i][1], got[i][2]), got[i][3]) for i in sorted(got)]
+                local = [(SampleLine(got[i][0], DOC_HASH_OF_NONE, got[i][1], got[i][2]), _unwire_metrics(got[i][3])) for i in sorted(got)]
             else:
-                local = [tuple(got[i]) for i in sorted(got)]
+                local = [(got[i][0], _unwire_metrics(got[i][1])) for i in sorted(got)]
         samples, metric_items = [], defaultdict(list)
         for example, metrics in local:
             if log_samples:

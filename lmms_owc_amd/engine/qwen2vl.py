@@ -369,6 +369,17 @@ class Qwen2VLEngine:
             self._kv = kv = (torch.empty(int(elems), dtype=BF16, device=self.device), torch.empty(int(elems), dtype=BF16, device=self.device))
         return kv[0][:elems], kv[1][:elems]
 
+    def held_bytes(self) -> int:
+        """Device bytes this engine keeps between passes and reuses (the K / V pair and the workspace): memory a batch-size decision
+        must count as FREE, or the batch of a later task would depend on what an earlier one left allocated (`engine_batch`)."""
+        kv = 2 * self._kv[0].numel() * self._kv[0].element_size() if self._kv is not None else 0
+        return kv + (self._ws.numel() if self._ws is not None else 0)
+
+    def release_kv(self) -> None:
+        """Hand the K / V pair (tens of GB after a large pass) back: for a caller that is done generating and needs the memory for
+        something else (another model on the same GPU).  The next pass simply reserves a new pair."""
+        self._kv = None
+
     # -- vision tower ------------------------------------------------------------------
     def encode_images(self, pixel_values: torch.Tensor, grid_thw) -> torch.Tensor:
         """pixel_values [sum(t*h*w), 1176] bf16 (device) -> merged embeddings [sum/4, d_model] bf16."""

@@ -197,6 +197,9 @@ class PassPipeline:
         import os
         from concurrent.futures import ThreadPoolExecutor
 
+        self._cpu_affinity_before = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
+        self._cpu_affinity = pin_to_gpu_numa_node(getattr(self, "_device", None))   # before any worker thread or pinned buffer exists
+
         # host preparation: `OWC_PREP_THREADS` PIL workers (JPEG round trip + bicubic resize release the GIL) behind ONE
         # preparation thread that runs up to two engine batches ahead of the GPU (`_generate_rows`)
         # 8 workers prepare ~900 images/s per rank (JPEG round trip of a 448x448 image ~ 8 ms per worker), several times the GPU's
@@ -211,6 +214,42 @@ class PassPipeline:
         self._pinned_free, self._pinned_lock = [], threading.Lock()
 
     PINNED_POOL_BYTES = 4 << 30   # retained (idle) pinned staging per rank; buffers in flight are bounded by the look-ahead
+
+    def _h2d_groups(self, groups: list) -> list:
+        """The uint8 image stacks of a pass -> device.  Pinned stacks (what `_prepare_chunk` stages: 1.2 GB for 2048 images of
+        448 x 448) cross on a COPY STREAM of their own: a pass is launched while the previous one is still computing, so its
+        copy runs beside that pass's kernels instead of queueing behind them on the compute stream (round 4 measured 0.6 % of a
+        pass); the compute stream waits for the copy's event, the device buffers are handed to it (`record_stream`), and the
+        pinned stacks go back to the staging pool only after the pass's own event (`_run_passes.finish`).  Anything else
+        (pageable numpy stacks of a direct call) takes the compute stream as before."""
+        from .. import _lib
+
+        if not groups or not all(isinstance(g, torch.Tensor) and g.is_pinned() for g in groups) or os_env_off("OWC_COPY_STREAM"):
+            return [_lib.h2d(g, self._device) for g in groups]
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(device=self._device)
+        cur = torch.cuda.current_stream(self._device)
+        with torch.cuda.stream(self._copy_stream):
+            out = [g.to(self._device, non_blocking=True) for g in groups]
+            done = torch.cuda.Event()
+            done.record(self._copy_stream)
+        cur.wait_event(done)
+        for t in out:
+            t.record_stream(cur)
+        return out
+
+    def release_host_resources(self) -> None:
+        """Stop the worker pools, drop the pinned staging buffers and give the calling thread its CPU affinity back (a process that
+        goes on to do host-side work of its own after the last task: bench.py's CPU baseline)."""
+        import os
+
+        for pool in (getattr(self, "_pool", None), getattr(self, "_prep_thread", None)):
+            if pool is not None:
+                pool.shutdown(wait=True)
+        self._pinned_free = []
+        before = getattr(self, "_cpu_affinity_before", None)
+        if before and hasattr(os, "sched_setaffinity"):
+            os.sched_setaffinity(0, before)
 
     def _pinned_take(self, shape: tuple) -> torch.Tensor:
         """Pinned staging buffer for one same-size image run: reused across chunks (page-locking a fresh GB per chunk costs
@@ -388,6 +427,93 @@ class PassPipeline:
         assert carried is None and len(rows) == len(requests)
         return reordered.get_original([rows[i] for i in range(len(requests))])
 
+
+
+def os_env_off(name: str) -> bool:
+    import os
+
+    return os.environ.get(name, "1") == "0"
+
+
+def gpu_local_cpus(pci_bus_id: str, sysfs: str = "/sys/bus/pci/devices") -> list[int]:
+    """CPUs of the NUMA node a PCI device hangs off (`local_cpulist`, e.g. "0-31,128-159"); [] when sysfs does not say."""
+    try:
+        from pathlib import Path
+
+        text = (Path(sysfs) / pci_bus_id.lower() / "local_cpulist").read_text().strip()
+    except OSError:
+        return []
+    cpus: list[int] = []
+    for part in filter(None, text.split(",")):
+        lo, _, hi = part.partition("-")
+        cpus += list(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def numa_share(cpus: list[int], k: int, n: int, allowed: set | None = None) -> list[int]:
+    """The k-th of n shares of a node's `cpus` (restricted to `allowed`): the ranks whose GPUs share a NUMA node split its cores
+    between them instead of all roaming the node.  Every contiguous run of the list is cut into n slices and share k takes its
+    slice of EACH run: a `local_cpulist` of "0-31,128-159" lists the cores and then their SMT siblings, so a rank gets whole cores
+    (0-7 + 128-135), not another rank's hyper-threads."""
+    cpus = sorted(c for c in cpus if allowed is None or c in allowed)
+    if not cpus or n <= 0:
+        return []
+    runs, cur = [], [cpus[0]]
+    for c in cpus[1:]:
+        if c == cur[-1] + 1:
+            cur.append(c)
+        else:
+            runs.append(cur)
+            cur = [c]
+    runs.append(cur)
+    if min(len(r) for r in runs) // n < 1:
+        return cpus           # fewer CPUs per run than ranks: no split
+    out: list[int] = []
+    for r in runs:
+        per = len(r) // n
+        out += r[k * per:(k + 1) * per]
+    return out
+
+
+def pin_to_gpu_numa_node(device) -> list[int] | None:
+    """One process per GPU on a two-socket host (the reference launches its ranks with `accelerate launch`,
+    /root/reference/scripts/schedule_batch.sh:109-112, /root/reference/src/utils/_core_utils.py:53-69, and leaves placement to the
+    kernel): this rank's launch thread, its PIL workers and its pinned staging buffers (first touch) belong on the socket its GPU
+    hangs off - a rank that prepares images on the far socket pays the inter-socket link twice (JPEG bytes in, pinned uint8 out)
+    and competes with the ranks that live there.  The process's affinity becomes this rank's share of its GPU's `local_cpulist`
+    (the ranks of a node split it evenly, in local-rank order); threads started later inherit it.  Off with OWC_NUMA_PIN=0; a no-op
+    without a CUDA device, without sysfs topology, inside a cpuset that excludes the node, or on a single-node host."""
+    import os
+
+    if os.environ.get("OWC_NUMA_PIN", "1") == "0" or device is None or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        import torch
+
+        dev = torch.device(device)
+        if dev.type != "cuda" or not torch.cuda.is_available():
+            return None
+        n_dev = torch.cuda.device_count()
+
+        def bus_id(i: int) -> str:
+            p = torch.cuda.get_device_properties(i)
+            return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+
+        mine = gpu_local_cpus(bus_id(dev.index or 0))
+        allowed = set(os.sched_getaffinity(0))
+        if not mine or not (set(mine) & allowed) or set(mine) >= allowed:
+            return None     # no topology, a cpuset that excludes the node, or one node that holds everything we may use anyway
+        # the ranks of this job whose GPUs hang off the same node, in local-rank order (one rank per visible device)
+        ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+        same = [i for i in range(min(n_dev, ranks_here)) if set(gpu_local_cpus(bus_id(i))) == set(mine)] if ranks_here > 1 else [dev.index or 0]
+        k = same.index(dev.index or 0) if (dev.index or 0) in same else 0
+        share = numa_share(mine, k, max(len(same), 1), allowed)
+        if not share:
+            return None
+        os.sched_setaffinity(0, share)
+        return share
+    except (OSError, RuntimeError, AttributeError, ValueError):
+        return None
 
 
 def hand_over_below(n_own: int, n_carried_in: int, capacity: int) -> int:

@@ -130,6 +130,7 @@ class LLaVA(PassPipeline, Model):
         if max_new_tokens not in cache:
             free, _ = torch.cuda.mem_get_info(self._device)
             free += torch.cuda.memory_reserved(self._device) - torch.cuda.memory_allocated(self._device)
+            free += getattr(self._model, "held_bytes", lambda: 0)()   # the engine's own K / V pair + workspace are reused by the next pass
             cache[max_new_tokens] = max(self.batch_size, min(512, int(0.25 * free / per_req)))
         return cache[max_new_tokens]
 
@@ -386,12 +387,8 @@ class LLaVA(PassPipeline, Model):
         eng = self._model
         feats, rows_per_prompt = None, [np.zeros(0, np.int64)] * prep["n"]
         if prep["groups"]:
-            n_v = sum(g.shape[0] for g in prep["groups"])
-            u8 = torch.empty((n_v, *prep["groups"][0].shape[1:]), dtype=torch.uint8, device=self._device)
-            o = 0
-            for g in prep["groups"]:
-                u8[o:o + g.shape[0]].copy_(g, non_blocking=True)
-                o += g.shape[0]
+            devs = self._h2d_groups(prep["groups"])          # pinned stacks: on the copy stream, beside the previous pass's kernels
+            u8 = devs[0] if len(devs) == 1 else torch.cat(devs)
             feats = eng.encode_views(eng.patchify(u8, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD))
             rows = eng.feature_rows(prep["views_per_image"], prep["sizes"])
             rows_per_prompt, cur = [], 0

@@ -135,6 +135,7 @@ class Qwen2VL(PassPipeline, Model):
         if max_new_tokens not in cache:
             free, _ = torch.cuda.mem_get_info(self._device)
             free += torch.cuda.memory_reserved(self._device) - torch.cuda.memory_allocated(self._device)
+            free += getattr(self._model, "held_bytes", lambda: 0)()   # the engine's own K / V pair + workspace are reused by the next pass
             cache[max_new_tokens] = max(self.batch_size, min(2048, int(0.25 * free / per_req)))
         return cache[max_new_tokens]
 
@@ -461,11 +462,11 @@ class Qwen2VL(PassPipeline, Model):
                 i = j
         rows = sum(g.shape[0] * (g.shape[2] // 14) * (g.shape[3] // 14) for g in groups)
         pix = torch.empty((rows, 1176), dtype=torch.bfloat16, device=self._device)
+        dev_groups = self._h2d_groups(groups)
         r0 = 0
-        for g in groups:
+        for g, dg in zip(groups, dev_groups):
             n = g.shape[0] * (g.shape[2] // 14) * (g.shape[3] // 14)
-            ops.patchify_u8(_lib.h2d(g, self._device), imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD,
-                            out=pix[r0:r0 + n])
+            ops.patchify_u8(dg, imageproc.OPENAI_CLIP_MEAN, imageproc.OPENAI_CLIP_STD, out=pix[r0:r0 + n])
             r0 += n
         return pix
 

@@ -25,7 +25,8 @@ MODEL_NAME = "sentence-transformers/all-MiniLM-L6-v2"
 
 
 def set_sentence_bert(scorer, tokenizer) -> None:
-    """Inject an encoder + tokenizer (tests, custom encoders such as all-mpnet-base-v2 are loaded the same way)."""
+    """Inject an encoder + tokenizer (tests; any BERT-architecture sentence encoder - absolute position embeddings, post-LayerNorm -
+    whose weights `BertWeights` takes)."""
     global sentence_bert_model, sentence_bert_processor
     sentence_bert_model, sentence_bert_processor = scorer, tokenizer
 

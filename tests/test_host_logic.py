@@ -222,6 +222,27 @@ def test_evaluate_two_ranks_byte_identical_to_one(tmp_path, lines):
     assert samples[1]["filtered_resps"] == [" class 1 é"] and samples[0]["resps"] == [["something else, entirely longer than the others"]]
 
 
+def test_metric_values_cross_ranks_unchanged():
+    """Round 4's ADVICE: the per-document metric values of an N-rank run reach rank 0 inside a JSON record.  JSON turns a tuple into a
+    list, an int key into a string and an unknown object into its str(): rank 0 would aggregate other objects than a 1-rank run does.
+    Values that JSON does not carry unchanged therefore travel pickled (what the reference's `gather_object` does with everything,
+    `_engine.py:298-315`); JSON-native values - every metric the shipped tasks produce - travel as they are."""
+    import json
+
+    from lmms_owc_amd import utils
+    from lmms_owc_amd.engine import evaluate as E
+
+    native = {"exact_match": 1.0, "textual_inclusion": 0, "semantic": {"pred": "a cat", "target": "cat", "scores": [0.25, 0.5]}, "flag": None}
+    assert E._wire_metrics(native) is native
+    odd = {"pair": (1, "a"), 3: 0.5, "nan": float("nan"), "set": frozenset({2, 5})}
+    for m in (native, odd):
+        wire = json.loads(json.dumps([None, E._wire_metrics(m)], default=utils.convert_non_serializable, ensure_ascii=False))[1]
+        back = E._unwire_metrics(wire)
+        assert set(back) == set(m) and all(type(back[k]) is type(m[k]) for k in m)
+        assert all(back[k] == m[k] or (m[k] != m[k] and back[k] != back[k]) for k in m)     # (nan != nan)
+    assert type(E._unwire_metrics(json.loads(json.dumps(E._wire_metrics(odd))))["pair"]) is tuple
+
+
 def test_evaluate_rank_with_empty_shard(tmp_path):
     """limit=1 on two ranks: rank 1 owns no document (the reference pads by re-running a request; here the shard is
     simply empty and contributes zero-filled records); files byte-identical to the single-rank run."""

@@ -86,6 +86,30 @@ def child(args) -> None:
     lm._dims, lm._model = Dims(), None
     if args.threads:
         os.environ["OWC_PREP_THREADS"] = str(args.threads)
+    pinned = None
+    if args.pin:   # what `pin_to_gpu_numa_node` does on a GPU box, with the GPU -> node map EMULATED: the ranks split evenly over the nodes
+        from lmms_owc_amd.models._base import numa_share
+
+        nodes = sorted(Path("/sys/devices/system/node").glob("node[0-9]*"), key=lambda p: int(p.name[4:]))
+        lists = []
+        for nd in nodes:
+            cpus = []
+            for part in filter(None, (nd / "cpulist").read_text().strip().split(",")):
+                lo, _, hi = part.partition("-")
+                cpus += list(range(int(lo), int(hi or lo) + 1))
+            if cpus:
+                lists.append(cpus)
+        if len(lists) > 1:
+            per_node = -(-args.ranks // len(lists))
+            node, k = rank // per_node, rank % per_node
+            here = min(per_node, args.ranks - node * per_node)
+            pinned = numa_share(lists[node], k, here, set(os.sched_getaffinity(0)))
+            if pinned:
+                os.sched_setaffinity(0, pinned)
+    if args.pillow_blocks:
+        Image.core.set_blocks_max(args.pillow_blocks)
+    if args.switch_interval_ms:
+        sys.setswitchinterval(args.switch_interval_ms * 1e-3)
     lm._start_workers()
 
     r = np.random.default_rng(100 + rank)
@@ -114,7 +138,8 @@ def child(args) -> None:
     lt = lm.last_timing
     print(json.dumps({"rank": rank, "images": n, "seconds": dt, "images_per_s": n / dt, "prep_threads": lm._prep_threads,
                       "chunks": lt.get("chunks"), "pass_sizes": lt.get("pass_sizes"), "first_chunk_prep_s": lt.get("first_chunk_prep_s"),
-                      "prep_wait_s": lt.get("prep_wait_s", 0.0), "gpu_seconds_emulated": n / args.gpu_rate}), flush=True)
+                      "prep_wait_s": lt.get("prep_wait_s", 0.0), "gpu_seconds_emulated": n / args.gpu_rate,
+                      "pinned_cpus": None if not pinned else f"{len(pinned)}: {pinned[0]}..{pinned[-1]}"}), flush=True)
 
 
 def main() -> None:
@@ -128,6 +153,9 @@ def main() -> None:
     ap.add_argument("--threads", type=int, default=0, help="OWC_PREP_THREADS per rank (0: the plug-in's default for LOCAL_WORLD_SIZE)")
     ap.add_argument("--size", default="448x448")
     ap.add_argument("--sizes", default=None, choices=["food101", "dtd", "flowers102"])
+    ap.add_argument("--pin", action="store_true", help="pin every rank to its share of one NUMA node (emulated GPU -> node map: ranks split evenly)")
+    ap.add_argument("--pillow-blocks", type=int, default=0, help="Pillow's arena cache (Image.core.set_blocks_max): freed image blocks are reused instead of unmapped")
+    ap.add_argument("--switch-interval-ms", type=float, default=0.0, help="sys.setswitchinterval: how long a thread keeps the GIL while others wait (default 5 ms)")
     ap.add_argument("--child", action="store_true")
     ap.add_argument("--sync-dir", default=None)
     args = ap.parse_args()
@@ -158,8 +186,8 @@ def main() -> None:
                       "per_rank_images_per_s": [round(x["images_per_s"], 1) for x in rows],
                       "per_rank_prep_wait_s": [round(x["prep_wait_s"], 3) for x in rows],
                       "per_rank_first_chunk_prep_s": [round(x["first_chunk_prep_s"], 3) for x in rows],
-                      "rank0_pass_sizes": rows[0].get("pass_sizes"),
-                      "image_sizes": args.sizes or args.size}))
+                      "rank0_pass_sizes": rows[0].get("pass_sizes"), "pinned_cpus_per_rank": [x.get("pinned_cpus") for x in rows],
+                      "pillow_blocks_max": args.pillow_blocks, "switch_interval_ms": args.switch_interval_ms or 5.0, "image_sizes": args.sizes or args.size}))
 
 
 if __name__ == "__main__":
