@@ -426,8 +426,15 @@ typedef struct owc_bert_layer {
 typedef struct owc_bert_weights {
   int32_t n_layers, hidden, n_heads, inter, vocab, max_pos;
   float ln_eps;
-  const float *word_emb, *pos_emb, *type_emb, *emb_ln_w, *emb_ln_b;
+  const float *word_emb, *pos_emb, *type_emb, *emb_ln_w, *emb_ln_b; /* type_emb: row 0 is added; NULL = none (MPNet) */
   const owc_bert_layer* layers; /* HOST array */
+  /* MPNet (HF modeling_mpnet.py: MPNetEmbeddings / MPNetEncoder.compute_position_bias; all-mpnet-base-v2 is BASELINE.json configs[0]'s
+   * encoder): a token in column c of a right-padded row takes position embedding c + pos_offset (padding_idx + 1 = 2; BERT: 0), and
+   * rel_bias[head][(key column - query column) + rel_span - 1] - the learned [32 buckets][heads] table expanded over the offsets
+   * -(rel_span - 1) .. rel_span - 1 by the caller (the bucket function is integer / log bookkeeping) - is added to every scaled score,
+   * the same table in every layer.  NULL / 0 / 0 for BERT.  head_dim 32 or 64. */
+  const float* rel_bias;
+  int32_t rel_span, pos_offset;
 } owc_bert_weights;
 
 size_t owc_bert_workspace_bytes(const owc_bert_weights* w, int n, int L);

@@ -21,7 +21,7 @@ _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
 _timing_ok = False
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = range(6)
 
@@ -100,6 +100,7 @@ class BertWeights(C.Structure):
         ("vocab", C.c_int32), ("max_pos", C.c_int32), ("ln_eps", f32),
         ("word_emb", vp), ("pos_emb", vp), ("type_emb", vp), ("emb_ln_w", vp), ("emb_ln_b", vp),
         ("layers", C.POINTER(BertLayer)),
+        ("rel_bias", vp), ("rel_span", C.c_int32), ("pos_offset", C.c_int32),    # MPNet (include/owc.h); NULL / 0 / 0 for BERT
     ]
 
 

@@ -1,4 +1,5 @@
-// Sentence encoder (all-MiniLM-L6-v2 == 6-layer BERT, hidden 384) + cosine scorer, fp32.
+// Sentence encoder (all-MiniLM-L6-v2 == 6-layer BERT, hidden 384; round 5: MPNet - all-mpnet-base-v2, BASELINE.json configs[0] - through
+// the same kernels: no token-type embedding, position ids = column + 2, one relative-position bias table added to the scores) + cosine scorer, fp32.
 // Replaces the arithmetic of encode_sentence_bert (src/data/pipelines/text/_text.py:193-202:
 // BertModel forward, mask-weighted mean pooling with clamp(min=1e-9), L2 normalisation) and of
 // semantic_similarity's paired torch.bmm (src/data/metrics/_group.py:537-544), plus the
@@ -16,12 +17,13 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 __global__ __launch_bounds__(256) void bert_embed_ln_kernel(
     const int* __restrict__ ids, const int* __restrict__ tok_pos, const float* __restrict__ word, const float* __restrict__ pos,
     const float* __restrict__ type0, const float* __restrict__ g, const float* __restrict__ b,
-    float* __restrict__ out, int T, int L, int H, float eps) {
+    float* __restrict__ out, int T, int L, int H, float eps, int pos_offset) {
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + w;
   if (t >= T) return;
   const float* we = word + (long)ids[t] * H;
-  const float* pe = pos + (long)(tok_pos ? tok_pos[t] : t % L) * H;  // packed rows carry their own position id
+  // packed rows carry their own column; MPNet's position ids are column + 2 (pos_offset; padding_idx + 1), BERT's the column
+  const float* pe = pos + (long)((tok_pos ? tok_pos[t] : t % L) + pos_offset) * H;
   float v[16];
   float sum = 0.f;
   const int per = (H + 63) / 64;
@@ -30,7 +32,7 @@ __global__ __launch_bounds__(256) void bert_embed_ln_kernel(
     const int c = i * 64 + l;
     v[i] = 0.f;
     if (i < per && c < H) {
-      v[i] = we[c] + type0[c] + pe[c];
+      v[i] = type0 ? we[c] + type0[c] + pe[c] : we[c] + pe[c];   // (MPNet has no token-type embedding)
       sum += v[i];
     }
   }
@@ -96,13 +98,15 @@ template <int HD>
 __global__ __launch_bounds__(64) void bert_attn_kernel(const float* __restrict__ qkv,
                                                        const int* __restrict__ mask,
                                                        float* __restrict__ ctx, int L, int H,
-                                                       int n_heads, float scale) {
+                                                       int n_heads, float scale, const float* __restrict__ relb, int rel_span) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* ks = (float*)smem;           // [L][HD]
   float* vs = ks + (size_t)L * HD;    // [L][HD]
   int* ms = (int*)(vs + (size_t)L * HD);
   const int s = blockIdx.x / n_heads, h = blockIdx.x % n_heads;
   const long base = (long)s * L;
+  // MPNet: one learned bias per (head, key column - query column), added to the scaled score (`rel_bias`, include/owc.h)
+  const float* rb = relb ? relb + (long)h * (2 * rel_span - 1) + (rel_span - 1) : nullptr;
   for (int i = threadIdx.x; i < L * (HD / 4); i += blockDim.x) {
     const int j = i / (HD / 4), c = i % (HD / 4);
     const float* row = qkv + (base + j) * 3 * H + h * HD + c * 4;
@@ -126,6 +130,7 @@ __global__ __launch_bounds__(64) void bert_attn_kernel(const float* __restrict__
 #pragma unroll
       for (int d = 0; d < HD; ++d) sc += q[d] * ks[j * HD + d];
       sc *= scale;
+      if (rb) sc += rb[j - i];
       const float mn = fmaxf(m, sc);
       const float a = expf(m - mn), p = expf(sc - mn);
       lsum = lsum * a + p;
@@ -182,11 +187,13 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(const float* __restrict_
 // in the pooling, so dropping their rows changes no result.
 template <int HD>
 __global__ __launch_bounds__(64) void bert_attn_packed_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_start,
-                                                              float* __restrict__ ctx, int H, int n_heads, float scale) {
+                                                              float* __restrict__ ctx, int H, int n_heads, float scale,
+                                                              const float* __restrict__ relb, int rel_span) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int s = blockIdx.x / n_heads, h = blockIdx.x % n_heads;
   const long base = seq_start[s];
   const int L = seq_start[s + 1] - (int)base;
+  const float* rb = relb ? relb + (long)h * (2 * rel_span - 1) + (rel_span - 1) : nullptr;   // (right-padded rows: packed index = column)
   float* ks = (float*)smem;           // [L][HD]
   float* vs = ks + (size_t)L * HD;    // [L][HD]
   for (int i = threadIdx.x; i < L * (HD / 4); i += blockDim.x) {
@@ -210,6 +217,7 @@ __global__ __launch_bounds__(64) void bert_attn_packed_kernel(const float* __res
 #pragma unroll
       for (int d = 0; d < HD; ++d) sc += q[d] * ks[j * HD + d];
       sc *= scale;
+      if (rb) sc += rb[j - i];
       const float mn = fmaxf(m, sc);
       const float a = expf(m - mn), p = expf(sc - mn);
       lsum = lsum * a + p;
@@ -383,8 +391,10 @@ int owc_bert_embed(owc_ctx* ctx, const owc_bert_weights* w, const int32_t* ids, 
                    int n, int L, float* out, void* workspace, size_t ws_bytes, void* stream) {
   if (!ctx || !w || !ids || !mask || !out || !workspace) return OWC_ERR_ARG;
   const int H = w->hidden, NH = w->n_heads, I = w->inter;
-  if (n <= 0 || L <= 0 || L > w->max_pos || H > 1024 || (H % NH) != 0 || H / NH != 32)
-    OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_bert_embed: unsupported shape (head_dim must be 32, hidden <= 1024)");
+  const int HD = NH > 0 ? H / NH : 0;
+  if (n <= 0 || L <= 0 || L + w->pos_offset > w->max_pos || H > 1024 || (H % NH) != 0 || (HD != 32 && HD != 64))
+    OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_bert_embed: unsupported shape (head_dim must be 32 or 64, hidden <= 1024)");
+  if (w->rel_bias && L > w->rel_span) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_bert_embed: sequence longer than the relative-bias table");
   if (ws_bytes < owc_bert_workspace_bytes(w, n, L)) OWC_FAIL(ctx, OWC_ERR_WORKSPACE, "owc_bert_embed: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int T = n * L;
@@ -396,23 +406,26 @@ int owc_bert_embed(owc_ctx* ctx, const owc_bert_weights* w, const int32_t* ids, 
   float* qkv = (float*)p;
   p += align256((size_t)T * 3 * H * 4);
   float* ff = (float*)p;
-  const size_t attn_lds = (size_t)L * 32 * 4 * 2 + (size_t)L * 4;
+  const size_t attn_lds = (size_t)L * HD * 4 * 2 + (size_t)L * 4;
   if (attn_lds > 160 * 1024) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_bert_embed: sequence too long for the LDS-resident attention");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)bert_attn_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)bert_attn_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)bert_attn_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OWC_ERR_HIP;
     attr_set = true;
   }
   hipLaunchKernelGGL(bert_embed_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, st, ids, (const int*)nullptr, w->word_emb, w->pos_emb,
-                     w->type_emb, w->emb_ln_w, w->emb_ln_b, x, T, L, H, w->ln_eps);
-  const float scale = 1.0f / sqrtf(32.0f);
+                     w->type_emb, w->emb_ln_w, w->emb_ln_b, x, T, L, H, w->ln_eps, w->pos_offset);
+  const float scale = 1.0f / sqrtf((float)HD);
   for (int i = 0; i < w->n_layers; ++i) {
     const owc_bert_layer& Ly = w->layers[i];
     OWC_TRY(owc_launch_gemm_f32_bert(x, H, Ly.qkv_w, H, Ly.qkv_b, nullptr, 0, qkv, 3 * H, T, 3 * H, H,
                                 OWC_EPI_NONE, ctx->zeros, st));
-    hipLaunchKernelGGL(bert_attn_kernel<32>, dim3(n * NH), dim3(64), attn_lds, st, qkv, mask, cx, L, H, NH, scale);
+    if (HD == 32)
+      hipLaunchKernelGGL(bert_attn_kernel<32>, dim3(n * NH), dim3(64), attn_lds, st, qkv, mask, cx, L, H, NH, scale, w->rel_bias, w->rel_span);
+    else
+      hipLaunchKernelGGL(bert_attn_kernel<64>, dim3(n * NH), dim3(64), attn_lds, st, qkv, mask, cx, L, H, NH, scale, w->rel_bias, w->rel_span);
     // x = LN(dense(ctx) + x)
     OWC_TRY(owc_launch_gemm_f32_bert(cx, H, Ly.o_w, H, Ly.o_b, x, H, x, H, T, H, H, OWC_EPI_RESIDUAL, ctx->zeros, st));
     hipLaunchKernelGGL(ln_f32_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, Ly.ln1_w, Ly.ln1_b, T, H, w->ln_eps);
@@ -438,8 +451,10 @@ int owc_bert_embed_packed(owc_ctx* ctx, const owc_bert_weights* w, const int32_t
                           void* stream) {
   if (!ctx || !w || !tok_ids || !tok_pos || !seq_start || !out || !workspace) return OWC_ERR_ARG;
   const int H = w->hidden, NH = w->n_heads, I = w->inter;
-  if (n <= 0 || T <= 0 || max_len <= 0 || max_len > w->max_pos || H > 1024 || (H % NH) != 0 || H / NH != 32)
-    OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_bert_embed_packed: unsupported shape (head_dim must be 32, hidden <= 1024)");
+  const int HD = NH > 0 ? H / NH : 0;
+  if (n <= 0 || T <= 0 || max_len <= 0 || max_len + w->pos_offset > w->max_pos || H > 1024 || (H % NH) != 0 || (HD != 32 && HD != 64))
+    OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_bert_embed_packed: unsupported shape (head_dim must be 32 or 64, hidden <= 1024)");
+  if (w->rel_bias && max_len > w->rel_span) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_bert_embed_packed: sequence longer than the relative-bias table");
   if (ws_bytes < owc_bert_packed_workspace_bytes(w, T)) OWC_FAIL(ctx, OWC_ERR_WORKSPACE, "owc_bert_embed_packed: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   char* p = (char*)workspace;
@@ -450,23 +465,26 @@ int owc_bert_embed_packed(owc_ctx* ctx, const owc_bert_weights* w, const int32_t
   float* qkv = (float*)p;
   p += align256((size_t)T * 3 * H * 4);
   float* ff = (float*)p;
-  const size_t attn_lds = (size_t)max_len * 32 * 4 * 2;
+  const size_t attn_lds = (size_t)max_len * HD * 4 * 2;
   if (attn_lds > 160 * 1024) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_bert_embed_packed: sequence too long for the LDS-resident attention");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)bert_attn_packed_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)bert_attn_packed_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)bert_attn_packed_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OWC_ERR_HIP;
     attr_set = true;
   }
   hipLaunchKernelGGL(bert_embed_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, st, tok_ids, tok_pos, w->word_emb, w->pos_emb,
-                     w->type_emb, w->emb_ln_w, w->emb_ln_b, x, T, 1, H, w->ln_eps);
-  const float scale = 1.0f / sqrtf(32.0f);
+                     w->type_emb, w->emb_ln_w, w->emb_ln_b, x, T, 1, H, w->ln_eps, w->pos_offset);
+  const float scale = 1.0f / sqrtf((float)HD);
   for (int i = 0; i < w->n_layers; ++i) {
     const owc_bert_layer& Ly = w->layers[i];
     OWC_TRY(owc_launch_gemm_f32_bert(x, H, Ly.qkv_w, H, Ly.qkv_b, nullptr, 0, qkv, 3 * H, T, 3 * H, H,
                                 OWC_EPI_NONE, ctx->zeros, st));
-    hipLaunchKernelGGL(bert_attn_packed_kernel<32>, dim3(n * NH), dim3(64), attn_lds, st, qkv, seq_start, cx, H, NH, scale);
+    if (HD == 32)
+      hipLaunchKernelGGL(bert_attn_packed_kernel<32>, dim3(n * NH), dim3(64), attn_lds, st, qkv, seq_start, cx, H, NH, scale, w->rel_bias, w->rel_span);
+    else
+      hipLaunchKernelGGL(bert_attn_packed_kernel<64>, dim3(n * NH), dim3(64), attn_lds, st, qkv, seq_start, cx, H, NH, scale, w->rel_bias, w->rel_span);
     OWC_TRY(owc_launch_gemm_f32_bert(cx, H, Ly.o_w, H, Ly.o_b, x, H, x, H, T, H, H, OWC_EPI_RESIDUAL, ctx->zeros, st));
     hipLaunchKernelGGL(ln_f32_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, Ly.ln1_w, Ly.ln1_b, T, H, w->ln_eps);
     OWC_TRY(owc_launch_gemm_f32_bert(x, H, Ly.fc1_w, H, Ly.fc1_b, nullptr, 0, ff, I, T, I, H, OWC_EPI_GELU_ERF,

@@ -20,6 +20,22 @@ MINILM_L6 = dict(vocab_size=30522, hidden_size=384, num_hidden_layers=6, num_att
                  intermediate_size=1536, max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12)
 
 
+def mpnet_relative_bucket(rel: torch.Tensor, num_buckets: int = 32, max_distance: int = 128) -> torch.Tensor:
+    """MPNet's bucket of a relative position `rel` = key column - query column (HF modeling_mpnet.py, MPNetEncoder.
+    relative_position_bucket - index bookkeeping, evaluated once per checkpoint with the float32 log HF itself uses): half of the
+    buckets per direction, one bucket per distance below 8, logarithmic bins from 8 to 128, the last bin beyond."""
+    import math
+
+    n = -rel.long()
+    half = num_buckets // 2
+    ret = (n < 0).long() * half
+    n = n.abs()
+    max_exact = half // 2
+    large = max_exact + (torch.log(n.float() / max_exact) / math.log(max_distance / max_exact) * (half - max_exact)).long()
+    large = torch.minimum(large, torch.full_like(large, half - 1))
+    return ret + torch.where(n < max_exact, n, large)
+
+
 class BertWeights:
     """fp32 device weights of a BertModel (HF names without the `bert.` prefix) + the C struct."""
 
@@ -37,17 +53,23 @@ class BertWeights:
             return t
 
         n = cfg["num_hidden_layers"]
+        # MPNet (sentence-transformers/all-mpnet-base-v2, BASELINE.json configs[0]) names its attention `attention.attn.{q,k,v,o}` +
+        # `attention.LayerNorm` and carries ONE relative-position bias table for all layers; BERT (all-MiniLM-L6-v2, what the
+        # reference's encode_sentence_bert loads, _text.py:161) `attention.self.{query,key,value}` + `attention.output.*`
+        self.mpnet = "encoder.relative_attention_bias.weight" in sd
+        qkv_names = [f"attention.attn.{k}" for k in "qkv"] if self.mpnet else [f"attention.self.{k}" for k in ("query", "key", "value")]
+        o_name, ln1_name = ("attention.attn.o", "attention.LayerNorm") if self.mpnet else ("attention.output.dense", "attention.output.LayerNorm")
         layers = (_lib.BertLayer * n)()
         for i in range(n):
             p = f"encoder.layer.{i}."
-            qkv_w = torch.cat([get(p + f"attention.self.{k}.weight") for k in ("query", "key", "value")], 0).contiguous()
-            qkv_b = torch.cat([get(p + f"attention.self.{k}.bias") for k in ("query", "key", "value")], 0).contiguous()
+            qkv_w = torch.cat([get(p + k + ".weight") for k in qkv_names], 0).contiguous()
+            qkv_b = torch.cat([get(p + k + ".bias") for k in qkv_names], 0).contiguous()
             self._keep += [qkv_w, qkv_b]
             L = layers[i]
             L.qkv_w, L.qkv_b = qkv_w.data_ptr(), qkv_b.data_ptr()
-            L.o_w, L.o_b = get(p + "attention.output.dense.weight").data_ptr(), get(p + "attention.output.dense.bias").data_ptr()
-            L.ln1_w = get(p + "attention.output.LayerNorm.weight").data_ptr()
-            L.ln1_b = get(p + "attention.output.LayerNorm.bias").data_ptr()
+            L.o_w, L.o_b = get(p + o_name + ".weight").data_ptr(), get(p + o_name + ".bias").data_ptr()
+            L.ln1_w = get(p + ln1_name + ".weight").data_ptr()
+            L.ln1_b = get(p + ln1_name + ".bias").data_ptr()
             L.fc1_w, L.fc1_b = get(p + "intermediate.dense.weight").data_ptr(), get(p + "intermediate.dense.bias").data_ptr()
             L.fc2_w, L.fc2_b = get(p + "output.dense.weight").data_ptr(), get(p + "output.dense.bias").data_ptr()
             L.ln2_w, L.ln2_b = get(p + "output.LayerNorm.weight").data_ptr(), get(p + "output.LayerNorm.bias").data_ptr()
@@ -57,7 +79,16 @@ class BertWeights:
         w.vocab, w.max_pos, w.ln_eps = cfg["vocab_size"], cfg["max_position_embeddings"], cfg["layer_norm_eps"]
         w.word_emb = get("embeddings.word_embeddings.weight").data_ptr()
         w.pos_emb = get("embeddings.position_embeddings.weight").data_ptr()
-        w.type_emb = get("embeddings.token_type_embeddings.weight").data_ptr()
+        if self.mpnet:
+            w.type_emb, w.pos_offset = None, 2                  # no token types; position ids = column + padding_idx + 1
+            span = min(int(cfg["max_position_embeddings"]) - 2, 512)
+            table = get("encoder.relative_attention_bias.weight")                            # [buckets, heads]
+            rel = torch.arange(-(span - 1), span, device=self.device)                         # key column - query column
+            bias = table[mpnet_relative_bucket(rel, table.shape[0])].t().contiguous()        # [heads, 2 span - 1]
+            self._keep.append(bias)
+            w.rel_bias, w.rel_span = bias.data_ptr(), span
+        else:
+            w.type_emb = get("embeddings.token_type_embeddings.weight").data_ptr()
         w.emb_ln_w = get("embeddings.LayerNorm.weight").data_ptr()
         w.emb_ln_b = get("embeddings.LayerNorm.bias").data_ptr()
         w.layers = C.cast(layers, C.POINTER(_lib.BertLayer))

@@ -25,8 +25,8 @@ MODEL_NAME = "sentence-transformers/all-MiniLM-L6-v2"
 
 
 def set_sentence_bert(scorer, tokenizer) -> None:
-    """Inject an encoder + tokenizer (tests; any BERT-architecture sentence encoder - absolute position embeddings, post-LayerNorm -
-    whose weights `BertWeights` takes)."""
+    """Inject an encoder + tokenizer (tests; a BERT- or MPNet-architecture sentence encoder whose weights `BertWeights` takes:
+    all-MiniLM-L6-v2, the reference's default, or all-mpnet-base-v2, the encoder BASELINE.json configs[0] names)."""
     global sentence_bert_model, sentence_bert_processor
     sentence_bert_model, sentence_bert_processor = scorer, tokenizer
 
@@ -42,11 +42,12 @@ def _load_default(rank: int | None):
     sentence_bert_processor = AutoTokenizer.from_pretrained(path)
     cfg = AutoConfig.from_pretrained(path).to_dict()
     sd = _load_state_dict(path)
-    sd = {k[len("bert."):] if k.startswith("bert.") else k: v for k, v in sd.items()}
+    sd = {k.split(".", 1)[1] if k.startswith(("bert.", "mpnet.")) else k: v for k, v in sd.items()}
     device = torch.device("cuda", (rank or 0) % max(torch.cuda.device_count(), 1))
     keys = ("vocab_size", "hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size",
             "max_position_embeddings", "type_vocab_size", "layer_norm_eps")
-    sentence_bert_model = SentenceScorer(BertWeights({k: cfg[k] for k in keys}, sd, device))
+    # (BertWeights tells BERT from MPNet - e.g. OWC_SENTENCE_BERT_PATH=sentence-transformers/all-mpnet-base-v2 - by the checkpoint's names)
+    sentence_bert_model = SentenceScorer(BertWeights({k: cfg[k] for k in keys if k in cfg}, sd, device))
 
 
 def _load_state_dict(path: str) -> dict:

@@ -202,6 +202,57 @@ def bert_weights(c: dict, seed: int = 1234) -> dict[str, np.ndarray]:
     return out
 
 
+def mpnet_cfg(kind: str = "tiny") -> dict:
+    """MPNetConfig fields.  "base" = sentence-transformers/all-mpnet-base-v2 (BASELINE.json configs[0]'s wording; public config.json)."""
+    if kind == "tiny":
+        return dict(vocab_size=120, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                    max_position_embeddings=66, layer_norm_eps=1e-5, relative_attention_num_buckets=32)
+    return dict(vocab_size=30527, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                max_position_embeddings=514, layer_norm_eps=1e-5, relative_attention_num_buckets=32)
+
+
+def mpnet_shapes(c: dict) -> dict[str, tuple]:
+    H, I = c["hidden_size"], c["intermediate_size"]
+    s = {"embeddings.word_embeddings.weight": (c["vocab_size"], H),
+         "embeddings.position_embeddings.weight": (c["max_position_embeddings"], H),
+         "embeddings.LayerNorm.weight": (H,), "embeddings.LayerNorm.bias": (H,),
+         "encoder.relative_attention_bias.weight": (c["relative_attention_num_buckets"], c["num_attention_heads"])}
+    for i in range(c["num_hidden_layers"]):
+        p = f"encoder.layer.{i}."
+        for n in ("q", "k", "v", "o"):
+            s[p + f"attention.attn.{n}.weight"] = (H, H)
+            s[p + f"attention.attn.{n}.bias"] = (H,)
+        s.update({p + "attention.LayerNorm.weight": (H,), p + "attention.LayerNorm.bias": (H,),
+                  p + "intermediate.dense.weight": (I, H), p + "intermediate.dense.bias": (I,),
+                  p + "output.dense.weight": (H, I), p + "output.dense.bias": (H,),
+                  p + "output.LayerNorm.weight": (H,), p + "output.LayerNorm.bias": (H,)})
+    return s
+
+
+def mpnet_weights(c: dict, seed: int = 1234) -> dict[str, np.ndarray]:
+    out = {}
+    for k, shp in mpnet_shapes(c).items():
+        r = _rng(seed, "mpnet." + k)
+        if k.endswith("LayerNorm.weight"):
+            x = 1.0 + 0.1 * r.standard_normal(shp)
+        elif k.endswith("bias"):
+            x = 0.05 * r.standard_normal(shp)
+        elif "relative_attention_bias" in k:
+            x = 1.5 * r.standard_normal(shp)     # a bias that matters: of the order of the scaled scores
+        elif "embeddings" in k:
+            x = 0.3 * r.standard_normal(shp)
+        else:
+            x = 2.0 * r.standard_normal(shp) / np.sqrt(shp[1])
+        out[k] = x.astype(np.float32)
+    return out
+
+
+def mpnet_label_tokens(n: int, L: int, vocab: int, seed: int):
+    """Like `label_tokens` with MPNet's padding id (1): real ids in [2, vocab), pad = 1."""
+    ids, mask = label_tokens(n, L, vocab - 1, seed)
+    return np.where(mask > 0, ids + 1, 1).astype(np.int64), mask
+
+
 def label_tokens(n: int, L: int, vocab: int, seed: int):
     """Synthetic tokenised labels: ids [n, L] (0 = pad), mask [n, L]; lengths uniform in [2, L]."""
     r = _rng(seed, "labels")

@@ -71,3 +71,22 @@ def test_ragged_256_labels_at_minilm_size():
     got = B.mean_average(g["semantic_similarity_none"])
     for k, v in meta["mean_average"].items():
         assert abs(got[k] - v) < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["tiny", "base"])
+def test_mpnet_embeddings_match_the_reference_hook_around_hf_mpnet(kind):
+    """BASELINE.json configs[0] names all-mpnet-base-v2.  `bert_np.mpnet_forward` (relative-position bias buckets, position ids =
+    column + 2, no token types) against the REFERENCE's encode_sentence_bert run around HF's MPNetModel on seeded weights
+    (tools/gen_golden.py scorer_mpnet; tiny and full all-mpnet-base-v2 size, ragged labels padded with MPNet's pad id)."""
+    g = np.load(GOLD / "scorer_mpnet.npz")
+    meta = json.loads((GOLD / "scorer_mpnet.json").read_text())[kind]
+    c = recipes.mpnet_cfg(kind)
+    assert c == meta["cfg"]
+    w = recipes.mpnet_weights(c, meta["weights_seed"])
+    ids, mask = recipes.mpnet_label_tokens(meta["n"], meta["L"], c["vocab_size"], seed=meta["label_seed"])
+    np.testing.assert_allclose(B.mpnet_forward(w, c, ids[:2], mask[:2]), g[f"{kind}_hidden0"], atol=2e-5)
+    np.testing.assert_allclose(B.sentence_embed(w, c, ids, mask), g[f"{kind}_embeds"], atol=2e-6)
+    # the bucket function: one bucket per distance below 8, logarithmic bins up to 128, 16 buckets per direction
+    b = B.mpnet_relative_bucket(np.arange(-200, 201))
+    assert b[200] == 0 and list(b[201:209]) == [16 + i for i in range(1, 8)] + [24] and b[0] == 15 and b[-1] == 31
+    assert list(b[192:200]) == [8, 7, 6, 5, 4, 3, 2, 1]

@@ -141,3 +141,25 @@ def test_packed_rows_equal_padded_rows(gpu):
     # device tensors are accepted as well (the layout is built from a host copy of the mask)
     d = sc.embed(torch.from_numpy(ids).to(gpu), torch.from_numpy(holes).to(gpu))
     assert torch.equal(d, a)
+
+
+@pytest.mark.parametrize("kind", ["tiny", "base"])
+def test_mpnet_embed_matches_reference_golden(gpu, kind):
+    """all-mpnet-base-v2 (BASELINE.json configs[0]'s encoder) through owc_bert_embed / owc_bert_embed_packed: head_dim 64, position ids
+    = column + 2, no token types, the relative-position bias table expanded over the key - query offsets at load.  Against the
+    REFERENCE's encode_sentence_bert around HF's MPNetModel (tests/golden/scorer_mpnet.npz: tiny and the full 12 x 768 size), packed
+    and padded rows, a batch split in the middle; <= 2e-5 like the MiniLM encoder."""
+    import json
+
+    from lmms_owc_amd.engine.scorer import BertWeights, SentenceScorer
+
+    g = np.load(GOLD / "scorer_mpnet.npz")
+    meta = json.loads((GOLD / "scorer_mpnet.json").read_text())[kind]
+    c = recipes.mpnet_cfg(kind)
+    ids, mask = recipes.mpnet_label_tokens(meta["n"], meta["L"], c["vocab_size"], seed=meta["label_seed"])
+    w = BertWeights(c, recipes.mpnet_weights(c, meta["weights_seed"]), gpu)
+    assert w.mpnet and w.c.pos_offset == 2 and w.c.rel_span == c["max_position_embeddings"] - 2
+    for max_batch in (10, 16384):
+        sc = SentenceScorer(w, max_batch=max_batch)
+        np.testing.assert_allclose(to_np(sc.embed(ids, mask)), g[f"{kind}_embeds"], atol=2e-5)
+    np.testing.assert_allclose(to_np(sc.embed(ids, mask, packed=False)), g[f"{kind}_embeds"], atol=2e-5)

@@ -283,13 +283,49 @@ def gen_scorer_ragged():
     print("scorer ragged golden:", {k: v.shape for k, v in out.items()})
 
 
+def gen_scorer_mpnet():
+    """BASELINE.json configs[0] names all-mpnet-base-v2: the reference's own encode_sentence_bert (CPU fp32 branch) around HF's
+    MPNetModel on seeded weights - a tiny config and the full all-mpnet-base-v2 size - with ragged labels padded by MPNet's pad id (1)."""
+    from transformers import MPNetConfig, MPNetModel
+
+    _, text_mod, _ = import_reference()
+    out, meta = {}, {"versions": versions()}
+    for kind, n, L in (("tiny", 24, 12), ("base", 48, 16)):
+        c = recipes.mpnet_cfg(kind)
+        w = recipes.mpnet_weights(c, 1234)
+        m = MPNetModel(MPNetConfig(**c), add_pooling_layer=False)
+        missing, unexpected = m.load_state_dict({k: torch.from_numpy(a.copy()) for k, a in w.items()}, strict=False)
+        assert not unexpected and not [k for k in missing if "position_ids" not in k], (missing, unexpected)
+        text_mod.sentence_bert_model = m.eval()
+        text_mod.sentence_bert_processor = IdTokenizer(pad=1)
+        ids, mask = recipes.mpnet_label_tokens(n, L, c["vocab_size"], seed=41)
+        texts = [" ".join(str(int(t)) for t, mk in zip(r, mr) if mk) for r, mr in zip(ids, mask)]
+        saved = torch.cuda.is_available
+        torch.cuda.is_available = lambda: False   # the reference's CPU fp32 branch (_text.py:165-170)
+        try:
+            b = text_mod.encode_sentence_bert({"text": list(texts)}, input_column="text")
+        finally:
+            torch.cuda.is_available = saved
+        out[f"{kind}_embeds"] = np.array(b["text_sentence_bert_embeds"], dtype=np.float32)
+        with torch.no_grad():
+            out[f"{kind}_hidden0"] = m(input_ids=torch.from_numpy(ids[:2]), attention_mask=torch.from_numpy(mask[:2]))[0].numpy()
+        meta[kind] = {"n": n, "L": L, "label_seed": 41, "weights_seed": 1234, "cfg": c}
+    text_mod.sentence_bert_model = text_mod.sentence_bert_processor = None
+    np.savez_compressed(GOLD / "scorer_mpnet.npz", **out)
+    (GOLD / "scorer_mpnet.json").write_text(json.dumps({**meta, "what": "reference encode_sentence_bert (CPU fp32) around HF MPNetModel, seeded weights"}, indent=1))
+    print("scorer mpnet golden:", {k: v.shape for k, v in out.items()})
+
+
 class IdTokenizer:
     """Stand-in for AutoTokenizer: a label is a string of space-separated token ids (no tokenizer files offline)."""
+
+    def __init__(self, pad: int = 0):
+        self.pad = pad
 
     def __call__(self, text, padding=True, truncation=True, return_tensors="pt"):
         rows = [[int(t) for t in s.split()] for s in text]
         L = max(len(r) for r in rows)
-        ids = torch.tensor([r + [0] * (L - len(r)) for r in rows])
+        ids = torch.tensor([r + [self.pad] * (L - len(r)) for r in rows])
         mask = torch.tensor([[1] * len(r) + [0] * (L - len(r)) for r in rows])
 
         class Enc(dict):
@@ -680,3 +716,5 @@ if __name__ == "__main__":
         gen_scorer()
     if "scorer_ragged" in which:
         gen_scorer_ragged()
+    if "scorer_mpnet" in which:
+        gen_scorer_mpnet()
