@@ -208,31 +208,14 @@ class PassPipeline:
         ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
         self._prep_threads = int(os.environ.get("OWC_PREP_THREADS", max(2, min(8, (os.cpu_count() or 8) // ranks_here))))
         self._pool = ThreadPoolExecutor(max_workers=self._prep_threads)
-        # units in preparation at once (results are consumed in submission order): with ONE preparation thread the PIL pool idles
-        # during a unit's serial parts (prompt ids, grouping, the tail of its last worker round) - tools/soak_host_ranks.py
-        self._prep_thread = ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("OWC_PREP_UNITS", "2"))))
+        # ONE unit in preparation at a time (OWC_PREP_UNITS): two raise one rank's ceiling by ~14 % on an idle host but cost 3 % at the
+        # production rate with 8 ranks on a 256-core host (0.975 -> 0.946 of 8 x 205 images/s, profiles/r05_host_soak.txt) - and so did
+        # nothing else tried there for the 8-rank ceiling (a 0.5 ms GIL switch interval, Pillow's block cache, 12 / 16 workers): it sits
+        # at ~3100-3300 images/s = 2.0 x the consumption at Food-101 sizes whatever the knob, ~4 busy cores per rank
+        self._prep_thread = ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("OWC_PREP_UNITS", "1"))))
         import threading
 
         self._pinned_free, self._pinned_lock = [], threading.Lock()
-        # Two interpreter-wide settings of a process whose job is this pipeline (measured on a 256-core host with 8 ranks,
-        # tools/run_host_soak_r5.sh: the preparation ceiling 3070 -> 3325 images/s with the pinning above):
-        #  * the GIL switch interval: a PIL worker that comes back from C (JPEG codec, resize: the GIL is released there) waits up
-        #    to the interval for the launching / preparation thread to let go - 0.5 ms instead of 5 (OWC_GIL_SWITCH_MS, 0 = leave);
-        #  * Pillow's block cache: every image operation allocates its pixel blocks (1 MB for 512 x 512) with mmap and unmaps them
-        #    when the image dies - page faults and the process's memory-map lock, shared by all workers (OWC_PILLOW_BLOCKS, 0 = leave).
-        import sys
-
-        ms = float(os.environ.get("OWC_GIL_SWITCH_MS", "0.5"))
-        if ms > 0:
-            sys.setswitchinterval(min(sys.getswitchinterval(), ms * 1e-3))
-        blocks = int(os.environ.get("OWC_PILLOW_BLOCKS", "256"))
-        if blocks > 0:
-            try:
-                from PIL import Image
-
-                Image.core.set_blocks_max(max(blocks, Image.core.get_blocks_max()))
-            except Exception:   # noqa: BLE001  (an optional tuning of a third-party library)
-                pass
 
     PINNED_POOL_BYTES = 4 << 30   # retained (idle) pinned staging per rank; buffers in flight are bounded by the look-ahead
 
