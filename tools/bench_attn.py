@@ -73,13 +73,18 @@ def main():
                       ln3, n_seq=nb3, n_heads=Hq3, kv_group=Hq3 // Hkv3, head_dim=128, max_q_len=S3, causal=True, scale=128 ** -0.5)
 
     from lmms_owc_amd import _lib
+    for kv in [a[6:] for a in sys.argv[1:] if a.startswith("--set=")]:     # --set=attn_waves=4 ...
+        k, v = kv.split("=")
+        _lib.check(_lib.load().owc_tuning_set(k.encode(), int(v)), 0)
+        print("set", k, v)
     vals = [0]
     for a in sys.argv[1:]:
         if a.startswith("--dbg="):
             vals = [int(v, 0) for v in a[6:].split(",")]
     for rep in range(2):
       for v in vals:
-        _lib.load().owc_tuning_set(b"attn_dbg", v)
+        if v or len(vals) > 1:
+            _lib.load().owc_tuning_set(b"attn_dbg", v)
         print(f"-- attn_dbg = {v:#x}")
         bench_all(vit, prefill, prefill_long, n, H, L, hd, nb, Hq, S, nb3, Hq3, S3,
                   extra=[(f"vit hd80 {n_b}x{L_b}", vit_at(n_b, L_b), 4.0 * n_b * H * L_b * L_b * hd) for n_b, L_b in big])
