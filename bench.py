@@ -1363,6 +1363,10 @@ def decode_regime_leg(engine, dims, batches=(1, 32, 128), s_prompt: int = 286, t
             "achieved": head["achieved"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": head["frac"], "traffic": None,
             "batch": head["batch"], "ms_per_step": head["ms_per_step"], "by_batch": rows,
             "weight_bytes_per_step": wbytes,
+            "regime": "the REFERENCE's batch size (1) and mid batches: the HBM-bound side of the decode loop.  The product does not run "
+                      "here - `engine_batch=auto` decodes a whole pass together (2048 rows, MFMA-bound: 30.8 ms per step) and reaches "
+                      "these row counts only in the tail of a pass - so `achieved` says how good the weight stream is, not how the "
+                      "headline is made",
             "method": f"(t({t_long} new tokens) - t({t_short} new tokens)) / {t_long - t_short} on text-only prompts of {s_prompt} tokens, 3 repeats each, "
                       "host clock around synchronised generates (every generate is >= 50 ms); `achieved` = the reference's own batch size (1)"}
 
