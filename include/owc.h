@@ -226,6 +226,15 @@ int owc_sample_bf16(owc_ctx* ctx, const void* logits, int64_t ld, int rows, int 
 /* greedy argmax over bf16 logits rows (lowest index on ties). */
 int owc_argmax_bf16(owc_ctx* ctx, const void* logits, int64_t ld, int rows, int vocab,
                     int32_t* out, void* stream);
+/* Beam search, the arithmetic of one step (HF GenerationMixin._beam_search, reached through `num_beams=gen_kwargs["num_beams"]`,
+ * /root/reference/src/models/_qwen2_vl.py:308-329, _llava_hf.py:365-376): per row of bf16 logits [rows, vocab] (row stride ld)
+ *   logz[r]               = log sum_v exp(logits[r][v])      (fp32; log_softmax(x)[v] = x[v] - logz)
+ *   top_val / top_idx[r][] = the k largest logits and their token ids, descending, the lowest id first among equal values
+ * k = 2 x num_beams is what a step needs from every running hypothesis (k <= 64).  The hypothesis bookkeeping that consumes them
+ * (accumulated scores, finished slots with the length penalty, parents for the KV cache) is host integer / scalar work:
+ * lmms_owc_amd/engine/beam.py. */
+int owc_beam_candidates(owc_ctx* ctx, const void* logits, int64_t ld, int rows, int vocab, int k, float* logz, float* top_val,
+                        int32_t* top_idx, void* stream);
 /* out[r] = log softmax(logits[r])[target[r]] in fp32 (0 where target[r] < 0): the per-token terms of HF's causal-LM loss,
  * which LLaVA.loglikelihood averages (reference src/models/_llava_hf.py:243-245, outputs["loss"]). */
 int owc_token_logprob_bf16(owc_ctx* ctx, const void* logits, int64_t ld, const int32_t* target, int rows, int vocab, float* out,

@@ -21,7 +21,7 @@ _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
 _timing_ok = False
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = range(6)
 
@@ -128,6 +128,7 @@ SIGNATURES: dict[str, tuple] = {
     "owc_embed_tokens": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "owc_argmax_bf16": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "owc_sample_bf16": (i32, [vp, vp, i64, i32, i32, C.POINTER(Sampling), vp, i32, vp, vp]),
+    "owc_beam_candidates": (i32, [vp, vp, i64, i32, i32, i32, vp, vp, vp, vp]),
     "owc_token_logprob_bf16": (i32, [vp, vp, i64, vp, i32, i32, vp, vp]),
     "owc_patchify_u8": (i32, [vp, vp, vp, i64, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp]),
     "owc_vit_workspace_bytes": (sz, [C.POINTER(VitWeights), i32]),

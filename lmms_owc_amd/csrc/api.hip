@@ -16,7 +16,7 @@
 
 extern "C" {
 
-int owc_abi_version(void) { return 17; }
+int owc_abi_version(void) { return 18; }
 
 int owc_has_timing_knobs(void) {   // 1 only in libowc_hip_timing.so (tools/); the product library answers 0
 #ifdef OWC_TIMING_KNOBS
@@ -185,6 +185,13 @@ int owc_argmax_bf16(owc_ctx* ctx, const void* logits, int64_t ld, int rows, int 
                     void* stream) {
   if (!ctx || !logits || !out) return OWC_ERR_ARG;
   RET(ctx, "owc_argmax_bf16", owc_launch_argmax(logits, ld, rows, vocab, out, ST(stream)));
+}
+
+int owc_beam_candidates(owc_ctx* ctx, const void* logits, int64_t ld, int rows, int vocab, int k, float* logz, float* top_val,
+                        int32_t* top_idx, void* stream) {
+  if (!ctx || !logits || !logz || !top_val || !top_idx) return OWC_ERR_ARG;
+  if (rows <= 0 || vocab <= 0 || k <= 0 || k > vocab || k > 64) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_beam_candidates: need 1 <= k <= min(64, vocab)");
+  RET(ctx, "owc_beam_candidates", owc_launch_beam_candidates(logits, ld, rows, vocab, k, logz, top_val, top_idx, ST(stream)));
 }
 
 int owc_sample_bf16(owc_ctx* ctx, const void* logits, int64_t ld, int rows, int vocab, const owc_sampling* sampling,

@@ -521,6 +521,86 @@ __global__ __launch_bounds__(SAMPLE_T) void sample_kernel(const bf16_t* __restri
   }
 }
 
+// Beam search, the arithmetic of one step (HF GenerationMixin._beam_search: `log_softmax(logits.float())`, then `torch.topk` over
+// beams x vocabulary - of which a beam's own best K suffice, K = 2 x num_beams): per row of bf16 logits its log-sum-exp (fp32:
+// max + log(sum exp(x - max)), fixed summation order) and its K largest logits with their token ids, descending, the LOWEST id
+// first among equal bf16 values.  One block of 1024 threads per row; the K picks are K sweeps of the row (300 KB, L2-resident
+// after the first): "the best (value, id) strictly after the previous pick".  A path the reference's task configs never take
+// (all `num_beams: 1`): simple and deterministic beats fast here.
+constexpr int BEAM_T = 1024;
+__global__ __launch_bounds__(BEAM_T) void beam_candidates_kernel(const bf16_t* __restrict__ logits, long ld, int V, int K,
+                                                                 float* __restrict__ logz, float* __restrict__ top_val,
+                                                                 int* __restrict__ top_idx) {
+  __shared__ float sv[BEAM_T / 64];
+  __shared__ int si[BEAM_T / 64];
+  __shared__ float bcast_v;
+  __shared__ int bcast_i;
+  const int row = blockIdx.x, tid = threadIdx.x, w = tid >> 6;
+  const bf16_t* x = logits + (long)row * ld;
+  auto block_best = [&](float v, int i) {   // (max value, min id among equals) over the block -> bcast_v / bcast_i
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(i, o, 64);
+      if (ov > v || (ov == v && oi < i)) {
+        v = ov;
+        i = oi;
+      }
+    }
+    __syncthreads();   // (the previous round's broadcast has been read by everybody)
+    if ((tid & 63) == 0) {
+      sv[w] = v;
+      si[w] = i;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int k = 1; k < BEAM_T / 64; ++k)
+        if (sv[k] > v || (sv[k] == v && si[k] < i)) {
+          v = sv[k];
+          i = si[k];
+        }
+      bcast_v = v;
+      bcast_i = i;
+    }
+    __syncthreads();
+  };
+  // the K largest: sweep k finds the best (value, id) lexicographically after the previous pick
+  float pv = INFINITY;
+  int pi = -1;
+  float row_max = 0.f;
+  for (int k = 0; k < K; ++k) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += BEAM_T) {
+      const float f = bf2f(x[i]);
+      if ((f < pv || (f == pv && i > pi)) && (f > best || (f == best && i < bi))) {
+        best = f;
+        bi = i;
+      }
+    }
+    block_best(best, bi);
+    pv = bcast_v;
+    pi = bcast_i;
+    if (k == 0) row_max = pv;
+    if (tid == 0) {
+      top_val[(long)row * K + k] = pv;
+      top_idx[(long)row * K + k] = pi;
+    }
+  }
+  // log-sum-exp: per-thread strided sums, then a fixed tree
+  float s = 0.f;
+  for (int i = tid; i < V; i += BEAM_T) s += __expf(bf2f(x[i]) - row_max);
+  s = wave_sum(s);
+  __syncthreads();
+  if ((tid & 63) == 0) sv[w] = s;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int k = 0; k < BEAM_T / 64; ++k) t += sv[k];
+    logz[row] = row_max + __logf(t);
+  }
+}
+
 // Decode bookkeeping (HF GenerationMixin greedy loop): finished sequences emit pad, EOS marks done.
 //   out_row (optional): row of out_tokens (and index into `forced`) that compact row b belongs to - after an EOS-aware
 //     row compaction the B live rows are a subset of the original batch (NULL: identity);
@@ -830,6 +910,12 @@ int owc_launch_embed(const int* ids, const int* img_index, const void* table, co
 int owc_launch_token_logprob(const void* logits, long ld, const int* target, int rows, int V, float* out, hipStream_t st) {
   if (rows <= 0 || V <= 0) return OWC_ERR_SHAPE;
   hipLaunchKernelGGL(token_logprob_kernel, dim3(rows), dim3(256), 0, st, (const bf16_t*)logits, ld, target, V, out);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_beam_candidates(const void* logits, long ld, int rows, int V, int K, float* logz, float* top_val, int* top_idx,
+                               hipStream_t st) {
+  hipLaunchKernelGGL(beam_candidates_kernel, dim3(rows), dim3(BEAM_T), 0, st, (const bf16_t*)logits, ld, V, K, logz, top_val, top_idx);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 

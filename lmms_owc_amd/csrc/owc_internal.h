@@ -55,6 +55,8 @@ int owc_launch_mrope_kv(void* qkv, long ld, const int* pos3, long pos_stride, co
 int owc_launch_embed(const int* ids, const int* img_index, const void* table, const void* img,
                      void* out, int T, int d, hipStream_t st);
 int owc_launch_argmax(const void* logits, long ld, int rows, int V, int* out, hipStream_t st);
+int owc_launch_beam_candidates(const void* logits, long ld, int rows, int V, int K, float* logz, float* top_val, int* top_idx,
+                               hipStream_t st);
 int owc_launch_sample(const void* logits, long ld, int rows, int V, const owc_sampling* sp, const int* row_map, int step,
                       const int* step_state, int* out, hipStream_t st);
 int owc_launch_token_logprob(const void* logits, long ld, const int* target, int rows, int V, float* out, hipStream_t st);

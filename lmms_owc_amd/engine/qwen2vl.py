@@ -503,31 +503,7 @@ class Qwen2VLEngine:
             vc.view(d.n_layers, n_slots, Hkv, s_max, d.head_dim)[:, B:Bx, :, :w_c].copy_(cin["v"])
 
         # positions (host integer bookkeeping)
-        pos_list, max_pos = [], np.empty(B, dtype=np.int64)
-        img_index = []
-        img_cursor = 0
-        for b, ids in enumerate(prompts):
-            ids = np.asarray(ids)
-            if grids_per_prompt[b]:
-                p3, _ = positions.mrope_positions(ids, grids_per_prompt[b], d.image_token_id, d.merge)
-            else:
-                p3 = np.tile(np.arange(len(ids), dtype=np.int32)[None], (3, 1))
-            pos_list.append(p3)
-            max_pos[b] = int(p3.max())
-            is_img = ids == d.image_token_id
-            idx = np.full(len(ids), -1, dtype=np.int32)
-            n_img = int(is_img.sum())
-            if img_rows is not None:
-                rows = np.asarray(img_rows[b], dtype=np.int32)
-                if len(rows) != n_img or (n_img and (img_embeds is None or rows.min() < 0 or rows.max() >= img_embeds.shape[0])):
-                    raise ValueError("image token count does not match the image feature rows")
-                idx[is_img] = rows
-            else:
-                idx[is_img] = np.arange(img_cursor, img_cursor + n_img, dtype=np.int32)
-            img_cursor += n_img
-            img_index.append(idx)
-        if img_rows is None and img_cursor and (img_embeds is None or img_embeds.shape[0] != img_cursor):
-            raise ValueError("image token count does not match the image embeddings")
+        pos_list, max_pos, img_index = self._positions_and_image_rows(prompts, grids_per_prompt, img_embeds, img_rows)
         if int(max_pos.max()) + max_new_tokens + 1 > d.max_positions:
             raise ValueError("prompt + generation exceeds the rope table (raise Qwen2VLDims.max_positions)")
 
@@ -695,6 +671,152 @@ class Qwen2VLEngine:
             return out_tokens, step_logits
         return (out_tokens, first_logits) if return_logits else out_tokens
 
+    def _positions_and_image_rows(self, prompts, grids_per_prompt, img_embeds, img_rows):
+        """Per prompt: its M-RoPE position ids [3, len] (HF get_rope_index), the largest of them, and for every token the row of
+        `img_embeds` it takes its embedding from (-1: the token table)."""
+        d = self.d
+        pos_list, max_pos = [], np.empty(len(prompts), dtype=np.int64)
+        img_index = []
+        img_cursor = 0
+        for b, ids in enumerate(prompts):
+            ids = np.asarray(ids)
+            if grids_per_prompt[b]:
+                p3, _ = positions.mrope_positions(ids, grids_per_prompt[b], d.image_token_id, d.merge)
+            else:
+                p3 = np.tile(np.arange(len(ids), dtype=np.int32)[None], (3, 1))
+            pos_list.append(p3)
+            max_pos[b] = int(p3.max())
+            is_img = ids == d.image_token_id
+            idx = np.full(len(ids), -1, dtype=np.int32)
+            n_img = int(is_img.sum())
+            if img_rows is not None:
+                rows = np.asarray(img_rows[b], dtype=np.int32)
+                if len(rows) != n_img or (n_img and (img_embeds is None or rows.min() < 0 or rows.max() >= img_embeds.shape[0])):
+                    raise ValueError("image token count does not match the image feature rows")
+                idx[is_img] = rows
+            else:
+                idx[is_img] = np.arange(img_cursor, img_cursor + n_img, dtype=np.int32)
+            img_cursor += n_img
+            img_index.append(idx)
+        if img_rows is None and img_cursor and (img_embeds is None or img_embeds.shape[0] != img_cursor):
+            raise ValueError("image token count does not match the image embeddings")
+        return pos_list, max_pos, img_index
+
+    def generate_beam(self, prompts: list, img_embeds: torch.Tensor | None, grids_per_prompt: list, max_new_tokens: int, num_beams: int,
+                      *, eos_token_id: int, pad_token_id: int = 0, img_rows: list | None = None, length_penalty: float = 1.0,
+                      early_stopping=False, return_scores: bool = False):
+        """Beam search for a batch of prompts: what the reference asks HF for with `num_beams` > 1 in a request's gen_kwargs
+        (/root/reference/src/models/_qwen2_vl.py:308-329, _llava_hf.py:365-376; `do_sample=False`, HF's `length_penalty=1.0`,
+        `early_stopping=False`, the best hypothesis returned).  Every prompt is searched on its own, exactly as a batch-size-1
+        `generate` call would (`engine/beam.BeamSearcher`: HF's bookkeeping, pinned on HF's own run in tests/test_oracle_beam.py);
+        the B x num_beams running hypotheses share the decode steps.
+
+        Device side per step: `owc_llm_decode_step` on the B x num_beams rows (fed token, position, cache slot per row), then
+        `owc_beam_candidates` (log-sum-exp + the 2 x num_beams best logits per row) - 8 (1 + 4 num_beams) bytes per row come back.
+        The KV cache follows the hypotheses by SLOT: a running beam that continues a parent takes over the parent's slot; when a
+        parent is continued more than once, the extra children get a copy of its rows in the slot of a parent nobody continued.
+        The prompt is prefilled once per prompt (the num_beams hypotheses start identical: HF gives all but the first a score of
+        -1e9 at the first step).  Returns int32 [B, max_new_tokens] (EOS kept, pad behind it) and optionally the scores."""
+        from .beam import BeamSearcher
+
+        d = self.d
+        B, k = len(prompts), int(num_beams)
+        if k < 2:
+            raise ValueError("generate_beam is for num_beams >= 2 (one beam is `generate`)")
+        R = B * k                                   # (decode steps are launched directly: the rows' slots change between steps)
+        lens = np.array([len(p) for p in prompts], dtype=np.int64)
+        Hkv, G = d.n_kv_heads, d.n_q_heads // d.n_kv_heads
+        s_max = (int(lens.max()) + max_new_tokens + 15) // 16 * 16
+        kc, vc = self.reserve_kv(d.n_layers * R * Hkv * s_max * d.head_dim)
+        cache = _lib.KvCache(kc.data_ptr(), vc.data_ptr(), R, s_max)
+        kv5 = (kc.view(d.n_layers, R, Hkv, s_max, d.head_dim), vc.view(d.n_layers, R, Hkv, s_max, d.head_dim))
+        pos_list, max_pos, img_index = self._positions_and_image_rows(prompts, grids_per_prompt, img_embeds, img_rows)
+        if int(max_pos.max()) + max_new_tokens + 1 > d.max_positions:
+            raise ValueError("prompt + generation exceeds the rope table (raise Qwen2VLDims.max_positions)")
+        # ---- prefill: prompt b into slot b * k (the slots of a prompt's beams are b * k .. b * k + k - 1)
+        first_logits = torch.empty((B, d.vocab), dtype=BF16, device=self.device)
+        next_tok = torch.empty(B, dtype=I32, device=self.device)
+        share, self.share_prefix = self.share_prefix, False       # (the shared-prefix broadcast writes to CONSECUTIVE slots)
+        try:
+            b0 = 0
+            while b0 < B:   # launch groups of whole prompts, as in `generate`
+                b1, rows = b0, 0
+                while b1 < B and (b1 == b0 or rows + lens[b1] <= self.prefill_chunk_tokens):
+                    rows += int(lens[b1])
+                    b1 += 1
+                self._prefill_chunk(prompts, pos_list, img_index, img_embeds, lens, b0, b1, cache, next_tok, first_logits, None,
+                                    slot_of=lambda i: i * k)
+                b0 = b1
+        finally:
+            self.share_prefix = share
+        bs = BeamSearcher(B, k, max_new_tokens, eos_token_id, pad_token_id, length_penalty, early_stopping)
+        K2 = 2 * k
+        # step 0: every beam of a prompt sees the prefill's logits
+        logz, tv, ti = ops.beam_candidates(first_logits, K2)
+        logz, tv, ti = (x.cpu().numpy() for x in (logz, tv, ti))
+        parent, token, more = bs.step(np.repeat(logz[:, None], k, 1), np.repeat(tv[:, None], k, 1), np.repeat(ti[:, None], k, 1))
+        # all k running beams continue "beam 0" = the prompt: its cache rows go to the prompt's other slots
+        base = torch.arange(B, device=self.device) * k
+        for j in range(1, k):
+            for t5 in kv5:
+                t5[:, base + j, :, : int(lens.max())] = t5[:, base, :, : int(lens.max())]
+        slot = (np.arange(B)[:, None] * k + np.arange(k)[None, :]).astype(np.int64)            # slot of running beam [b, j]
+        ar = np.arange(R, dtype=np.int64)
+        q_start, o_start = self._i32(ar * (d.n_q_heads + 2 * Hkv)), self._i32(ar * d.n_q_heads)
+        q_len = self._i32(np.full(R, G))
+        done = torch.zeros(R, dtype=torch.uint8, device=self.device)
+        scratch_tok = torch.empty((R, 1), dtype=I32, device=self.device)
+        logits = torch.empty((R, d.vocab), dtype=BF16, device=self.device)
+        ws = self._workspace(self._lib.owc_llm_workspace_bytes(C.byref(self.w.llm), R, R))
+        g = 1                                                                                    # tokens every running beam holds
+        while more:
+            # state of the R rows for this step: the fed token is the beam's newest, at rope position max_pos + g, cache row len + g - 1
+            st = np.empty((5, R), np.int64)
+            st[0] = token.reshape(-1)
+            st[1] = np.repeat(max_pos, k) + g
+            st[2] = slot.reshape(-1)
+            st[3] = np.repeat(lens, k) + g - 1
+            st[4] = st[2] * Hkv * s_max
+            dev = self._i32(st.astype(np.int32))
+            klen = self._i32((st[3] + 1).astype(np.int32))
+            rc = self._lib.owc_llm_decode_step(
+                self._ctx, C.byref(self.w.llm), C.byref(cache), dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(),
+                dev[3].data_ptr(), dev[4].data_ptr(), klen.data_ptr(), q_start.data_ptr(), o_start.data_ptr(), q_len.data_ptr(),
+                done.data_ptr(), scratch_tok.data_ptr(), 1, 0, None, R, -1, -1, pad_token_id, None, None, None,
+                logits.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, self.dev_index)
+            logz, tv, ti = ops.beam_candidates(logits, K2)
+            logz, tv, ti = (x.cpu().numpy() for x in (logz, tv, ti))
+            parent, token, more = bs.step(logz.reshape(B, k), tv.reshape(B, k, K2), ti.reshape(B, k, K2))
+            g += 1
+            if not more:
+                break
+            # the cache follows the hypotheses: first child of a parent keeps its slot, further children copy it into a freed slot
+            new_slot = np.empty_like(slot)
+            src, dst = [], []
+            for b in range(B):
+                taken = set()
+                free = [int(slot[b, j]) for j in range(k) if j not in set(parent[b].tolist())]
+                for j in range(k):
+                    p_ = int(parent[b, j])
+                    if p_ not in taken:
+                        taken.add(p_)
+                        new_slot[b, j] = slot[b, p_]
+                    else:
+                        new_slot[b, j] = free.pop()
+                        src.append(int(slot[b, p_]))
+                        dst.append(int(new_slot[b, j]))
+            if src:
+                rows_now = int(lens.max()) + g - 1
+                s_t = torch.tensor(src, device=self.device)
+                d_t = torch.tensor(dst, device=self.device)
+                for t5 in kv5:
+                    t5[:, d_t, :, :rows_now] = t5[:, s_t, :, :rows_now]
+            slot = new_slot
+        toks, scores = bs.result()
+        out = torch.from_numpy(toks.astype(np.int32)).to(self.device)
+        return (out, scores) if return_scores else out
+
     def _carry_export(self, carry, cin, B, NC, n, cur, state, done2, row_of, steps_run, out_tokens, kc, vc, s_max, Bx,
                       max_new_tokens, forced_tokens, pad_token_id, n_slots, stream_of=None) -> None:
         """End of a pass with straggler hand-over: after the last enqueued step has run, split the rows that were still in the
@@ -826,19 +948,22 @@ class Qwen2VLEngine:
                 p = int(neq[0])
         return p if p >= self.min_shared_prefix else 0
 
-    def _prefill_chunk(self, prompts, pos_list, img_index, img_embeds, lens, b0, b1, cache, next_tok, first_logits, sampling=None):
+    def _prefill_chunk(self, prompts, pos_list, img_index, img_embeds, lens, b0, b1, cache, next_tok, first_logits, sampling=None,
+                       slot_of=None):
+        """`slot_of` (optional): prompt index -> cache slot (default: the prompt's own index; beam search spaces them num_beams apart)."""
         d = self.d
         n = b1 - b0
+        slot_of = slot_of or (lambda i: i)
         P = self._common_prefix(prompts, b0, b1)
         sl = lens[b0:b1] - P                       # rows each prompt contributes
         ids = [np.asarray(prompts[b], dtype=np.int32)[P:] for b in range(b0, b1)]
         pos3 = [pos_list[b][:, P:] for b in range(b0, b1)]
         iidx = [img_index[b][P:] for b in range(b0, b1)]
-        tok_slot = [np.full(int(sl[i]), b0 + i, dtype=np.int32) for i in range(n)]
+        tok_slot = [np.full(int(sl[i]), slot_of(b0 + i), dtype=np.int32) for i in range(n)]
         tok_idx = [np.arange(P, int(lens[b0 + i]), dtype=np.int32) for i in range(n)]
         starts = np.concatenate([[0], np.cumsum(sl)[:-1]])
         q_len, k_len = sl.copy(), lens[b0:b1].copy()
-        k_start = np.arange(b0, b1, dtype=np.int64) * d.n_kv_heads * cache.s_max
+        k_start = np.array([slot_of(i) for i in range(b0, b1)], dtype=np.int64) * d.n_kv_heads * cache.s_max
         last = starts + sl - 1
         if P:  # the shared prefix rides along as one extra segment at the end of the packed rows
             ids.append(np.asarray(prompts[b0], dtype=np.int32)[:P])

@@ -309,8 +309,7 @@ class PassPipeline:
             switches (one pass = one key; a straggler is only ever handed to a pass of ITS key)."""
             gk = u[0][1]
             smp = sampling_from_gen_kwargs(gk, getattr(self, "_default_top_k", 50))
-            return (int(gk.get("max_new_tokens", default_max_new)),
-                    None if smp is None else (smp["temperature"], smp["top_p"], smp["top_k"]))
+            return pass_key(int(gk.get("max_new_tokens", default_max_new)), smp, beams_from_gen_kwargs(gk))
 
         unit_keys = [unit_key(u) for u in units]
         taken = 0                               # units launched so far = index of the next pass's first unit
@@ -399,7 +398,7 @@ class PassPipeline:
             carry = None
             more = left - prep["n"] > 0 and unit_keys[taken] == preps[0]["key"]
             hand_over = (tok.eos_token_id is not None and tok.eos_token_id >= 0 and (more or carried is not None)
-                         and not getattr(self, "_no_carry", False))
+                         and not getattr(self, "_no_carry", False) and prep.get("num_beams", 1) == 1)   # (a beam-search pass runs to its end)
             if not self.last_timing["chunks"]:
                 # slots for carried sequences are reserved once per task: when ANY pass of it can hand over to a successor of its key
                 some = more or any(a == b for a, b in zip(unit_keys[taken:], unit_keys[taken + 1:]))
@@ -533,21 +532,35 @@ def hand_over_below(n_own: int, n_carried_in: int, capacity: int) -> int:
     return max(8, min(n_own // 2, capacity - n_carried_in))
 
 
+def pass_key(max_new: int, sampling: dict | None, num_beams: int = 1) -> tuple:
+    """What one engine pass is uniform in: generation length, sampling switches, beams."""
+    smp = None if sampling is None else (sampling["temperature"], sampling["top_p"], sampling["top_k"])
+    return (int(max_new), smp) if num_beams == 1 else (int(max_new), smp, int(num_beams))
+
+
+def beams_from_gen_kwargs(gen_kwargs: dict) -> int:
+    """`num_beams` of a request (reference src/models/_qwen2_vl.py:308-329, _llava_hf.py:355-376: default 1, handed to HF's generate)."""
+    k = int(gen_kwargs.get("num_beams", 1) or 1)
+    if k < 1:
+        raise ValueError("num_beams must be >= 1")
+    return k
+
+
 def sampling_from_gen_kwargs(gen_kwargs: dict, default_top_k: int = 50) -> dict | None:
     """The reference's generation switches -> the engine's `sampling` argument (None = greedy).
 
     Reference (src/models/_qwen2_vl.py:308-329, _llava_hf.py:355-376): `temperature` (default 0), `top_p` (default None),
     `num_beams` (default 1) from the request's gen_kwargs, `do_sample = temperature > 0`.  HF then samples through
     temperature -> top-k -> top-p with top_k from the checkpoint's generation_config.json (HF's own default is 50; Qwen2-VL's
-    ships `top_k: 1`, which makes its sampling the argmax) - `default_top_k` carries that value.  Beam search is not built:
-    num_beams != 1 raises (every task YAML of the reference is greedy, one beam).  The random stream is the library's documented
-    Philox stream keyed by torch's seed (the reference seeds torch with `--seed`, eval_model.py), one stream per DOCUMENT."""
-    if int(gen_kwargs.get("num_beams", 1) or 1) != 1:
-        raise NotImplementedError("beam search is not implemented by the HIP decoder (num_beams must be 1; the reference's task "
-                                  "configs are all greedy, one beam)")
+    ships `top_k: 1`, which makes its sampling the argmax) - `default_top_k` carries that value.  `num_beams` > 1 with temperature 0
+    is beam search (`beams_from_gen_kwargs`, `Qwen2VLEngine.generate_beam`); with temperature > 0 (beam sampling) it raises.  The
+    random stream is the library's documented Philox stream keyed by torch's seed (the reference seeds torch with `--seed`, eval_model.py), one stream per DOCUMENT."""
     t = gen_kwargs.get("temperature", 0) or 0
     if not float(t) > 0:
         return None
+    if beams_from_gen_kwargs(gen_kwargs) != 1:
+        raise NotImplementedError("beam SAMPLING (num_beams > 1 with temperature > 0) is not implemented by the HIP decoder; beam search "
+                                  "(temperature 0) and one-beam sampling are")
     import torch
 
     return {"temperature": float(t), "top_p": gen_kwargs.get("top_p"), "top_k": int(default_top_k), "seed": int(torch.initial_seed())}

@@ -22,7 +22,7 @@ from .. import _lib, utils
 from ..engine.llava import DIMS, NEXT_PINPOINTS, LlavaDims, LlavaEngine, LlavaWeights
 from . import imageproc
 from ._api import register_model
-from ._base import Model, PassPipeline, sampling_from_gen_kwargs
+from ._base import Model, PassPipeline, beams_from_gen_kwargs, pass_key, sampling_from_gen_kwargs
 from ._qwen2_vl import ByteTokenizer, LazyCheckpoint
 
 __all__ = ["LLaVA"]
@@ -217,7 +217,7 @@ class LLaVA(PassPipeline, Model):
                     break
                 smp = None if sampling is None else {**sampling, "stream_ids": [int(doc_ids[i]) * 64 + round_idx for i in active]}
                 rows = self._generate_chunk([contexts[i] for i in active], [visuals_per_doc[i] for i in active], max_new, feature_cache,
-                                            sampling=smp)
+                                            sampling=smp, num_beams=beams_from_gen_kwargs(gen_kwargs))
                 for i, ans in zip(active, self.decode_tokens(rows)):
                     results[i].append(ans)
                 round_idx += 1
@@ -304,7 +304,7 @@ class LLaVA(PassPipeline, Model):
         return feats, rows
 
     def _generate_chunk(self, contexts, visuals_per_doc, max_new: int, feature_cache: dict | None = None,
-                        sampling: dict | None = None) -> list[np.ndarray]:
+                        sampling: dict | None = None, num_beams: int = 1) -> list[np.ndarray]:
         """One engine pass: single-turn prompts (context + that document's images) -> greedy token rows cut at EOS."""
         eng, tok = self._model, self._tokenizer
         feats, rows = self._encode_visuals([v for vs in visuals_per_doc for v in vs], feature_cache)
@@ -317,8 +317,12 @@ class LLaVA(PassPipeline, Model):
             prompts.append(self._prompt_ids(ctx, [len(r) for r in mine]))
             rows_per_prompt.append(np.concatenate(mine) if mine else np.zeros(0, np.int64))
         eos = tok.eos_token_id
-        out = eng.generate_from_features(prompts, feats, rows_per_prompt, max_new, eos_token_id=eos, pad_token_id=eos,
-                                         sampling=sampling).cpu().numpy()
+        if num_beams > 1:
+            out = eng.generate_beam(prompts, feats, [[] for _ in prompts], max_new, num_beams, eos_token_id=eos, pad_token_id=eos,
+                                    img_rows=rows_per_prompt).cpu().numpy()
+        else:
+            out = eng.generate_from_features(prompts, feats, rows_per_prompt, max_new, eos_token_id=eos, pad_token_id=eos,
+                                             sampling=sampling).cpu().numpy()
         res = []
         for r in out:
             stop = np.flatnonzero(r == eos)
@@ -370,16 +374,17 @@ class LLaVA(PassPipeline, Model):
             dst, offs = buf.numpy(), np.cumsum([0] + [v.shape[0] for v in views])
             list(self._pool.map(lambda k: np.copyto(dst[offs[k]:offs[k + 1]], views[k]), range(len(views))))
             groups.append(buf)
-        key = (max_new, None if sampling is None else (sampling["temperature"], sampling["top_p"], sampling["top_k"]))
+        num_beams = beams_from_gen_kwargs(gen_kwargs)
+        key = pass_key(max_new, sampling, num_beams)
         return {"prompts": prompts, "images_per_prompt": images_per_prompt, "views_per_image": [v.shape[0] for v in views], "sizes": sizes,
-                "groups": groups, "max_new": max_new, "n": len(chunk), "sampling": sampling, "doc_ids": [int(x) for x in doc_ids], "key": key}
+                "groups": groups, "max_new": max_new, "n": len(chunk), "sampling": sampling, "doc_ids": [int(x) for x in doc_ids], "key": key, "num_beams": num_beams}
 
     @staticmethod
     def _merge_preps(preps: list[dict]) -> dict:
         cat = lambda k: [x for p in preps for x in p[k]]  # noqa: E731
         return {"prompts": cat("prompts"), "images_per_prompt": cat("images_per_prompt"), "views_per_image": cat("views_per_image"),
                 "sizes": cat("sizes"), "groups": cat("groups"), "max_new": preps[0]["max_new"], "n": sum(p["n"] for p in preps),
-                "sampling": preps[0]["sampling"], "doc_ids": cat("doc_ids")}
+                "sampling": preps[0]["sampling"], "doc_ids": cat("doc_ids"), "num_beams": preps[0].get("num_beams", 1)}
 
     def _launch_chunk(self, prep: dict, eos_token_id: int, pad: int, carry: dict | None = None):
         """GPU stage of one pass (everything enqueued, nothing waits): H2D of the staged views + owc_clip_patchify_u8 + CLIP tower +
@@ -398,9 +403,13 @@ class LLaVA(PassPipeline, Model):
                 rows_per_prompt.append(np.concatenate(mine) if mine else np.zeros(0, np.int64))
         smp = None if prep.get("sampling") is None else {**prep["sampling"], "stream_ids": prep["doc_ids"]}   # one stream per document
         # (pad = EOS, as the reference passes pad_token_id=self.eot_token_id, :365-376)
-        out = eng.generate_from_features(prep["prompts"], feats, rows_per_prompt, prep["max_new"], eos_token_id=eos_token_id,
-                                         pad_token_id=eos_token_id if eos_token_id is not None and eos_token_id >= 0 else 0,
-                                         sampling=smp, carry=carry)
+        pad = eos_token_id if eos_token_id is not None and eos_token_id >= 0 else 0
+        if prep.get("num_beams", 1) > 1:
+            out = eng.generate_beam(prep["prompts"], feats, [[] for _ in prep["prompts"]], prep["max_new"], prep["num_beams"],
+                                    eos_token_id=eos_token_id, pad_token_id=pad, img_rows=rows_per_prompt)
+        else:
+            out = eng.generate_from_features(prep["prompts"], feats, rows_per_prompt, prep["max_new"], eos_token_id=eos_token_id,
+                                             pad_token_id=pad, sampling=smp, carry=carry)
         host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
         host.copy_(out, non_blocking=True)
         ev = torch.cuda.Event()

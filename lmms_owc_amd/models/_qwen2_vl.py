@@ -19,7 +19,7 @@ from .. import _lib, ops, utils
 from ..engine.qwen2vl import DIMS, Qwen2VLDims, Qwen2VLEngine, Qwen2VLWeights
 from . import imageproc
 from ._api import register_model
-from ._base import Model, PassPipeline, sampling_from_gen_kwargs
+from ._base import Model, PassPipeline, beams_from_gen_kwargs, pass_key, sampling_from_gen_kwargs
 
 __all__ = ["Qwen2VL"]
 
@@ -202,6 +202,7 @@ class Qwen2VL(PassPipeline, Model):
                 raise ValueError(f"Expected `gen_kwargs['until']` to be of type Union[str,list] but got {type(until)}")
             max_new = int(gen_kwargs.get("max_new_tokens", 128))
             sampling = sampling_from_gen_kwargs(gen_kwargs, getattr(self, "_default_top_k", 50))
+            num_beams = beams_from_gen_kwargs(gen_kwargs)
             docs = [self.task_dict[task][split][did] for did in doc_ids]
             # round 0: the reference flattens the batch's visuals and hands message i the i-th entry (:409-413, :482-483) - at its
             # batch size of one that is the document's FIRST image; later rounds get the list the task returns, whole
@@ -289,8 +290,12 @@ class Qwen2VL(PassPipeline, Model):
                     prompts.append(self._messages_ids(messages[i], [g[1] * g[2] // 4 for g in round_grids[-1]]))
                 # (sampling: one stream per document and ROUND - a round's draws must not repeat the previous round's)
                 smp = None if sampling is None else {**sampling, "stream_ids": [int(doc_ids[i]) * 64 + round_idx for i in active]}
-                out = self._model.generate(prompts, emb, round_grids, max_new, eos_token_id=tok.eos_token_id, pad_token_id=pad,
-                                           img_rows=round_rows, sampling=smp).cpu().numpy()
+                if num_beams > 1:
+                    out = self._model.generate_beam(prompts, emb, round_grids, max_new, num_beams, eos_token_id=tok.eos_token_id,
+                                                    pad_token_id=pad, img_rows=round_rows).cpu().numpy()
+                else:
+                    out = self._model.generate(prompts, emb, round_grids, max_new, eos_token_id=tok.eos_token_id, pad_token_id=pad,
+                                               img_rows=round_rows, sampling=smp).cpu().numpy()
                 rows = []
                 for r in out:
                     stop = np.flatnonzero(r == tok.eos_token_id)
@@ -416,9 +421,10 @@ class Qwen2VL(PassPipeline, Model):
             list(self._pool.map(lambda k, i=i, dst=dst: np.copyto(dst[k - i], images[k]), range(i, j)))
             groups.append(buf)
             i = j
-        key = (max_new, None if sampling is None else (sampling["temperature"], sampling["top_p"], sampling["top_k"]))
+        num_beams = beams_from_gen_kwargs(gen_kwargs)
+        key = pass_key(max_new, sampling, num_beams)
         return {"prompts": prompts, "grids": grids_per_prompt, "groups": groups, "max_new": max_new, "n": len(chunk),
-                "sampling": sampling, "doc_ids": [int(d) for d in doc_ids], "key": key}
+                "sampling": sampling, "doc_ids": [int(d) for d in doc_ids], "key": key, "num_beams": num_beams}
 
     def _generate_rows(self, requests: list) -> list[np.ndarray]:
         """Token rows (cut at EOS) per request, in request order: the two-stage pass pipeline of `_base.PassPipeline`."""
@@ -428,7 +434,7 @@ class Qwen2VL(PassPipeline, Model):
     def _merge_preps(preps: list[dict]) -> dict:
         return {"prompts": [x for p in preps for x in p["prompts"]], "grids": [x for p in preps for x in p["grids"]],
                 "groups": [x for p in preps for x in p["groups"]], "max_new": preps[0]["max_new"], "n": sum(p["n"] for p in preps),
-                "sampling": preps[0]["sampling"], "doc_ids": [x for p in preps for x in p["doc_ids"]]}
+                "sampling": preps[0]["sampling"], "doc_ids": [x for p in preps for x in p["doc_ids"]], "num_beams": preps[0].get("num_beams", 1)}
 
     def _launch_chunk(self, prep: dict, eos_token_id: int, pad: int, carry: dict | None = None):
         """GPU stage of one prepared chunk: H2D + patchify + vision tower + prefill + decode are ENQUEUED (nothing waits), the ids
@@ -438,8 +444,12 @@ class Qwen2VL(PassPipeline, Model):
         if prep["groups"]:
             emb = self._model.encode_images(self._pixel_values(prep["groups"]), [g for gs in prep["grids"] for g in gs])
         smp = None if prep.get("sampling") is None else {**prep["sampling"], "stream_ids": prep["doc_ids"]}   # one stream per document
-        out = self._model.generate(prep["prompts"], emb, prep["grids"], prep["max_new"], eos_token_id=eos_token_id, pad_token_id=pad,
-                                   sampling=smp, carry=carry)
+        if prep.get("num_beams", 1) > 1:
+            out = self._model.generate_beam(prep["prompts"], emb, prep["grids"], prep["max_new"], prep["num_beams"],
+                                            eos_token_id=eos_token_id, pad_token_id=pad)
+        else:
+            out = self._model.generate(prep["prompts"], emb, prep["grids"], prep["max_new"], eos_token_id=eos_token_id, pad_token_id=pad,
+                                       sampling=smp, carry=carry)
         host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
         host.copy_(out, non_blocking=True)
         ev = torch.cuda.Event()

@@ -168,6 +168,17 @@ def argmax_bf16(logits):
     return out
 
 
+def beam_candidates(logits, k: int):
+    """bf16 logits [rows, vocab] -> (logz float32 [rows], top_val float32 [rows, k], top_idx int32 [rows, k]): `owc_beam_candidates`."""
+    rows = logits.shape[0]
+    logz = torch.empty((rows,), dtype=F32, device=logits.device)
+    top_val = torch.empty((rows, k), dtype=F32, device=logits.device)
+    top_idx = torch.empty((rows, k), dtype=I32, device=logits.device)
+    _call("owc_beam_candidates", _dev(logits), logits.data_ptr(), logits.stride(0), rows, logits.shape[1], int(k), logz.data_ptr(),
+          top_val.data_ptr(), top_idx.data_ptr())
+    return logz, top_val, top_idx
+
+
 def sample_bf16(logits, temperature: float, top_k: int = 0, top_p: float | None = None, seed: int = 0, stream_ids=None, row_map=None,
                 step: int = 0):
     """One draw per row of bf16 logits [rows, vocab] by owc_sampling (HF temperature -> top-k -> top-p -> multinomial; the library's

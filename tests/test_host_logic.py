@@ -750,3 +750,20 @@ def test_hand_over_threshold_policy():
     assert hand_over_below(2048, 2000, 1024) == 8       # more came in than the slots reserved: (nearly) everything finishes here
     assert hand_over_below(128, 0, 1024) == 64          # a small pass of the adaptive ramp
     assert hand_over_below(10, 0, 256) == 8
+
+
+def test_gen_kwargs_to_pass_key():
+    """What the plug-ins read out of a request's gen_kwargs (reference src/models/_qwen2_vl.py:308-329): temperature 0 -> greedy,
+    > 0 -> the sampler with HF's defaults; num_beams > 1 -> beam search, which does not combine with sampling; requests are grouped
+    into engine passes by (length, sampling switches, beams)."""
+    from lmms_owc_amd.models._base import beams_from_gen_kwargs, pass_key, sampling_from_gen_kwargs
+
+    assert sampling_from_gen_kwargs({"temperature": 0, "num_beams": 4}) is None and beams_from_gen_kwargs({"num_beams": 4}) == 4
+    assert beams_from_gen_kwargs({}) == 1 and beams_from_gen_kwargs({"num_beams": None}) == 1
+    smp = sampling_from_gen_kwargs({"temperature": 0.5, "top_p": 0.9})
+    assert smp["temperature"] == 0.5 and smp["top_p"] == 0.9 and smp["top_k"] == 50
+    with pytest.raises(NotImplementedError, match="beam SAMPLING"):
+        sampling_from_gen_kwargs({"temperature": 0.5, "num_beams": 2})
+    with pytest.raises(ValueError):
+        beams_from_gen_kwargs({"num_beams": -2})
+    assert pass_key(16, None) == (16, None) and pass_key(16, None, 3) == (16, None, 3) and pass_key(16, smp) != pass_key(16, None)

@@ -371,3 +371,27 @@ def test_gemm_f32(gpu, m, n, k, epi):
         out = ops.gemm_f32(a, w, b)
         want = y
     np.testing.assert_allclose(to_np(out), want, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("V,k", [(512, 4), (1000, 7), (151936, 8), (32064, 64)])
+def test_beam_candidates_vs_numpy(gpu, V, k):
+    """`owc_beam_candidates` (the device half of beam search): per row the log-sum-exp of the bf16 logits and the k largest
+    (value, id), ties by the lowest id (bf16 logits over a 150 k vocabulary tie often) - against numpy on the same bf16 values."""
+    from lmms_owc_amd import ops
+
+    rng = np.random.default_rng(V + k)
+    rows = 5
+    x = torch.from_numpy((rng.normal(size=(rows, V)) * 3).astype(np.float32)).to(torch.bfloat16)
+    x[1, : V // 2] = x[1, V // 2: V // 2 * 2]          # planted ties, also at the top
+    x[2, 7] = x[2, V - 3] = 40.0
+    x[3] = 1.5                                          # a constant row: ids 0 .. k-1
+    logz, tv, ti = (to_np(t) for t in ops.beam_candidates(x.to(gpu), k))
+    f = x.float().numpy()
+    order = np.lexsort((np.broadcast_to(np.arange(V), f.shape), -f.astype(np.float64)), axis=-1)[:, :k]
+    assert np.array_equal(ti, order)
+    assert np.array_equal(tv, np.take_along_axis(f, order, -1))
+    m = f.max(-1).astype(np.float64)
+    want = m + np.log(np.exp(f.astype(np.float64) - m[:, None]).sum(-1))
+    np.testing.assert_allclose(logz, want, rtol=0, atol=2e-5 * max(1.0, np.abs(want).max()))
+    with pytest.raises(Exception):
+        ops.beam_candidates(x.to(gpu), 65)

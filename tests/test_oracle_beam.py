@@ -1,0 +1,98 @@
+"""Pin oracle/beam_np.py on HF's OWN beam search: `generate(num_beams=k, do_sample=False)` of a tiny seeded Qwen2 decoder (fp32, CPU)
+against `beam_np.beam_search` fed by that model's forward - the call the reference makes with `num_beams` from a request's gen_kwargs
+(/root/reference/src/models/_qwen2_vl.py:308-329).  Cases: 2 / 3 / 4 beams, an EOS id the beams do reach (hypotheses finish early
+and compete length-penalised), one they never reach (every hypothesis ends at the length limit)."""
+import numpy as np
+import pytest
+
+from oracle import beam_np as BM
+
+
+@pytest.fixture(scope="module")
+def tiny_lm():
+    import torch
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+
+    torch.manual_seed(7)
+    cfg = Qwen2Config(vocab_size=97, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=128, tie_word_embeddings=False)
+    m = Qwen2ForCausalLM(cfg).eval().float()
+    with torch.no_grad():
+        for p in m.parameters():          # wider logits than the default init: beams of different quality
+            p.mul_(3.0)
+    return m
+
+
+def _hf_beams(m, prompt, k, T, eos, pad):
+    import torch
+
+    with torch.no_grad():
+        out = m.generate(input_ids=torch.tensor([prompt]), attention_mask=torch.ones(1, len(prompt), dtype=torch.long), num_beams=k,
+                         do_sample=False, max_new_tokens=T, eos_token_id=eos, pad_token_id=pad, use_cache=True)
+    new = out[0, len(prompt):].tolist()
+    return np.array(new + [pad] * (T - len(new)))
+
+
+@pytest.mark.parametrize("k,T,eos_rank", [(2, 6, None), (3, 8, 0), (4, 8, 1), (3, 10, 2), (2, 5, 0)])
+def test_beam_search_matches_hf_generate(tiny_lm, k, T, eos_rank):
+    import torch
+
+    m = tiny_lm
+    r = np.random.default_rng(100 * k + T)
+    pad = 0
+    for trial in range(4):
+        prompt = r.integers(1, 97, 5 + trial).tolist()
+
+        def logits_fn(conts):
+            with torch.no_grad():
+                ids = torch.tensor([prompt + c for c in conts])
+                return m(input_ids=ids).logits[:, -1, :].float().numpy()
+
+        # an EOS id the search meets: the eos_rank-th most frequent token of an EOS-free beam run (None: an id that never wins)
+        free, _ = BM.beam_search(logits_fn, len(prompt), k, T, -1, pad)
+        if eos_rank is None:
+            eos = 96 if 96 not in free else 95
+        else:
+            vals, counts = np.unique(free, return_counts=True)
+            eos = int(vals[np.argsort(-counts, kind="stable")][min(eos_rank, len(vals) - 1)])
+        want = _hf_beams(m, prompt, k, T, eos, pad)
+        got, _ = BM.beam_search(logits_fn, len(prompt), k, T, eos, pad)
+        assert np.array_equal(got, want), (k, T, eos, trial, got, want)
+
+
+def test_product_bookkeeping_equals_the_oracle_on_a_batch():
+    """`lmms_owc_amd.engine.beam.BeamSearcher` (the product's host side: B prompts at once, fed per running row with the log-sum-exp
+    and the 2 x num_beams best logits - what `owc_beam_candidates` returns) against `beam_np.beam_search` prompt by prompt, on a
+    synthetic "model" (logits = a seeded function of the sequence), with EOS ids the search meets: same tokens, same scores - also
+    for prompts whose search ends steps before the others'."""
+    from lmms_owc_amd.engine.beam import BeamSearcher
+
+    V, B, T = 61, 7, 9
+    rng = np.random.default_rng(5)
+    table = rng.normal(size=(V, V, V)).astype(np.float32) * 2.5
+
+    def logits_of(prompt_seed: int, seq: list) -> np.ndarray:
+        a = (prompt_seed * 7 + len(seq)) % V
+        b = seq[-1] if seq else prompt_seed % V
+        c = seq[-2] if len(seq) > 1 else (prompt_seed * 3) % V
+        return table[a, b] + 0.5 * table[c, a]
+
+    for k, eos in ((2, 11), (3, 40), (4, 7)):
+        want = [BM.beam_search(lambda conts, s=s: np.stack([logits_of(s, c) for c in conts]), 0, k, T, eos, 0) for s in range(B)]
+        bs = BeamSearcher(B, k, T, eos, 0)
+        seqs = [[[] for _ in range(k)] for _ in range(B)]
+        more, steps = True, 0
+        while more:
+            lg = np.stack([np.stack([logits_of(s, seqs[s][j]) for j in range(k)]) for s in range(B)])       # [B, k, V]
+            order = np.lexsort((np.broadcast_to(np.arange(V), lg.shape), -lg.astype(np.float64)), axis=-1)[..., : 2 * k]
+            top_val = np.take_along_axis(lg, order, -1)
+            m = lg.max(-1)
+            logz = m + np.log(np.exp(lg - m[..., None]).sum(-1, dtype=np.float32))
+            parent, token, more = bs.step(logz, top_val, order.astype(np.int32))
+            seqs = [[seqs[s][parent[s, j]] + [int(token[s, j])] for j in range(k)] for s in range(B)]
+            steps += 1
+        toks, scores = bs.result()
+        for s in range(B):
+            assert np.array_equal(toks[s], want[s][0]), (k, eos, s, toks[s], want[s][0])
+            assert abs(scores[s] - want[s][1]) < 1e-4
+        assert steps <= T

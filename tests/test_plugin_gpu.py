@@ -102,11 +102,40 @@ def test_sampled_generate_until_through_gen_kwargs(gpu):
         outs[tag] = lm.generate_until(task.instances)
     assert outs["a"] == outs["b"] and outs["a"] != outs["greedy"] and outs["c"] != outs["a"]
     task = load_task("synthetic:3:56x84:3")
-    task.generation_kwargs.update({"num_beams": 4})
+    task.generation_kwargs.update({"num_beams": 4, "temperature": 0.7})
     task.build_all_requests(limit=None, rank=0, world_size=1)
     lm.task_dict[task.task_name] = task.dataset
-    with pytest.raises(NotImplementedError, match="beam search"):
+    with pytest.raises(NotImplementedError, match="beam SAMPLING"):
         lm.generate_until(task.instances)
+
+
+@pytest.mark.parametrize("model_type", ["qwen2-vl", "llava"])
+def test_num_beams_reaches_the_beam_search(gpu, model_type):
+    """`--gen_kwargs num_beams=3` (reference src/models/_qwen2_vl.py:308-329, _llava_hf.py:365-376 hand it to HF's generate) runs
+    `generate_beam`: the answers equal the engine-level call on the same prompts, do not depend on the plug-in's batch size, and the
+    one-beam requests of the same task still take the greedy path."""
+    from lmms_owc_amd.models import get_model
+    from lmms_owc_amd.tasks import load_task
+
+    outs, calls = {}, []
+    for tag, bs, gk in (("greedy", 4, {}), ("b1", 1, {"num_beams": 3}), ("b4", 4, {"num_beams": 3})):
+        task = load_task("synthetic:7:56x84:3")
+        task.generation_kwargs.update(gk)
+        task.build_all_requests(limit=None, rank=0, world_size=1)
+        lm = get_model("custom-model", model_type=model_type, model_name_or_path="synthetic:tiny", batch_size=bs)
+        lm.task_dict[task.task_name] = task.dataset
+        eng = lm._model
+        orig = eng.generate_beam
+
+        def spy(*a, _orig=orig, _tag=tag, **kw):
+            calls.append((_tag, len(a[0]), a[4]))
+            return _orig(*a, **kw)
+
+        eng.generate_beam = spy
+        outs[tag] = lm.generate_until(task.instances)
+    assert outs["b1"] == outs["b4"] and len(outs["b4"]) == 7
+    assert [c for c in calls if c[0] == "greedy"] == [] and sum(c[1] for c in calls if c[0] == "b4") == 7
+    assert all(c[2] == 3 for c in calls)
 
 
 def test_evaluate_then_offline_metrics(gpu, scorer, tmp_path, capsys):

