@@ -59,6 +59,8 @@ int owc_tuning_set(const char* name, int value) {
     owc_gemm_set_ring_128(value);
     owc_gemm_fp8_set_ring_128(value);
   }
+  else if (!strcmp(name, "gemm_nt_min_mb")) owc_gemm_set_nt_min_mb(value);   // streaming C stores for outputs above this many MiB (negative: default)
+  else if (!strcmp(name, "gemm_persist")) owc_gemm_set_persist(value);   // persistent 256x256 ping-pong kernel: 0 off, negative: default
   else if (!strcmp(name, "gemm_pp128")) owc_gemm_set_pp128(value);   // 256x128 ping-pong tiles: 0 off, n > 0: from n tiles, negative: default
   else if (!strcmp(name, "decode_fuse")) owc_llm_set_decode_fuse(value);
   else if (!strcmp(name, "decode_norm_fuse")) owc_gemm_set_norm_fuse_max_m(value);   // max rows (<= 4) for the RMSNorm-fused skinny GEMM; 0 = off

@@ -61,6 +61,12 @@ int g_norm_fuse_max_m = 2; // rows up to which the decoder's RMSNorm is fused in
                            // Measured, 7B decode step in ms, separate / fused: 1 row 3.78 / 3.44, 2 rows 3.78 / 3.65, 4 rows 3.88 / 4.11 - every wave
                            // normalises every row itself, so beyond 2 rows the redundant work outweighs the launch it saves
 int g_pingpong = 1;       // 256x256 launches with K % 128 == 0 use the ping-pong kernel (A-B knob "gemm_pingpong", 0 = lock-step kernel)
+int g_persist = 0;        // 1: 256x256 ping-pong launches with more tiles than CUs and a bias / GELU / rotary epilogue run the persistent form (knob
+                          // "gemm_persist").  OFF: measured +3-5 % on bias-free K = 1280 launches, +-0 with a bias, -2-4 % with a residual, -0.4 % on
+                          // the 7B bench end to end (profiles/r05_gemm_persistent_*.txt; the kernel's header says what bounds it)
+int g_nt_min_mb = 64;     // outputs larger than this many MiB leave the 256x256 ping-pong kernels as streaming (non-temporal) stores (knob "gemm_nt_min_mb";
+                          // round 2-4: 512.  Round 5, per launch at 250-335 MB of C: +0.7 ... +3.2 %, never slower; the 7B bench +0.3 / +0.9 % in two
+                          // interleaved pairs: profiles/r05_gemm_persistent_*.txt)
 int g_pp128_min_tiles = 128;  // the 256x128 ping-pong kernel runs from this many of its tiles, up to 256 = one round (knob "gemm_pp128"; 0 off)
 int g_big_min_m = 129;   // M at and above which the 256x256 kernels may run (knob "gemm_big_min_m"; round 1: 1024)
 
@@ -812,6 +818,274 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// PERSISTENT form of the ping-pong kernel (round 5; built, bit-identical, measured - and OFF by default, `g_persist`): one block per
+// CU walks its output tiles (tile ids blockIdx.x, + gridDim.x, ...) and the operand ring never drains - the LDS-DMA slots that the last
+// two K-tiles of an output tile leave empty in gemm_bf16_nt_256pp_kernel carry K-tiles 0 and 1 of the NEXT output tile, so its first
+// MFMA section starts one barrier after this tile's last.
+// Why it was built: per output tile the one-tile-per-block kernel pays ~6.4 us that are not MFMAs (fit over K = 1280 ... 18944 on one
+// box: t = 6.4 us + 1.35 us per K-tile): 19 % of a K = 1280 launch (the vision tower's qkv / proj / fc1), 8 % at K = 3584.
+// What the timing build then showed (profiles/r05_gemm_persistent_*.txt, K = 1280, per tile): no epilogue at all 27.5 us; the
+// epilogue's arithmetic without its stores +2.3 us; the STORES ALONE (raw accumulator bits, no arithmetic) +4.4 us; everything 33.0
+// (the one-tile-per-block kernel: 29.9 without / 36.2 with its epilogue).  So most of the 6.4 us is neither the block's dispatch nor its
+// first loads (this kernel removes those: ~1.5 us) but the 128 KB of C a CU writes per tile, which retire at ~28 GB/s per CU next to
+// the operand stream - and vmcnt is IN ORDER on gfx9: a counted wait for a load issued after a store cannot pass before the store has
+// retired, so the K loop of the next tile stalls on the previous tile's stores however early they are issued.  Tried against that:
+// the tile stored in two batches 1.5 K-tiles apart, every wait right behind a batch needing only loads issued before it (below:
+// same 4.7 us); a start-up skew between the blocks of an XCD (+-0: the blocks share operand panels through the L2 and re-align);
+// streaming (nt) stores (+1 ... +6 % per launch, for both kernels: `g_nt_min_mb` now 64).  Net, interleaved A/B per launch: bias-free
+// K = 1280 +3 ... +5 %, with a bias +-0 ... +3 % (the bias / rotary-table loads of the epilogue wait - in order - for the ring loads
+// issued just before them), with a residual -2 ... -4 %, long K +-0 ... +1 %; the 7B bench end to end -0.3 ... -0.5 %.
+// What a tile boundary does here:
+//   * the C tile does NOT go through LDS (the ring owns it): gemm_epilogue_lines() trades 16-byte pieces between lanes fr and
+//     fr ^ 8 so that a store instruction writes 8 rows x 128 contiguous bytes - full lines straight from registers, no barrier;
+//   * rows 0-63 of a wave tile are final after the last K-tile's second phase and are stored in its third, rows 64-127 at the boundary;
+//   * the accumulators are zeroed by 128 moves (the compiler folds them into zero-C MFMAs where it peels).
+// Schedule, waits and fragment sets inside a K-tile are gemm_bf16_nt_256pp_kernel's (K % 128 == 0 keeps the buffer / fragment-set
+// parity across tile boundaries); each output element is the same ascending K chain: bit-identical results
+// (test_gemm_persistent_pingpong_race_screen, test_vision_tower_bits_with_and_without_the_persistent_gemm).  The pointers the DMA
+// reads from move to the next output tile in the middle of K-tile nk - 2 (after its A-half issue for K-tile nk - 1, the last issue
+// that belongs to this tile).  gridDim.x is a multiple of 8, so a block's tiles stay on its XCD's part of the XCD-aware walk.
+// Requires K % 128 == 0, K >= 384; bf16 outputs of the tile's own width (no F32 / SwiGLU epilogue).
+// ------------------------------------------------------------------------------------------------
+template <int EPI, bool NT>   // NT: streaming (non-temporal) C stores, for outputs far larger than the caches
+__global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_persist_kernel(
+    const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ W, long ldw,
+    const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv, long ldc, int M, int N, int K,
+    int tiles_m, int tiles_n, int flags, owc_gemm_aux aux) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int nblk = tiles_m * tiles_n;
+  const int nk = K / BK;
+
+  auto tile_origin = [&](int bid, int& m0, int& n0) {   // identical to gemm_bf16_nt_256_kernel
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int width = GROUP_M2 * tiles_n;
+    const int group = lid / width;
+    const int first_m = group * GROUP_M2;
+    const int gsize = min(tiles_m - first_m, GROUP_M2);
+    m0 = (first_m + (lid % width) % gsize) * BT;
+    n0 = ((lid % width) / gsize) * BT;
+  };
+  // ---- what the DMA reads: the output tile whose K-tiles are being issued (one or two K-tiles ahead of the MFMAs)
+  const char *abase, *wbase;
+  unsigned aoff[2][2], woff[2][2];
+  // (32-bit arithmetic from an opaque copy of the lane id, one offset after the other: this runs in the middle of a K-tile with every
+  //  fragment register live - nothing of it may be hoisted into long-lived registers or interleaved into a wide front of temporaries)
+  const unsigned lda2 = (unsigned)(lda * 2), ldw2 = (unsigned)(ldw * 2);
+  auto point_loads_at = [&](int m0, int n0) {
+    abase = (const char*)(A + (long)m0 * lda);
+    wbase = (const char*)(W + (long)n0 * ldw);
+    const int mlim = M - 1 - m0, nlim = N - 1 - n0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int lx = l;
+        asm volatile("" : "+v"(lx));
+        const int row = 128 * h + 16 * w + 8 * j + (lx >> 3);
+        const unsigned c16 = (unsigned)(((lx & 7) ^ ((row >> 1) & 7)) << 4);
+        aoff[h][j] = (unsigned)min(row, mlim) * lda2 + c16;
+        woff[h][j] = (unsigned)min(row, nlim) * ldw2 + c16;
+        asm volatile("" : "+v"(aoff[h][j]), "+v"(woff[h][j]));
+      }
+  };
+  auto issue_a = [&](int kt, int h) {  // A half-tile h of K-tile kt (of the tile the DMA points at) -> buffer kt & 1
+    char* dst = lds + (kt & 1) * STAGE_BYTES + (128 * h + 16 * w) * 128;
+    const char* ab = abase + (long)kt * (BK * 2);
+    asm volatile("" : "+s"(ab), "+v"(aoff[h][0]), "+v"(aoff[h][1]));
+    glds16(ab + aoff[h][0], dst);
+    glds16(ab + aoff[h][1], dst + 1024);
+  };
+  auto issue_w = [&](int kt, int h) {
+    char* dst = lds + (kt & 1) * STAGE_BYTES + OP_BYTES + (128 * h + 16 * w) * 128;
+    const char* wb = wbase + (long)kt * (BK * 2);
+    asm volatile("" : "+s"(wb), "+v"(woff[h][0]), "+v"(woff[h][1]));
+    glds16(wb + woff[h][0], dst);
+    glds16(wb + woff[h][1], dst + 1024);
+  };
+
+  const int wr = w >> 2, wc = w & 3;
+  const int fr = l & 15, fq = l >> 4;
+  const int swz = (fr >> 1) & 7;
+  const int rowA = (wr * 128 + fr) * 128;
+  const int rowW = OP_BYTES + (wc * 64 + fr) * 128;
+  const int ch0 = ((0 + fq) ^ swz) << 4, ch1 = ((4 + fq) ^ swz) << 4;
+
+  f32x4 acc[4][8];  // [nt][mt]
+  bf16x8 fa[2][4], wy[2][2], wx0[2][2], wx1[2][2];
+
+  auto read_a = [&](const char* sbase, int mh) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      fa[0][t] = *(const bf16x8*)(sbase + rowA + (mh * 4 + t) * 2048 + ch0);
+      fa[1][t] = *(const bf16x8*)(sbase + rowA + (mh * 4 + t) * 2048 + ch1);
+    }
+  };
+  auto read_w = [&](bf16x8 (&dst)[2][2], const char* sbase, int nh) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      dst[0][t] = *(const bf16x8*)(sbase + rowW + (nh * 2 + t) * 2048 + ch0);
+      dst[1][t] = *(const bf16x8*)(sbase + rowW + (nh * 2 + t) * 2048 + ch1);
+    }
+  };
+#define OWC_PS_SYNC_L(VM)                                                                         \
+  do {                                                                                            \
+    if constexpr ((VM) >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((VM) < 0 ? 0 : (VM)) : "memory"); \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                               \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+  } while (0)
+  // MFMA section: one C quadrant over the whole K-tile (k-step 0 then 1: every output element stays ONE ascending chain)
+  auto quadrant = [&](const bf16x8 (&wf)[2][2], int mh, int nh) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[nh * 2 + n][mh * 4 + m] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][n], fa[ks][m], acc[nh * 2 + n][mh * 4 + m], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // vmcnt is IN ORDER on gfx9 (loads and stores share the counter and retire in issue order), so the C stores of an output tile sit
+  // in the counter between the loads issued before and after them - and they are slow to retire: a CU's stores of one tile (128 KB)
+  // take ~4.4 us next to the operand stream (timing build, stores of raw accumulator bits only: profiles/).  A counted wait that
+  // only needs loads issued BEFORE a batch of stores may leave that batch in flight: its steady-state count + the batch.  The
+  // schedule is arranged so that every wait right behind a batch is of that kind, and the tile is stored in two batches 1.5 K-tiles
+  // apart, each with ~2 us until a wait needs a load that is younger than it:
+  //   K-tile nk-1  p1  issue A half 1 of K-tile 0'                              (0', 1': K-tiles of the NEXT output tile)
+  //                p2  rows 0-63 of the wave tile are final (quadrants (0,0), (0,1)): batch S0 = 8 stores; issue W half 0 of 1'
+  //                    wait W(0') [older than S0]: in flight A(0') 4 + S0 8 + 2 = 14
+  //                p3  issue W half 1, A halves 0 AND 1 of 1' (the A half 1 would be K-tile 0's p1 issue: it is brought forward so
+  //                    that K-tile 0's waits need nothing younger than the stores)    wait A(0'): S0 8 + 8 = 16
+  //   boundary         rows 64-127 final: batch S1 = 8 stores
+  //   K-tile 0     p2  issue W half 0 of 2     wait W(1') [younger than S0, older than S1]: A(1') 4 + S1 8 + 2 = 14
+  //                p3  issue W half 1, A half 0 of 2     wait A(1'): S1 8 + 6 = 14
+  //   K-tile 1     p2  wait W(2): the steady-state 6 - the first wait that needs S1 retired
+  // The store counts hold for INTERIOR tiles (every wave issues all 16 stores); for a tile on the ragged edge, and for the block's
+  // first tile, the steady-state counts are used - merely stricter.
+  auto wait_sync = [&](int n) {   // n in {6, 8, 14, 16}: block-uniform
+    if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int m0, n0;        // the output tile the MFMAs are working on
+  bool interior = false, lax = false;   // this tile / the previous one issued every store
+  // One K-tile of the stream: K-tiles kt1 = "u + 1" and kt2 = "u + 2" of whatever output tile the DMA points at are issued.
+  // `first`: K-tile 0 of an output tile (no p1 issue; waits that leave the previous tile's second store batch in flight).
+  // `last`: K-tile nk - 1 (stores the first half of the tile; also issues A half 1 of kt2 = K-tile 1').  `turn`: called after p1's
+  // issue (the point where K-tile nk - 2 hands the DMA over to the next output tile).  All of them are block-uniform: scalar branches
+  // around a wait.  (The copies of the K-tile pair follow each other in a straight line; with copies behind an if / else - a peeled
+  // "last tile of the block" tail - the register allocator moved the accumulators between them: MFMAs with vDst != srcC, 300 spills.)
+  auto ktile = [&](auto first_c, auto last_c, int u, int kt1, int kt2, bf16x8 (&wcur)[2][2], bf16x8 (&wnxt)[2][2], auto&& turn) {
+    constexpr bool first = decltype(first_c)::value, last = decltype(last_c)::value;
+    const char* cur = lds + (u & 1) * STAGE_BYTES;
+    const char* nxt = lds + ((u + 1) & 1) * STAGE_BYTES;
+    // p0
+    read_a(cur, 0);
+    OWC_PS_SYNC_L(-1);
+    quadrant(wcur, 0, 0);
+    // p1
+    read_w(wy, cur, 1);
+    if constexpr (!first) issue_a(kt1, 1);
+    turn();
+    OWC_PS_SYNC_L(-1);
+    quadrant(wy, 0, 1);
+    // p2
+    if (last && !OWC_TK(flags & 4)) {   // rows 0-63 of the wave tile (the A fragments of those rows are dead, the next W set not yet read)
+      int lx = l;                       // (opaque lane id: nothing of the epilogue's addressing is hoisted out of the K loop)
+      asm volatile("" : "+v"(lx));
+      gemm_epilogue_lines<EPI, 8, NT, 0, 4>(acc, m0 + wr * 128, n0 + wc * 64, lx & 15, lx >> 4, bias, R, ldr, Cv, ldc, M, N, aux, flags);
+    }
+    read_a(cur, 1);
+    issue_w(kt2, 0);
+    wait_sync(((last && interior) || (first && lax)) ? 14 : 6);
+    quadrant(wy, 1, 1);
+    // p3
+    read_w(wnxt, nxt, 0);
+    issue_w(kt2, 1);
+    issue_a(kt2, 0);
+    if constexpr (last) issue_a(kt2, 1);              // (its LDS rows were last read one phase ago, in this K-tile's p2)
+    wait_sync(last ? (interior ? 16 : 8) : ((first && lax) ? 14 : 6));
+    quadrant(wcur, 1, 0);
+  };
+  auto nothing = [] {};
+  using Yes = std::true_type;
+  using No = std::false_type;
+
+  int tile = blockIdx.x;
+  tile_origin(tile, m0, n0);
+  point_loads_at(m0, n0);
+  // ---- prologue of the block's first output tile: K-tile 0 entirely, then what the previous tile's last K-tile would have issued for K-tile 1
+  issue_a(0, 0);
+  issue_a(0, 1);
+  issue_w(0, 0);
+  issue_w(0, 1);
+  issue_w(1, 0);
+  issue_w(1, 1);
+  issue_a(1, 0);
+  issue_a(1, 1);
+  asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");   // K-tile 0 landed and published
+  __builtin_amdgcn_sched_barrier(0);
+  read_w(wx0, lds, 0);
+  if (wr) {   // group 1 runs one barrier interval behind group 0
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // The block's last output tile runs the same code as every other: its spare DMA slots re-read K-tiles 0 / 1 of the tile itself
+  // (never consumed; drained before the block ends).
+  for (;;) {
+    const int next = tile + (int)gridDim.x;
+    const bool more = next < nblk;          // block-uniform
+    int m1 = m0, n1 = n0;
+    if (more) tile_origin(next, m1, n1);
+    interior = m0 + BT <= M && n0 + BT <= N && !OWC_TK(flags & (4 | 8));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // three copies of the K-tile pair in a straight line - K-tiles 0 / 1, the steady-state loop (no branch in it), K-tiles nk - 2 /
+    // nk - 1 whose "u + 2" slots carry K-tiles 0 / 1 of the next output tile (same buffer parity: nk is even)
+    ktile(Yes{}, No{}, 0, 1, 2, wx0, wx1, nothing);
+    ktile(No{}, No{}, 1, 2, 3, wx1, wx0, nothing);
+    int u = 2;
+#pragma unroll 1
+    for (; u + 2 < nk; u += 2) {
+      ktile(No{}, No{}, u, u + 1, u + 2, wx0, wx1, nothing);
+      ktile(No{}, No{}, u + 1, u + 2, u + 3, wx1, wx0, nothing);
+    }
+    ktile(No{}, No{}, u, u + 1, 0, wx0, wx1, [&] { point_loads_at(m1, n1); });
+    ktile(No{}, Yes{}, u + 1, 0, 1, wx1, wx0, nothing);
+    if (!OWC_TK(flags & 4)) {   // rows 64-127 of the wave tile
+      int lx = l;
+      asm volatile("" : "+v"(lx));
+      gemm_epilogue_lines<EPI, 8, NT, 4, 8>(acc, m0 + wr * 128, n0 + wc * 64, lx & 15, lx >> 4, bias, R, ldr, Cv, ldc, M, N, aux, flags);
+    } else if (acc[0][0][0] == 123.456f) {
+      ((float*)Cv)[0] = 1.f;
+    }
+    lax = interior;
+    if (!more) break;
+    tile = next;
+    m0 = m1;
+    n0 = n1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the spare slots' DMA has landed before the block gives its LDS back
+  if (!wr) {  // every wave has executed the same number of barriers
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef OWC_PS_SYNC_L
+}
+
+// ------------------------------------------------------------------------------------------------
 // Ping-pong kernel on a 256 x 128 tile (round 5): the role-alternating schedule of gemm_bf16_nt_256pp_kernel for launches whose
 // 256 x 256 tiles would leave more than half of the CUs idle - the o / down projections (N = 3584) of a decode step at
 // 1024-2048 rows (a full pass's decode batch: 8 x 14 = 112 tiles of 256^2, 224 of 256 x 128), which ran on the 128 x 128
@@ -1312,6 +1586,17 @@ bool launch_skinny(const void* A, long lda, const void* W, long ldw, const void*
   return false;
 }
 
+int cu_count() {   // compute units of the current device (the persistent kernel's grid)
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = -1;
+  }
+  return n;
+}
+
 template <int EPI>
 int launch(const void* A, long lda, const void* W, long ldw, const void* bias, const void* R,
            long ldr, void* C, long ldc, int M, int N, int K, const void* zeros, hipStream_t s,
@@ -1365,7 +1650,28 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
     // C far larger than L2 + Infinity Cache (256 MB): stream it out (`global_store ... nt`) instead of evicting the operand panels the
     // XCD's L2 is sharing: +0.3...3 % per launch on the path's shapes (vit.proj 1154 -> 1192 TFLOP/s, gate/up 1459 -> 1480), never
     // slower; a small C (decode steps) stays cacheable for the kernel that reads it next
-    const int flags = g_gemm_dbg | ((size_t)M * (size_t)N * 2 > ((size_t)512 << 20) ? 1024 : 0);
+    const int flags = g_gemm_dbg | ((size_t)M * (size_t)N * 2 > ((size_t)g_nt_min_mb << 20) ? 1024 : 0);
+    if constexpr (EPI != OWC_EPI_F32 && EPI != OWC_EPI_SWIGLU) {   // (the persistent form: off by default, see g_persist)
+      const int cus = cu_count();
+      if (g_persist && K >= 6 * BK && tiles_m * tiles_n > cus && cus >= 8) {
+        static bool set_ = false;
+        if (!set_) {
+          if (hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_persist_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * STAGE_BYTES) != hipSuccess ||
+              hipFuncSetAttribute((const void*)gemm_bf16_nt_256pp_persist_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * STAGE_BYTES) != hipSuccess) return OWC_ERR_HIP;
+          set_ = true;
+        }
+        if (flags & 1024)
+          hipLaunchKernelGGL((gemm_bf16_nt_256pp_persist_kernel<EPI, true>), dim3(cus & ~7), dim3(512), 2 * STAGE_BYTES, s, (const bf16_t*)A, lda,
+                             (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, flags, aux);
+        else
+          hipLaunchKernelGGL((gemm_bf16_nt_256pp_persist_kernel<EPI, false>), dim3(cus & ~7), dim3(512), 2 * STAGE_BYTES, s, (const bf16_t*)A, lda,
+                             (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, flags, aux);
+        owc_gemm_profile_end(prof, s);
+        return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+      }
+    }
     hipLaunchKernelGGL(gemm_bf16_nt_256pp_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), 2 * STAGE_BYTES, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
                        (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, flags, aux);
@@ -1661,3 +1967,5 @@ void owc_gemm_set_tall_tiles(int v) { g_tall_tiles = v != 0; g_wide_min_blocks =
 void owc_gemm_set_small_tiles(int v) { g_small_tiles = v < 0 ? 1 : v; }
 void owc_gemm_set_ring_128(int v) { g_ring_128 = v < 0 ? 1 : v != 0; }
 void owc_gemm_set_pp128(int v) { g_pp128_min_tiles = v < 0 ? 128 : v; }
+void owc_gemm_set_persist(int v) { g_persist = v < 0 ? 0 : v; }
+void owc_gemm_set_nt_min_mb(int v) { g_nt_min_mb = v < 0 ? 64 : v; }

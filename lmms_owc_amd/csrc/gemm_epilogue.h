@@ -216,6 +216,142 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
   }
 }
 
+// Epilogue WITHOUT the LDS image, for a kernel whose LDS stays busy (the persistent ping-pong GEMM, whose operand ring already carries the
+// NEXT output tile's K-tiles while this one is written): full 128-byte lines straight from registers.  After the permlane16 swap a lane
+// owns, for tile pair p of the wave's 64 columns, 16 bytes of row fr - four lanes cover 64 bytes of a row, a half line per store
+// instruction and row.  One more exchange fixes that: lanes fr and fr ^ 8 of a 16-lane row trade one of their two 16-byte pieces
+// (DPP row_ror:8), after which lanes 0-7 hold rows 0-7 / 8-15 of pair 0's columns and lanes 8-15 the same rows of pair 1's: a store
+// instruction then writes 8 rows x 128 contiguous bytes.  Arithmetic, rounding points and their order are gemm_epilogue's generic
+// branch, value for value.  (64-column wave tiles only; F32 / SwiGLU outputs are not taken.)
+__device__ __forceinline__ unsigned dpp_ror8(unsigned x) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+}
+
+// MH0, MH1: the m tiles [MH0, MH1) of the wave tile (multiples of 4) - the caller may write the tile in pieces
+template <int EPI, int MT, bool NT, int MH0 = 0, int MH1 = MT>
+__device__ __forceinline__ void gemm_epilogue_lines(const f32x4 (&acc)[4][MT], int mrow0, int ncol0, int fr, int fq,
+                                                    const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv, long ldc,
+                                                    int M, int N, const owc_gemm_aux& aux, int tk = 0) {
+  // tk (timing-knob build only): 8 = all the arithmetic, no stores; 16 = stores of the raw accumulator bits, no arithmetic
+  static_assert(EPI != OWC_EPI_F32 && EPI != OWC_EPI_SWIGLU, "bf16 outputs of the wave tile's own width only");
+  if (OWC_TK(tk & 16)) {
+    bf16_t* C = (bf16_t*)Cv;
+    const int nst = ncol0 + ((fr < 8) ? 0 : 32) + fq * 8;
+#pragma unroll
+    for (int mt = MH0; mt < MH1; ++mt) {
+      const int ra = mrow0 + mt * 16 + (fr & 7);
+      *(u32x4*)(C + (long)ra * ldc + nst) = __builtin_bit_cast(u32x4, acc[0][mt]);
+      *(u32x4*)(C + (long)(ra + 8) * ldc + nst) = __builtin_bit_cast(u32x4, acc[1][mt]);
+    }
+    return;
+  }
+  bf16_t* C = (bf16_t*)Cv;
+  const int odd = fq & 1;
+  const bool lo = fr < 8;
+  int ncol[2], nclamp[2];
+  float bv[2][8];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    ncol[p] = ncol0 + (2 * p + odd) * 16 + (fq >> 1) * 8;   // first of the lane's 8 columns of pair p (before the row exchange)
+    nclamp[p] = min(ncol[p], N - 8);
+    if (bias != nullptr) {
+      const bf16x8 b = *(const bf16x8*)(bias + nclamp[p]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[p][e] = bf2f(b[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[p][e] = 0.f;
+    }
+  }
+  const int nst = lo ? ncol[0] : ncol[1];   // the lane's columns in the stores
+#pragma unroll
+  for (int mh = MH0; mh < MH1; mh += 4) {
+    // the residual rows of four m tiles are read in one batch (R may alias C: an element is read before the instruction that stores it)
+    bf16x8 rr[2][4];
+    if constexpr (EPI == OWC_EPI_RESIDUAL) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          rr[p][t] = *(const bf16x8*)(R + (long)min(mrow0 + (mh + t) * 16 + fr, M - 1) * ldr + nclamp[p]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int mt = mh + t;
+      const int m = mrow0 + mt * 16 + fr;
+      u32x4 pk[2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[2 * p][mt][e];
+          v[4 + e] = acc[2 * p + 1][mt][e];
+          swap16(v[e], v[4 + e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + bv[p][e]);
+        if constexpr (EPI == OWC_EPI_VROPE) {
+          if (ncol[p] < aux.rope_cols) {   // (see gemm_epilogue: scalar form, every factor pinned - the packed-multiply form is refused)
+            const int quarter = aux.head_dim >> 2;
+            const int j0 = (ncol[p] % aux.head_dim) >> 1;
+            const int2 hw = *(const int2*)(aux.pos_hw + 2 * (long)min(m, M - 1));
+            const int ti = (j0 < quarter) ? hw.x * quarter + j0 : hw.y * quarter + (j0 - quarter);
+            const f32x4 c4 = *(const f32x4*)(aux.cos_t + ti);
+            const f32x4 s4 = *(const f32x4*)(aux.sin_t + ti);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x1 = v[2 * e], x2 = v[2 * e + 1], c = c4[e], sn = s4[e];
+              asm volatile("" : "+v"(x1), "+v"(x2), "+v"(c), "+v"(sn));
+              float t0 = x2 * sn, t1 = x1 * sn;
+              asm volatile("" : "+v"(t0), "+v"(t1));
+              v[2 * e] = __builtin_fmaf(x1, c, -t0);
+              v[2 * e + 1] = __builtin_fmaf(x2, c, t1);
+            }
+          }
+        }
+        if constexpr (EPI == OWC_EPI_QUICK_GELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = act_quick_gelu(v[e]);
+        } else if constexpr (EPI == OWC_EPI_GELU_ERF) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = act_gelu_erf(v[e]);
+        } else if constexpr (EPI == OWC_EPI_RESIDUAL) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bf2f(rr[p][t][e]);
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+        pk[p] = __builtin_bit_cast(u32x4, o);
+      }
+      // lanes fr < 8 give pair 1's piece of their row and get pair 0's piece of row fr + 8; lanes fr >= 8 the other way round
+      u32x4 first, second;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned got = dpp_ror8(lo ? pk[1][i] : pk[0][i]);
+        first[i] = lo ? pk[0][i] : got;     // row mt * 16 + (fr & 7)
+        second[i] = lo ? got : pk[1][i];    // row mt * 16 + (fr & 7) + 8
+      }
+      const int ra = mrow0 + mt * 16 + (fr & 7), rb = ra + 8;
+      if (OWC_TK(tk & 8)) {
+        if ((first[0] ^ second[1]) == 0x12345678u && first[2] == 0x9abcdef0u) *(u32x4*)(C + (long)ra * ldc + nst) = first;
+        continue;
+      }
+      if (nst < N) {
+        if (ra < M) {
+          if constexpr (NT) __builtin_nontemporal_store(first, (u32x4*)(C + (long)ra * ldc + nst));
+          else *(u32x4*)(C + (long)ra * ldc + nst) = first;
+        }
+        if (rb < M) {
+          if constexpr (NT) __builtin_nontemporal_store(second, (u32x4*)(C + (long)rb * ldc + nst));
+          else *(u32x4*)(C + (long)rb * ldc + nst) = second;
+        }
+      }
+    }
+  }
+}
+
 // Second half of the LDS-staged epilogue: the block's output tile (rows x cols bf16, pitch = cols * 2 bytes) leaves LDS as
 // whole rows - a wave-instruction covers 64 lanes x 16 B = 1 KiB of consecutive row segments.
 template <int WAVES, bool NT = false>

@@ -47,6 +47,27 @@ def test_vision_slice_full_width(slice_model, gpu):
         assert np.abs(got - ref).mean() <= 0.004 * np.abs(ref).max()
 
 
+def test_vision_tower_bits_with_and_without_the_persistent_gemm(slice_model, gpu):
+    """The vision tower's GEMMs at 16 384 patch rows (960 / 320 / 1280 output tiles: qkv with the rotary epilogue, proj and fc2 adding
+    into the residual stream in place, fc1 with quick-GELU) run the persistent ping-pong kernel: the embeddings equal those of the
+    one-tile-per-block kernel bit for bit, five times (the race screen at model level)."""
+    from lmms_owc_amd import _lib
+
+    cfg, w, eng = slice_model
+    lib = _lib.load()
+    grid = [(1, 32, 32)] * 16
+    pix = torch.from_numpy(recipes.pixel_values(grid, 11)).to(torch.bfloat16).to(gpu)
+    try:
+        assert lib.owc_tuning_set(b"gemm_persist", 0) == 0
+        want = eng.encode_images(pix, grid).clone()
+        assert lib.owc_tuning_set(b"gemm_persist", 1) == 0
+        for i in range(5):
+            got = eng.encode_images(pix, grid)
+            assert torch.equal(got, want), (i, (got != want).sum().item())
+    finally:
+        lib.owc_tuning_set(b"gemm_persist", -1)
+
+
 def test_qwen25_vision_slice_full_width(gpu):
     """Qwen2.5-VL's vision tower at its real widths (registry names qwen2.5-vl-7b / -3b, /root/reference/src/models/_qwen2_vl.py:
     106-115, 635-648): hidden 1280 x 16 heads, gated MLP of 3420 (zero-padded to 3456 = 27 x 128 at load, so its down projection

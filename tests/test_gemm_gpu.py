@@ -344,6 +344,46 @@ def test_gemm_256x128_pingpong_race_screen(gpu, m, n, k, epi):
         lib.owc_tuning_set(b"gemm_mid_max_tiles", 256)
 
 
+@pytest.mark.parametrize("m,n,k,epi", [(4352, 4096, 384, "none"),          # 272 tiles: 16 blocks walk two tiles; six K-tiles (the steady-state loop runs once)
+                                       (4100, 3848, 512, "residual"),      # ragged M and N (clamped rows in the last tile row / column), eight K-tiles
+                                       (8192, 5120, 1280, "quick_gelu"),   # 640 tiles = 2.5 rounds (the vision tower's fc1 shape)
+                                       (16384, 1280, 1280, "inplace"),     # C aliases R (the residual stream): proj / fc2
+                                       (6000, 2816, 512, "gelu_erf")])
+def test_gemm_persistent_pingpong_race_screen(gpu, m, n, k, epi):
+    """Round 5: `gemm_bf16_nt_256pp_persist_kernel` (off by default: `owc_tuning_set("gemm_persist", 1)`) - one block per CU walks its
+    output tiles, the LDS-DMA ring runs on across tile boundaries (the next tile's K-tiles 0 / 1 ride in the last two K-tiles' spare
+    slots), the C tile leaves in two batches as full 128-byte lines straight from registers (lanes fr / fr ^ 8 trade 16-byte pieces),
+    counted waits that leave a batch of stores in flight.  Against the
+    one-tile-per-block ping-pong kernel (knob off), 10 launches per shape: bit-identical - same K chain per output, same epilogue
+    arithmetic; blocks with one / two / three tiles, ragged edges, the epilogue families the C ABI reaches, an output that aliases the
+    residual.  (The rotary epilogue of the vision qkv projection: tests/test_fullsize_gpu.py::test_vision_tower_bits_with_and_without_the_persistent_gemm.)"""
+    from lmms_owc_amd import _lib, ops
+
+    lib = _lib.load()
+    a = bf16_randn((m, k), 150 + (m % 97), device=gpu)
+    w = bf16_randn((n, k), 151, 0.05, device=gpu)
+    b = bf16_randn((n,), 152, device=gpu)
+    r = bf16_randn((m, n), 153, device=gpu)
+    E = {"none": _lib.EPI_NONE, "residual": _lib.EPI_RESIDUAL, "inplace": _lib.EPI_RESIDUAL, "quick_gelu": _lib.EPI_QUICK_GELU,
+         "gelu_erf": _lib.EPI_GELU_ERF}[epi]
+
+    def run():
+        if epi == "inplace":
+            out = r.clone()
+            return ops.gemm_bf16(a, w, b, epilogue=E, residual=out, out=out)
+        return ops.gemm_bf16(a, w, b, epilogue=E, residual=r if epi == "residual" else None)
+
+    try:
+        assert lib.owc_tuning_set(b"gemm_persist", 0) == 0
+        want = run()
+        assert lib.owc_tuning_set(b"gemm_persist", 1) == 0
+        for i in range(10):
+            got = run()
+            assert torch.equal(got, want), (i, (got != want).sum().item())
+    finally:
+        lib.owc_tuning_set(b"gemm_persist", -1)
+
+
 @pytest.mark.parametrize("m,n,k,epi", [(128, 37888, 3584, "swiglu"), (100, 33000, 1024, "none"), (40, 37888, 128, "swiglu"),
                                        (64, 40960, 64, "none"), (65, 20512, 3584, "swiglu")])
 def test_gemm_wide_tiles_race_screen(gpu, m, n, k, epi):

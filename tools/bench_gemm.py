@@ -85,23 +85,29 @@ def main():
         vals = [int(v) for v in vals.split(",")]
         only = next((a for a in sys.argv[1:] if not a.startswith("--")), None)
         m_over = next((int(a[4:]) for a in sys.argv[1:] if a.startswith("--m=")), 0)
+        # --bias: with a bias vector; --epi=residual|quick_gelu: that epilogue (residual: added into the output in place)
+        with_bias = "--bias" in sys.argv
+        epi_name = next((a[6:] for a in sys.argv[1:] if a.startswith("--epi=")), "none")
+        epi = {"none": ops.EPI_NONE, "quick_gelu": _lib.EPI_QUICK_GELU, "residual": _lib.EPI_RESIDUAL}[epi_name]
         for name, m, n, k in SHAPES:
             if only and not name.startswith(only):
                 continue
             m = m_over or m
             a = torch.randn(m, k, device=dev).to(torch.bfloat16)
             w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
-            out = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+            out = torch.zeros(m, n, dtype=torch.bfloat16, device=dev)
+            bias = torch.randn(n, device=dev).to(torch.bfloat16) if with_bias else None
+            kw = dict(epilogue=epi, residual=out if epi_name == "residual" else None)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             res = {}
             for rnd in range(6):
                 for v in vals:
                     assert lib.owc_tuning_set(knob.encode(), v) == 0
                     for _ in range(2):
-                        ops.gemm_bf16(a, w, out=out)
+                        ops.gemm_bf16(a, w, bias, out=out, **kw)
                     e0.record()
                     for _ in range(10):
-                        ops.gemm_bf16(a, w, out=out)
+                        ops.gemm_bf16(a, w, bias, out=out, **kw)
                     e1.record()
                     torch.cuda.synchronize()
                     if rnd:
