@@ -301,6 +301,9 @@ class PassPipeline:
         reordered = utils.Collator([reg.args for reg in requests], _collate, grouping=True)
         max_new = max([int(r.args[1].get("max_new_tokens", default_max_new)) for r in requests] + [1])
         eb = self.engine_batch(max_new)
+        beams = max([beams_from_gen_kwargs(r.args[1]) for r in requests] + [1])
+        if beams > 1:   # a beam-search pass holds num_beams hypotheses (cache slots, decode rows) per request
+            eb = max(self.batch_size, eb // beams)
         unit = eb if eb < 256 else max(64, eb // 16)
         units = list(reordered.get_batched(n=unit, batch_fn=None))
 
