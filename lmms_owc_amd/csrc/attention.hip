@@ -35,6 +35,7 @@ namespace {
 int g_attn_dbg = 0;  // timing experiment (owc_tuning_set "attn_dbg", -DOWC_TIMING_KNOBS build only): 1 = no K/V DMA in the loop
 
 int g_decode_nbuf1_min_blocks = 256;  // fused decode attention: launches with more blocks than this use one V buffer per wave (knob "decode_attn_nbuf1")
+int g_attn_gqa_pack = 1;       // causal launches with kv_group > 1: (position, head) rows of a kv group packed into the blocks (knob "attn_gqa_pack", 0 = one head per block)
 int g_attn_class_prefill = 0;  // set by owc_llm_prefill around its non-causal last-token launch (profile class only)
 
 constexpr int QB = 128;  // query rows per block
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     long k_hs, const bf16_t* __restrict__ V, long v_ts, long v_hs, bf16_t* __restrict__ O, long o_ts,
     long o_hs, const int* __restrict__ q_start, const int* __restrict__ o_start,
     const int* __restrict__ k_start, const int* __restrict__ seq_len, const int* __restrict__ q_len, int n_heads, int kv_group, int nqb,
-    int n_pairs, float scale_log2e, int dbg, int qrows) {
+    int n_pairs, float scale_log2e, int dbg, int qrows, int pack) {
   // `qrows` (<= QB, a multiple of 32): query rows per block.  128 except for causal launches, where the rows of the longest
   // sequence are spread EVENLY over its blocks (272 prompt rows: 3 x 96 instead of 128 + 128 + 16 - the block of 16 rows streamed
   // five key tiles for one wave); a row's result does not depend on the block or wave that holds it (same key tiles, same order).
@@ -89,28 +90,40 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     qb = bid % nqb;
     pair = bid / nqb;
   }
-  const int b = pair / n_heads, h = pair % n_heads;
-  const int hk = h / kv_group;
+  // `pack` (round 5; causal GQA launches: pack = kv_group = G > 1): a pair is (sequence, KV HEAD) and the block's rows are the G x Lq
+  // (position, head) pairs of the group in position-major order - packed row R = position * G + head.  The G heads of a group
+  // read the same K / V rows, so a 128-row block then holds ~18 positions x 7 heads instead of 96-128 positions of one head: it
+  // needs the key tiles of 18 positions (S = 286: 46 block-tiles per sequence and kv head instead of 70, 16 blocks instead of 21,
+  // and all four waves of a block own rows).  A row's tiles, their order and its arithmetic are unchanged: the same bits.
+  const int G = pack > 0 ? pack : 1;
+  const int b = pack > 0 ? pair / (n_heads / G) : pair / n_heads;
+  const int h0 = pack > 0 ? (pair % (n_heads / G)) * G : pair % n_heads;   // the pair's (first) head
+  const int hk = h0 / kv_group;
   const int L = seq_len[b];                  // keys
-  const int Lq = q_len ? q_len[b] : L;       // query rows (== L except for the decode mapping)
-  if (qb * qrows >= Lq) return;
-  const bool active = w * 32 < qrows && (qb * qrows + w * 32) < Lq;  // wave-uniform: waves without rows only stage tiles
+  const int Lq = q_len ? q_len[b] : L;       // query positions (== L except for the decode mapping)
+  const int nrows = G * Lq;                  // rows of the pair
+  if (qb * qrows >= nrows) return;
+  const bool active = w * 32 < qrows && (qb * qrows + w * 32) < nrows;  // wave-uniform: waves without rows only stage tiles
   const long qs = q_start[b], ks0 = k_start[b];
   const long os = o_start ? (long)o_start[b] : qs;
 
-  // causal: query row i sits at absolute position coff + i (coff = L - Lq > 0 when a shared prefix's keys
+  // causal: query position i sits at absolute position coff + i (coff = L - Lq > 0 when a shared prefix's keys
   // precede the rows handled here) and sees keys <= coff + i
   const int coff = L - Lq;
-  const int kmax = CAUSAL ? min(L, qb * qrows + qrows + coff) : L;
+  const int blk_last_pos = min(Lq - 1, (qb * qrows + qrows - 1) / G);        // last position of the block's rows
+  const int wave_first_pos = (qb * qrows + w * 32) / G, wave_last_pos = (qb * qrows + w * 32 + 31) / G;
+  const int kmax = CAUSAL ? min(L, blk_last_pos + 1 + coff) : L;
   const int ntiles = (kmax + KB - 1) / KB;
 
   // ---- Q fragments (B operand): lane = query column fr, 8 consecutive d per k-step ----
   bf16x8 qf[2][C::KS];
-  int qrow[2];
+  int qrow[2], qpos[2], qh[2];   // packed row, its position, its head
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     qrow[qt] = qb * qrows + w * 32 + qt * 16 + fr;
-    const bf16_t* qp = Q + (qs + min(qrow[qt], Lq - 1)) * q_ts + (long)h * q_hs;
+    qpos[qt] = qrow[qt] / G;
+    qh[qt] = h0 + (qrow[qt] - qpos[qt] * G);
+    const bf16_t* qp = Q + (qs + min(qpos[qt], Lq - 1)) * q_ts + (long)qh[qt] * q_hs;
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
       const int c = ks * 4 + g;
@@ -204,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     // causal: a tile whose first key lies beyond the LAST row of this wave is masked for all 32 rows - it would add exp2(-inf) = 0
     // to every sum and leave the running maximum alone, so skipping it changes no bit (the wave still stages and meets the
     // barriers).  S = 286 prompts in 128-row blocks: 29 instead of 37 wave-tiles per prompt and head.
-    if (active && (!CAUSAL || t * KB <= qb * qrows + w * 32 + 31 + coff)) {
+    if (active && (!CAUSAL || t * KB <= wave_last_pos + coff)) {
 
     // ---- S^T = K . Q^T ----
     f32x4 s[4][2];
@@ -238,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     // ---- online softmax (lane = query column; keys 16kt + 4g + r) ----
     // ragged / causal masking is needed on the last tiles only: keep it a real (wave-uniform) branch -- written
     // as selects it costs ~70 VALU per tile on every tile, and the loop is VALU-bound
-    const bool edge = (t * KB + KB > L) || (CAUSAL && (t * KB + KB - 1 > qb * qrows + w * 32 + coff));
+    const bool edge = (t * KB + KB > L) || (CAUSAL && (t * KB + KB - 1 > wave_first_pos + coff));
     if (edge) {
       asm volatile("" ::: "memory");  // keeps the compiler from if-converting the block into selects
 #pragma unroll
@@ -248,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = t * KB + kt * 16 + g * 4 + r;
-            if (key >= L || (CAUSAL && key > qrow[qt] + coff)) s[kt][qt][r] = -1e30f;
+            if (key >= L || (CAUSAL && key > qpos[qt] + coff)) s[kt][qt][r] = -1e30f;
           }
     }
     // per 16-query tile: fast path p = exp2(s c - m_ref c), one add per value for the row sum; slow path (wave-uniform branch:
@@ -369,8 +382,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / lsum;
-    if (active && qrow[qt] < Lq) {   // (a wave beyond `qrows` holds rows of the NEXT block: it must not write them)
-      bf16_t* op = O + (os + qrow[qt]) * o_ts + (long)h * o_hs + g * 4;
+    if (active && qrow[qt] < nrows) {   // (a wave beyond `qrows` holds rows of the NEXT block: it must not write them)
+      bf16_t* op = O + (os + qpos[qt]) * o_ts + (long)qh[qt] * o_hs + g * 4;
 #pragma unroll
       for (int d = 0; d < C::DT; ++d) {
         bf16x4 ov;
@@ -388,10 +401,13 @@ int launch(const void* Q, long q_ts, long q_hs, const void* K, long k_ts, long k
            const int* o_start, const int* k_start, const int* seq_len, const int* q_len, int n_seq, int n_heads,
            int kv_group, int max_len, float scale, hipStream_t st) {
   using C = Cfg<HD>;
-  const int nqb = (max_len + QB - 1) / QB;
-  // causal: even split of the longest sequence's rows over its nqb blocks, in whole 32-row wave tiles
-  const int qrows = CAUSAL ? min(QB, ((max_len + nqb - 1) / nqb + 31) / 32 * 32) : QB;
-  const int n_pairs = n_seq * n_heads;
+  // causal GQA: the heads of a kv group are packed into the rows of a block (see the kernel): a pair is (sequence, kv head)
+  const int pack = (CAUSAL && kv_group > 1 && g_attn_gqa_pack && n_heads % kv_group == 0) ? kv_group : 0;
+  const int rows = (pack ? pack : 1) * max_len;      // rows of the longest pair
+  const int nqb = (rows + QB - 1) / QB;
+  // causal: even split of the longest pair's rows over its nqb blocks, in whole 32-row wave tiles
+  const int qrows = CAUSAL ? min(QB, ((rows + nqb - 1) / nqb + 31) / 32 * 32) : QB;
+  const int n_pairs = pack ? n_seq * (n_heads / pack) : n_seq * n_heads;
   const int lds_bytes = 4 * C::TILE;
   static bool attr_set = false;
   if (!attr_set) {
@@ -408,7 +424,7 @@ int launch(const void* Q, long q_ts, long q_hs, const void* K, long k_ts, long k
   hipLaunchKernelGGL((attn_fwd_kernel<HD, CAUSAL>), dim3(n_pairs * nqb), dim3(256), lds_bytes, st,
                      (const bf16_t*)Q, q_ts, q_hs, (const bf16_t*)K, k_ts, k_hs, (const bf16_t*)V,
                      v_ts, v_hs, (bf16_t*)O, o_ts, o_hs, q_start, o_start, k_start, seq_len, q_len, n_heads,
-                     kv_group, nqb, n_pairs, scale * 1.4426950408889634f, g_attn_dbg, qrows);
+                     kv_group, nqb, n_pairs, scale * 1.4426950408889634f, g_attn_dbg, qrows, pack);
   owc_gemm_profile_end(prof, st);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
@@ -729,5 +745,6 @@ int owc_launch_attn_decode_fused(const void* qkv, long ld, const int* pos, const
 }
 
 void owc_attn_set_decode_nbuf1(int v) { g_decode_nbuf1_min_blocks = v < 0 ? 256 : v; }
+void owc_attn_set_gqa_pack(int v) { g_attn_gqa_pack = v != 0; }
 void owc_attn_class_prefill(int on) { g_attn_class_prefill = on; }
 void owc_attn_set_dbg(int v) { g_attn_dbg = OWC_TK(true) ? v : 0; }

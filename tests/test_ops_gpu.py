@@ -140,6 +140,58 @@ def test_attention_causal_gqa_cache(gpu, lens):
         assert np.abs(got[s0:s0 + L] - want).max() <= 0.02 * np.abs(want).max() + 1e-3
 
 
+@pytest.mark.parametrize("Hq,Hkv,lens,prefix", [(28, 4, [286, 1, 31, 300, 64, 129, 97], 0), (28, 4, [286] * 9, 0), (12, 2, [130, 64, 257, 5], 0),
+                                                 (16, 8, [200, 333], 0), (28, 4, [271, 40, 150], 15), (6, 6, [286, 100], 0)])
+def test_attention_causal_gqa_packing_is_bit_identical(gpu, Hq, Hkv, lens, prefix):
+    """Round 5: causal launches with kv_group > 1 pack the (position, head) rows of a kv group into the blocks - position-major, so a
+    128-row block holds ~18 positions of all 7 heads and walks the key tiles of 18 positions, not of 128.  Against the one-head-per-block
+    mapping of rounds 1-4 (knob off): the SAME BITS (a row's key tiles, their order and its arithmetic do not change), for ragged
+    lengths (1 ... 333: several blocks, partial waves), group sizes 7 / 6 / 2, a shared prefix in front of the rows (q_len < seq_len:
+    the causal offset) and G = 1 (nothing to pack); and within 2 % of the fp32 reference."""
+    from lmms_owc_amd import _lib, ops
+
+    lib = _lib.load()
+    hd, s_max = 128, 352
+    n = len(lens)
+    T = sum(lens)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    q = bf16_randn((T, Hq * hd), 11, 1.0, gpu)
+    kc = bf16_randn((n, Hkv, s_max, hd), 12, 1.0, gpu)
+    vc = bf16_randn((n, Hkv, s_max, hd), 13, 1.0, gpu)
+    k_start = np.arange(n) * Hkv * s_max
+    klen = np.asarray(lens) + prefix      # keys = the shared prefix's + the rows' own
+
+    def run():
+        out = torch.zeros((T, Hq * hd), dtype=torch.bfloat16, device=gpu)
+        ops.attention(q, Hq * hd, hd, kc, hd, s_max * hd, vc, hd, s_max * hd, out, Hq * hd, hd, i32(starts, gpu), i32(k_start, gpu),
+                      i32(klen, gpu), n_seq=n, n_heads=Hq, kv_group=Hq // Hkv, head_dim=hd, max_q_len=max(lens), causal=True,
+                      scale=hd ** -0.5, q_len=i32(lens, gpu) if prefix else None)
+        return out
+
+    try:
+        assert lib.owc_tuning_set(b"attn_gqa_pack", 0) == 0
+        want = run()
+        assert lib.owc_tuning_set(b"attn_gqa_pack", 1) == 0
+        for _ in range(3):
+            got = run()
+            assert torch.equal(got, want), (got != want).sum().item()
+    finally:
+        lib.owc_tuning_set(b"attn_gqa_pack", 1)
+    qn, kn, vn = to_np(q).reshape(T, Hq, hd), to_np(kc), to_np(vc)
+    g = to_np(got).reshape(T, Hq, hd)
+    G = Hq // Hkv
+    for b in (0, n - 1):
+        s0, L, Lk = starts[b], lens[b], klen[b]
+        kk, vv = np.repeat(kn[b, :, :Lk], G, 0), np.repeat(vn[b, :, :Lk], G, 0)
+        sc = np.einsum("qhd,hkd->hqk", qn[s0:s0 + L].astype(np.float64), kk.astype(np.float64)) * hd ** -0.5
+        mask = np.arange(Lk)[None, :] > (np.arange(L)[:, None] + prefix)
+        sc[:, mask] = -np.inf
+        pr = np.exp(sc - sc.max(-1, keepdims=True))
+        pr /= pr.sum(-1, keepdims=True)
+        ref = np.einsum("hqk,hkd->qhd", pr, vv.astype(np.float64))
+        assert np.abs(g[s0:s0 + L] - ref).max() <= 0.02 * np.abs(ref).max() + 1e-3
+
+
 def test_attention_decode_mapping(gpu):
     """q_len = G query heads per kv group mapped onto kernel rows (what owc_llm_decode_step does)."""
     from lmms_owc_amd import ops
