@@ -723,6 +723,9 @@ class Qwen2VLEngine:
         B, k = len(prompts), int(num_beams)
         if k < 2:
             raise ValueError("generate_beam is for num_beams >= 2 (one beam is `generate`)")
+        if B == 0:
+            out = torch.empty((0, max_new_tokens), dtype=I32, device=self.device)
+            return (out, np.zeros(0, np.float32)) if return_scores else out
         R = B * k                                   # (decode steps are launched directly: the rows' slots change between steps)
         lens = np.array([len(p) for p in prompts], dtype=np.int64)
         Hkv, G = d.n_kv_heads, d.n_q_heads // d.n_kv_heads
