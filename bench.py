@@ -1322,7 +1322,7 @@ def attention_rooflines(prof: dict, d, B: int, T: int, steps: int, dt: float) ->
                      "share_of_step_time": p["ms"] * 1e-3 / time_or(dt)}
     p = prof["attn_decode"]
     gbs = dec_bytes / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else 0.0
-    out["decode"] = {"bound": "hbm", "kernel": "attn_fwd_kernel<128,false> (decode mapping: rows = the G q heads of a kv group)",
+    out["decode"] = {"bound": "hbm", "kernel": "attn_decode_fused_kernel<1|2> (rope + KV-cache write + attention of a decode step; a block = one (sequence, kv head), its 4 waves split the keys)",
                      "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
                      "algorithmic_bytes": "K + V rows of the sequence's cache, once per kv head per step: 2 * n_kv_heads * 128 * 2 B per token per layer",
                      "launches": p["launches"], "kernel_ms_total": p["ms"], "share_of_step_time": p["ms"] * 1e-3 / time_or(dt)}
