@@ -1266,20 +1266,39 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256x128pp_kernel(
     ktile(M0_{}, S1_{}, u + 1);
     ktile(M0_{}, S2_{}, u + 2);
   }
-  const int left = nk - u;   // 2, 3 or 4
-  if (left == 4) {
-    ktile(M0_{}, S0_{}, u);
-    ktile(M0_{}, S1_{}, u + 1);
-    ktile(M1_{}, S2_{}, u + 2);
-    ktile(M2_{}, S0_{}, u + 3);
-  } else if (left == 3) {
-    ktile(M0_{}, S0_{}, u);
-    ktile(M1_{}, S1_{}, u + 1);
-    ktile(M2_{}, S2_{}, u + 2);
-  } else {
-    ktile(M1_{}, S0_{}, u);
-    ktile(M2_{}, S1_{}, u + 1);
-  }
+  // The 2-4 last K-tiles run through ONE more copy of the K-tile whose ring slot and mode are run-time (block-uniform) values:
+  // scalar branches around an issue or a wait, the slot offset a scalar add.  (Round 5 first peeled them as three if / else chains of
+  // compile-time copies: the register allocator then moved the accumulators between the copies - MFMAs with vDst != srcC, 4-36
+  // spilled registers per instantiation, each reload a full vmcnt drain in front of the epilogue.)
+  auto ktile_rt = [&](int kt, int sl, int rem) {   // rem: K-tiles after this one (>= 2: the steady state)
+    const int sl1 = sl == 2 ? 0 : sl + 1, sl2 = sl == 0 ? 2 : sl - 1;
+    const char* cur = lds + sl * P128_STAGE;
+    // L0
+    read_a(cur);
+    if (rem >= 2) {
+      issue_w(kt + 2, sl2);
+      issue_a(kt + 2, sl2, 0);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (rem == 1) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    OWC_PP_SYNC_L(-1);
+    half(wx, 0);
+    // L1
+    read_w(wy, cur, 1);
+    if (rem >= 1) read_w(wx, lds + sl1 * P128_STAGE, 0);
+    if (rem >= 2) {
+      issue_a(kt + 2, sl2, 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (rem == 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    OWC_PP_SYNC_L(-1);
+    half(wy, 1);
+  };
+  const int left = nk - u;   // 2, 3 or 4 (u % 3 == 0: the tail starts in slot 0)
+#pragma unroll 1
+  for (int j = 0; j < left; ++j) ktile_rt(u + j, j >= 3 ? 0 : j, left - 1 - j);
   if (!grp) {  // group 0 waits for group 1's last MFMA section: every wave has executed the same number of barriers
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
