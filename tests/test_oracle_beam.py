@@ -23,12 +23,12 @@ def tiny_lm():
     return m
 
 
-def _hf_beams(m, prompt, k, T, eos, pad):
+def _hf_beams(m, prompt, k, T, eos, pad, **kw):
     import torch
 
     with torch.no_grad():
         out = m.generate(input_ids=torch.tensor([prompt]), attention_mask=torch.ones(1, len(prompt), dtype=torch.long), num_beams=k,
-                         do_sample=False, max_new_tokens=T, eos_token_id=eos, pad_token_id=pad, use_cache=True)
+                         do_sample=False, max_new_tokens=T, eos_token_id=eos, pad_token_id=pad, use_cache=True, **kw)
     new = out[0, len(prompt):].tolist()
     return np.array(new + [pad] * (T - len(new)))
 
@@ -96,3 +96,42 @@ def test_product_bookkeeping_equals_the_oracle_on_a_batch():
             assert np.array_equal(toks[s], want[s][0]), (k, eos, s, toks[s], want[s][0])
             assert abs(scores[s] - want[s][1]) < 1e-4
         assert steps <= T
+
+
+@pytest.mark.parametrize("k,T,lp,es", [(3, 8, 0.5, False), (3, 8, 2.0, False), (4, 9, 1.0, True), (2, 7, 1.5, True), (3, 8, 1.0, "never")])
+def test_length_penalty_and_early_stopping_match_hf(tiny_lm, k, T, lp, es):
+    """`generate_beam` exposes HF's `length_penalty` and `early_stopping` (the reference leaves both at HF's defaults): the oracle and
+    the product's `BeamSearcher` follow HF for other values as well - finished hypotheses scored by length ** penalty, the search ended
+    as soon as num_beams hypotheses are finished (True), by the attainable-score heuristic (False) or its optimistic form ("never")."""
+    import torch
+
+    from lmms_owc_amd.engine.beam import BeamSearcher
+
+    m = tiny_lm
+    r = np.random.default_rng(7 * k + T)
+    pad = 0
+    for trial in range(3):
+        prompt = r.integers(1, 97, 6 + trial).tolist()
+
+        def logits_fn(conts):
+            with torch.no_grad():
+                return m(input_ids=torch.tensor([prompt + c for c in conts])).logits[:, -1, :].float().numpy()
+
+        free, _ = BM.beam_search(logits_fn, len(prompt), k, T, -1, pad)
+        vals, counts = np.unique(free, return_counts=True)
+        eos = int(vals[np.argsort(-counts, kind="stable")][0])
+        want = _hf_beams(m, prompt, k, T, eos, pad, length_penalty=lp, early_stopping=es)
+        got, score = BM.beam_search(logits_fn, len(prompt), k, T, eos, pad, length_penalty=lp, early_stopping=es)
+        assert np.array_equal(got, want), (k, T, lp, es, trial, got, want)
+        # the product's bookkeeping, fed with the same logits the way the device feeds it
+        bs = BeamSearcher(1, k, T, eos, pad, lp, es)
+        seqs, more = [[] for _ in range(k)], True
+        while more:
+            lg = logits_fn(seqs)[None]                                                        # [1, k, V]
+            order = np.lexsort((np.broadcast_to(np.arange(lg.shape[-1]), lg.shape), -lg.astype(np.float64)), axis=-1)[..., : 2 * k]
+            mx = lg.max(-1)
+            logz = mx + np.log(np.exp(lg - mx[..., None]).sum(-1, dtype=np.float32))
+            parent, token, more = bs.step(logz, np.take_along_axis(lg, order, -1), order.astype(np.int32))
+            seqs = [seqs[parent[0, j]] + [int(token[0, j])] for j in range(k)]
+        toks, scores = bs.result()
+        assert np.array_equal(toks[0], want) and abs(scores[0] - score) < 1e-4
