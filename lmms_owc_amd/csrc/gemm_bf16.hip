@@ -1988,3 +1988,4 @@ void owc_gemm_set_ring_128(int v) { g_ring_128 = v < 0 ? 1 : v != 0; }
 void owc_gemm_set_pp128(int v) { g_pp128_min_tiles = v < 0 ? 128 : v; }
 void owc_gemm_set_persist(int v) { g_persist = v < 0 ? 0 : v; }
 void owc_gemm_set_nt_min_mb(int v) { g_nt_min_mb = v < 0 ? 64 : v; }
+int owc_gemm_nt_min_mb() { return g_nt_min_mb; }   // (the fp8 kernels use the same threshold)

@@ -295,7 +295,7 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_fp8_nt_256pp_kernel(
     const uint8_t* __restrict__ A, long lda, const float* __restrict__ SA, const uint8_t* __restrict__ W, long ldw,
     const float* __restrict__ SW, const bf16_t* __restrict__ bias, const bf16_t* R, long ldr, void* Cv, long ldc,
-    int M, int N, int K, int tiles_m, int tiles_n, owc_gemm_aux aux) {
+    int M, int N, int K, int tiles_m, int tiles_n, owc_gemm_aux aux, int nt_store) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -479,8 +479,12 @@ __global__ __launch_bounds__(512) void gemm_fp8_nt_256pp_kernel(
   gemm_epilogue<EPI, 8>(acc, m0 + wr * 128, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux, lds, CCOLS * 2, wr * 128,
                         wc * 64);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  store_ctile<8>(lds, BT, CCOLS, (bf16_t*)Cv, ldc, m0, EPI == OWC_EPI_SWIGLU ? (n0 >> 1) : n0, M,
-                 EPI == OWC_EPI_SWIGLU ? (N >> 1) : N, w, l);
+  if (nt_store)   // streaming (non-temporal) C stores for outputs far larger than the caches (as in the bf16 kernel: `gemm_nt_min_mb`)
+    store_ctile<8, true>(lds, BT, CCOLS, (bf16_t*)Cv, ldc, m0, EPI == OWC_EPI_SWIGLU ? (n0 >> 1) : n0, M,
+                         EPI == OWC_EPI_SWIGLU ? (N >> 1) : N, w, l);
+  else
+    store_ctile<8>(lds, BT, CCOLS, (bf16_t*)Cv, ldc, m0, EPI == OWC_EPI_SWIGLU ? (n0 >> 1) : n0, M,
+                   EPI == OWC_EPI_SWIGLU ? (N >> 1) : N, w, l);
 }
 
 
@@ -788,7 +792,8 @@ int launch_fp8(const void* A, long lda, const float* sa, const void* W, long ldw
   if (g_fp8_pingpong && K >= 2 * BKB && (K % (2 * BKB)) == 0)
     hipLaunchKernelGGL(gemm_fp8_nt_256pp_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), LDS_BYTES, s,
                        (const uint8_t*)A, lda, sa, (const uint8_t*)W, ldw, sw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C,
-                       ldc, M, N, K, tiles_m, tiles_n, aux);
+                       ldc, M, N, K, tiles_m, tiles_n, aux,
+                       (size_t)M * (size_t)(EPI == OWC_EPI_SWIGLU ? N / 2 : N) * 2 > ((size_t)owc_gemm_nt_min_mb() << 20) ? 1 : 0);
   else
     hipLaunchKernelGGL(gemm_fp8_nt_256_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), LDS_BYTES, s,
                        (const uint8_t*)A, lda, sa, (const uint8_t*)W, ldw, sw, (const bf16_t*)bias, (const bf16_t*)R, ldr, C,
