@@ -771,7 +771,7 @@ def main() -> None:
                          "4096 patches - the SUN397 / Stanford-Cars regime); 0 skips it")
     ap.add_argument("--no-big-legs", action="store_true",
                     help="skip the Qwen2-VL-72B fp8 (256 images) and LLaVA-NeXT-34B (16 images) legs that run after the CPU baseline on one GPU")
-    ap.add_argument("--big-leg-budget-s", type=float, default=540.0,
+    ap.add_argument("--big-leg-budget-s", type=float, default=600.0,
                     help="seconds since process start after which a big-model leg is not started any more")
     ap.add_argument("--no-calibration", action="store_true", help="skip the box calibration GEMM bursts around the timed region")
     ap.add_argument("--nominal-forward", action="store_true",
