@@ -37,6 +37,32 @@ import torch  # noqa: E402
 
 S_TEXT_BEFORE, S_IMG, S_TEXT_AFTER = 14, 256, 16  # 286-token prompt of the 448x448 classification query
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md (never the 2:1-sparsity figure)
+# CPU affinity of the process as the launcher gave it to us, before anything pins a thread (lmms_owc_amd.models._base.pin_to_gpu_numa_node)
+FULL_AFFINITY = frozenset(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else frozenset()
+
+
+def restore_full_affinity() -> dict:
+    """Before a CPU-baseline leg: EVERY thread of this process (/proc/self/task) must be allowed on every core the process started with.
+    A thread created while the launch thread was pinned to its GPU's NUMA share keeps that mask for good (round 5's CPU baseline ran
+    its 128 intra-op threads on one socket's share: 0.034 -> 0.020-0.031 images/s across records).  Threads found narrower are reset and
+    COUNTED in the record - `narrow_threads_found` must read 0 when the plug-in's own `release_host_resources` did its job."""
+    if not FULL_AFFINITY:
+        return {"checked": 0}
+    found, tids = 0, []
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        tids = [0]
+    for tid in tids:
+        try:
+            if frozenset(os.sched_getaffinity(tid)) != FULL_AFFINITY:
+                found += 1
+                os.sched_setaffinity(tid, FULL_AFFINITY)
+        except OSError:
+            pass
+    return {"checked": len(tids), "narrow_threads_found": found, "cpus_allowed": len(os.sched_getaffinity(0))}
+
+
 FULLSIZE_LOGIT_BOUND = 0.03   # max |HIP - HF| / max |HF| per teacher-forced step of the full 7B model (observed 1.7-2.1 %)
 TRAFFIC_KERNEL = "gemm_bf16_nt_256pp_kernel"   # what the default dispatch launches for the 7B gate/up prefill group
 RENDEZVOUS_FAILED = 75   # exit code of a rank whose init_process_group failed (EX_TEMPFAIL): self_launch retries on a new port
@@ -84,6 +110,7 @@ def cpu_baseline_lmm(dims, device, seed: int, new_tokens: int, pix_dev, hip_toke
     from lmms_owc_amd.engine.qwen2vl import hf_param_names, random_param
 
     d = dims
+    affinity = restore_full_affinity()
     threads = min(os.cpu_count() or 1, 128)
     torch.set_num_threads(threads)
     cfg = Qwen2VLConfig(
@@ -162,7 +189,7 @@ def cpu_baseline_lmm(dims, device, seed: int, new_tokens: int, pix_dev, hip_toke
     best = float(np.mean(times[1:])) if len(times) > 1 else float(times[0])
     import transformers
 
-    return {"value": 1.0 / best, "unit": "images/s", "cores": threads, "kind": "reference",
+    return {"value": 1.0 / best, "unit": "images/s", "cores": threads, "kind": "reference", "thread_affinity": affinity,
             "sample": f"{n_images} image(s) 448x448 = the HIP run's first images (same pixel_values, prompt ids and seeded weights), batch 1, "
                       f"bf16, transformers {transformers.__version__} Qwen2VLForConditionalGeneration.generate on CPU (greedy, {new_tokens} "
                       f"new tokens); mean of images after the first; per-image s = {[round(t, 2) for t in times]}",
@@ -369,14 +396,27 @@ class BoxCalibration:
     def __init__(self, device, seconds: float = 2.0):
         from lmms_owc_amd import ops as owc_ops
 
-        self.ops, self.seconds = owc_ops, seconds
-        g = torch.Generator(device=device).manual_seed(4242)
-        self.a = torch.randn((self.M, self.K), generator=g, device=device, dtype=torch.bfloat16)
-        self.w = torch.randn((self.N, self.K), generator=g, device=device, dtype=torch.bfloat16) * (self.K ** -0.5)
-        self.c = torch.empty((self.M, self.N // 2), device=device, dtype=torch.bfloat16)
+        self.ops, self.seconds, self.device = owc_ops, seconds, device
+        self.a = self.w = self.c = None
         self.runs = []
 
     def run(self) -> float:
+        """One burst.  The 3.2 GB of operands live only for the burst (nothing of the calibration stays resident
+        through the timed region; rounds 1-4 had no calibration at all, so the line's `box_calibration.ran` says whether a record's
+        timed steps were preceded by one)."""
+        from lmms_owc_amd import ops as owc_ops
+
+        g = torch.Generator(device=self.device).manual_seed(4242)
+        self.a = torch.randn((self.M, self.K), generator=g, device=self.device, dtype=torch.bfloat16)
+        self.w = torch.randn((self.N, self.K), generator=g, device=self.device, dtype=torch.bfloat16) * (self.K ** -0.5)
+        self.c = torch.empty((self.M, self.N // 2), device=self.device, dtype=torch.bfloat16)
+        try:
+            return self._burst_pair()
+        finally:
+            self.a = self.w = self.c = None     # back to torch's caching allocator (NOT emptied: that would also drop the blocks the warm-up
+                                                # steps left for the timed steps)
+
+    def _burst_pair(self) -> float:
         from lmms_owc_amd import ops as owc_ops
 
         flop = 2.0 * self.M * self.N * self.K
@@ -399,7 +439,8 @@ class BoxCalibration:
     def report(self, images_per_s_per_gpu: float) -> dict:
         tf = [r["tflops"] for r in self.runs]
         mean = float(np.mean(tf)) if tf else 0.0
-        return {"kernel": f"7B gate/up projection + SwiGLU epilogue, M = {self.M}, N = {self.N}, K = {self.K}, random operands, back to back",
+        return {"ran": bool(tf), "operands_resident_during_timed_region": False,
+                "kernel": f"7B gate/up projection + SwiGLU epilogue, M = {self.M}, N = {self.N}, K = {self.K}, random operands, back to back",
                 "tflops_before_timed_region": tf[0] if tf else None, "tflops_after_timed_region": tf[1] if len(tf) > 1 else None,
                 "tflops": mean, "frac_of_peak": mean / PEAK_BF16_TFLOPS, "runs": self.runs,
                 "value_per_calibration_tflops": images_per_s_per_gpu / mean if mean > 0 else None,
@@ -773,12 +814,16 @@ def main() -> None:
                     help="skip the Qwen2-VL-72B fp8 (256 images) and LLaVA-NeXT-34B (16 images) legs that run after the CPU baseline on one GPU")
     ap.add_argument("--big-leg-budget-s", type=float, default=600.0,
                     help="seconds since process start after which a big-model leg is not started any more")
+    ap.add_argument("--total-budget-s", type=float, default=840.0,
+                    help="seconds since process start after which a still-running big-model leg is abandoned: the line is printed "
+                         "with that leg marked skipped and the process exits 0")
     ap.add_argument("--no-calibration", action="store_true", help="skip the box calibration GEMM bursts around the timed region")
     ap.add_argument("--nominal-forward", action="store_true",
                     help="run the model's nominal forward: full last prefill layer on every row and no shared-prefix segment "
                          "(same tokens bit for bit; shows what the two dead-work eliminations are worth)")
-    ap.add_argument("--cpu-images", type=int, default=2,
-                    help="images of the CPU baseline (HF generate on the host cores, ~25-40 s each for 7B); the first is the warm-up, `value` = mean of the rest")
+    ap.add_argument("--cpu-images", type=int, default=4,
+                    help="images of the CPU baseline (HF generate on the host cores, ~25-40 s each for 7B; SURVEY.md section 8d: 4 for 7B); "
+                         "the first is the warm-up, `value` = mean of the rest")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
                     help="owc_tuning_set(KNOB, VALUE) before anything runs (A-B experiments; recorded in config.tuning)")
     ap.add_argument("--dry-run", action="store_true", help="launcher + rendezvous check on CPU (gloo); stops before HIP init")
@@ -927,7 +972,6 @@ def main() -> None:
     if calib is not None:
         calib.run()
         sync()
-        calib.a = calib.w = calib.c = None     # 3.2 GB back to the allocator
     lap("warmup_and_timed_steps")
     fp8_run = args.decoder_dtype == "fp8"
     assert out.shape == (B, T)
@@ -1170,6 +1214,68 @@ def main() -> None:
         # ---- BASELINE.json configs[3] / configs[4]'s LMM side on this GPU (never `value`): the headline model's weights, inputs and
         # caches go back to the driver first (73 GB of fp8 + bf16 weights, then 69.5 GB of bf16 weights)
         big = {"config5_qwen2vl_72b_fp8": None, "config4_llava_next_34b": None}
+
+        # The line is owed from here on, whatever the big-model legs do (a hang, a driver time-out or a fault in a leg
+        # that runs AFTER the measurement must not lose the measurement): `emit` assembles and prints it exactly once - from the normal
+        # path below, from a SIGTERM / SIGINT handler, or from a watchdog thread once the process is `--total-budget-s` old (then the
+        # process exits 0 with the unfinished leg marked as skipped).
+        import signal
+        import threading
+
+        emit_lock, emitted = threading.Lock(), [False]
+
+        def emit(why: str | None = None) -> None:
+            with emit_lock:
+                if emitted[0]:
+                    return
+                emitted[0] = True
+                if why:
+                    for name in big:
+                        if big[name] is None:
+                            big[name] = {"skipped": why}
+                finish_line()
+
+        def finish_line() -> None:
+            # ---- the line ends with what round 5 added (the driver's record keeps the END of the line)
+            result["images_per_s_from_host_uint8"] = result.pop("images_per_s_from_host_uint8")
+            result["images_per_s_from_pil"] = result.pop("images_per_s_from_pil")
+            result.update(big)
+            result["real_image_sizes"] = ragged
+            result["max_pixels_images"] = cap_leg
+            if calib is not None and calib.runs:
+                result["box_calibration"] = cal
+            cfgd = result["config"]
+            for k, leg in (("config3_mix", ragged), ("max_pixels", cap_leg)):
+                if leg and "images_per_s" in leg:
+                    cfgd[k + "_images_per_s"], cfgd[k + "_mfma_frac_end_to_end"] = leg["images_per_s"], leg.get("mfma_frac_end_to_end")
+                    if leg.get("roofline_attention_vision"):
+                        cfgd[k + "_vision_attn_tflops"] = leg["roofline_attention_vision"]["achieved"]
+                        cfgd[k + "_vision_attn_share"] = leg["roofline_attention_vision"]["share_of_leg_time"]
+            cfgd["qwen2vl_72b_fp8_images_per_s"] = (big["config5_qwen2vl_72b_fp8"] or {}).get("images_per_s")
+            cfgd["llava_next_34b_images_per_s"] = (big["config4_llava_next_34b"] or {}).get("value")
+            leg_seconds["total_since_process_start"] = round(time.perf_counter() - T_PROCESS_START, 1)
+            result["leg_seconds"] = leg_seconds
+            print(json.dumps(result), flush=True)
+
+        def on_signal(signum, _frame):
+            emit(f"signal {signum} during the big-model legs: the line was printed from the handler")
+            os._exit(0)
+
+        def watchdog():
+            while not emitted[0]:
+                if time.perf_counter() - T_PROCESS_START > args.total_budget_s:
+                    emit(f"--total-budget-s {args.total_budget_s:.0f} s reached inside this leg: the line was printed by the watchdog")
+                    os._exit(0)
+                time.sleep(1.0)
+
+        old_handlers = {}
+        if world == 1 and not args.no_big_legs and not args.no_extra_legs:
+            for sg in (signal.SIGTERM, signal.SIGINT):
+                try:
+                    old_handlers[sg] = signal.signal(sg, on_signal)
+                except (ValueError, OSError):
+                    pass
+            threading.Thread(target=watchdog, daemon=True, name="owc-bench-line-watchdog").start()
         if world == 1 and not args.no_big_legs and not args.no_extra_legs:
             engine = weights = pix = scorer = cls_z = emb0 = None
             import gc
@@ -1182,32 +1288,18 @@ def main() -> None:
                 gc.collect()
                 torch.cuda.empty_cache()
                 try:
-                    big[name] = fn()
-                except Exception as e:   # an extra leg must never sink the measurement
-                    big[name] = {"skipped": f"{type(e).__name__}: {str(e)[:200]}"}
+                    got = fn()
+                except BaseException as e:   # an extra leg must never sink the measurement (KeyboardInterrupt / SystemExit included)
+                    got = {"skipped": f"{type(e).__name__}: {str(e)[:200]}"}
+                with emit_lock:
+                    if not emitted[0]:
+                        big[name] = got
                 lap(name)
             gc.collect()
             torch.cuda.empty_cache()
-        # ---- the line ends with what round 5 added (the driver's record keeps the END of the line)
-        result["images_per_s_from_host_uint8"] = result.pop("images_per_s_from_host_uint8")
-        result["images_per_s_from_pil"] = result.pop("images_per_s_from_pil")
-        result.update(big)
-        result["real_image_sizes"] = ragged
-        result["max_pixels_images"] = cap_leg
-        if calib is not None and calib.runs:
-            result["box_calibration"] = cal
-        cfgd = result["config"]
-        for k, leg in (("config3_mix", ragged), ("max_pixels", cap_leg)):
-            if leg and "images_per_s" in leg:
-                cfgd[k + "_images_per_s"], cfgd[k + "_mfma_frac_end_to_end"] = leg["images_per_s"], leg.get("mfma_frac_end_to_end")
-                if leg.get("roofline_attention_vision"):
-                    cfgd[k + "_vision_attn_tflops"] = leg["roofline_attention_vision"]["achieved"]
-                    cfgd[k + "_vision_attn_share"] = leg["roofline_attention_vision"]["share_of_leg_time"]
-        cfgd["qwen2vl_72b_fp8_images_per_s"] = (big["config5_qwen2vl_72b_fp8"] or {}).get("images_per_s")
-        cfgd["llava_next_34b_images_per_s"] = (big["config4_llava_next_34b"] or {}).get("value")
-        leg_seconds["total_since_process_start"] = round(time.perf_counter() - T_PROCESS_START, 1)
-        result["leg_seconds"] = leg_seconds
-        print(json.dumps(result), flush=True)
+        emit()
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -1364,7 +1456,7 @@ def decode_regime_leg(engine, dims, batches=(1, 32, 128), s_prompt: int = 286, t
             "batch": head["batch"], "ms_per_step": head["ms_per_step"], "by_batch": rows,
             "weight_bytes_per_step": wbytes,
             "regime": "the REFERENCE's batch size (1) and mid batches: the HBM-bound side of the decode loop.  The product does not run "
-                      "here - `engine_batch=auto` decodes a whole pass together (2048 rows, MFMA-bound: 30.8 ms per step) and reaches "
+                      "here - `engine_batch=auto` decodes a whole pass together (2048 rows, MFMA-bound; its measured step time is this record's `by_batch` entry of the largest batch when `--decode-batches` includes it, and profiles/*decode* otherwise) and reaches "
                       "these row counts only in the tail of a pass - so `achieved` says how good the weight stream is, not how the "
                       "headline is made",
             "method": f"(t({t_long} new tokens) - t({t_short} new tokens)) / {t_long - t_short} on text-only prompts of {s_prompt} tokens, 3 repeats each, "

@@ -72,7 +72,9 @@ const char* owc_last_error(const owc_ctx* ctx);
  * kernel for launches of at most 128 rows x tens of thousands of columns), "gemm_ring_128" (0: no 128x64 tiles of that kernel - bf16
  * and fp8 - for a few hundred rows x a few thousand columns, where 64x64 tiles need more than a round and a half of the chip),
  * "gemm_pp128" (the 256x128-tile ping-pong kernel for launches with too few 256x256 tiles to fill the chip - the o / down projections
- * of a decode step at 1024-2048 rows: 0 off, n > 0: from n tiles of 256x128, negative: the default).
+ * of a decode step at 1024-2048 rows: 0 off, n > 0: from n tiles of 256x128, negative: the default), "gemm_walk" (block id -> output
+ * tile of the 256x256 ping-pong kernels: 0 the rows-of-4 walk of rounds 1-5, 1 / negative (default) column groups of <= 8 tile columns
+ * walked down all tile rows when the output has at least as many tile rows as tile columns).
  * Every knob above selects between kernels that return the SAME results.  The timing-only experiment knobs "gemm_dbg" /
  * "attn_dbg" (parts of a kernel switched off to price them; outputs are garbage) exist only in libowc_hip_timing.so, which
  * `python -m lmms_owc_amd.build --timing` builds with -DOWC_TIMING_KNOBS for tools/; the product library does not know them.
@@ -207,8 +209,11 @@ int owc_embed_tokens(owc_ctx* ctx, const int32_t* ids, const int32_t* img_index,
  *   offset, 0, 0);
  *   stream_id (optional, int32 per ORIGINAL batch row; NULL: the row index): a sequence's draws depend on (seed, its stream id,
  *   step) only - not on the batch it runs in, not on row compaction, not on the rank count when the caller passes document ids.
- *   Weights are exact integers floor(2^40 exp((l - max) / T)); the kept set is cut by logit VALUE, so where HF's sort would split
- *   a run of equal bf16 logits at the top-k / top-p cut, all of them stay eligible (a superset by ties only). */
+ *   Weights are exact integers floor(2^40 exp((l - max) / T)).  Ties at a cut: top-k keeps every token whose value equals the k-th
+ *   largest (exactly HF's TopKLogitsWarper, which removes `scores < k-th value`); where the top-p cut falls inside a run of equal
+ *   bf16 logits, HF keeps a prefix of the run in its unspecified sort order - this library keeps the same NUMBER of them and takes
+ *   the lowest token ids.  Hence top_k = 1 with a top_p < 1 (Qwen2-VL's generation_config.json: top_k 1, top_p 0.001) leaves exactly
+ *   one token, the lowest id among the maxima: the draw equals owc_argmax_bf16 bit for bit, ties included. */
 typedef struct owc_sampling {
   float temperature; /* > 0 */
   int32_t top_k;

@@ -345,9 +345,13 @@ __global__ __launch_bounds__(ARGMAX_T) void argmax_kernel(const bf16_t* __restri
 //   * weight of token i: q_i = floor(2^40 * exp2((l_i - max) * log2(e) / T)), a 64-bit integer (sum over 152 k tokens < 2^58);
 //   * the kept set is cut by VALUE: bf16 logits have 65 536 possible values, an order-preserving 16-bit key is histogrammed by its
 //     high byte (counts + integer mass, LDS atomics on integers are order-independent), then by its low byte inside the bin that
-//     holds the cut: top-k keeps every token whose value is >= the k-th largest value, top-p (on the top-k survivors, as HF applies
-//     it) every token whose value is >= the value at which the descending cumulative mass reaches top_p.  Where HF's sort would
-//     split a run of EQUAL logits at the cut, all of them are kept (a superset by ties only; stated in include/owc.h);
+//     holds the cut: top-k keeps every token whose value is >= the k-th largest value (HF's TopKLogitsWarper removes `scores <
+//     k-th value`: a run of equal logits at the cut stays WHOLE there too), top-p (on the top-k survivors, as HF applies it) the
+//     tokens in front of which the descending cumulative mass is still below top_p.  Where that cut falls inside a run of EQUAL
+//     logits HF keeps a prefix of the run in its (unspecified) sort order; this kernel keeps the same NUMBER of them -
+//     ceil((top_p Z - mass above the run) / weight) - and takes the LOWEST token ids (round 6: before, the whole run stayed).  So
+//     with Qwen2-VL's generation_config (top_k 1, top_p 0.001) exactly one token survives, the lowest id among the maxima: the
+//     greedy argmax, bit for bit, ties included;
 //   * the draw: Philox4x32-10 keyed by the 64-bit seed, counter (stream id, step, 0, 0) -> r in [0, 2^64);
 //     target = floor(r * Z_kept / 2^64); the token is the first one, in INDEX order, whose running kept mass exceeds target.
 // ------------------------------------------------------------------------------------------------------------------------
@@ -386,6 +390,7 @@ __global__ __launch_bounds__(SAMPLE_T) void sample_kernel(const bf16_t* __restri
   __shared__ unsigned long long part[SAMPLE_T];
   __shared__ unsigned long long sh_u64[2];
   __shared__ int sh_i[4];
+  __shared__ int part_c[SAMPLE_T];
   const int row = blockIdx.x, tid = threadIdx.x;
   const bf16_t* x = logits + (long)row * ld;
   if (step_state) step = step_state[0];
@@ -453,6 +458,7 @@ __global__ __launch_bounds__(SAMPLE_T) void sample_kernel(const bf16_t* __restri
   }
   __syncthreads();
   unsigned long long Z = sh_u64[0];
+  int n_keep_cut = -1;   // how many of the tokens whose value IS the cut value stay (lowest ids first); -1: all of them
   if (top_p > 0.f && top_p < 1.f) {
     const unsigned long long need = (unsigned long long)((double)Z * (double)top_p);
     if (tid == 0) {
@@ -472,10 +478,21 @@ __global__ __launch_bounds__(SAMPLE_T) void sample_kernel(const bf16_t* __restri
       for (; b > 0 && c + mass[b] < need; --b) c += mass[b];
       const uint32_t kp = (hb << 8) | (uint32_t)b;
       sh_i[2] = (int)(kp > key_cut ? kp : key_cut);
-      sh_u64[0] = c + mass[b];   // kept mass (bins above + the cut value's own)
+      // inside the run of tokens that share the cut value (equal weight q each): token j of the run (j = 0, 1, ...) has c + j q in
+      // front of it and stays while that is < need - HF's `cumulative_probs <= 1 - top_p` removal read from the top
+      const unsigned long long q = cnt[b] ? mass[b] / cnt[b] : 0;
+      unsigned long long nk = cnt[b];
+      if (kp >= key_cut && q > 0 && need > c) {
+        const unsigned long long want = (need - c + q - 1) / q;
+        if (want < nk) nk = want;
+      }
+      if (nk < 1) nk = 1;
+      sh_i[3] = nk < cnt[b] ? (int)nk : -1;
+      sh_u64[0] = c + (nk < cnt[b] ? nk * q : mass[b]);   // kept mass (bins above + the kept part of the cut value's run)
     }
     __syncthreads();
     key_cut = (uint32_t)sh_i[2];
+    n_keep_cut = sh_i[3];
     Z = sh_u64[0];
     __syncthreads();
   }
@@ -489,10 +506,31 @@ __global__ __launch_bounds__(SAMPLE_T) void sample_kernel(const bf16_t* __restri
   // ---- first token, in index order, whose running kept mass exceeds target: contiguous chunk per thread, block scan, rescan
   const int chunk = (V + SAMPLE_T - 1) / SAMPLE_T;
   const int i0 = tid * chunk, i1 = min(V, i0 + chunk);
+  int rank0 = 0;   // tokens of the cut value's run in front of this thread's chunk (only when the run is cut: n_keep_cut >= 0)
+  if (n_keep_cut >= 0) {
+    int c = 0;
+    for (int i = i0; i < i1; ++i) c += sample_key(x[i]) == key_cut;
+    part_c[tid] = c;
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int t = 0; t < SAMPLE_T; ++t) {
+        const int c_t = part_c[t];
+        part_c[t] = run;
+        run += c_t;
+      }
+    }
+    __syncthreads();
+    rank0 = part_c[tid];
+  }
   unsigned long long mine = 0;
-  for (int i = i0; i < i1; ++i) {
-    const bf16_t v = x[i];
-    if (sample_key(v) >= key_cut) mine += weight(v);
+  {
+    int rank = rank0;
+    for (int i = i0; i < i1; ++i) {
+      const bf16_t v = x[i];
+      const uint32_t k = sample_key(v);
+      if (k > key_cut || (k == key_cut && (n_keep_cut < 0 || rank++ < n_keep_cut))) mine += weight(v);
+    }
   }
   part[tid] = mine;
   __syncthreads();
@@ -506,10 +544,11 @@ __global__ __launch_bounds__(SAMPLE_T) void sample_kernel(const bf16_t* __restri
   __syncthreads();
   if (tid == sh_i[0]) {
     unsigned long long c = sh_u64[1];
-    int pick = -1, last_kept = -1;
+    int pick = -1, last_kept = -1, rank = rank0;
     for (int i = i0; i < i1; ++i) {
       const bf16_t v = x[i];
-      if (sample_key(v) < key_cut) continue;
+      const uint32_t k = sample_key(v);
+      if (k < key_cut || (k == key_cut && n_keep_cut >= 0 && rank++ >= n_keep_cut)) continue;
       last_kept = i;
       c += weight(v);
       if (c > target) {

@@ -69,10 +69,61 @@ int g_nt_min_mb = 64;     // outputs larger than this many MiB leave the 256x256
                           // interleaved pairs: profiles/r05_gemm_persistent_*.txt)
 int g_pp128_min_tiles = 128;  // the 256x128 ping-pong kernel runs from this many of its tiles, up to 256 = one round (knob "gemm_pp128"; 0 off)
 int g_big_min_m = 129;   // M at and above which the 256x256 kernels may run (knob "gemm_big_min_m"; round 1: 1024)
+int g_walk = 1;          // tile order of the 256x256 ping-pong kernels (knob "gemm_walk"): 0 = rows-of-4 walk of rounds 1-5 for every shape; 1 = column
+                         // groups where the output has at least as many tile rows as tile columns (`tile_origin`, below)
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 constexpr int GROUP_M = 8;
+constexpr int FLAG_COLWALK = 1 << 16;   // kernel `dbg` / `flags` bit: column-group tile order (set by launch(), see g_walk)
+
+// Block id -> output tile of the 256x256 kernels.  The 32 CUs of an XCD hold 32 CONSECUTIVE tiles of the XCD's contiguous share of the
+// walk (blocks are dealt to the XCDs round-robin and start in id order) and run their K loops in lock-step, so per K-step the XCD's L2
+// fetches one operand panel per distinct tile ROW and per distinct tile COLUMN among them: 4 x 8 tiles = 12 panels for 64 panel reads
+// (the 80 % L2 hit rate of profiles/*_pmc_gemm_traffic.json), and whatever the window holds beyond 12 is fabric traffic - energy,
+// on a chip that runs this kernel power-limited.
+//   rows-of-4 walk (rounds 1-5): 4 tile rows x all tiles_n columns, m fastest.  A window is 4 x 8 only while 4 * tiles_n is a multiple
+//   of 32: with 14 columns (N = 3584: the o / down projections) 56 tiles per row group make every other window straddle two groups
+//   (4 x 6 + 4 x 2 of the next: 8 + 8 = 16 panels), 18 columns (qkv) two windows in five, 5 columns (the vision proj / fc2) all.
+//   column-group walk (round 6): the tile columns are cut into ceil(tiles_n / 8) groups of (nearly) equal width w <= 8, a group is
+//   walked down ALL tiles_m rows with n fastest: a window is 32 / w rows x w columns wherever it starts (4 x 8, 4.6 x 7, 5.3 x 6,
+//   6.4 x 5: 12-12.6 panels), and it leaves its group only at the group's end - once per tiles_m * w tiles.  Used when tiles_m >=
+//   tiles_n (the prefill / vision launch groups: 256-512 tile rows); wide-and-short outputs keep the rows-of-4 walk.
+// The map is a bijection of [0, tiles_m * tiles_n) either way; results do not depend on it (each tile is computed the same way).
+__device__ __forceinline__ void tile_origin(int bid, int tiles_m, int tiles_n, bool colwalk, int group_m, int bt, int& m0, int& n0) {
+  const int nblk = tiles_m * tiles_n;
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  if (colwalk) {
+    const int ng = (tiles_n + 7) >> 3;
+    const int base = tiles_n / ng, rem = tiles_n - base * ng;   // `rem` groups of base + 1 columns, then ng - rem of base
+    const int wide = rem * (base + 1) * tiles_m;
+    int w, col0, within;
+    if (lid < wide) {
+      w = base + 1;
+      const int g = lid / (w * tiles_m);
+      col0 = g * w;
+      within = lid - g * w * tiles_m;
+    } else {
+      w = base;
+      const int l2 = lid - wide;
+      const int g = l2 / (w * tiles_m);
+      col0 = rem * (base + 1) + g * w;
+      within = l2 - g * w * tiles_m;
+    }
+    const int row = within / w;
+    m0 = row * bt;
+    n0 = (col0 + within - row * w) * bt;
+  } else {
+    const int width = group_m * tiles_n;
+    const int group = lid / width;
+    const int first_m = group * group_m;
+    const int gsize = min(tiles_m - first_m, group_m);
+    m0 = (first_m + (lid % width) % gsize) * bt;
+    n0 = ((lid % width) / gsize) * bt;
+  }
+}
 
 // KTAIL = false (K % 64 == 0): no per-piece predicate / select, and the LDS-DMA takes the scalar-base + 32-bit lane-offset form (the loop
 // then holds no vector instruction but the MFMAs: vector work beside MFMAs is paid in full, tools/probes/probe_mfma_valu_overlap.hip).
@@ -625,23 +676,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
-  const int nblk = tiles_m * tiles_n;
   const int nk = K / BK;
 
-  // tile id -> (m0, n0): identical to gemm_bf16_nt_256_kernel
+  // tile id -> (m0, n0): gemm_bf16_nt_256_kernel's rows-of-4 walk, or the column-group walk (tile_origin)
   int m0, n0;
-  {
-    const int bid = blockIdx.x;
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int width = GROUP_M2 * tiles_n;
-    const int group = lid / width;
-    const int first_m = group * GROUP_M2;
-    const int gsize = min(tiles_m - first_m, GROUP_M2);
-    m0 = (first_m + (lid % width) % gsize) * BT;
-    n0 = ((lid % width) / gsize) * BT;
-  }
+  tile_origin(blockIdx.x, tiles_m, tiles_n, (dbg & FLAG_COLWALK) != 0, GROUP_M2, BT, m0, n0);
   const char* abase = (const char*)(A + (long)m0 * lda);
   const char* wbase = (const char*)(W + (long)n0 * ldw);
   // DMA sources of this wave: half h, piece j -> rows 128h + 16w + 8j .. +8 (lane: row + (l >> 3), chunk l & 7, swizzled)
@@ -859,16 +898,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_persist_kernel(
   const int nblk = tiles_m * tiles_n;
   const int nk = K / BK;
 
-  auto tile_origin = [&](int bid, int& m0, int& n0) {   // identical to gemm_bf16_nt_256_kernel
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int width = GROUP_M2 * tiles_n;
-    const int group = lid / width;
-    const int first_m = group * GROUP_M2;
-    const int gsize = min(tiles_m - first_m, GROUP_M2);
-    m0 = (first_m + (lid % width) % gsize) * BT;
-    n0 = ((lid % width) / gsize) * BT;
+  auto tile_origin = [&](int bid, int& m0, int& n0) {   // as gemm_bf16_nt_256pp_kernel
+    ::tile_origin(bid, tiles_m, tiles_n, (flags & FLAG_COLWALK) != 0, GROUP_M2, BT, m0, n0);
   };
   // ---- what the DMA reads: the output tile whose K-tiles are being issued (one or two K-tiles ahead of the MFMAs)
   const char *abase, *wbase;
@@ -1669,7 +1700,8 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
     // C far larger than L2 + Infinity Cache (256 MB): stream it out (`global_store ... nt`) instead of evicting the operand panels the
     // XCD's L2 is sharing: +0.3...3 % per launch on the path's shapes (vit.proj 1154 -> 1192 TFLOP/s, gate/up 1459 -> 1480), never
     // slower; a small C (decode steps) stays cacheable for the kernel that reads it next
-    const int flags = g_gemm_dbg | ((size_t)M * (size_t)N * 2 > ((size_t)g_nt_min_mb << 20) ? 1024 : 0);
+    const int flags = g_gemm_dbg | ((size_t)M * (size_t)N * 2 > ((size_t)g_nt_min_mb << 20) ? 1024 : 0) |
+                      ((g_walk && tiles_m >= tiles_n) ? FLAG_COLWALK : 0);
     if constexpr (EPI != OWC_EPI_F32 && EPI != OWC_EPI_SWIGLU) {   // (the persistent form: off by default, see g_persist)
       const int cus = cu_count();
       if (g_persist && K >= 6 * BK && tiles_m * tiles_n > cus && cus >= 8) {
@@ -1987,5 +2019,6 @@ void owc_gemm_set_small_tiles(int v) { g_small_tiles = v < 0 ? 1 : v; }
 void owc_gemm_set_ring_128(int v) { g_ring_128 = v < 0 ? 1 : v != 0; }
 void owc_gemm_set_pp128(int v) { g_pp128_min_tiles = v < 0 ? 128 : v; }
 void owc_gemm_set_persist(int v) { g_persist = v < 0 ? 0 : v; }
+void owc_gemm_set_walk(int v) { g_walk = v < 0 ? 1 : v; }
 void owc_gemm_set_nt_min_mb(int v) { g_nt_min_mb = v < 0 ? 64 : v; }
 int owc_gemm_nt_min_mb() { return g_nt_min_mb; }   // (the fp8 kernels use the same threshold)

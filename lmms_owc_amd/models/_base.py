@@ -197,8 +197,23 @@ class PassPipeline:
         import os
         from concurrent.futures import ThreadPoolExecutor
 
+        # NUMA placement (round 6): `os.sched_setaffinity(0, ...)` moves the CALLING THREAD only, and every thread
+        # started while it is in force inherits the mask for good - round 5 pinned the launch thread here and restored only that
+        # thread later, so torch's intra-op workers (created lazily, whenever the first CPU op ran) kept the one-node mask and
+        # bench.py's CPU baseline ran its 128 threads on one socket's share.  Now: the mask is applied to exactly the threads that
+        # want it - the launch thread (kernel launches, first touch of the pinned staging buffers) and, by an `initializer`, the PIL
+        # workers and the preparation thread - and `unpin_host_threads()` gives EVERY thread of the process (/proc/self/task) the
+        # original mask back, whoever inherited what in between.
         self._cpu_affinity_before = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
         self._cpu_affinity = pin_to_gpu_numa_node(getattr(self, "_device", None))   # before any worker thread or pinned buffer exists
+        share = self._cpu_affinity
+
+        def pin_worker() -> None:
+            if share and hasattr(os, "sched_setaffinity"):
+                try:
+                    os.sched_setaffinity(0, share)
+                except OSError:
+                    pass
 
         # host preparation: `OWC_PREP_THREADS` PIL workers (JPEG round trip + bicubic resize release the GIL) behind ONE
         # preparation thread that runs up to two engine batches ahead of the GPU (`_generate_rows`)
@@ -207,12 +222,13 @@ class PassPipeline:
         # 4-8 workers 0.89 of the engine rate, 32 workers 0.85, 64 workers 0.80)
         ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
         self._prep_threads = int(os.environ.get("OWC_PREP_THREADS", max(2, min(8, (os.cpu_count() or 8) // ranks_here))))
-        self._pool = ThreadPoolExecutor(max_workers=self._prep_threads)
+        self._pool = ThreadPoolExecutor(max_workers=self._prep_threads, thread_name_prefix="owc-pil", initializer=pin_worker)
         # ONE unit in preparation at a time (OWC_PREP_UNITS): two raise one rank's ceiling by ~14 % on an idle host but cost 3 % at the
         # production rate with 8 ranks on a 256-core host (0.975 -> 0.946 of 8 x 205 images/s, profiles/r05_host_soak.txt) - and so did
         # nothing else tried there for the 8-rank ceiling (a 0.5 ms GIL switch interval, Pillow's block cache, 12 / 16 workers): it sits
         # at ~3100-3300 images/s = 2.0 x the consumption at Food-101 sizes whatever the knob, ~4 busy cores per rank
-        self._prep_thread = ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("OWC_PREP_UNITS", "1"))))
+        self._prep_thread = ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("OWC_PREP_UNITS", "1"))), thread_name_prefix="owc-prep",
+                                               initializer=pin_worker)
         import threading
 
         self._pinned_free, self._pinned_lock = [], threading.Lock()
@@ -242,18 +258,38 @@ class PassPipeline:
             t.record_stream(cur)
         return out
 
-    def release_host_resources(self) -> None:
-        """Stop the worker pools, drop the pinned staging buffers and give the calling thread its CPU affinity back (a process that
-        goes on to do host-side work of its own after the last task: bench.py's CPU baseline)."""
+    def unpin_host_threads(self) -> int:
+        """Give EVERY thread of this process the CPU affinity it had before `_start_workers` pinned the rank to its GPU's NUMA share:
+        the launch thread, the workers, and whatever was started in between and inherited the mask (torch's OpenMP / oneDNN intra-op
+        workers, tokenizer pools).  Called when generation is over and host-side work follows - the engine's scoring pass, bench.py's
+        CPU baseline.  Returns the number of threads whose mask was reset (0 when nothing was pinned)."""
         import os
 
+        before = getattr(self, "_cpu_affinity_before", None)
+        if not before or not getattr(self, "_cpu_affinity", None) or not hasattr(os, "sched_setaffinity"):
+            return 0
+        n = 0
+        try:
+            tids = [int(t) for t in os.listdir("/proc/self/task")]
+        except OSError:
+            tids = [0]
+        for tid in tids:
+            try:
+                os.sched_setaffinity(tid, before)
+                n += 1
+            except OSError:      # a thread that exited between the listing and the call
+                pass
+        self._cpu_affinity = None
+        return n
+
+    def release_host_resources(self) -> None:
+        """Stop the worker pools, drop the pinned staging buffers and give every thread of the process its CPU affinity back (a process
+        that goes on to do host-side work of its own after the last task: bench.py's CPU baseline)."""
         for pool in (getattr(self, "_pool", None), getattr(self, "_prep_thread", None)):
             if pool is not None:
                 pool.shutdown(wait=True)
         self._pinned_free = []
-        before = getattr(self, "_cpu_affinity_before", None)
-        if before and hasattr(os, "sched_setaffinity"):
-            os.sched_setaffinity(0, before)
+        self.unpin_host_threads()
 
     def _pinned_take(self, shape: tuple) -> torch.Tensor:
         """Pinned staging buffer for one same-size image run: reused across chunks (page-locking a fresh GB per chunk costs

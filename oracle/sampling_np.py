@@ -7,8 +7,10 @@ TopPLogitsWarper (descending cumulative softmax mass; everything behind the poin
 token stays), softmax, one multinomial draw (transformers generation/logits_process.py).  transformers is third-party and absent
 from /root/reference; the three warpers are restated from its published behaviour and PINNED against the installed transformers'
 own warpers in tests/test_oracle_sampling.py.  The draw itself is random: parity is the DISTRIBUTION (and the support), not
-torch's random stream.  One stated difference: where the top-p cut falls inside a run of EQUAL logits, HF keeps a prefix of the
-run in its sort order; this restatement (and the HIP kernel) keep the whole run.
+torch's random stream.  Ties: top-k keeps a run of equal logits at its cut whole, exactly as HF does (`scores < k-th value` is
+what it removes).  Where the top-p cut falls inside a run of EQUAL logits HF keeps a prefix of the run in torch.sort's order,
+which is unspecified among equal values; this restatement (and the HIP kernel) keep the same NUMBER of them and take the lowest
+token ids - pinned on the kept COUNT and the kept mass in tests/test_oracle_sampling.py.
 """
 
 from __future__ import annotations
@@ -28,7 +30,8 @@ def sampling_probs(logits: np.ndarray, temperature: float, top_k: int = 0, top_p
         order = np.argsort(-s, kind="stable")
         cum = np.cumsum(p[order])
         first = int(np.searchsorted(cum, top_p, side="left"))      # the token at which the cumulative mass reaches top_p stays
-        vcut = s[order[min(first, len(s) - 1)]]
-        s = np.where(s < vcut, -np.inf, s)
+        keep = np.zeros(len(s), bool)
+        keep[order[:min(first, len(s) - 1) + 1]] = True             # stable order: lowest ids first inside a run of equal logits
+        s = np.where(keep, s, -np.inf)
     p = np.exp(s - s.max())
     return p / p.sum()

@@ -384,6 +384,47 @@ def test_gemm_persistent_pingpong_race_screen(gpu, m, n, k, epi):
         lib.owc_tuning_set(b"gemm_persist", -1)
 
 
+@pytest.mark.parametrize("persist", [0, 1])
+@pytest.mark.parametrize("m,n,k,epi", [(16384, 3584, 512, "residual"),     # 64 x 14 tiles: two column groups of 7
+                                       (8192, 4608, 384, "none"),          # 32 x 18: three groups of 6
+                                       (12288, 1280, 1280, "quick_gelu"),  # 48 x 5: one group of 5 (the vision proj / fc2 width)
+                                       (9000, 3848, 256, "none"),          # ragged M and N; 36 x 16 tiles: two groups of 8
+                                       (5000, 5120, 384, "gelu_erf"),      # 20 x 20 tiles: tiles_m == tiles_n, groups 7 / 7 / 6
+                                       (2304, 6400, 384, "none")])         # 9 x 25: fewer tile rows than columns - keeps the rows-of-4 walk
+def test_gemm_tile_walk_does_not_change_a_bit(gpu, m, n, k, epi, persist):
+    """Round 6: the block id -> output tile map of the 256x256 ping-pong kernels (`tile_origin`, gemm_bf16.hip) walks column groups of
+    <= 8 tile columns down all tile rows when tiles_m >= tiles_n (knob "gemm_walk", default 1), instead of rows of 4 across all
+    columns: an XCD's 32 co-resident tiles then always span 12-12.6 operand panels instead of up to 16.  A tile is computed the
+    same way wherever it runs: outputs must equal the rounds-1-5 walk bit for bit - which also proves the new map covers every
+    tile exactly once (a tile computed twice leaves another one unwritten: the canary below would survive)."""
+    from lmms_owc_amd import _lib, ops
+
+    lib = _lib.load()
+    a = bf16_randn((m, k), 160 + (m % 89), device=gpu)
+    w = bf16_randn((n, k), 161, 0.05, device=gpu)
+    b = bf16_randn((n,), 162, device=gpu)
+    r = bf16_randn((m, n), 163, device=gpu)
+    E = {"none": _lib.EPI_NONE, "residual": _lib.EPI_RESIDUAL, "quick_gelu": _lib.EPI_QUICK_GELU, "gelu_erf": _lib.EPI_GELU_ERF}[epi]
+
+    def run():
+        out = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device=gpu)   # canary: every element must be written
+        ops.gemm_bf16(a, w, b, epilogue=E, residual=r if epi == "residual" else None, out=out)
+        return out
+
+    try:
+        assert lib.owc_tuning_set(b"gemm_persist", persist) == 0
+        assert lib.owc_tuning_set(b"gemm_walk", 0) == 0
+        want = run()
+        assert not torch.isnan(want).any()
+        assert lib.owc_tuning_set(b"gemm_walk", 1) == 0
+        for i in range(3):
+            got = run()
+            assert torch.equal(got, want), (i, (got != want).sum().item())
+    finally:
+        lib.owc_tuning_set(b"gemm_walk", -1)
+        lib.owc_tuning_set(b"gemm_persist", -1)
+
+
 @pytest.mark.parametrize("m,n,k,epi", [(128, 37888, 3584, "swiglu"), (100, 33000, 1024, "none"), (40, 37888, 128, "swiglu"),
                                        (64, 40960, 64, "none"), (65, 20512, 3584, "swiglu")])
 def test_gemm_wide_tiles_race_screen(gpu, m, n, k, epi):

@@ -365,6 +365,45 @@ def test_sampling_extremes_and_ties(gpu):
     assert drawn == {1, 2, 4}
 
 
+def test_sampling_top_p_cut_inside_tied_logits(gpu):
+    """Round 6: where the top-p cut falls inside a run of equal bf16 logits the kernel keeps HF's NUMBER of
+    them (oracle/sampling_np.py, pinned on transformers' TopPLogitsWarper in tests/test_oracle_sampling.py) and takes the lowest ids;
+    before, the whole run stayed eligible.  Support and distribution against the oracle; then the case the reference actually runs
+    into: Qwen2-VL's generation_config.json (top_k 1, top_p 0.001) with a temperature > 0 must return `owc_argmax_bf16` bit for bit,
+    tied maxima included."""
+    from lmms_owc_amd import ops
+    from oracle import sampling_np as S
+
+    R = 40000
+    r = np.random.default_rng(11)
+    rows = [(np.array([2.0, 0.0, 2.0, 2.0, 2.0, 1.0, 2.0, -1.0], np.float32), 1.0, 0, 0.5),
+            (np.array([3.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0, 1.0, 1.0], np.float32), 1.0, 0, 0.8),
+            (np.array([1.0, 3.0, 3.0, 2.0, 3.0, 0.0, -1.0, 0.5], np.float32), 1.0, 2, 0.6),
+            (np.round(r.standard_normal(5003) * 2).astype(np.float32), 0.9, 40, 0.7),           # integer logits: the cut bin holds hundreds
+            (np.round(r.standard_normal(152064) * 1.5).astype(np.float32) * 0.5, 1.1, 0, 0.3)]  # runs spread over all 1024 threads' chunks
+    for row, T, k, p in rows:
+        V = len(row)
+        probs = S.sampling_probs(row, T, k, p)
+        n = R if V < 10000 else 4000
+        logits = torch.from_numpy(row).to(torch.bfloat16).to(gpu)[None].expand(n, V).contiguous()
+        got = to_np(ops.sample_bf16(logits, T, k, p, seed=77)).astype(np.int64)
+        counts = np.bincount(got, minlength=V)
+        assert (counts[probs == 0] == 0).all(), f"a token outside the kept set was drawn (V={V}, k={k}, p={p}): {np.flatnonzero((counts > 0) & (probs == 0))[:8]}"
+        exp = probs * n
+        big = exp >= 20
+        z = (counts[big] - exp[big]) / np.sqrt(exp[big] * (1 - probs[big]) + 1e-12)
+        assert np.abs(z).max() < 5.0, (V, k, p, np.abs(z).max())
+    # top_k 1 + top_p 0.001 at any temperature == the greedy argmax, ties included (lowest index)
+    g = torch.Generator(device=gpu).manual_seed(3)
+    for V in (152064, 517):
+        logits = torch.round(torch.randn((256, V), generator=g, device=gpu) * 2).to(torch.bfloat16)   # integer values: many tied maxima
+        assert (logits.float() == logits.float().max(dim=1, keepdim=True).values).sum(dim=1).max().item() > 1
+        want = ops.argmax_bf16(logits)
+        for T in (0.01, 1.0, 3.0):
+            got = ops.sample_bf16(logits, T, 1, 0.001, seed=5)
+            assert torch.equal(got.to(want.dtype), want), (V, T)
+
+
 def test_embed_argmax_patchify(gpu):
     from lmms_owc_amd import ops
 

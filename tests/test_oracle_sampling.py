@@ -34,3 +34,38 @@ def test_top_k_keeps_ties_like_hf():
     want = torch.softmax(TopKLogitsWarper(top_k=2)(torch.zeros((1, 1), dtype=torch.long), torch.from_numpy(logits)[None].clone())[0].double(), -1)
     got = S.sampling_probs(logits, 1.0, 2, None)
     assert np.allclose(got, want.numpy()) and (got > 0).sum() == 3
+
+
+def test_top_p_cut_inside_a_run_of_equal_logits_keeps_hf_count_and_mass():
+    """Where the top-p cut falls inside a run of EQUAL logits, HF's TopPLogitsWarper keeps a prefix of the run in torch.sort's order
+    (which of the equal tokens: unspecified).  The restatement keeps the same NUMBER of tokens - hence the same kept mass and the same
+    probability for every kept token - and takes the lowest ids of the run."""
+    from transformers.generation.logits_process import TopKLogitsWarper, TopPLogitsWarper
+
+    ids = torch.zeros((1, 1), dtype=torch.long)
+    r = np.random.default_rng(3)
+    cases = [(np.array([2.0, 0.0, 2.0, 2.0, 2.0, 1.0, 2.0, -1.0], np.float32), 0, 0.5),      # five tied maxima, cut inside them
+             (np.array([2.0, 0.0, 2.0, 2.0, 2.0, 1.0, 2.0, -1.0], np.float32), 0, 0.001),    # exactly one survivor
+             (np.array([3.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0], np.float32), 0, 0.8),       # cut inside the second run
+             (np.array([1.0, 3.0, 3.0, 2.0, 3.0, 0.0], np.float32), 2, 0.6),                 # top-k keeps 3 ties, top-p cuts inside them
+             (np.round(r.standard_normal(512) * 2).astype(np.float32), 40, 0.7)]             # integer logits: many runs
+    for logits, k, p in cases:
+        scores = torch.from_numpy(logits)[None].clone()
+        if k:
+            scores = TopKLogitsWarper(top_k=k)(ids, scores)
+        scores = TopPLogitsWarper(top_p=p)(ids, scores)
+        want = torch.softmax(scores[0].double(), -1).numpy()
+        got = S.sampling_probs(logits, 1.0, k, p)
+        assert (got > 0).sum() == (want > 0).sum(), (logits, k, p)
+        assert np.allclose(np.sort(got), np.sort(want), atol=1e-9)            # the same multiset of probabilities
+        for v in np.unique(logits):                                            # per value: the same count kept, ours = the lowest ids
+            idx = np.flatnonzero(logits == v)
+            n_kept = int((want[idx] > 0).sum())
+            assert np.array_equal(np.flatnonzero(got[idx] > 0), np.arange(n_kept)), (v, n_kept)
+    # top_k = 1 with top_p < 1 (Qwen2-VL's generation_config.json: top_k 1, top_p 0.001): one survivor = the argmax (lowest id among ties)
+    logits = np.array([0.0, 5.0, 1.0, 5.0, 5.0], np.float32)
+    got = S.sampling_probs(logits, 0.01, 1, 0.001)
+    assert np.array_equal(got, np.array([0.0, 1.0, 0.0, 0.0, 0.0]))
+    # top_k = 1 ALONE keeps every tied maximum: HF's own behaviour (`scores < k-th value` is what it removes)
+    hf = TopKLogitsWarper(top_k=1)(ids, torch.from_numpy(logits)[None].clone())[0]
+    assert torch.isfinite(hf).sum().item() == 3 and (S.sampling_probs(logits, 1.0, 1, None) > 0).sum() == 3

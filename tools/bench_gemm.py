@@ -144,6 +144,44 @@ def main():
             lib.owc_tuning_set(b"gemm_dbg", 0)
             print(f"{name:18s} " + "  ".join(f"dbg{v}: {sorted(r)[len(r) // 2]:7.1f}" for v, r in res.items()), flush=True)
         return
+    if "--vs-vendor" in sys.argv:
+        # Interleaved A/B against the vendor library (hipBLASLt through torch.matmul) on the SAME operands in ONE process: rounds
+        # alternate ours / vendor (rule 24 of the HIP guide: no ranking across processes or boxes).  A yardstick only - the vendor
+        # library is never on the product path.  Output per shape: median and best TFLOP/s of both and the ratio of the medians.
+        import statistics
+
+        only = [a for a in sys.argv[1:] if not a.startswith("--")]
+        m_over = next((int(a[4:]) for a in sys.argv[1:] if a.startswith("--m=")), 0)
+        rounds = next((int(a[9:]) for a in sys.argv[1:] if a.startswith("--rounds=")), 7)
+        for name, m, n, k in SHAPES:
+            if only and name not in only:
+                continue
+            m = m_over if (m_over and not name.startswith("vit")) else m
+            if name.startswith("vit") and m_over:
+                m = 2 * m_over   # the vision launch group is twice the prefill group (131072 / 65536 rows)
+            a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+            w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+            out = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+            wt = w.t()
+            fns = {"ours": lambda: ops.gemm_bf16(a, w, out=out), "vendor": lambda: torch.matmul(a, wt, out=out)}
+            res = {"ours": [], "vendor": []}
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = max(3, min(20, int(2e-2 / (2.0 * m * n * k / 1.4e15))))   # ~20 ms per timed burst
+            for rnd in range(rounds + 1):
+                for who in ("ours", "vendor"):
+                    for _ in range(2):
+                        fns[who]()
+                    e0.record()
+                    for _ in range(reps):
+                        fns[who]()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if rnd:
+                        res[who].append(2.0 * m * n * k / (e0.elapsed_time(e1) / reps) / 1e9)
+            mo, mv = statistics.median(res["ours"]), statistics.median(res["vendor"])
+            print(f"{name:18s} M={m:6d} N={n:6d} K={k:6d}  ours med {mo:7.1f} max {max(res['ours']):7.1f} | vendor med {mv:7.1f} "
+                  f"max {max(res['vendor']):7.1f} TFLOP/s | ours / vendor {mo / mv:.3f}", flush=True)
+        return
     if "--ab" in sys.argv:
         knob = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--knob=")), "gemm_dbg")
         return ab(dev, next((a for a in sys.argv[1:] if not a.startswith("--")), None), knob.encode())
