@@ -73,8 +73,8 @@ const char* owc_last_error(const owc_ctx* ctx);
  * and fp8 - for a few hundred rows x a few thousand columns, where 64x64 tiles need more than a round and a half of the chip),
  * "gemm_pp128" (the 256x128-tile ping-pong kernel for launches with too few 256x256 tiles to fill the chip - the o / down projections
  * of a decode step at 1024-2048 rows: 0 off, n > 0: from n tiles of 256x128, negative: the default), "gemm_walk" (block id -> output
- * tile of the 256x256 ping-pong kernels: 0 the rows-of-4 walk of rounds 1-5, 1 / negative (default) column groups of <= 8 tile columns
- * walked down all tile rows when the output has at least as many tile rows as tile columns).
+ * tile of the 256x256 ping-pong kernels: 0 the rows-of-4 walk of rounds 1-5, 2 column groups of <= 8 tile columns walked down all
+ * tile rows, 1 / negative (default) column groups where they measured faster - K >= 4.5 N with at least as many tile rows as columns).
  * Every knob above selects between kernels that return the SAME results.  The timing-only experiment knobs "gemm_dbg" /
  * "attn_dbg" (parts of a kernel switched off to price them; outputs are garbage) exist only in libowc_hip_timing.so, which
  * `python -m lmms_owc_amd.build --timing` builds with -DOWC_TIMING_KNOBS for tools/; the product library does not know them.
@@ -415,6 +415,25 @@ int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cac
                         uint8_t* done, int32_t* out_tokens, int out_stride, int step, int32_t* step_state, int B,
                         int eos_id0, int eos_id1, int pad_id, const int32_t* out_row, const int32_t* forced_tok,
                         const owc_sampling* sampling, void* logits_out, void* workspace, size_t ws_bytes, void* stream);
+
+/* Repetition penalty of the generation(s) that follow on this context (HF RepetitionPenaltyLogitsProcessor; in force in the
+ * reference whenever the checkpoint's generation_config.json carries `repetition_penalty` != 1 - HF merges that file into every
+ * `generate` call, greedy ones included: /root/reference/src/models/_qwen2_vl.py:319-329 does not override it; Qwen2-VL /
+ * Qwen2.5-VL instruct checkpoints ship 1.05).  Semantics: before the argmax (or the sampling warpers) of a sequence's next-token
+ * logits, in fp32, every token id that occurs in its prompt (image placeholders included) or was fed to it since gets
+ * score = score < 0 ? score * penalty : score / penalty, once per distinct id.
+ *   seen: caller-owned device bitmap [n_slots][words_per_row] of uint32 (words_per_row * 32 >= vocab), one row per KV-cache SLOT,
+ *   ZEROED by the caller before a sequence's prefill; owc_llm_prefill marks the prompt ids (tok_slot; shared-prefix rows in every
+ *   slot of the launch), owc_llm_decode_step marks the token it is fed (slot[b]) - under teacher forcing the forced token, as HF's
+ *   input_ids would hold - and both apply the penalty through the bitmap row of the sequence.  Greedy: exact fp32 arithmetic on
+ *   the fly inside the argmax.  Sampled (`sampling` != NULL): the penalised values are written back as bf16 in front of the draw.
+ *   seen == NULL switches it off (the default).  Not applied in OWC_PREFILL_SCORE_ROWS mode (loglikelihood reads raw logits). */
+int owc_llm_set_repetition_penalty(owc_ctx* ctx, float penalty, uint32_t* seen, int words_per_row);
+/* the two pieces on their own (op-level tests): mark ids[t] in bitmap row slot[t] (slot NULL: row t); penalised greedy argmax of
+ * bf16 logits rows through bitmap rows row_slot[r] (NULL: row r), lowest index on ties. */
+int owc_seen_mark(owc_ctx* ctx, const int32_t* ids, const int32_t* slot, int n, int vocab, uint32_t* seen, int words_per_row, void* stream);
+int owc_argmax_penalized_bf16(owc_ctx* ctx, const void* logits, int64_t ld, int rows, int vocab, const uint32_t* seen, int words_per_row,
+                              const int32_t* row_slot, float penalty, int32_t* out, void* stream);
 
 /* first-token bookkeeping after prefill: same done/pad/out_tokens update as a decode step. */
 int owc_decode_update(owc_ctx* ctx, int32_t* next_tok, uint8_t* done, int32_t* out_tokens,

@@ -21,7 +21,7 @@ _lib: C.CDLL | None = None
 _ctx: dict[int, C.c_void_p] = {}
 _timing_ok = False
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = range(6)
 
@@ -143,6 +143,9 @@ SIGNATURES: dict[str, tuple] = {
     "owc_llm_decode_step": (i32, [vp, C.POINTER(LlmWeights), C.POINTER(KvCache), vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                   vp, vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, C.POINTER(Sampling), vp, vp, sz, vp]),
     "owc_decode_update": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "owc_llm_set_repetition_penalty": (i32, [vp, f32, vp, i32]),
+    "owc_seen_mark": (i32, [vp, vp, vp, i32, i32, vp, i32, vp]),
+    "owc_argmax_penalized_bf16": (i32, [vp, vp, i64, i32, i32, vp, i32, vp, f32, vp, vp]),
     "owc_decode_compact": (i32, [vp, vp, i32] + [vp] * 17),
     "owc_bert_workspace_bytes": (sz, [C.POINTER(BertWeights), i32, i32]),
     "owc_bert_embed": (i32, [vp, C.POINTER(BertWeights), vp, vp, i32, i32, vp, vp, sz, vp]),

@@ -16,7 +16,7 @@
 
 extern "C" {
 
-int owc_abi_version(void) { return 18; }
+int owc_abi_version(void) { return 19; }
 
 int owc_has_timing_knobs(void) {   // 1 only in libowc_hip_timing.so (tools/); the product library answers 0
 #ifdef OWC_TIMING_KNOBS

@@ -337,6 +337,117 @@ __global__ __launch_bounds__(ARGMAX_T) void argmax_kernel(const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Repetition penalty (round 6).  HF's RepetitionPenaltyLogitsProcessor is in force in the REFERENCE whenever the checkpoint's
+// generation_config.json carries `repetition_penalty` != 1 (Qwen2-VL / Qwen2.5-VL instruct checkpoints ship 1.05): the reference
+// calls `model.generate(..., do_sample = temperature > 0, temperature, top_p, num_beams, max_new_tokens)`
+// (/root/reference/src/models/_qwen2_vl.py:319-329) and HF merges every generation_config field the call does not override, so
+// GREEDY decoding is penalised too.  The processor (transformers generation/logits_process.py): the next-token logits go to
+// fp32; for every token id that occurs in input_ids - the PROMPT (image placeholders included) and everything generated so far -
+// score = score < 0 ? score * p : score / p, once per distinct id; then the warpers / argmax.
+// Here: a bitmap of the ids a sequence has seen (one row of `wpr` 32-bit words per KV-cache SLOT, caller-owned, zeroed by the
+// caller before the prefill), marked by seen_mark_kernel from the prompt rows at prefill and from the token FED at every decode
+// step (under teacher forcing that is the forced token: what HF's input_ids would hold), and an argmax that applies the penalty
+// in fp32 to the marked ids on the fly (argmax_penalized_kernel: argmax_kernel + one bitmap word per 32 logits).  For sampled
+// requests penalize_rows_kernel writes the penalised values back as bf16 in front of sample_kernel (one rounding HF does not do;
+// the greedy path has none).
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ void seen_mark_kernel(const int* __restrict__ ids, const int* __restrict__ slot, int n, int V, unsigned* __restrict__ seen,
+                                 int wpr, int bcast_first, int bcast_n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int id = ids[t];
+  if (id < 0 || id >= V) return;
+  const int sl = slot ? slot[t] : t;
+  const unsigned bit = 1u << (id & 31);
+  if (sl >= 0) {
+    atomicOr(&seen[(long)sl * wpr + (id >> 5)], bit);
+  } else {   // a shared-prefix row of the prefill (tok_slot = -1): it belongs to every sequence of the launch
+    for (int s2 = bcast_first; s2 < bcast_first + bcast_n; ++s2) atomicOr(&seen[(long)s2 * wpr + (id >> 5)], bit);
+  }
+}
+
+__device__ __forceinline__ float rep_penalize(float v, float p) { return v < 0.f ? v * p : v / p; }
+
+__global__ __launch_bounds__(ARGMAX_T) void argmax_penalized_kernel(const bf16_t* __restrict__ logits, long ld, int V,
+                                                                    const unsigned* __restrict__ seen, int wpr,
+                                                                    const int* __restrict__ row_slot, const int* __restrict__ row_index,
+                                                                    float penalty, int* __restrict__ out) {
+  __shared__ float sv[ARGMAX_T / 64];
+  __shared__ int si[ARGMAX_T / 64];
+  const int row = blockIdx.x;
+  const bf16_t* x = logits + (long)row * ld;
+  // the sequence's bitmap row: slot = row_slot[row_index[row]] (prefill: tok_slot of the prompt's last row), row_slot[row] (decode), or row
+  const int ri = row_index ? row_index[row] : row;
+  const unsigned char* bits = (const unsigned char*)(seen + (long)(row_slot ? row_slot[ri] : ri) * wpr);   // little endian: byte c = ids 8c .. 8c + 7
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  const int nch = V >> 3;
+  for (int ch = threadIdx.x; ch < nch; ch += ARGMAX_T) {
+    const bf16x8 v = *(const bf16x8*)(x + (long)ch * 8);
+    const unsigned m = bits[ch];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = bf2f(v[e]);
+      if ((m >> e) & 1u) f = rep_penalize(f, penalty);
+      const int i = ch * 8 + e;
+      if (f > best || (f == best && i < bi)) {
+        best = f;
+        bi = i;
+      }
+    }
+  }
+  for (int i = nch * 8 + threadIdx.x; i < V; i += ARGMAX_T) {
+    float f = bf2f(x[i]);
+    if ((bits[i >> 3] >> (i & 7)) & 1u) f = rep_penalize(f, penalty);
+    if (f > best || (f == best && i < bi)) {
+      best = f;
+      bi = i;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sv[w] = best;
+    si[w] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < ARGMAX_T / 64; ++k)
+      if (sv[k] > best || (sv[k] == best && si[k] < bi)) {
+        best = sv[k];
+        bi = si[k];
+      }
+    out[row] = bi;
+  }
+}
+
+__global__ __launch_bounds__(1024) void penalize_rows_kernel(bf16_t* __restrict__ logits, long ld, int V, const unsigned* __restrict__ seen,
+                                                             int wpr, const int* __restrict__ row_slot, const int* __restrict__ row_index,
+                                                             float penalty) {
+  const int row = blockIdx.x;
+  bf16_t* x = logits + (long)row * ld;
+  const int ri = row_index ? row_index[row] : row;
+  const unsigned* bits = seen + (long)(row_slot ? row_slot[ri] : ri) * wpr;
+  for (int wd = threadIdx.x; wd * 32 < V; wd += blockDim.x) {
+    unsigned m = bits[wd];
+    while (m) {
+      const int e = __builtin_ctz(m);
+      m &= m - 1;
+      const int i = wd * 32 + e;
+      if (i < V) x[i] = f2bf(rep_penalize(bf2f(x[i]), penalty));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Temperature / top-k / top-p sampling of one token per row (HF GenerationMixin._sample with TemperatureLogitsWarper ->
 // TopKLogitsWarper -> TopPLogitsWarper -> softmax -> multinomial; reached from the reference at src/models/_qwen2_vl.py:319-329
 // with do_sample = temperature > 0, and _llava_hf.py:365-376).  One block of 1024 threads per row, everything that decides the
@@ -961,6 +1072,27 @@ int owc_launch_beam_candidates(const void* logits, long ld, int rows, int V, int
 int owc_launch_argmax(const void* logits, long ld, int rows, int V, int* out, hipStream_t st) {
   if (rows <= 0 || V <= 0 || (ld & 7)) return OWC_ERR_SHAPE;
   hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(ARGMAX_T), 0, st, (const bf16_t*)logits, ld, V, out);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_seen_mark(const int* ids, const int* slot, int n, int V, unsigned* seen, int wpr, int bcast_first, int bcast_n, hipStream_t st) {
+  if (n <= 0) return OWC_OK;
+  if (!ids || !seen || wpr * 32 < V) return OWC_ERR_SHAPE;
+  hipLaunchKernelGGL(seen_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ids, slot, n, V, seen, wpr, bcast_first, bcast_n);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_argmax_penalized(const void* logits, long ld, int rows, int V, const unsigned* seen, int wpr, const int* row_slot,
+                                const int* row_index, float penalty, int* out, hipStream_t st) {
+  if (rows <= 0 || V <= 0 || (ld & 7) || !seen || wpr * 32 < V || !(penalty > 0.f)) return OWC_ERR_SHAPE;
+  hipLaunchKernelGGL(argmax_penalized_kernel, dim3(rows), dim3(ARGMAX_T), 0, st, (const bf16_t*)logits, ld, V, seen, wpr, row_slot, row_index, penalty, out);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
+int owc_launch_penalize_rows(void* logits, long ld, int rows, int V, const unsigned* seen, int wpr, const int* row_slot,
+                             const int* row_index, float penalty, hipStream_t st) {
+  if (rows <= 0 || V <= 0 || !seen || wpr * 32 < V || !(penalty > 0.f)) return OWC_ERR_SHAPE;
+  hipLaunchKernelGGL(penalize_rows_kernel, dim3(rows), dim3(1024), 0, st, (bf16_t*)logits, ld, V, seen, wpr, row_slot, row_index, penalty);
   return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
 }
 

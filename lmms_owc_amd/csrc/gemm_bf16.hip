@@ -23,6 +23,7 @@
 //    tiles in GROUP_M-major order so A/W panels are reused out of that XCD's L2.
 #include "owc_common.h"
 #include "gemm_epilogue.h"
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 
@@ -70,7 +71,8 @@ int g_nt_min_mb = 64;     // outputs larger than this many MiB leave the 256x256
 int g_pp128_min_tiles = 128;  // the 256x128 ping-pong kernel runs from this many of its tiles, up to 256 = one round (knob "gemm_pp128"; 0 off)
 int g_big_min_m = 129;   // M at and above which the 256x256 kernels may run (knob "gemm_big_min_m"; round 1: 1024)
 int g_walk = 1;          // tile order of the 256x256 ping-pong kernels (knob "gemm_walk"): 0 = rows-of-4 walk of rounds 1-5 for every shape; 1 = column
-                         // groups where the output has at least as many tile rows as tile columns (`tile_origin`, below)
+                         // groups (`tile_origin`, below) where they measured faster: outputs with at least as many tile rows as tile columns
+                         // and K >= 4.5 N (the down projections); 2 = column groups for every shape (A-B)
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
@@ -87,10 +89,18 @@ constexpr int FLAG_COLWALK = 1 << 16;   // kernel `dbg` / `flags` bit: column-gr
 //   (4 x 6 + 4 x 2 of the next: 8 + 8 = 16 panels), 18 columns (qkv) two windows in five, 5 columns (the vision proj / fc2) all.
 //   column-group walk (round 6): the tile columns are cut into ceil(tiles_n / 8) groups of (nearly) equal width w <= 8, a group is
 //   walked down ALL tiles_m rows with n fastest: a window is 32 / w rows x w columns wherever it starts (4 x 8, 4.6 x 7, 5.3 x 6,
-//   6.4 x 5: 12-12.6 panels), and it leaves its group only at the group's end - once per tiles_m * w tiles.  Used when tiles_m >=
-//   tiles_n (the prefill / vision launch groups: 256-512 tile rows); wide-and-short outputs keep the rows-of-4 walk.
+//   6.4 x 5: 12-12.6 panels), and it leaves its group only at the group's end - once per tiles_m * w tiles.
+//   MEASURED (profiles/r06_gemm_tile_walk_ab.txt, interleaved A/B per launch at the model's launch groups): fewer panels per
+//   window is not the whole story.  The rows-of-4 walk reads A ONCE per launch (a 4-row band stays in the Infinity Cache while its
+//   XCD sweeps the columns; the eight XCDs sweep the same W columns together), the column walk re-reads all of A once per column
+//   GROUP from HBM: 7B down (K = 18944, 2 groups) +2.6 %, vision fc2 (K = 5120, 1 group) +0.9 %, vit25.down +0.5 %, proj +-0 -
+//   (fc2 -0.7 % on a second box) but o (2 groups) -2.5 %, qkv (3) -4.5 %, vision qkv / fc1 (2-3) -1...-6 %, gate/up (19 groups)
+//   -5.7 %.  So launch() selects it only for K >= 4.5 N with tiles_m >= tiles_n (the down projections: +2.6 / +2.6 % on two boxes).
 // The map is a bijection of [0, tiles_m * tiles_n) either way; results do not depend on it (each tile is computed the same way).
-__device__ __forceinline__ void tile_origin(int bid, int tiles_m, int tiles_n, bool colwalk, int group_m, int bt, int& m0, int& n0) {
+//   Also measured and NOT kept (same file): the rows-of-4 walk inside N chunks of 48-192 MiB of W rows, so that a W larger than the
+//   256 MB Infinity Cache (7B gate/up: 271 MB) stays cache-resident under all row bands: -1 ... -6 % at every chunk size.
+__device__ __forceinline__ void tile_origin(int bid, int tiles_m, int tiles_n, int flags, int group_m, int bt, int& m0, int& n0) {
+  const bool colwalk = (flags & FLAG_COLWALK) != 0;
   const int nblk = tiles_m * tiles_n;
   const int q = nblk >> 3, r = nblk & 7;
   const int xcd = bid & 7, idx = bid >> 3;
@@ -680,7 +690,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
 
   // tile id -> (m0, n0): gemm_bf16_nt_256_kernel's rows-of-4 walk, or the column-group walk (tile_origin)
   int m0, n0;
-  tile_origin(blockIdx.x, tiles_m, tiles_n, (dbg & FLAG_COLWALK) != 0, GROUP_M2, BT, m0, n0);
+  tile_origin(blockIdx.x, tiles_m, tiles_n, dbg, GROUP_M2, BT, m0, n0);
   const char* abase = (const char*)(A + (long)m0 * lda);
   const char* wbase = (const char*)(W + (long)n0 * ldw);
   // DMA sources of this wave: half h, piece j -> rows 128h + 16w + 8j .. +8 (lane: row + (l >> 3), chunk l & 7, swizzled)
@@ -899,7 +909,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_persist_kernel(
   const int nk = K / BK;
 
   auto tile_origin = [&](int bid, int& m0, int& n0) {   // as gemm_bf16_nt_256pp_kernel
-    ::tile_origin(bid, tiles_m, tiles_n, (flags & FLAG_COLWALK) != 0, GROUP_M2, BT, m0, n0);
+    ::tile_origin(bid, tiles_m, tiles_n, flags, GROUP_M2, BT, m0, n0);
   };
   // ---- what the DMA reads: the output tile whose K-tiles are being issued (one or two K-tiles ahead of the MFMAs)
   const char *abase, *wbase;
@@ -1701,7 +1711,7 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
     // XCD's L2 is sharing: +0.3...3 % per launch on the path's shapes (vit.proj 1154 -> 1192 TFLOP/s, gate/up 1459 -> 1480), never
     // slower; a small C (decode steps) stays cacheable for the kernel that reads it next
     const int flags = g_gemm_dbg | ((size_t)M * (size_t)N * 2 > ((size_t)g_nt_min_mb << 20) ? 1024 : 0) |
-                      ((g_walk && tiles_m >= tiles_n) ? FLAG_COLWALK : 0);
+                      ((g_walk == 2 || (g_walk == 1 && tiles_m >= tiles_n && 2 * (long)K >= 9 * (long)N)) ? FLAG_COLWALK : 0);
     if constexpr (EPI != OWC_EPI_F32 && EPI != OWC_EPI_SWIGLU) {   // (the persistent form: off by default, see g_persist)
       const int cus = cu_count();
       if (g_persist && K >= 6 * BK && tiles_m * tiles_n > cus && cus >= 8) {

@@ -8,6 +8,10 @@ struct owc_ctx {
   int device = 0;
   void* zeros = nullptr;  // 256-byte device zero page (K-tail source of the LDS-DMA GEMMs)
   std::string err;
+  // repetition penalty of the generation in progress (owc_llm_set_repetition_penalty; rep_seen == nullptr: off)
+  float rep_penalty = 1.f;
+  unsigned* rep_seen = nullptr;   // [slots][rep_wpr] bitmap of the token ids each sequence has seen, caller-owned
+  int rep_wpr = 0;
 };
 
 #define OWC_CHECK_HIP(ctx, expr)                                                        \
@@ -55,6 +59,11 @@ int owc_launch_mrope_kv(void* qkv, long ld, const int* pos3, long pos_stride, co
 int owc_launch_embed(const int* ids, const int* img_index, const void* table, const void* img,
                      void* out, int T, int d, hipStream_t st);
 int owc_launch_argmax(const void* logits, long ld, int rows, int V, int* out, hipStream_t st);
+int owc_launch_seen_mark(const int* ids, const int* slot, int n, int V, unsigned* seen, int wpr, int bcast_first, int bcast_n, hipStream_t st);
+int owc_launch_argmax_penalized(const void* logits, long ld, int rows, int V, const unsigned* seen, int wpr, const int* row_slot,
+                                const int* row_index, float penalty, int* out, hipStream_t st);
+int owc_launch_penalize_rows(void* logits, long ld, int rows, int V, const unsigned* seen, int wpr, const int* row_slot,
+                             const int* row_index, float penalty, hipStream_t st);
 int owc_launch_beam_candidates(const void* logits, long ld, int rows, int V, int K, float* logz, float* top_val, int* top_idx,
                                hipStream_t st);
 int owc_launch_sample(const void* logits, long ld, int rows, int V, const owc_sampling* sp, const int* row_map, int step,

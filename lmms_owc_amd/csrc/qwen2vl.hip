@@ -306,6 +306,12 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
     qs = (float*)cv.take((size_t)T * 4);
   }
 
+  const bool rep = ctx->rep_seen != nullptr && !scoring;   // repetition penalty in force (owc_llm_set_repetition_penalty)
+  if (rep) {
+    if (ctx->rep_wpr * 32 < w->vocab) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_llm_prefill: repetition-penalty bitmap narrower than the vocabulary");
+    // every prompt row marks its id in its sequence's bitmap row (shared-prefix rows: in every sequence of the launch)
+    OWC_TRY(owc_launch_seen_mark(ids, tok_slot, T, w->vocab, ctx->rep_seen, ctx->rep_wpr, bcast_first_slot, bcast_n_slots, st));
+  }
   OWC_TRY(owc_launch_embed(ids, img_index, w->embed, img_embeds, x, T, d, st));
   OWC_TRY(llm_layers(ctx, w, cache, x, h, qkv, attn, mlp, q8, qs, pos3, T, tok_slot, tok_idx, seq_start, nullptr,
                      k_start, seq_len, q_len, n_seq, T, max_len, false, bcast_first_slot, bcast_n_slots, scoring ? nullptr : last_index,
@@ -320,7 +326,11 @@ int owc_llm_prefill(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cache* 
     owc_sampling sp = *sampling;
     if (sp.stream_id) sp.stream_id += sampling_row0;
     if (sp.step_offset) sp.step_offset += sampling_row0;
+    if (rep) OWC_TRY(owc_launch_penalize_rows(logits, w->vocab, n_out, w->vocab, ctx->rep_seen, ctx->rep_wpr, tok_slot, last_index, ctx->rep_penalty, st));
     OWC_TRY(owc_launch_sample(logits, w->vocab, n_out, w->vocab, &sp, nullptr, 0, nullptr, next_tok, st));
+  } else if (rep) {
+    OWC_TRY(owc_launch_argmax_penalized(logits, w->vocab, n_out, w->vocab, ctx->rep_seen, ctx->rep_wpr, tok_slot, last_index, ctx->rep_penalty,
+                                        next_tok, st));
   } else {
     OWC_TRY(owc_launch_argmax(logits, w->vocab, n_out, w->vocab, next_tok, st));
   }
@@ -358,6 +368,11 @@ int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cac
     qs = (float*)cv.take((size_t)B * 4);
   }
 
+  const bool rep = ctx->rep_seen != nullptr;
+  if (rep) {   // the token fed now is part of HF's input_ids when this step's logits are processed
+    if (ctx->rep_wpr * 32 < w->vocab) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_llm_decode_step: repetition-penalty bitmap narrower than the vocabulary");
+    OWC_TRY(owc_launch_seen_mark(tok_io, slot, B, w->vocab, ctx->rep_seen, ctx->rep_wpr, 0, 0, st));
+  }
   OWC_TRY(owc_launch_embed(tok_io, nullptr, w->embed, nullptr, x, B, d, st));
   // the three mrope streams of a generated token are identical: pos_stride 0 re-reads `pos`
   OWC_TRY(llm_layers(ctx, w, cache, x, h, qkv, attn, mlp, q8, qs, pos, 0, slot, write_idx, q_start, o_start,
@@ -365,14 +380,48 @@ int owc_llm_decode_step(owc_ctx* ctx, const owc_llm_weights* w, const owc_kv_cac
   OWC_TRY(owc_launch_rmsnorm(x, d, w->final_norm_w, last, d, B, d, w->rms_eps, nullptr, st));
   OWC_TRY(owc_launch_gemm_bf16(last, d, w->lm_head_w, d, nullptr, nullptr, 0, logits, w->vocab, B,
                                w->vocab, d, OWC_EPI_NONE, ctx->zeros, st));
-  if (sampling)
+  if (sampling) {
+    if (rep) OWC_TRY(owc_launch_penalize_rows(logits, w->vocab, B, w->vocab, ctx->rep_seen, ctx->rep_wpr, slot, nullptr, ctx->rep_penalty, st));
     OWC_TRY(owc_launch_sample(logits, w->vocab, B, w->vocab, sampling, out_row, step, step_state, tok_io, st));
-  else
+  } else if (rep) {
+    OWC_TRY(owc_launch_argmax_penalized(logits, w->vocab, B, w->vocab, ctx->rep_seen, ctx->rep_wpr, slot, nullptr, ctx->rep_penalty, tok_io, st));
+  } else {
     OWC_TRY(owc_launch_argmax(logits, w->vocab, B, w->vocab, tok_io, st));
+  }
   OWC_TRY(owc_launch_decode_update(tok_io, done, out_tokens, out_stride, step, step_state, B, eos_id0, eos_id1,
                                    pad_id, out_row, forced_tok, st));
   if (step_state) OWC_TRY(owc_launch_decode_advance(pos, write_idx, k_len, step_state, B, st));
   return OWC_OK;
+}
+
+int owc_llm_set_repetition_penalty(owc_ctx* ctx, float penalty, uint32_t* seen, int words_per_row) {
+  if (!ctx) return OWC_ERR_ARG;
+  if (!seen) {
+    ctx->rep_seen = nullptr;
+    ctx->rep_penalty = 1.f;
+    ctx->rep_wpr = 0;
+    return OWC_OK;
+  }
+  if (!(penalty > 0.f) || words_per_row <= 0) OWC_FAIL(ctx, OWC_ERR_ARG, "owc_llm_set_repetition_penalty: need penalty > 0 and words_per_row > 0");
+  ctx->rep_seen = seen;
+  ctx->rep_penalty = penalty;
+  ctx->rep_wpr = words_per_row;
+  return OWC_OK;
+}
+
+int owc_argmax_penalized_bf16(owc_ctx* ctx, const void* logits, int64_t ld, int rows, int vocab, const uint32_t* seen, int words_per_row,
+                              const int32_t* row_slot, float penalty, int32_t* out, void* stream) {
+  if (!ctx || !logits || !seen || !out) return OWC_ERR_ARG;
+  int rc = owc_launch_argmax_penalized(logits, ld, rows, vocab, seen, words_per_row, row_slot, nullptr, penalty, out, (hipStream_t)stream);
+  if (rc != OWC_OK) ctx->err = "owc_argmax_penalized_bf16: bad shape or launch failure";
+  return rc;
+}
+
+int owc_seen_mark(owc_ctx* ctx, const int32_t* ids, const int32_t* slot, int n, int vocab, uint32_t* seen, int words_per_row, void* stream) {
+  if (!ctx || !ids || !seen) return OWC_ERR_ARG;
+  int rc = owc_launch_seen_mark(ids, slot, n, vocab, seen, words_per_row, 0, 0, (hipStream_t)stream);
+  if (rc != OWC_OK) ctx->err = "owc_seen_mark: bad shape or launch failure";
+  return rc;
 }
 
 }  // extern "C"

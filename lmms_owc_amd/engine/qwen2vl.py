@@ -343,6 +343,9 @@ class Qwen2VLEngine:
         self._kv: tuple | None = None      # the engine's grow-only K / V cache pair (reserve_kv)
         self._lib = _lib.load()
         self._ctx = _lib.ctx(self.dev_index)
+        # HF's repetition penalty for every generation of this engine (1.0 = off): a model plug-in sets it from the checkpoint's
+        # generation_config.json (`Qwen2VL.load_model`); `generate(..., repetition_penalty=...)` overrides it per call
+        self.repetition_penalty = 1.0
 
     # -- helpers -----------------------------------------------------------------------
     def _workspace(self, nbytes: int) -> torch.Tensor:
@@ -431,12 +434,27 @@ class Qwen2VLEngine:
         _lib.check(rc, self.dev_index)
 
     # -- decoder -----------------------------------------------------------------------
-    def generate(self, prompts: list, img_embeds: torch.Tensor | None, grids_per_prompt: list, max_new_tokens: int,
+    def generate(self, *args, **kw):
+        """`_generate_impl` (its docstring is the interface) with the context's repetition-penalty option cleared on every exit path."""
+        try:
+            return self._generate_impl(*args, **kw)
+        finally:
+            self._lib.owc_llm_set_repetition_penalty(self._ctx, 1.0, None, 0)
+
+    def _generate_impl(self, prompts: list, img_embeds: torch.Tensor | None, grids_per_prompt: list, max_new_tokens: int,
                  *, eos_token_id: int = -1, pad_token_id: int = 0, stop_check_every: int = 1, compact_rows: bool = True,
                  return_logits: bool = False, img_rows: list | None = None, forced_tokens=None,
                  return_step_logits: bool = False, stats: dict | None = None, sampling: dict | None = None,
-                 carry: dict | None = None):
+                 carry: dict | None = None, repetition_penalty: float | None = None):
         """Greedy generation for a batch of prompts.
+
+        `repetition_penalty` (default: the engine's `self.repetition_penalty`, which a model plug-in sets from the checkpoint's
+        generation_config.json - HF merges that file into every `generate` call the reference makes, greedy ones included,
+        /root/reference/src/models/_qwen2_vl.py:319-329): HF's RepetitionPenaltyLogitsProcessor - before the argmax (or the draw)
+        every token id of the sequence's prompt (image placeholders included) and everything fed to it since gets
+        logit < 0 ? logit * p : logit / p in fp32 (`owc_llm_set_repetition_penalty`, include/owc.h).  1.0 = off.  The penalty is a
+        function of the sequence's own history, so batch invariance holds; straggler hand-over between passes is switched off while
+        it is on (a pass then runs every sequence to its end: the seen-token bitmap lives with the pass's cache slots).
 
         prompts[b]: 1-D int array of token ids holding image_token_id placeholders;
         grids_per_prompt[b]: list of (t, h, w) for that prompt's images, in order;
@@ -474,7 +492,14 @@ class Qwen2VLEngine:
         lens = np.array([len(p) for p in prompts], dtype=np.int64)
         s_max = int(lens.max()) + max_new_tokens
         Hkv, G = d.n_kv_heads, d.n_q_heads // d.n_kv_heads
+        rep = float(self.repetition_penalty if repetition_penalty is None else repetition_penalty)
+        if not rep > 0:
+            raise ValueError("repetition_penalty must be > 0 (1.0 = off)")
         cin = carry.get("in") if carry is not None else None
+        if rep != 1.0 and carry is not None:
+            if cin is not None and len(cin["tags"]):
+                raise ValueError("a carried-in sequence cannot join a pass that runs with a repetition penalty")
+            carry = {**carry, "below": 0, "_caller": carry}   # no hand-over: every sequence ends in this pass
         if carry is not None and (eos_token_id < 0 or return_step_logits or return_logits or self.graph_decode):
             raise ValueError("carry needs EOS handling on and no logits output")
         NC = 0 if cin is None else len(cin["tags"])
@@ -547,6 +572,11 @@ class Qwen2VLEngine:
                                  int(sampling.get("seed", 0)) & 0xFFFFFFFFFFFFFFFF, streams.data_ptr(), step_off.data_ptr())
             samp_ref = C.byref(samp)
 
+        seen = None
+        if rep != 1.0:   # one bitmap row of the vocabulary per cache slot: which ids the sequence has seen (prompt + fed tokens)
+            wpr = (d.vocab + 31) // 32
+            seen = torch.zeros((n_slots, wpr), dtype=I32, device=self.device)
+            _lib.check(self._lib.owc_llm_set_repetition_penalty(self._ctx, rep, seen.data_ptr(), wpr), self.dev_index)
         # ---- prefill in chunks of whole prompts (chunk size counted in packed ROWS: with a shared prefix every
         # prompt contributes len - P rows, so more prompts fit the same GEMM M)
         p_all = self._common_prefix(prompts, 0, B)
@@ -663,6 +693,8 @@ class Qwen2VLEngine:
             self._carry_export(carry, cin, B, NC, n if T_out > 1 else Bx, cur, state, done2, row_of, steps_run, out_tokens, kc, vc,
                                s_max, Bx, max_new_tokens, forced_tokens, pad_token_id, n_slots,
                                None if sampling is None else sid)
+            if "_caller" in carry:   # (repetition penalty: the engine ran on a copy with the hand-over off - hand the results back)
+                carry["_caller"].update({k: v for k, v in carry.items() if k not in ("_caller", "below")})
             out_tokens = out_tokens[:B, :max_new_tokens]
         if stats is not None:
             stats["live_rows_per_step"] = live_per_step
@@ -723,6 +755,9 @@ class Qwen2VLEngine:
         B, k = len(prompts), int(num_beams)
         if k < 2:
             raise ValueError("generate_beam is for num_beams >= 2 (one beam is `generate`)")
+        if float(self.repetition_penalty) != 1.0:
+            raise NotImplementedError("beam search with a repetition penalty (generation_config.json `repetition_penalty` != 1) is not "
+                                      "implemented by the HIP decoder; greedy and sampled one-beam generation are")
         if B == 0:
             out = torch.empty((0, max_new_tokens), dtype=I32, device=self.device)
             return (out, np.zeros(0, np.float32)) if return_scores else out

@@ -162,12 +162,20 @@ class Qwen2VL(PassPipeline, Model):
 
             self._tokenizer = AutoTokenizer.from_pretrained(str(path))
             self.chat_template = getattr(self._tokenizer, "chat_template", None)
-            gc = path / "generation_config.json"   # HF merges it into every generate(): its top_k applies when a request samples
+            # HF merges generation_config.json into every generate() call for the fields the call does not pass.  The reference
+            # passes do_sample / temperature / top_p / num_beams / max_new_tokens / eos / pad (src/models/_qwen2_vl.py:319-329), so
+            # what the file still decides: `top_k` (when a request samples) and `repetition_penalty` - which HF applies to GREEDY
+            # decoding as well (RepetitionPenaltyLogitsProcessor is added whenever the value is not 1.0; the Qwen2-VL / Qwen2.5-VL
+            # instruct checkpoints ship 1.05)
+            gc = path / "generation_config.json"
             if gc.exists():
-                self._default_top_k = int(json.loads(gc.read_text()).get("top_k", 50) or 0)
+                gcfg = json.loads(gc.read_text())
+                self._default_top_k = int(gcfg.get("top_k", 50) or 0)
+                self._repetition_penalty = float(gcfg.get("repetition_penalty") or 1.0)
         self._dims = dims
         self._start_workers()
         self._model = Qwen2VLEngine(weights)
+        self._model.repetition_penalty = float(getattr(self, "_repetition_penalty", 1.0))
         self._processor = self._tokenizer
 
     def loglikelihood(self, requests: list) -> list[tuple[float, bool]]:

@@ -168,6 +168,21 @@ def argmax_bf16(logits):
     return out
 
 
+def seen_mark_(seen, ids, slot=None):
+    """Mark token ids[t] in row slot[t] (None: row t) of the uint32 bitmap `seen` [rows, words] (int32 tensor viewed as bits): `owc_seen_mark`."""
+    _call("owc_seen_mark", _dev(seen), ids.data_ptr(), _lib.ptr(slot), ids.numel(), seen.shape[1] * 32, seen.data_ptr(), seen.shape[1])
+    return seen
+
+
+def argmax_penalized_bf16(logits, seen, penalty: float, row_slot=None):
+    """Greedy argmax of bf16 logits [rows, vocab] under HF's repetition penalty: ids marked in bitmap row row_slot[r] (None: r) of
+    `seen` [slots, words >= vocab / 32] get score < 0 ? score * p : score / p in fp32 first: `owc_argmax_penalized_bf16`."""
+    out = torch.empty((logits.shape[0],), dtype=I32, device=logits.device)
+    _call("owc_argmax_penalized_bf16", _dev(logits), logits.data_ptr(), logits.stride(0), logits.shape[0], logits.shape[1],
+          seen.data_ptr(), seen.shape[1], _lib.ptr(row_slot), float(penalty), out.data_ptr())
+    return out
+
+
 def beam_candidates(logits, k: int):
     """bf16 logits [rows, vocab] -> (logz float32 [rows], top_val float32 [rows, k], top_idx int32 [rows, k]): `owc_beam_candidates`."""
     rows = logits.shape[0]

@@ -247,13 +247,30 @@ def greedy_argmax(logits: np.ndarray) -> np.ndarray:
     return np.argmax(logits, -1)
 
 
+def repetition_penalty_scores(logits: np.ndarray, seen_ids, penalty: float) -> np.ndarray:
+    """HF RepetitionPenaltyLogitsProcessor (transformers generation/logits_process.py; third-party, absent from /root/reference,
+    restated from its published behaviour and PINNED on the installed transformers in tests/test_oracle_sampling.py): the
+    next-token scores are float32; every token id that occurs in `seen_ids` (HF's input_ids: the prompt and everything generated so
+    far) gets score < 0 ? score * penalty : score / penalty - once, however often the id occurs (gather / scatter semantics).
+    In force in the reference whenever the checkpoint's generation_config.json has `repetition_penalty` != 1: HF merges the file's
+    fields into `generate` calls that do not pass them (/root/reference/src/models/_qwen2_vl.py:319-329 does not), greedy or not."""
+    s = np.asarray(logits, np.float32).copy()
+    idx = np.unique(np.asarray(seen_ids, np.int64))
+    p = np.float32(penalty)
+    v = s[idx]
+    s[idx] = np.where(v < 0, v * p, v / p).astype(np.float32)
+    return s
+
+
 def generate(w: dict, cfg: Cfg, input_ids: np.ndarray, pixel_values: np.ndarray | None, grid_thw, max_new_tokens: int,
              *, bf16=False, eos_token_id: int | None = None, pad_token_id: int = 0, return_logits=False, fp8: dict | None = None,
-             forced_tokens=None, vit=None):
+             forced_tokens=None, vit=None, repetition_penalty: float = 1.0):
     """Greedy generation for ONE prompt (reference batch size is 1, src/models/_base.py:103-104):
     HF:1144-1205 (embed + image scatter + rope index) then the GenerationMixin greedy loop.
     `forced_tokens` (teacher forcing, parity tests): the token fed after step j is forced_tokens[j] instead of the
-    argmax, so step j+1's logits are conditional on a given continuation; `out` still holds the argmax."""
+    argmax, so step j+1's logits are conditional on a given continuation; `out` still holds the argmax.
+    `repetition_penalty` != 1: `repetition_penalty_scores` on every step's logits over the prompt ids + the tokens fed so far
+    before the argmax (the returned logits stay the raw ones)."""
     tc = cfg.text
     ids = np.asarray(input_ids).astype(np.int64)
     x = maybe_bf16(w[T + "embed_tokens.weight"][ids], bf16)
@@ -270,8 +287,10 @@ def generate(w: dict, cfg: Cfg, input_ids: np.ndarray, pixel_values: np.ndarray 
     all_logits = [logits[0].copy()]
     out, done = [], False
     cur_len = len(ids)
+    history = [int(t) for t in ids]
     for step in range(max_new_tokens):
-        tok = pad_token_id if done else int(greedy_argmax(logits[0]))
+        scores = logits[0] if repetition_penalty == 1.0 else repetition_penalty_scores(logits[0], history, repetition_penalty)
+        tok = pad_token_id if done else int(greedy_argmax(scores))
         out.append(tok)
         if eos_token_id is not None and tok == eos_token_id:
             done = True
@@ -280,6 +299,7 @@ def generate(w: dict, cfg: Cfg, input_ids: np.ndarray, pixel_values: np.ndarray 
                 break
             continue
         feed = tok if forced_tokens is None else int(forced_tokens[step])
+        history.append(feed)
         x = maybe_bf16(w[T + "embed_tokens.weight"][np.array([feed])], bf16)
         p = np.full((3, 1), cur_len + delta, np.int64)  # HF:1130-1137: arange(past, past+1) + rope_deltas
         h = llm_forward(w, cfg, x, p, cache, bf16=bf16, fp8=fp8)

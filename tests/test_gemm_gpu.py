@@ -390,11 +390,11 @@ def test_gemm_persistent_pingpong_race_screen(gpu, m, n, k, epi):
                                        (12288, 1280, 1280, "quick_gelu"),  # 48 x 5: one group of 5 (the vision proj / fc2 width)
                                        (9000, 3848, 256, "none"),          # ragged M and N; 36 x 16 tiles: two groups of 8
                                        (5000, 5120, 384, "gelu_erf"),      # 20 x 20 tiles: tiles_m == tiles_n, groups 7 / 7 / 6
-                                       (2304, 6400, 384, "none")])         # 9 x 25: fewer tile rows than columns - keeps the rows-of-4 walk
+                                       (2304, 6400, 384, "none")])         # 9 x 25: fewer tile rows than columns (4 groups of 7 / 6 / 6 / 6)
 def test_gemm_tile_walk_does_not_change_a_bit(gpu, m, n, k, epi, persist):
     """Round 6: the block id -> output tile map of the 256x256 ping-pong kernels (`tile_origin`, gemm_bf16.hip) walks column groups of
-    <= 8 tile columns down all tile rows when tiles_m >= tiles_n (knob "gemm_walk", default 1), instead of rows of 4 across all
-    columns: an XCD's 32 co-resident tiles then always span 12-12.6 operand panels instead of up to 16.  A tile is computed the
+    <= 8 tile columns down all tile rows (knob "gemm_walk": 2 for every shape, default 1 = where it measured faster: K >= 2.5 N),
+    instead of rows of 4 across all columns: an XCD's 32 co-resident tiles then always span 12-12.6 operand panels instead of up to 16.  A tile is computed the
     same way wherever it runs: outputs must equal the rounds-1-5 walk bit for bit - which also proves the new map covers every
     tile exactly once (a tile computed twice leaves another one unwritten: the canary below would survive)."""
     from lmms_owc_amd import _lib, ops
@@ -416,7 +416,7 @@ def test_gemm_tile_walk_does_not_change_a_bit(gpu, m, n, k, epi, persist):
         assert lib.owc_tuning_set(b"gemm_walk", 0) == 0
         want = run()
         assert not torch.isnan(want).any()
-        assert lib.owc_tuning_set(b"gemm_walk", 1) == 0
+        assert lib.owc_tuning_set(b"gemm_walk", 2) == 0     # column groups whatever the shape
         for i in range(3):
             got = run()
             assert torch.equal(got, want), (i, (got != want).sum().item())

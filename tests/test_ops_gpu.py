@@ -391,11 +391,18 @@ def test_sampling_top_p_cut_inside_tied_logits(gpu):
         assert (counts[probs == 0] == 0).all(), f"a token outside the kept set was drawn (V={V}, k={k}, p={p}): {np.flatnonzero((counts > 0) & (probs == 0))[:8]}"
         exp = probs * n
         big = exp >= 20
-        z = (counts[big] - exp[big]) / np.sqrt(exp[big] * (1 - probs[big]) + 1e-12)
-        assert np.abs(z).max() < 5.0, (V, k, p, np.abs(z).max())
+        if big.any():
+            z = (counts[big] - exp[big]) / np.sqrt(exp[big] * (1 - probs[big]) + 1e-12)
+            assert np.abs(z).max() < 5.0, (V, k, p, np.abs(z).max())
+        # tokens too rare to test one by one: by VALUE (equal logits = equal probability: the kept part of a run shares its mass evenly)
+        for v in np.unique(row[probs > 0]):
+            idx = np.flatnonzero((row == v) & (probs > 0))
+            e = exp[idx].sum()
+            if e >= 20:
+                assert abs(counts[idx].sum() - e) < 5.0 * np.sqrt(e), (V, k, p, float(v), int(counts[idx].sum()), float(e))
     # top_k 1 + top_p 0.001 at any temperature == the greedy argmax, ties included (lowest index)
     g = torch.Generator(device=gpu).manual_seed(3)
-    for V in (152064, 517):
+    for V in (152064, 520):   # (owc_argmax_bf16 reads 16-byte vectors: row stride a multiple of 8)
         logits = torch.round(torch.randn((256, V), generator=g, device=gpu) * 2).to(torch.bfloat16)   # integer values: many tied maxima
         assert (logits.float() == logits.float().max(dim=1, keepdim=True).values).sum(dim=1).max().item() > 1
         want = ops.argmax_bf16(logits)
@@ -486,3 +493,34 @@ def test_beam_candidates_vs_numpy(gpu, V, k):
     np.testing.assert_allclose(logz, want, rtol=0, atol=2e-5 * max(1.0, np.abs(want).max()))
     with pytest.raises(Exception):
         ops.beam_candidates(x.to(gpu), 65)
+
+
+@pytest.mark.parametrize("V", [152064, 1000, 520])
+def test_penalised_argmax_and_seen_bitmap(gpu, V):
+    """`owc_seen_mark` + `owc_argmax_penalized_bf16` against oracle `repetition_penalty_scores` (pinned on HF's processor): rows that
+    share bitmap rows through `row_slot`, duplicate ids, negative and positive maxima, ties (lowest index), ids at the word edges."""
+    from lmms_owc_amd import ops
+
+    r = np.random.default_rng(V)
+    rows, slots = 48, 7
+    logits = (torch.from_numpy(np.round(r.standard_normal((rows, V)) * 3, 1).astype(np.float32)) - (1.0 if V == 1000 else 0.0)).to(torch.bfloat16)
+    if V == 1000:
+        logits[:8] -= 20.0        # all-negative rows: the penalty multiplies
+    row_slot = r.integers(0, slots, rows)
+    top1 = np.argmax(logits.float().numpy(), 1)
+    # a slot's history: random ids, ids at the bitmap's word edges, and the plain argmax of HALF of the rows that use the slot
+    hist = [np.unique(np.concatenate([r.integers(0, V, 40), [0, 31, 32, V - 1], top1[(row_slot == s) & (np.arange(rows) % 2 == 0)]])) for s in range(slots)]
+    seen = torch.zeros((slots, (V + 31) // 32), dtype=torch.int32, device=gpu)
+    ids = np.concatenate([np.concatenate([h, h[:5]]) for h in hist])          # duplicates are marked once
+    slot_of = np.concatenate([np.full(len(h) + 5, s) for s, h in enumerate(hist)])
+    ops.seen_mark_(seen, i32(ids, gpu), i32(slot_of, gpu))
+    bits = seen.cpu().numpy().view(np.uint32)
+    for s in range(slots):
+        marked = np.flatnonzero(np.unpackbits(np.ascontiguousarray(bits[s]).view(np.uint8), bitorder="little")[:V])
+        assert np.array_equal(marked, hist[s])
+    for penalty in (1.05, 1.5, 0.7):
+        got = to_np(ops.argmax_penalized_bf16(logits.to(gpu), seen, penalty, i32(row_slot, gpu))).astype(int)
+        x = logits.float().numpy()
+        want = np.array([int(np.argmax(Q.repetition_penalty_scores(x[i], hist[row_slot[i]], penalty))) for i in range(rows)])
+        assert np.array_equal(got, want), np.flatnonzero(got != want)
+    assert (want != np.argmax(x, 1)).any()     # the penalty moved some argmax

@@ -422,3 +422,85 @@ def test_beam_search_equals_the_oracle_driven_by_the_engines_own_logits(setup, g
     # and the search is not the greedy path: with beams the best hypothesis differs from the argmax chain on at least one prompt ... or
     # scores at least as well as it (the greedy chain is one of the candidates while it stays among the k best)
     assert got.shape == (len(prompts), T)
+
+
+def _penalised_replay(step_logits, prompt_ids, tokens, penalty, eos=None):
+    """The greedy loop replayed on the host from the engine's own RAW step logits [T, V] (bf16 values): every token must be the
+    lowest-index argmax of `oracle.repetition_penalty_scores` over the prompt ids + the tokens fed before it."""
+    hist = [int(t) for t in prompt_ids]
+    for j in range(step_logits.shape[0]):
+        scores = Q.repetition_penalty_scores(step_logits[j], hist, penalty)
+        want = int(np.argmax(scores))
+        assert int(tokens[j]) == want, (j, int(tokens[j]), want)
+        if eos is not None and want == eos:
+            return j + 1
+        hist.append(want)
+    return step_logits.shape[0]
+
+
+def test_repetition_penalty_matches_hf_processor_semantics(setup, gpu):
+    """Round 6.  HF's RepetitionPenaltyLogitsProcessor is in force in the reference whenever the checkpoint's generation_config.json has
+    `repetition_penalty` != 1 (tests/test_oracle_sampling.py pins that HF merges it into the reference's greedy `generate` call, and
+    pins the oracle's restatement on HF's processor).  Engine: `owc_llm_set_repetition_penalty` - a seen-token bitmap per cache slot
+    marked from the prompt rows at prefill and from the fed token at every decode step, applied in fp32 inside the argmax.
+    Asserted: every token of every row == the host replay of the penalised greedy loop on the engine's own raw step logits (exact);
+    the penalty really decides tokens on this model; batched == alone; shared-prefix prefill == plain prefill; row compaction and
+    EOS change nothing; the option does not leak into the next (un-penalised) call."""
+    from lmms_owc_amd.engine.qwen2vl import Qwen2VLEngine
+
+    cfg, w, eng, g = setup
+    T, p = 10, 1.3
+    cases = []
+    for case in ("a", "b"):
+        grid = [tuple(r) for r in g[f"{case}_grid"].tolist()]
+        cases.append((g[f"{case}_ids"], grid, recipes.pixel_values(grid, 7)))
+    cases.append((recipes.prompt_ids(cfg, [(1, 4, 4)], seed=99), [(1, 4, 4)], recipes.pixel_values([(1, 4, 4)], 8)))
+    pix_all = np.concatenate([c[2] for c in cases])
+    grids_all = [gg for c in cases for gg in c[1]]
+    emb = eng.encode_images(torch.from_numpy(pix_all).to(torch.bfloat16).to(gpu), grids_all)
+    prompts, grids = [c[0] for c in cases], [c[1] for c in cases]
+    plain = to_np(eng.generate(prompts, emb, grids, T)).astype(int)
+    toks, sl = eng.generate(prompts, emb, grids, T, repetition_penalty=p, return_step_logits=True)
+    toks, sl = to_np(toks).astype(int), to_np(sl)
+    for b in range(len(cases)):
+        _penalised_replay(sl[:, b], prompts[b], toks[b], p)
+    assert (toks != plain).any(), "the penalty decided no token on this model: the test would not see a missing penalty"
+    assert np.array_equal(to_np(eng.generate(prompts, emb, grids, T)).astype(int), plain), "the option leaked into the next call"
+    # alone == in the batch
+    off = 0
+    for b, (ids, grid, pix) in enumerate(cases):
+        n = sum(t * h * w_ // 4 for t, h, w_ in grid)
+        alone = to_np(eng.generate([ids], emb[off:off + n], [grid], T, repetition_penalty=p))[0].astype(int)
+        off += n
+        assert np.array_equal(alone, toks[b]), (b, alone, toks[b])
+    # the engine attribute is the default (what a plug-in sets from generation_config.json)
+    eng.repetition_penalty = p
+    try:
+        assert np.array_equal(to_np(eng.generate(prompts, emb, grids, T)).astype(int), toks)
+    finally:
+        eng.repetition_penalty = 1.0
+    # shared-prefix prefill (prefix rows marked in every slot of the launch) == plain prefill
+    r = np.random.default_rng(5)
+    head = r.integers(10, 400, 7)
+    text = [np.concatenate([head, r.integers(10, 400, 3 + i)]).astype(np.int64) for i in range(5)]
+    none = [[] for _ in text]
+    shared = Qwen2VLEngine(eng.w, vit_chunk_tokens=64, prefill_chunk_tokens=4096, share_prefix=True, min_shared_prefix=2)
+    unshared = Qwen2VLEngine(eng.w, vit_chunk_tokens=64, prefill_chunk_tokens=4096, share_prefix=False)
+    a = to_np(shared.generate(text, None, none, T, repetition_penalty=p))
+    b_ = to_np(unshared.generate(text, None, none, T, repetition_penalty=p))
+    assert np.array_equal(a, b_)
+    # EOS + row compaction: the bitmap lives with the cache SLOT, so dropping finished rows changes nothing
+    eos = int(a[0, 3])
+    kw = dict(eos_token_id=eos, pad_token_id=0, repetition_penalty=p)
+    c1 = to_np(unshared.generate(text, None, none, T, compact_rows=False, **kw))
+    c2 = to_np(unshared.generate(text, None, none, T, compact_rows=True, **kw))
+    assert np.array_equal(c1, c2)
+    for i in range(len(text)):
+        stop = np.flatnonzero(a[i] == eos)
+        n_keep = (stop[0] + 1) if len(stop) else T
+        assert np.array_equal(c1[i, :n_keep], a[i, :n_keep]) and (c1[i, n_keep:] == 0).all()
+    # sampled requests: penalised values written back as bf16 in front of the draw - runs, is a function of the seed
+    smp = {"temperature": 0.8, "top_k": 20, "top_p": 0.9, "seed": 7}
+    s1 = to_np(unshared.generate(text, None, none, T, sampling=smp, repetition_penalty=p))
+    s2 = to_np(unshared.generate(text, None, none, T, sampling=smp, repetition_penalty=p))
+    assert np.array_equal(s1, s2) and s1.min() >= 0 and s1.max() < 512

@@ -88,14 +88,14 @@ def main():
         # --bias: with a bias vector; --epi=residual|quick_gelu: that epilogue (residual: added into the output in place)
         with_bias = "--bias" in sys.argv
         epi_name = next((a[6:] for a in sys.argv[1:] if a.startswith("--epi=")), "none")
-        epi = {"none": ops.EPI_NONE, "quick_gelu": _lib.EPI_QUICK_GELU, "residual": _lib.EPI_RESIDUAL}[epi_name]
+        epi = {"none": ops.EPI_NONE, "quick_gelu": _lib.EPI_QUICK_GELU, "residual": _lib.EPI_RESIDUAL, "swiglu": ops.EPI_SWIGLU}[epi_name]
         for name, m, n, k in SHAPES:
             if only and not name.startswith(only):
                 continue
             m = m_over or m
             a = torch.randn(m, k, device=dev).to(torch.bfloat16)
             w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
-            out = torch.zeros(m, n, dtype=torch.bfloat16, device=dev)
+            out = torch.zeros(m, n // 2 if epi_name == "swiglu" else n, dtype=torch.bfloat16, device=dev)
             bias = torch.randn(n, device=dev).to(torch.bfloat16) if with_bias else None
             kw = dict(epilogue=epi, residual=out if epi_name == "residual" else None)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
