@@ -814,6 +814,9 @@ def main() -> None:
                     help="skip the Qwen2-VL-72B fp8 (256 images) and LLaVA-NeXT-34B (16 images) legs that run after the CPU baseline on one GPU")
     ap.add_argument("--big-leg-budget-s", type=float, default=600.0,
                     help="seconds since process start after which a big-model leg is not started any more")
+    ap.add_argument("--shape-table", default=None, metavar="CSV",
+                    help="write the timed region's bf16 GEMM launches grouped by (M, N, K, epilogue) - launches, total / avg / min / max "
+                         "time, TFLOP/s - to this CSV (the line's roofline.by_shape holds the first 12 rows)")
     ap.add_argument("--total-budget-s", type=float, default=840.0,
                     help="seconds since process start after which a still-running big-model leg is abandoned: the line is printed "
                          "with that leg marked skipped and the process exits 0")
@@ -947,6 +950,25 @@ def main() -> None:
         _lib.check(lib.owc_profile_read(ctx, NK, ms, wk, n), local)
         return {k: {"ms": ms[i], "work": wk[i], "launches": int(n[i])} for i, k in enumerate(_lib.PROF_KINDS)}
 
+    def read_shape_table(peak_tflops: float) -> list:
+        """The bf16 GEMM launches of the profile just read, one row per (M, N, K, epilogue): what `roofline.achieved` is the sum of.
+        A reader can redo the arithmetic: tflops = 2 M N K / avg_us / 1e6; sum(launches * 2MNK) / sum(total_us) = roofline.achieved."""
+        cap = 512
+        shp, st = (C.c_int32 * (4 * cap))(), (C.c_double * (4 * cap))()
+        cnt = lib.owc_profile_shapes(ctx, cap, shp, st)
+        epi = {0: "none", 1: "quick_gelu", 2: "gelu_erf", 3: "residual", 4: "swiglu", 5: "f32", 6: "vision_rope"}
+        rows = []
+        for i in range(max(0, min(cnt, cap))):
+            m, n_, k, e = (int(shp[4 * i + j]) for j in range(4))
+            launches, tot, mn, mx = int(st[4 * i]), st[4 * i + 1], st[4 * i + 2], st[4 * i + 3]
+            flop = 2.0 * m * n_ * k
+            rows.append({"M": m, "N": n_, "K": k, "epilogue": epi.get(e, str(e)), "launches": launches, "total_ms": tot,
+                         "avg_us": tot / launches * 1e3, "min_us": mn * 1e3, "max_us": mx * 1e3, "flop_per_launch": flop,
+                         "tflops": flop * launches / (tot * 1e-3) / 1e12 if tot > 0 else 0.0,
+                         "frac_of_peak": flop * launches / (tot * 1e-3) / 1e12 / peak_tflops if tot > 0 else 0.0})
+        rows.sort(key=lambda r: -r["total_ms"])
+        return rows
+
     for _ in range(args.warmup):
         step()
     sync()
@@ -968,10 +990,20 @@ def main() -> None:
     dt_local = time.perf_counter() - t0          # barrier-bracketed: what `value` is computed from (max over ranks)
     dt_own = t_own - t0                          # without the wait for the other ranks: the per-rank rates
     prof = read_profile() if rank == 0 else None
+    shape_table = read_shape_table(PEAK_BF16_TFLOPS) if rank == 0 else None
     lib.owc_gemm_profile_enable(ctx, 0)
     if calib is not None:
         calib.run()
         sync()
+    if rank == 0 and args.shape_table and shape_table:
+        import csv
+
+        with open(args.shape_table, "w", newline="") as fh:
+            wr = csv.writer(fh)
+            wr.writerow(["M", "N", "K", "epilogue", "launches", "total_ms", "avg_us", "min_us", "max_us", "flop_per_launch", "tflops", "frac_of_peak"])
+            for r in shape_table:
+                wr.writerow([r["M"], r["N"], r["K"], r["epilogue"], r["launches"], f"{r['total_ms']:.4f}", f"{r['avg_us']:.2f}", f"{r['min_us']:.2f}",
+                             f"{r['max_us']:.2f}", f"{r['flop_per_launch']:.6g}", f"{r['tflops']:.1f}", f"{r['frac_of_peak']:.4f}"])
     lap("warmup_and_timed_steps")
     fp8_run = args.decoder_dtype == "fp8"
     assert out.shape == (B, T)
@@ -1174,7 +1206,12 @@ def main() -> None:
                          "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tflops / peak,
                          "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_source": traffic,
                          "launches": g["launches"], "kernel_ms_total": g["ms"], "share_of_step_time": g["ms"] * 1e-3 / time_or(dt),
-                         "method": "HIP events around every launch of the timed region on the launch stream; achieved = sum(2MNK) / sum(t)"},
+                         "method": "HIP events around every launch of the timed region on the launch stream; achieved = sum(2MNK) / sum(t)",
+                         # the 12 shapes that hold the most time (the full table: --shape-table FILE); `shapes` = how many there are
+                         "by_shape": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items() if k != "flop_per_launch"}
+                                      for r in (shape_table or [])[:12]],
+                         "shapes": len(shape_table or []),
+                         "by_shape_covers_ms": sum(r["total_ms"] for r in (shape_table or [])[:12])},
             "roofline_attention": attention_rooflines(prof, dims, B, T, args.steps, dt),
             "roofline_decode": decode_leg,
             "eos_terminated": eos_leg,

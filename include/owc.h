@@ -106,6 +106,10 @@ enum owc_prof_kind {
   OWC_PROF_KINDS = 7
 };
 int owc_profile_read(owc_ctx* ctx, int n_kinds, double* total_ms, double* total_work, int64_t* launches);
+/* The bf16 GEMM launches of the last owc_profile_read / owc_gemm_profile_read, grouped by shape (round 6: the per-SHAPE table a
+ * roofline fraction can be recomputed from).  Entry i: shape[4 i ..] = (M, N, K, epilogue), stats[4 i ..] = (launches, total ms,
+ * min ms, max ms) of its launches.  Returns the number of distinct shapes (entries beyond max_n are not written), -1 on bad arguments. */
+int owc_profile_shapes(owc_ctx* ctx, int max_n, int32_t* shape, double* stats);
 
 /* ---- op level (each is one kernel launch; used by the model drivers below and by tests) ------ */
 

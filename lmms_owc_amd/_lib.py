@@ -156,6 +156,7 @@ SIGNATURES: dict[str, tuple] = {
     "owc_gemm_profile_enable": (i32, [vp, i32]),
     "owc_gemm_profile_read": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "owc_profile_read": (i32, [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "owc_profile_shapes": (i32, [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
 }
 
 PROF_KINDS = ("gemm_bf16", "gemm_fp8", "attn_vision", "attn_prefill", "scorer_gemm", "cosine_topk", "attn_decode")   # enum owc_prof_kind

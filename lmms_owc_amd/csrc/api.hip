@@ -288,4 +288,9 @@ int owc_profile_read(owc_ctx* ctx, int n_kinds, double* total_ms, double* total_
   RET(ctx, "owc_profile_read", rc);
 }
 
+int owc_profile_shapes(owc_ctx* ctx, int max_n, int32_t* shape, double* stats) {
+  if (!ctx || !shape || !stats || max_n <= 0) return -1;
+  return owc_profile_shapes_collect(max_n, shape, stats);
+}
+
 }  // extern "C"

@@ -29,17 +29,28 @@
 
 int owc_gemm_profile_begin(double flops, int kind, hipStream_t s);
 void owc_gemm_profile_end(int handle, hipStream_t s);
+static int gemm_profile_begin_shape(int M, int N, int K, int epi, hipStream_t s);
 
 namespace {
 
 // ---- optional live profiling of THIS kernel (bench.py roofline leg): one HIP-event pair per launch on
 // the launch stream, summed by owc_gemm_profile_read().  Off by default (zero cost).
+struct ShapeKey {
+  int m = 0, n = 0, k = 0, epi = -1;
+};
+struct ShapeStat {
+  ShapeKey key;
+  long launches = 0;
+  double total_ms = 0.0, min_ms = 0.0, max_ms = 0.0;
+};
 struct GemmProfile {
   bool on = false;
   std::vector<hipEvent_t> ev;  // start/stop pairs
   std::vector<double> flops;
   std::vector<int> kind;  // OWC_PROF_* launch class (include/owc.h)
+  std::vector<ShapeKey> shape;   // (M, N, K, epilogue) of a bf16 GEMM launch; epi = -1: not recorded for this launch class
   size_t used = 0;
+  std::vector<ShapeStat> last_shapes;   // the bf16 GEMM launches of the last collect, grouped by shape (owc_profile_shapes)
 };
 GemmProfile g_prof;
 int g_gemm_dbg = 0;       // timing-experiment knob (owc_tuning_set "gemm_dbg" of the -DOWC_TIMING_KNOBS build only), results are garbage unless 0 or 512:
@@ -1690,7 +1701,7 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
       return OWC_ERR_HIP;
     attr_set = true;
   }
-  const int prof = owc_gemm_profile_begin(2.0 * (double)M * (double)N * (double)K, 0, s);
+  const int prof = gemm_profile_begin_shape(M, N, K, EPI, s);
   // (the wide ring tiles below beat the skinny kernel on their shapes at every M: 48.5 us against 53.9 ... 70.1 us at M = 1 ... 32)
   const bool wide = g_tall_tiles && (K % BK) == 0 && (EPI == OWC_EPI_NONE || EPI == OWC_EPI_SWIGLU) && M <= 128 &&
                     (N + 159) / 160 <= 256 && (N + 159) / 160 >= g_wide_min_blocks;
@@ -1902,7 +1913,7 @@ static int launch_ring_norma(const void* X, long ldx, const void* gamma, float e
   aux.gamma = gamma;
   aux.eps = eps;
   const int tn_ = (N + TN_ - 1) / TN_;
-  const int prof = owc_gemm_profile_begin(2.0 * (double)M * (double)N * (double)K, 0, s);
+  const int prof = gemm_profile_begin_shape(M, N, K, EPI, s);
   hipLaunchKernelGGL((gemm_bf16_nt_64_kernel<EPI, NS_, false, 32, TN_, KPS_, true>), dim3(tn_), dim3(256), lds_bytes, s, (const bf16_t*)X,
                      ldx, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)nullptr, 0, C, ldc, M, N, K, nullptr, 1, tn_, aux);
   owc_gemm_profile_end(prof, s);
@@ -1937,7 +1948,7 @@ int owc_launch_gemm_bf16_rmsnorm(const void* X, long ldx, const void* gamma, flo
       return OWC_ERR_HIP;
     attr_set = true;
   }
-  const int prof = owc_gemm_profile_begin(2.0 * (double)M * (double)N * (double)K, 0, s);
+  const int prof = gemm_profile_begin_shape(M, N, K, epi, s);
   if (swiglu) {
     hipLaunchKernelGGL((gemm_bf16_skinny_norm_kernel<OWC_EPI_SWIGLU, 5>), dim3(N / 32), dim3(64), lds_bytes, s, (const bf16_t*)X, ldx,
                        (const bf16_t*)gamma, eps, (const bf16_t*)W, ldw, (const bf16_t*)bias, (bf16_t*)C, ldc, M, N, K);
@@ -1978,8 +1989,22 @@ int owc_gemm_profile_begin(double flops, int kind, hipStream_t s) {
   g_prof.used += 2;
   g_prof.flops.push_back(flops);
   g_prof.kind.push_back(kind);
+  g_prof.shape.push_back(ShapeKey());
   (void)hipEventRecord(g_prof.ev[idx], s);
   return idx;
+}
+
+// ... the same for a bf16 GEMM launch, which also records its shape: the per-shape table of the timed region (owc_profile_shapes)
+static int gemm_profile_begin_shape(int M, int N, int K, int epi, hipStream_t s) {
+  const int h = owc_gemm_profile_begin(2.0 * (double)M * (double)N * (double)K, 0, s);
+  if (h >= 0) {
+    ShapeKey& key = g_prof.shape.back();
+    key.m = M;
+    key.n = N;
+    key.k = K;
+    key.epi = epi;
+  }
+  return h;
 }
 
 void owc_gemm_profile_end(int handle, hipStream_t s) {
@@ -1995,6 +2020,7 @@ int owc_profile_collect(int n_kinds, double* total_ms, double* total_work, long*
     launches[k] = 0;
   }
   const size_t n = g_prof.used / 2;
+  g_prof.last_shapes.clear();
   for (size_t i = 0; i < n; ++i) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return OWC_ERR_HIP;
@@ -2003,11 +2029,49 @@ int owc_profile_collect(int n_kinds, double* total_ms, double* total_work, long*
     total_ms[k] += t;
     total_work[k] += g_prof.flops[i];
     ++launches[k];
+    const ShapeKey& key = g_prof.shape[i];
+    if (key.epi >= 0) {   // a bf16 GEMM launch: group by (M, N, K, epilogue) - a few dozen distinct shapes per model, linear search
+      ShapeStat* st = nullptr;
+      for (auto& c : g_prof.last_shapes)
+        if (c.key.m == key.m && c.key.n == key.n && c.key.k == key.k && c.key.epi == key.epi) {
+          st = &c;
+          break;
+        }
+      if (!st) {
+        g_prof.last_shapes.push_back(ShapeStat());
+        st = &g_prof.last_shapes.back();
+        st->key = key;
+        st->min_ms = st->max_ms = t;
+      }
+      ++st->launches;
+      st->total_ms += t;
+      st->min_ms = t < st->min_ms ? t : st->min_ms;
+      st->max_ms = t > st->max_ms ? t : st->max_ms;
+    }
   }
   g_prof.used = 0;
   g_prof.flops.clear();
   g_prof.kind.clear();
+  g_prof.shape.clear();
   return OWC_OK;
+}
+
+// The bf16 GEMM launches of the LAST owc_profile_collect grouped by shape: entry i = shape[4 i ..] = (M, N, K, epilogue),
+// stats[4 i ..] = (launches, total ms, min ms, max ms).  Returns the number of distinct shapes (which may exceed max_n: call again).
+int owc_profile_shapes_collect(int max_n, int* shape, double* stats) {
+  const int n = (int)g_prof.last_shapes.size();
+  for (int i = 0; i < n && i < max_n; ++i) {
+    const ShapeStat& c = g_prof.last_shapes[i];
+    shape[4 * i] = c.key.m;
+    shape[4 * i + 1] = c.key.n;
+    shape[4 * i + 2] = c.key.k;
+    shape[4 * i + 3] = c.key.epi;
+    stats[4 * i] = (double)c.launches;
+    stats[4 * i + 1] = c.total_ms;
+    stats[4 * i + 2] = c.min_ms;
+    stats[4 * i + 3] = c.max_ms;
+  }
+  return n;
 }
 
 int owc_gemm_profile_collect(double* total_ms, double* total_flops, long* launches) {  // classes 0 (bf16 GEMM), 1 (fp8 GEMM)

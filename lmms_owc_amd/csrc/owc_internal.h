@@ -88,6 +88,7 @@ void owc_gemm_profile_set(int on);
 int owc_gemm_profile_collect(double* total_ms, double* total_flops, long* launches);  // arrays of 2: [bf16, fp8]
 int owc_profile_collect(int n_kinds, double* total_ms, double* total_work, long* launches);  // OWC_PROF_* classes [0, n_kinds)
 int owc_gemm_profile_begin(double flops, int kind, hipStream_t s);
+int owc_profile_shapes_collect(int max_n, int* shape, double* stats);
 void owc_gemm_profile_end(int handle, hipStream_t s);
 void owc_gemm_set_big_min_m(int m);
 void owc_gemm_set_dbg(int v);

@@ -523,4 +523,5 @@ def test_penalised_argmax_and_seen_bitmap(gpu, V):
         x = logits.float().numpy()
         want = np.array([int(np.argmax(Q.repetition_penalty_scores(x[i], hist[row_slot[i]], penalty))) for i in range(rows)])
         assert np.array_equal(got, want), np.flatnonzero(got != want)
-    assert (want != np.argmax(x, 1)).any()     # the penalty moved some argmax
+        if penalty > 1:
+            assert (want != np.argmax(x, 1)).any()     # the penalty moved some argmax (the plain maximum of half the rows is in their history)

@@ -30,6 +30,9 @@ def main() -> None:
     ap.add_argument("--command", default="")
     ap.add_argument("--seq", type=int, default=None, help="measurement sequence number (bench.py reads the highest one of a kernel); "
                                                           "default: one more than the highest under profiles/")
+    ap.add_argument("--grid", type=int, default=None,
+                    help="only dispatches with this Grid_Size (threads): picks ONE shape out of a whole-program trace - the 7B gate/up "
+                         "launch of bench.py's timed region is gemm_bf16_nt_256pp_kernel<4> with 256 x 148 blocks x 512 threads = 19398656")
     ap.add_argument("passes", nargs="+")
     a = ap.parse_args()
     acc, cnt = collections.defaultdict(float), collections.Counter()
@@ -40,7 +43,7 @@ def main() -> None:
                 rd = csv.DictReader(fh)
                 header = header or rd.fieldnames
                 for r in rd:
-                    if a.kernel in r["Kernel_Name"]:
+                    if a.kernel in r["Kernel_Name"] and (a.grid is None or int(r["Grid_Size"]) == a.grid):
                         acc[r["Counter_Name"]] += float(r["Counter_Value"])
                         cnt[r["Counter_Name"]] += 1
                         raw_rows.append([r.get(k, "") for k in header])
