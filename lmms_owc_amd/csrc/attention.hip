@@ -395,6 +395,653 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 6: the vision towers' attention (non-causal, head_dim 80 / 64) on v_mfma_f32_32x32x16_bf16.
+//
+// Why another MFMA shape.  Round 5's counters on attn_fwd_kernel<80>: matrix pipe busy 37 % of the cycles, vector ALU 56 % - and the
+// two ADD UP: a 16x16x32 MFMA occupies its SIMD's matrix pipe for 16 cycles and holds the SIMD's vector issue for 8 of them
+// (MI355X_MICROARCH.md, "vector-instruction ISSUE cost"), so at best half of an MFMA's time can carry other instructions.  The
+// 32x32x16 MFMA does the same work per cycle (32 cycles for 4 x the output) but holds the vector issue for 8 of its 32: three
+// quarters of the matrix time are open to the softmax's vector work and the LDS reads.  Per wave and 64-key tile (32 query rows,
+// head_dim 80): matrix time 704 cycles either way (QK^T 10 x 32 + PV 12 x 32 against 24 x 16 + 20 x 16), open issue cycles 528
+// against 352, for ~620 cycles of exp2 / fma / add / cvt and ~130 of LDS issue.  head_dim 80 = 5 k-steps of 16: no padded half step
+// in QK^T (the 32-deep MFMA ran 3 steps for 2.5); PV pays instead (3 d blocks of 32 for 2.5).
+//
+// Layout (one 256-thread block = 4 waves = 128 query rows of one (image, head); wave = 32 rows; lane = (q = l & 31, hi = l >> 5)):
+//  * S^T = K . Q^T in two 32-key blocks: A = K rows (lane: S^T row i = l & 31 -> key pi(i) of the block, dims 16 ks + 8 hi ..),
+//    B = Q (registers, loaded once).  The accumulator of lane (q, hi) holds S^T rows i = (r & 3) + 8 (r >> 2) + 4 hi, r = 0..15: one
+//    QUERY per lane, 16 of the block's 32 keys; the other 16 live in lane l ^ 32 (a row maximum is one permlane32 swap).
+//  * P never leaves the registers: registers 8h .. 8h + 7 of key block kb, rounded to bf16, ARE the B operand of PV k-step (kb, h)
+//    (16 keys each); the A operand V^T takes the same keys in the same slots through two transposing LDS reads (4 keys each).
+//  * pi: WHICH key a S^T row stands for is free (it permutes S^T rows and P slots consistently); it is chosen - with a per-row
+//    rotation of the 16-byte chunks of the LDS image - so that both the K row reads (ds_read_b128, 32 rows at one chunk) and the
+//    V transposing reads (4 keys x 64 bytes per half wave) are bank-conflict free on natural 160-byte / 128-byte rows
+//    (exhaustive search over bit permutations of i and rotations against the bank model of MI355X_MICROARCH.md "LDS"):
+//      head_dim 80:  pi(i) = bits (i0 -> 1, i1 -> 2, i2 -> 0, i3 -> 3, i4 -> 4), chunk' = (chunk + ((row >> 3) & 1)) mod 10
+//      head_dim 64:  pi(i) = bits (i0 -> 0, i1 -> 3, i2 -> 1, i3 -> 2, i4 -> 4), chunk' = (chunk + ((row >> 1) & 7)) mod 8
+//  * online softmax with the LAZY reference maximum of attn_fwd_kernel (same rule, same threshold; a row is two lanes here).
+// Results differ from attn_fwd_kernel in the last bits only (another summation order inside the MFMAs); accuracy against a float64
+// attention: tests/test_attention_accuracy_gpu.py (same bounds, both kernels).  `owc_tuning_set("attn_mfma32", 0)` selects the
+// 16x16x32 kernel again.
+// ------------------------------------------------------------------------------------------------------------------------
+int g_attn_mfma32 = 1;
+
+template <int HD>
+struct Cfg32 {
+  static constexpr int CPR = HD / 8;
+  static constexpr int ROWB = HD * 2;
+  static constexpr int TILE = KB * ROWB;
+  static constexpr int NP = TILE / 1024;
+  static constexpr int KS16 = HD / 16;          // 16-deep k-steps of QK^T
+  static constexpr int DB = (HD + 31) / 32;     // 32-wide d blocks of O (head_dim 80: the third one half used)
+  __device__ static __forceinline__ int pi(int i) {   // S^T row of a 32-key block -> key of the block
+    if constexpr (HD == 80) return ((i & 1) << 1) | ((i & 2) << 1) | ((i & 4) >> 2) | (i & 24);
+    else return (i & 1) | ((i & 2) << 2) | ((i & 4) >> 1) | ((i & 8) >> 1) | (i & 16);
+  }
+  __device__ static __forceinline__ int rot(int row) {   // chunk rotation of a tile row
+    if constexpr (HD == 80) return (row >> 3) & 1;
+    else return (row >> 1) & 7;
+  }
+  __device__ static __forceinline__ int chunk(int row, int c) {   // position of source chunk c in the LDS row
+    const int x = c + rot(row);
+    return x >= CPR ? x - CPR : x;
+  }
+};
+
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(
+    const bf16_t* __restrict__ Q, long q_ts, long q_hs, const bf16_t* __restrict__ K, long k_ts,
+    long k_hs, const bf16_t* __restrict__ V, long v_ts, long v_hs, bf16_t* __restrict__ O, long o_ts,
+    long o_hs, const int* __restrict__ q_start, const int* __restrict__ o_start,
+    const int* __restrict__ k_start, const int* __restrict__ seq_len, int n_heads, int kv_group, int nqb,
+    int n_pairs, float scale_log2e) {
+  using C = Cfg32<HD>;
+  static_assert(HD == 80 || HD == 64, "layouts searched for head_dim 80 and 64");
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // [2 buf][K tile | V tile]
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int ql = l & 31, hi = l >> 5;
+
+  const int bid = blockIdx.x;
+  int qb, pair;
+  if ((n_pairs & 7) == 0) {
+    qb = (bid >> 3) % nqb;
+    pair = (bid / (8 * nqb)) * 8 + (bid & 7);
+  } else {
+    qb = bid % nqb;
+    pair = bid / nqb;
+  }
+  const int b = pair / n_heads, h0 = pair % n_heads;
+  const int hk = h0 / kv_group;
+  const int L = seq_len[b];
+  if (qb * QB >= L) return;
+  const bool active = (qb * QB + w * 32) < L;   // wave-uniform: waves without rows only stage tiles
+  const long qs = q_start[b], ks0 = k_start[b];
+  const long os = o_start ? (long)o_start[b] : qs;
+  const int ntiles = (L + KB - 1) / KB;
+
+  // ---- Q fragments (B operand): lane = query column ql, dims 16 ks + 8 hi .. + 7
+  const int qrow = qb * QB + w * 32 + ql;
+  bf16x8 qf[C::KS16];
+  {
+    const bf16_t* qp = Q + (qs + min(qrow, L - 1)) * q_ts + (long)h0 * q_hs;
+#pragma unroll
+    for (int ks = 0; ks < C::KS16; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16 + hi * 8);
+  }
+
+  // ---- staging: piece p = w + 4 i of a tile's 2 NP pieces (K first, then V); LDS position (row, c') <- source chunk c' - rot(row)
+  const bf16_t* Kb = K + (long)hk * k_hs;
+  const bf16_t* Vb = V + (long)hk * v_hs;
+  constexpr int NPW = (2 * C::NP + 3) / 4;
+  constexpr bool STATIC_KV = (C::NP % 4) == 0;
+  const char* Kseq = (const char*)(Kb + ks0 * k_ts);
+  const char* Vseq = (const char*)(Vb + ks0 * v_ts);
+  auto piece_isv = [&](int i) { return STATIC_KV ? (4 * i >= C::NP) : (w + 4 * i >= C::NP); };
+  auto piece_row = [&](int i) {
+    const int pp = w + 4 * i - (piece_isv(i) ? C::NP : 0);
+    return (pp * 64 + l) / C::CPR;
+  };
+  unsigned poff[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int pp = w + 4 * i - (piece_isv(i) ? C::NP : 0);
+    const int ci = pp * 64 + l;
+    const int row = ci / C::CPR;
+    const int cp = ci - row * C::CPR;                 // position in the LDS row
+    int c = cp - C::rot(row);                         // the source chunk that belongs there
+    c = c < 0 ? c + C::CPR : c;
+    poff[i] = (unsigned)((long)row * (piece_isv(i) ? v_ts : k_ts) * 2 + c * 16);
+  }
+  auto stage = [&](int buf, int t) {
+    char* base = lds + buf * (2 * C::TILE);
+    if ((t * KB + KB) <= L) {
+      const char* kt0 = Kseq + (long)t * KB * k_ts * 2;
+      const char* vt0 = Vseq + (long)t * KB * v_ts * 2;
+      asm volatile("" : "+s"(kt0), "+s"(vt0));
+#pragma unroll
+      for (int i = 0; i < NPW; ++i)
+        if (w + 4 * i < 2 * C::NP) {
+          const bool isv = piece_isv(i);
+          glds16((isv ? vt0 : kt0) + poff[i], base + (isv ? C::TILE - C::NP * 1024 : 0) + (w + 4 * i) * 1024);
+        }
+    } else {   // the ragged last tile: rows beyond the sequence re-read its last row (their scores are masked below)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < NPW; ++i)
+        if (w + 4 * i < 2 * C::NP) {
+          const bool isv = piece_isv(i);
+          const long ts2 = (isv ? v_ts : k_ts) * 2;
+          const int row = piece_row(i);
+          const char* src = (isv ? Vseq : Kseq) + (long)min(t * KB + row, L - 1) * ts2 + (poff[i] - (unsigned)((long)row * ts2));
+          glds16(src, base + (isv ? C::TILE - C::NP * 1024 : 0) + (w + 4 * i) * 1024);
+        }
+    }
+  };
+
+  f32x16 o[C::DB];
+#pragma unroll
+  for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float nmc = 0.f, lrun = 0.f;   // -m_ref * c of the lane's query row (uniform over the row's two lanes), its running sum
+  constexpr float LAZY_BIG = 1024.f;
+
+  // fragment addresses inside a tile (bytes): K row reads and the two V transposing reads of a k-step
+  const int krow_b = C::pi(ql);                                   // key of a block this lane's S^T row stands for
+  int koff[C::KS16];                                              // K: row krow_b, source chunk 2 ks + hi
+#pragma unroll
+  for (int ks = 0; ks < C::KS16; ++ks) koff[ks] = krow_b * C::ROWB + C::chunk(krow_b, 2 * ks + hi) * 16;
+  // V: lane (16-lane group gp = l >> 4, its row qq = (l & 15) >> 2, column quad p4 = l & 3) supplies the address of key
+  //    pi(qq + 4 hi + 8 rd + 16 h) of block kb, columns 32 db + 16 (gp & 1) + 4 p4 ..
+  const int vq = (l & 15) >> 2, vp4 = l & 3, vg = (l >> 4) & 1;
+
+  stage(0, 0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntiles) stage(cur ^ 1, t + 1);
+    const char* kt_ = lds + cur * (2 * C::TILE);
+    const char* vt_ = kt_ + C::TILE;
+    if (active) {
+      // ---- S^T = K . Q^T, two 32-key blocks
+      f32x16 s[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < C::KS16; ++ks) {
+          const bf16x8 kf = *(const bf16x8*)(kt_ + kb * 32 * C::ROWB + koff[ks]);
+          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+        }
+      }
+      // ---- ragged last tile: keys beyond the sequence (a real, wave-uniform branch)
+      if (t * KB + KB > L) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = t * KB + kb * 32 + C::pi((r & 3) + 8 * (r >> 2) + 4 * hi);
+            if (key >= L) s[kb][r] = -1e30f;
+          }
+      }
+      // ---- online softmax, lazy reference maximum (attn_fwd_kernel's rule; the row's other half is lane l ^ 32)
+      float x[2][16];
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float pa = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], scale_log2e, nmc));
+          const float pb = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r + 1], scale_log2e, nmc));
+          x[kb][r] = pa;
+          x[kb][r + 1] = pb;
+          s0 += pa;
+          s1 += pb;
+        }
+      asm volatile("" : "+v"(s0), "+v"(s1));
+      float sum = s0 + s1;
+      if (t == 0 || __builtin_amdgcn_ballot_w64(sum > LAZY_BIG) != 0) {
+        asm volatile("" ::: "memory");
+        float mx = -1e30f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        {   // the row's maximum / whether the row asks: over its two lanes
+          const unsigned u = __float_as_uint(mx);
+          const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+          mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        float ask = sum > LAZY_BIG ? 1.f : 0.f;
+        {
+          const unsigned u = __float_as_uint(ask);
+          const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+          ask = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float over = __builtin_fmaf(mx, scale_log2e, nmc);
+        const float d = (t == 0) ? over : (ask > 0.f ? over : 0.f);
+        if (t != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(-d);
+          lrun *= alpha;
+#pragma unroll
+          for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+        nmc -= d;
+        s0 = 0.f;
+        s1 = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const float pa = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], scale_log2e, nmc));
+            const float pb = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r + 1], scale_log2e, nmc));
+            x[kb][r] = pa;
+            x[kb][r + 1] = pb;
+            s0 += pa;
+            s1 += pb;
+          }
+        asm volatile("" : "+v"(s0), "+v"(s1));
+        sum = s0 + s1;
+      }
+      lrun += sum;
+      bf16x8 pf[2][2];   // [kb][h]: registers 8 h .. 8 h + 7 of block kb = the 8 key slots of this lane in PV k-step (kb, h)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pf[kb][h][e] = f2bf(x[kb][8 * h + e]);
+
+      // ---- O^T += V^T . P^T: 4 k-steps of 16 keys x DB d blocks of 32
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int key0 = kb * 32 + C::pi(vq + 4 * hi + 16 * h);        // rd = 0
+          const int key1 = kb * 32 + C::pi(vq + 4 * hi + 8 + 16 * h);    // rd = 1
+#pragma unroll
+          for (int db = 0; db < C::DB; ++db) {
+            const int col = db * 32 + 16 * vg + 4 * vp4;
+            const int ch = min(col >> 3, C::CPR - 1);   // (head_dim 80, third block: columns 80-95 do not exist - any finite data, rows discarded)
+            const int a0 = key0 * C::ROWB + C::chunk(key0, ch) * 16 + (col & 7) * 2;
+            const int a1 = key1 * C::ROWB + C::chunk(key1, ch) * 16 + (col & 7) * 2;
+            const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vt_ + a0));
+            const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vt_ + a1));
+            const bf16x8 vf = (bf16x8){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][h], o[db], 0, 0, 0);
+          }
+        }
+    }  // active
+    __syncthreads();
+  }
+
+  // ---- epilogue: O[q][32 db + 8 rg + 4 hi + j] = o[db][4 rg + j] / l
+  float lsum = lrun;
+  lsum += __shfl_xor(lsum, 32, 64);
+  const float inv = 1.0f / lsum;
+  if (active && qrow < L) {
+    bf16_t* op = O + (os + qrow) * o_ts + (long)h0 * o_hs;
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d0 = db * 32 + 8 * rg + 4 * hi;
+        if (d0 < HD) {
+          bf16x4 ov;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ov[j] = f2bf(o[db][4 * rg + j] * inv);
+          *(bf16x4*)(op + d0) = ov;
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The same kernel SOFTWARE-PIPELINED (round 6, knob "attn_mfma32" = 2): a wave's matrix and vector work only overlap when they sit
+// next to each other in its instruction stream (in-order issue: a block of 10 MFMAs followed by a block of 100 vector instructions
+// runs them one after the other, whatever the other waves of the SIMD do - the round-5 counters).  So the loop is skewed by one
+// tile: iteration t computes S(t+1) = K(t+1) . Q^T while it exponentiates S(t) - the two are independent - with the vector work cut
+// into slices placed BETWEEN the MFMAs (`sched_barrier` pins the order written here), and then O += V(t)^T . P(t) with the
+// transposing reads and the bf16 conversion of the later k-steps between those MFMAs.  K tiles therefore run two ahead (a ring
+// of three), V tiles one ahead (two); one block barrier per tile as before.
+// Same arithmetic as attn_fwd32_kernel in the same order per element: the two give the same bits (tested).
+// ------------------------------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(
+    const bf16_t* __restrict__ Q, long q_ts, long q_hs, const bf16_t* __restrict__ K, long k_ts,
+    long k_hs, const bf16_t* __restrict__ V, long v_ts, long v_hs, bf16_t* __restrict__ O, long o_ts,
+    long o_hs, const int* __restrict__ q_start, const int* __restrict__ o_start,
+    const int* __restrict__ k_start, const int* __restrict__ seq_len, int n_heads, int kv_group, int nqb,
+    int n_pairs, float scale_log2e) {
+  using C = Cfg32<HD>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // [3 K tiles][2 V tiles]
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int ql = l & 31, hi = l >> 5;
+
+  const int bid = blockIdx.x;
+  int qb, pair;
+  if ((n_pairs & 7) == 0) {
+    qb = (bid >> 3) % nqb;
+    pair = (bid / (8 * nqb)) * 8 + (bid & 7);
+  } else {
+    qb = bid % nqb;
+    pair = bid / nqb;
+  }
+  const int b = pair / n_heads, h0 = pair % n_heads;
+  const int hk = h0 / kv_group;
+  const int L = seq_len[b];
+  if (qb * QB >= L) return;
+  const bool active = (qb * QB + w * 32) < L;
+  const long qs = q_start[b], ks0 = k_start[b];
+  const long os = o_start ? (long)o_start[b] : qs;
+  const int ntiles = (L + KB - 1) / KB;
+
+  const int qrow = qb * QB + w * 32 + ql;
+  bf16x8 qf[C::KS16];
+  {
+    const bf16_t* qp = Q + (qs + min(qrow, L - 1)) * q_ts + (long)h0 * q_hs;
+#pragma unroll
+    for (int ks = 0; ks < C::KS16; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16 + hi * 8);
+  }
+
+  // ---- staging: a K (or V) tile is NP pieces of 1 KiB; wave w takes pieces w, w + 4, ...
+  const bf16_t* Kb = K + (long)hk * k_hs;
+  const bf16_t* Vb = V + (long)hk * v_hs;
+  constexpr int NPW1 = (C::NP + 3) / 4;
+  const char* Kseq = (const char*)(Kb + ks0 * k_ts);
+  const char* Vseq = (const char*)(Vb + ks0 * v_ts);
+  unsigned koffs[NPW1], voffs[NPW1];
+  int prow[NPW1];
+#pragma unroll
+  for (int i = 0; i < NPW1; ++i) {
+    const int ci = (w + 4 * i) * 64 + l;
+    const int row = ci / C::CPR;
+    const int cp = ci - row * C::CPR;
+    int c = cp - C::rot(row);
+    c = c < 0 ? c + C::CPR : c;
+    prow[i] = row;
+    koffs[i] = (unsigned)((long)row * k_ts * 2 + c * 16);
+    voffs[i] = (unsigned)((long)row * v_ts * 2 + c * 16);
+  }
+  char* const kring = lds;
+  char* const vring = lds + 3 * C::TILE;
+  auto stage_tile = [&](char* dst, const char* seq, long ts, const unsigned (&offs)[NPW1], int t) {
+    if ((t * KB + KB) <= L) {
+      const char* t0 = seq + (long)t * KB * ts * 2;
+      asm volatile("" : "+s"(t0));
+#pragma unroll
+      for (int i = 0; i < NPW1; ++i)
+        if (w + 4 * i < C::NP) glds16(t0 + offs[i], dst + (w + 4 * i) * 1024);
+    } else {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < NPW1; ++i)
+        if (w + 4 * i < C::NP) {
+          const long ts2 = ts * 2;
+          const char* src = seq + (long)min(t * KB + prow[i], L - 1) * ts2 + (offs[i] - (unsigned)((long)prow[i] * ts2));
+          glds16(src, dst + (w + 4 * i) * 1024);
+        }
+    }
+  };
+
+  f32x16 o[C::DB];
+#pragma unroll
+  for (int d = 0; d < C::DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float nmc = 0.f, lrun = 0.f;
+  constexpr float LAZY_BIG = 1024.f;
+
+  const int krow_b = C::pi(ql);
+  int koff[C::KS16];
+#pragma unroll
+  for (int ks = 0; ks < C::KS16; ++ks) koff[ks] = krow_b * C::ROWB + C::chunk(krow_b, 2 * ks + hi) * 16;
+  const int vq = (l & 15) >> 2, vp4 = l & 3, vg = (l >> 4) & 1;
+  // V read offsets of the 4 k-steps x DB d blocks x 2 reads are too many to keep: the per-k-step row parts (8) and the per-block
+  // column parts are kept and combined by adds
+  int vrow[2][2][2];   // [kb][h][rd] -> key row byte offset
+  int vrot[2][2][2];   // rot of that row (chunks)
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int rd = 0; rd < 2; ++rd) {
+        const int key = kb * 32 + C::pi(vq + 4 * hi + 8 * rd + 16 * h);
+        vrow[kb][h][rd] = key * C::ROWB;
+        vrot[kb][h][rd] = C::rot(key);
+      }
+  auto v_addr = [&](int kb, int h, int rd, int db) {
+    const int col = db * 32 + 16 * vg + 4 * vp4;
+    const int ch = min(col >> 3, C::CPR - 1);
+    int x = ch + vrot[kb][h][rd];
+    x = x >= C::CPR ? x - C::CPR : x;
+    return vrow[kb][h][rd] + x * 16 + (col & 7) * 2;
+  };
+
+  auto qk_plain = [&](f32x16 (&s)[2], const char* kt_) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < C::KS16; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(kt_ + kb * 32 * C::ROWB + koff[ks]);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+      }
+    }
+  };
+
+  // one tile: S(t) in `sc`; computes S(t+1) into `sn` (from K ring slot kn) while it exponentiates sc, then O += V(t)^T P(t)
+  auto tile = [&](f32x16 (&sc)[2], f32x16 (&sn)[2], int t, const char* kn_, const char* vt_) {
+    if (t * KB + KB > L) {   // ragged last tile
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * KB + kb * 32 + C::pi((r & 3) + 8 * (r >> 2) + 4 * hi);
+          if (key >= L) sc[kb][r] = -1e30f;
+        }
+    }
+    // ---- phase A: S(t+1) MFMAs with the fast-path exponentials of S(t) between them
+    float x[2][16];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sn[kb][r] = 0.f;
+    constexpr int NM = 2 * C::KS16;            // MFMAs of phase A
+    constexpr int PER = (32 + NM - 3) / (NM - 2);   // exponentials per slice: everything done two MFMAs before the end
+    bf16x8 kf_next = *(const bf16x8*)(kn_ + koff[0]);
+    int done = 0;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const int kb = m / C::KS16, ks = m % C::KS16;
+      const bf16x8 kf = kf_next;
+      if (m + 1 < NM) kf_next = *(const bf16x8*)(kn_ + ((m + 1) / C::KS16) * 32 * C::ROWB + koff[(m + 1) % C::KS16]);
+      __builtin_amdgcn_sched_barrier(0);
+      sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sn[kb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < PER; j += 2) {
+        if (done < 32) {
+          const int kb2 = done >> 4, r = done & 15;
+          const float pa = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb2][r], scale_log2e, nmc));
+          const float pb = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb2][r + 1], scale_log2e, nmc));
+          x[kb2][r] = pa;
+          x[kb2][r + 1] = pb;
+          s0 += pa;
+          s1 += pb;
+          done += 2;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(s0), "+v"(s1));
+    float sum = s0 + s1;
+    if (t == 0 || __builtin_amdgcn_ballot_w64(sum > LAZY_BIG) != 0) {
+      asm volatile("" ::: "memory");
+      float mx = -1e30f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
+      {
+        const unsigned u = __float_as_uint(mx);
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
+      float ask = sum > LAZY_BIG ? 1.f : 0.f;
+      {
+        const unsigned u = __float_as_uint(ask);
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        ask = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
+      const float over = __builtin_fmaf(mx, scale_log2e, nmc);
+      const float d = (t == 0) ? over : (ask > 0.f ? over : 0.f);
+      if (t != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        lrun *= alpha;
+#pragma unroll
+        for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      }
+      nmc -= d;
+      s0 = 0.f;
+      s1 = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float pa = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][r], scale_log2e, nmc));
+          const float pb = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][r + 1], scale_log2e, nmc));
+          x[kb][r] = pa;
+          x[kb][r + 1] = pb;
+          s0 += pa;
+          s1 += pb;
+        }
+      asm volatile("" : "+v"(s0), "+v"(s1));
+      sum = s0 + s1;
+    }
+    lrun += sum;
+    // ---- phase B: O += V(t)^T P(t); the transposing reads run one MFMA ahead, the bf16 conversion of the NEXT k-step's P sits
+    //      between this k-step's MFMAs
+    bf16x8 pf;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pf[e] = f2bf(x[0][e]);
+    bf16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vt_ + v_addr(0, 0, 0, 0)));
+    bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vt_ + v_addr(0, 0, 1, 0)));
+#pragma unroll
+    for (int kstep = 0; kstep < 4; ++kstep) {
+      const int kb = kstep >> 1, h = kstep & 1;
+      bf16x8 pf_next = pf;
+#pragma unroll
+      for (int db = 0; db < C::DB; ++db) {
+        const bf16x8 vf = (bf16x8){va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+        const int nstep = db + 1 < C::DB ? kstep : kstep + 1, ndb = db + 1 < C::DB ? db + 1 : 0;
+        if (nstep < 4) {
+          va = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vt_ + v_addr(nstep >> 1, nstep & 1, 0, ndb)));
+          vb = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vt_ + v_addr(nstep >> 1, nstep & 1, 1, ndb)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (db == 0 && kstep + 1 < 4) {
+          const int kb2 = (kstep + 1) >> 1, h2 = (kstep + 1) & 1;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pf_next[e] = f2bf(x[kb2][8 * h2 + e]);
+        }
+      }
+      pf = pf_next;
+      (void)kb;
+      (void)h;
+    }
+  };
+
+  // ---- prologue: K(0), K(1), V(0) in flight; S(0)
+  stage_tile(kring, Kseq, k_ts, koffs, 0);
+  stage_tile(vring, Vseq, v_ts, voffs, 0);
+  if (ntiles > 1) stage_tile(kring + C::TILE, Kseq, k_ts, koffs, 1);
+  __syncthreads();
+  f32x16 sa[2], sb[2];
+  if (active) qk_plain(sa, kring);
+  // iteration t: K(t+1) in ring slot (t+1) % 3 (clamped to the last tile: the extra S of the last iteration is never used)
+  for (int t = 0; t < ntiles; t += 2) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int tt = t + half;
+      if (tt < ntiles) {
+        if (tt > 0) __syncthreads();   // K(tt+1), V(tt) landed (every wave waited for its own pieces: the barrier's vmcnt(0)); K(tt-1) / V(tt-1) free
+        if (tt + 2 < ntiles) stage_tile(kring + ((tt + 2) % 3) * C::TILE, Kseq, k_ts, koffs, tt + 2);
+        if (tt + 1 < ntiles) stage_tile(vring + ((tt + 1) & 1) * C::TILE, Vseq, v_ts, voffs, tt + 1);
+        if (active) {
+          const char* kn_ = kring + (min(tt + 1, ntiles - 1) % 3) * C::TILE;
+          const char* vt_ = vring + (tt & 1) * C::TILE;
+          if (half == 0) tile(sa, sb, tt, kn_, vt_);
+          else tile(sb, sa, tt, kn_, vt_);
+        }
+      }
+    }
+  }
+
+  float lsum = lrun;
+  lsum += __shfl_xor(lsum, 32, 64);
+  const float inv = 1.0f / lsum;
+  if (active && qrow < L) {
+    bf16_t* op = O + (os + qrow) * o_ts + (long)h0 * o_hs;
+#pragma unroll
+    for (int db = 0; db < C::DB; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d0 = db * 32 + 8 * rg + 4 * hi;
+        if (d0 < HD) {
+          bf16x4 ov;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ov[j] = f2bf(o[db][4 * rg + j] * inv);
+          *(bf16x4*)(op + d0) = ov;
+        }
+      }
+  }
+}
+
+template <int HD>
+int launch32(const void* Q, long q_ts, long q_hs, const void* K, long k_ts, long k_hs, const void* V,
+             long v_ts, long v_hs, void* O, long o_ts, long o_hs, const int* q_start,
+             const int* o_start, const int* k_start, const int* seq_len, int n_seq, int n_heads,
+             int kv_group, int max_len, float scale, hipStream_t st) {
+  using C = Cfg32<HD>;
+  const int nqb = (max_len + QB - 1) / QB;
+  const int n_pairs = n_seq * n_heads;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)attn_fwd32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * C::TILE) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_fwd32p_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * C::TILE) != hipSuccess)
+      return OWC_ERR_HIP;
+    attr_set = true;
+  }
+  const int prof = owc_gemm_profile_begin(0.0, OWC_PROF_ATTN_VISION, st);
+  if (g_attn_mfma32 == 2)
+    hipLaunchKernelGGL((attn_fwd32p_kernel<HD>), dim3(n_pairs * nqb), dim3(256), 5 * C::TILE, st, (const bf16_t*)Q, q_ts, q_hs,
+                       (const bf16_t*)K, k_ts, k_hs, (const bf16_t*)V, v_ts, v_hs, (bf16_t*)O, o_ts, o_hs, q_start, o_start, k_start,
+                       seq_len, n_heads, kv_group, nqb, n_pairs, scale * 1.4426950408889634f);
+  else
+    hipLaunchKernelGGL((attn_fwd32_kernel<HD>), dim3(n_pairs * nqb), dim3(256), 4 * C::TILE, st, (const bf16_t*)Q, q_ts, q_hs,
+                       (const bf16_t*)K, k_ts, k_hs, (const bf16_t*)V, v_ts, v_hs, (bf16_t*)O, o_ts, o_hs, q_start, o_start, k_start,
+                       seq_len, n_heads, kv_group, nqb, n_pairs, scale * 1.4426950408889634f);
+  owc_gemm_profile_end(prof, st);
+  return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+}
+
 template <int HD, bool CAUSAL>
 int launch(const void* Q, long q_ts, long q_hs, const void* K, long k_ts, long k_hs, const void* V,
            long v_ts, long v_hs, void* O, long o_ts, long o_hs, const int* q_start,
@@ -701,6 +1348,14 @@ int owc_launch_attention(const void* Q, long q_ts, long q_hs, const void* K, lon
   if (n_seq <= 0 || n_heads <= 0 || kv_group <= 0 || max_len <= 0) return OWC_ERR_SHAPE;
   if ((q_ts & 7) || (q_hs & 7) || (k_ts & 7) || (k_hs & 7) || (v_ts & 7) || (v_hs & 7) || (o_ts & 3) || (o_hs & 3))
     return OWC_ERR_SHAPE;
+  // the vision towers (non-causal, every query row of a sequence, head_dim 80 / 64): the 32x32x16 kernel
+  if (!causal && !q_len && g_attn_mfma32 && (head_dim == 80 || head_dim == 64)) {
+    if (head_dim == 80)
+      return launch32<80>(Q, q_ts, q_hs, K, k_ts, k_hs, V, v_ts, v_hs, O, o_ts, o_hs, q_start, o_start, k_start, seq_len, n_seq, n_heads,
+                          kv_group, max_len, scale, st);
+    return launch32<64>(Q, q_ts, q_hs, K, k_ts, k_hs, V, v_ts, v_hs, O, o_ts, o_hs, q_start, o_start, k_start, seq_len, n_seq, n_heads,
+                        kv_group, max_len, scale, st);
+  }
 #define OWC_ATTN_CASE(HD_)                                                                         \
   if (head_dim == HD_)                                                                             \
     return causal ? launch<HD_, true>(Q, q_ts, q_hs, K, k_ts, k_hs, V, v_ts, v_hs, O, o_ts, o_hs, \
@@ -746,5 +1401,6 @@ int owc_launch_attn_decode_fused(const void* qkv, long ld, const int* pos, const
 
 void owc_attn_set_decode_nbuf1(int v) { g_decode_nbuf1_min_blocks = v < 0 ? 256 : v; }
 void owc_attn_set_gqa_pack(int v) { g_attn_gqa_pack = v != 0; }
+void owc_attn_set_mfma32(int v) { g_attn_mfma32 = v < 0 ? 1 : v; }
 void owc_attn_class_prefill(int on) { g_attn_class_prefill = on; }
 void owc_attn_set_dbg(int v) { g_attn_dbg = OWC_TK(true) ? v : 0; }

@@ -122,6 +122,7 @@ int owc_launch_gemm_bf16_aux(const void* A, long lda, const void* W, long ldw, c
 void owc_attn_set_dbg(int v);
 void owc_attn_class_prefill(int on);
 void owc_attn_set_gqa_pack(int v);
+void owc_attn_set_mfma32(int v);
 void owc_attn_set_decode_nbuf1(int v);  // profile class of the next non-causal head_dim-128 launches
 void owc_llm_set_prune_last(int v);
 void owc_llm_set_decode_fuse(int v);

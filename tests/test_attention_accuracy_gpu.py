@@ -33,6 +33,20 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=[0, 1, 2], ids=["mfma16x16x32", "mfma32x32x16", "mfma32x32x16-pipelined"], autouse=True)
+def vision_kernel(request, gpu):
+    """Round 6: the non-causal head_dim 80 / 64 launches have three kernels (knob "attn_mfma32": 0 = attn_fwd_kernel of rounds 1-5,
+    1 = attn_fwd32_kernel, 2 = its software-pipelined form attn_fwd32p_kernel); every case of this file runs under each of them - the
+    causal head_dim-128 cases are the same kernel three times."""
+    from lmms_owc_amd import _lib
+
+    lib = _lib.load()
+    assert lib.owc_tuning_set(b"attn_mfma32", request.param) == 0
+    yield request.param
+    lib.owc_tuning_set(b"attn_mfma32", -1)
+
+
 RMS_BOUND = 0.0026
 MAX_ULPS = 2.0
 ULP = 2.0 ** -8
@@ -94,6 +108,7 @@ def _check_exact(got, ref, tag):
 
 
 CASES = [("vision", 4, 4, 1024, 80, False), ("vision", 2, 2, 3996, 80, False), ("vision", 2, 2, 4096, 80, False),
+         ("clip", 4, 4, 577, 64, False),     # CLIP ViT-L/14-336: 576 patches + CLS, head_dim 64
          ("prefill", 4, 2, 286, 128, True), ("prefill", 4, 2, 2388, 128, True)]
 
 
@@ -230,3 +245,30 @@ def test_attention_ragged_masked_tails(gpu, lens, logit_std):
             assert np.abs(g_ - ref).max() <= MAX_ULPS * ULP * np.abs(ref).max(), (n, np.abs(g_ - ref).max() / np.abs(ref).max())
             if n >= 256:
                 _check_statistical(g_, ref, f"ragged lens {lens} logit std {logit_std}: sequence of {n}")
+
+
+def test_pipelined_kernel_gives_the_bits_of_the_plain_32x32_kernel(gpu):
+    """attn_fwd32p_kernel skews the loop by one tile and interleaves the instruction stream; per element it is the same arithmetic in
+    the same order as attn_fwd32_kernel: bit-identical outputs, ragged lengths, several sequences, both head dims."""
+    from lmms_owc_amd import _lib, ops
+
+    lib = _lib.load()
+    for H, hd, lens in ((4, 80, [1024, 1000, 64, 1, 130, 3996]), (4, 64, [577, 577, 50, 257])):
+        T = sum(lens)
+        g = torch.Generator().manual_seed(T)
+        qkv = (torch.randn(T, 3, H, hd, generator=g) * 1.7).to(torch.bfloat16)
+        E = H * hd
+        dq = qkv.reshape(T, 3 * E).to(gpu)
+        starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+        outs = []
+        try:
+            for v in (1, 2):
+                assert lib.owc_tuning_set(b"attn_mfma32", v) == 0
+                out = torch.zeros((T, E), dtype=torch.bfloat16, device=gpu)
+                ops.attention(dq, 3 * E, hd, dq[:, E:], 3 * E, hd, dq[:, 2 * E:], 3 * E, hd, out, E, hd, _i32(starts, gpu), _i32(starts, gpu),
+                              _i32(lens, gpu), n_seq=len(lens), n_heads=H, kv_group=1, head_dim=hd, max_q_len=max(lens), causal=False,
+                              scale=hd ** -0.5)
+                outs.append(out)
+        finally:
+            lib.owc_tuning_set(b"attn_mfma32", -1)
+        assert torch.equal(outs[0], outs[1]), (hd, (outs[0] != outs[1]).sum().item())

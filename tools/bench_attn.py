@@ -77,6 +77,29 @@ def main():
         k, v = kv.split("=")
         _lib.check(_lib.load().owc_tuning_set(k.encode(), int(v)), 0)
         print("set", k, v)
+    sweep = next((a[8:] for a in sys.argv[1:] if a.startswith("--sweep=")), None)
+    if sweep:   # --sweep=<knob>:v0,v1,...  the vision shapes with the values of one knob INTERLEAVED in one process (median of 6 rounds)
+        knob, vs = sweep.split(":")
+        vs = [int(v) for v in vs.split(",")]
+        shapes = [("vit hd80 64x1024", vit, 4.0 * n * H * L * L * hd)] + [(f"vit hd80 {n_b}x{L_b}", vit_at(n_b, L_b), 4.0 * n_b * H * L_b * L_b * hd)
+                                                                          for n_b, L_b in big]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for name, fn, flops in shapes:
+            res = {v: [] for v in vs}
+            for rnd in range(7):
+                for v in vs:
+                    _lib.check(_lib.load().owc_tuning_set(knob.encode(), v), 0)
+                    for _ in range(2):
+                        fn()
+                    e0.record()
+                    for _ in range(10):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if rnd:
+                        res[v].append(e0.elapsed_time(e1) / 10)
+            print(f"{name:24s} [{knob}] " + "  ".join(f"{v}: {sorted(r)[len(r) // 2]:7.3f} ms ({flops / sorted(r)[len(r) // 2] / 1e9:7.1f} TF)" for v, r in res.items()), flush=True)
+        return
     vals = [0]
     for a in sys.argv[1:]:
         if a.startswith("--dbg="):

@@ -38,8 +38,12 @@ def main() -> None:
     for f in sorted(Path(a.trace_dir).rglob("*kernel_trace.csv")):
         with open(f) as fh:
             for r in csv.DictReader(fh):
-                acc[(short(r["Kernel_Name"]), int(r["Grid_Size"]), int(r["Workgroup_Size"]))].append(
-                    (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+                if "Grid_Size" in r:      # (counter-collection CSVs)
+                    grid, wg = int(r["Grid_Size"]), int(r["Workgroup_Size"])
+                else:                     # kernel-trace CSVs give the three dimensions
+                    grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+                    wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
+                acc[(short(r["Kernel_Name"]), grid, wg)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     rows = []
     for (name, grid, wg), ts in acc.items():
         tot = sum(ts)
