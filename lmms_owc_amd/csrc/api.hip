@@ -65,7 +65,7 @@ int owc_tuning_set(const char* name, int value) {
   else if (!strcmp(name, "gemm_pp128")) owc_gemm_set_pp128(value);   // 256x128 ping-pong tiles: 0 off, n > 0: from n tiles, negative: default
   else if (!strcmp(name, "decode_fuse")) owc_llm_set_decode_fuse(value);
   else if (!strcmp(name, "decode_norm_fuse")) owc_gemm_set_norm_fuse_max_m(value);   // max rows (<= 4) for the RMSNorm-fused skinny GEMM; 0 = off
-  else if (!strcmp(name, "attn_mfma32")) owc_attn_set_mfma32(value);   // vision attention (head_dim 80 / 64, non-causal): 0 = the 16x16x32 kernel of rounds 1-5, else (default) the 32x32x16 kernel
+  else if (!strcmp(name, "attn_mfma32")) owc_attn_set_mfma32(value);   // vision attention (head_dim 80 / 64, non-causal): 0 / negative (default) = attn_fwd_kernel (16x16x32 MFMA), 1 = the 32x32x16 kernel, 2 = its software-pipelined form
   else if (!strcmp(name, "attn_gqa_pack")) owc_attn_set_gqa_pack(value);   // causal GQA attention: 0 = one head per block (rounds 1-4), else the heads of a kv group packed into the rows
   else if (!strcmp(name, "decode_attn_nbuf1")) owc_attn_set_decode_nbuf1(value);   // block count above which the fused decode attention single-buffers V
   else if (!strcmp(name, "prefill_prune_last")) owc_llm_set_prune_last(value);

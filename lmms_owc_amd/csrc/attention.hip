@@ -421,10 +421,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
 //      head_dim 64:  pi(i) = bits (i0 -> 0, i1 -> 3, i2 -> 1, i3 -> 2, i4 -> 4), chunk' = (chunk + ((row >> 1) & 7)) mod 8
 //  * online softmax with the LAZY reference maximum of attn_fwd_kernel (same rule, same threshold; a row is two lanes here).
 // Results differ from attn_fwd_kernel in the last bits only (another summation order inside the MFMAs); accuracy against a float64
-// attention: tests/test_attention_accuracy_gpu.py (same bounds, both kernels).  `owc_tuning_set("attn_mfma32", 0)` selects the
-// 16x16x32 kernel again.
+// attention: tests/test_attention_accuracy_gpu.py (same bounds, all kernels).  NOT the default: see g_attn_mfma32 for what it measured.
 // ------------------------------------------------------------------------------------------------------------------------
-int g_attn_mfma32 = 1;
+int g_attn_mfma32 = 0;   // 0 (default): attn_fwd_kernel; 1: attn_fwd32_kernel; 2: attn_fwd32p_kernel (knob "attn_mfma32").  MEASURED, one box, interleaved
+                         // (profiles/r06_attn_mfma32_ab.txt): 64 x 1024 patches 781 / 683 / 694 TFLOP/s, 16 x 4096: 937 / 830 / 845 - the
+                         // 32x32x16 kernels are 10-12 % SLOWER and the software pipelining is worth +1.5 %: neither the free issue slots nor the
+                         // interleave is what bounds this loop (round 5's timing build said the same from the other side: with ALL MFMAs
+                         // removed the kernel got 12 % faster).  They stay in the tree as the tested alternative, not on the path.
 
 template <int HD>
 struct Cfg32 {
@@ -1401,6 +1404,6 @@ int owc_launch_attn_decode_fused(const void* qkv, long ld, const int* pos, const
 
 void owc_attn_set_decode_nbuf1(int v) { g_decode_nbuf1_min_blocks = v < 0 ? 256 : v; }
 void owc_attn_set_gqa_pack(int v) { g_attn_gqa_pack = v != 0; }
-void owc_attn_set_mfma32(int v) { g_attn_mfma32 = v < 0 ? 1 : v; }
+void owc_attn_set_mfma32(int v) { g_attn_mfma32 = v < 0 ? 0 : v; }
 void owc_attn_class_prefill(int on) { g_attn_class_prefill = on; }
 void owc_attn_set_dbg(int v) { g_attn_dbg = OWC_TK(true) ? v : 0; }
