@@ -135,6 +135,14 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
   } else {
     bf16_t* C = (bf16_t*)Cv;
     const int odd = fq & 1;
+    // VROPE: the (h, w) position of each of the lane's MT rows, fetched ONCE (round 6: it was re-read for every column pair, and the
+    // table loads of a pair waited behind it - 4 x MT dependent load chains per lane; profiles/r06_gemm_by_shape_timed_region.csv
+    // has the vision qkv launch at 1125 TFLOP/s against 1290 for the same shape with a plain epilogue)
+    int2 hwv[EPI == OWC_EPI_VROPE ? MT : 1];
+    if constexpr (EPI == OWC_EPI_VROPE) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) hwv[mt] = *(const int2*)(aux.pos_hw + 2 * (long)min(mrow0 + mt * 16 + fr, M - 1));
+    }
 #pragma unroll
     for (int p = 0; p < NTP; ++p) {
       const int n = ncol0 + (2 * p + odd) * 16 + (fq >> 1) * 8;  // first of this lane's 8 columns
@@ -173,7 +181,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
           if (n < aux.rope_cols) {
             const int quarter = aux.head_dim >> 2;
             const int j0 = (n % aux.head_dim) >> 1;  // multiple of 4, never straddles `quarter`
-            const int2 hw = *(const int2*)(aux.pos_hw + 2 * (long)min(m, M - 1));
+            const int2 hw = hwv[mt];
             const int ti = (j0 < quarter) ? hw.x * quarter + j0 : hw.y * quarter + (j0 - quarter);
             const f32x4 c4 = *(const f32x4*)(aux.cos_t + ti);
             const f32x4 s4 = *(const f32x4*)(aux.sin_t + ti);
