@@ -865,15 +865,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
   } else {
     // LDS is quiescent: every wave has passed the final barrier with its reads retired and no DMA pending
     constexpr int CCOLS = EPI == OWC_EPI_SWIGLU ? BT / 2 : BT;
+    const int cn0 = EPI == OWC_EPI_SWIGLU ? (n0 >> 1) : n0, cN = EPI == OWC_EPI_SWIGLU ? (N >> 1) : N;
+    // (Round 6 measured the epilogue in two row halves - the first half's stores issued under the second half's arithmetic, one more
+    //  barrier: per launch +0.1 ... +1 % with bias / GELU / residual / SwiGLU epilogues, +3 % on one shape, and +-0 on the 7B bench
+    //  (GEMM total 1386.8 vs 1386.7 TFLOP/s, profiles/r06_gemm_split_epilogue_ab.txt): the store tail is not a background drain that
+    //  arithmetic can hide behind.  Removed again.)
     gemm_epilogue<EPI, 8>(acc, m0 + wr * 128, n0 + wc * 64, fr, fq, bias, R, ldr, Cv, ldc, M, N, aux, lds, CCOLS * 2,
                           wr * 128, wc * 64);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (dbg & 1024)   // streaming (non-temporal) C stores: set by launch() for outputs far larger than the caches
-      store_ctile<8, true>(lds, BT, CCOLS, (bf16_t*)Cv, ldc, m0, EPI == OWC_EPI_SWIGLU ? (n0 >> 1) : n0, M,
-                           EPI == OWC_EPI_SWIGLU ? (N >> 1) : N, w, l);
+      store_ctile<8, true>(lds, BT, CCOLS, (bf16_t*)Cv, ldc, m0, cn0, M, cN, w, l);
     else
-      store_ctile<8>(lds, BT, CCOLS, (bf16_t*)Cv, ldc, m0, EPI == OWC_EPI_SWIGLU ? (n0 >> 1) : n0, M,
-                     EPI == OWC_EPI_SWIGLU ? (N >> 1) : N, w, l);
+      store_ctile<8>(lds, BT, CCOLS, (bf16_t*)Cv, ldc, m0, cn0, M, cN, w, l);
   }
 }
 

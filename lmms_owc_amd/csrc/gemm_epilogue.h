@@ -28,7 +28,8 @@ __device__ __forceinline__ void swap16(float& x, float& y) {
 // store_ctile() writes them out as whole rows.  Why: a lane group of the MFMA layout only covers 64 contiguous bytes of
 // a row, and half-line writes measurably slow the whole kernel (ablation: full-line pattern +2..8 %).
 // NTP: pairs of 16-column tiles the wave holds in acc[0 .. 2 NTP) (2 = a 64-column wave tile, 1 = a 32-column one)
-template <int EPI, int MT, bool FULL = false, int NTP = 2>
+// MT0 / MT1: only the m tiles [MT0, MT1) of the wave's MT are processed (a caller may run the epilogue in row pieces).
+template <int EPI, int MT, bool FULL = false, int NTP = 2, int MT0 = 0, int MT1 = MT>
 __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mrow0, int ncol0, int fr, int fq,
                                               const bf16_t* __restrict__ bias, const bf16_t* R, long ldr,
                                               void* Cv, long ldc, int M, int N, const owc_gemm_aux& aux,
@@ -36,7 +37,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
   if constexpr (EPI == OWC_EPI_F32) {
     float* C = (float*)Cv;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = MT0; mt < MT1; ++mt) {
       const int m = mrow0 + mt * 16 + fr;
 #pragma unroll
       for (int nt = 0; nt < 2 * NTP; ++nt) {
@@ -69,7 +70,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
       }
     }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = MT0; mt < MT1; ++mt) {
       const int m = mrow0 + mt * 16 + fr;
       bf16x4 o;
 #pragma unroll
@@ -103,7 +104,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
       }
     }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = MT0; mt < MT1; ++mt) {
       const int m = mrow0 + mt * 16 + fr;
       float o0[4], o1[4];
 #pragma unroll
@@ -141,7 +142,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
     int2 hwv[EPI == OWC_EPI_VROPE ? MT : 1];
     if constexpr (EPI == OWC_EPI_VROPE) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) hwv[mt] = *(const int2*)(aux.pos_hw + 2 * (long)min(mrow0 + mt * 16 + fr, M - 1));
+      for (int mt = MT0; mt < MT1; ++mt) hwv[mt] = *(const int2*)(aux.pos_hw + 2 * (long)min(mrow0 + mt * 16 + fr, M - 1));
     }
 #pragma unroll
     for (int p = 0; p < NTP; ++p) {
@@ -160,11 +161,27 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
       bf16x8 rr[MT];
       if constexpr (EPI == OWC_EPI_RESIDUAL) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = MT0; mt < MT1; ++mt)
           rr[mt] = *(const bf16x8*)(R + (long)min(mrow0 + mt * 16 + fr, M - 1) * ldr + nc);
       }
+      // VROPE: the cos / sin quadruples of ALL the m tiles of this column block are requested before the first is used (round 6: one
+      // dependent table load per m tile in front of its arithmetic was a chain of L2 round trips, ~4.6 us per 256x256 tile)
+      f32x4 c4v[EPI == OWC_EPI_VROPE ? MT : 1], s4v[EPI == OWC_EPI_VROPE ? MT : 1];
+      if constexpr (EPI == OWC_EPI_VROPE) {
+        if (n < aux.rope_cols) {
+          const int quarter = aux.head_dim >> 2;
+          const int j0 = (n % aux.head_dim) >> 1;  // multiple of 4, never straddles `quarter`
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
+          for (int mt = MT0; mt < MT1; ++mt) {
+            const int2 hw = hwv[mt];
+            const int ti = (j0 < quarter) ? hw.x * quarter + j0 : hw.y * quarter + (j0 - quarter);
+            c4v[mt] = *(const f32x4*)(aux.cos_t + ti);
+            s4v[mt] = *(const f32x4*)(aux.sin_t + ti);
+          }
+        }
+      }
+#pragma unroll
+      for (int mt = MT0; mt < MT1; ++mt) {
         const int m = mrow0 + mt * 16 + fr;
         float v[8];
 #pragma unroll
@@ -179,12 +196,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[4][MT], int mro
           // apply_rotary_pos_emb_vision (HF:225-236) on pair-interleaved columns: (2j, 2j+1) hold the
           // original (j, j + head_dim/2); angle j uses the row's h position for j < head_dim/4, else w.
           if (n < aux.rope_cols) {
-            const int quarter = aux.head_dim >> 2;
-            const int j0 = (n % aux.head_dim) >> 1;  // multiple of 4, never straddles `quarter`
-            const int2 hw = hwv[mt];
-            const int ti = (j0 < quarter) ? hw.x * quarter + j0 : hw.y * quarter + (j0 - quarter);
-            const f32x4 c4 = *(const f32x4*)(aux.cos_t + ti);
-            const f32x4 s4 = *(const f32x4*)(aux.sin_t + ti);
+            const f32x4 c4 = c4v[mt];
+            const f32x4 s4 = s4v[mt];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               // Scalar form on purpose, each factor pinned in its own register: the SLP vectoriser otherwise packs the pair into

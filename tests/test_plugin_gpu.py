@@ -81,6 +81,27 @@ def test_generate_until_with_straggler_hand_over_equals_without(gpu):
     assert len({len(a) for a in outs["carry"]}) > 3      # really ragged
 
 
+def test_repetition_penalty_through_the_plug_in_over_several_passes(gpu):
+    """Round 6: the plug-in's engine carries the checkpoint's `repetition_penalty` (what `Qwen2VL.load_model` reads from
+    generation_config.json; here set on the synthetic model).  Answers with the penalty differ from the plain greedy ones, do not depend
+    on the batch size or on how the documents are cut into engine passes (the straggler hand-over is switched off under a penalty: a
+    pass runs its sequences to the end), and a second run reproduces them."""
+    from lmms_owc_amd.models import get_model
+    from lmms_owc_amd.tasks import load_task
+
+    outs = {}
+    for tag, bs, eb, pen in (("plain", 4, 24, 1.0), ("a", 1, 24, 1.3), ("b", 4, 7, 1.3), ("c", 4, 24, 1.3)):
+        task = load_task("synthetic:40:56x84:3")
+        task.generation_kwargs.update({"max_new_tokens": 12})
+        task.build_all_requests(limit=None, rank=0, world_size=1)
+        lm = get_model("custom-model", model_type="qwen2-vl", model_name_or_path="synthetic:tiny", batch_size=bs, engine_batch=eb)
+        lm._model.repetition_penalty = pen
+        lm.task_dict[task.task_name] = task.dataset
+        outs[tag] = lm.generate_until(task.instances)
+    assert outs["a"] == outs["b"] == outs["c"] and len(outs["a"]) == 40
+    assert outs["a"] != outs["plain"]
+
+
 def test_sampled_generate_until_through_gen_kwargs(gpu):
     """`--gen_kwargs temperature=0.8,top_p=0.9` (reference src/models/_qwen2_vl.py:308-329: do_sample = temperature > 0) reaches the
     on-device sampler: the answers differ from the greedy ones, are reproducible under the same torch seed, do not depend on the
