@@ -98,50 +98,65 @@ template <int HD>
 __global__ __launch_bounds__(64) void bert_attn_kernel(const float* __restrict__ qkv,
                                                        const int* __restrict__ mask,
                                                        float* __restrict__ ctx, int L, int H,
-                                                       int n_heads, float scale, const float* __restrict__ relb, int rel_span) {
+                                                       int n_heads, float scale, const float* __restrict__ relb, int rel_span, int chunk) {
+  // `chunk` keys of K / V are LDS-resident at a time (round 6: the whole sequence had to fit - head_dim 64 stopped at 317 tokens,
+  // all-mpnet-base-v2 takes 512).  The online softmax walks the keys in ascending order whatever the chunking, and a thread keeps
+  // its query's (q, acc, m, l) in registers across chunks: the result does not depend on `chunk`, bit for bit.
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* ks = (float*)smem;           // [L][HD]
-  float* vs = ks + (size_t)L * HD;    // [L][HD]
-  int* ms = (int*)(vs + (size_t)L * HD);
+  float* ks = (float*)smem;               // [chunk][HD]
+  float* vs = ks + (size_t)chunk * HD;    // [chunk][HD]
+  int* ms = (int*)(vs + (size_t)chunk * HD);
   const int s = blockIdx.x / n_heads, h = blockIdx.x % n_heads;
   const long base = (long)s * L;
   // MPNet: one learned bias per (head, key column - query column), added to the scaled score (`rel_bias`, include/owc.h)
   const float* rb = relb ? relb + (long)h * (2 * rel_span - 1) + (rel_span - 1) : nullptr;
-  for (int i = threadIdx.x; i < L * (HD / 4); i += blockDim.x) {
-    const int j = i / (HD / 4), c = i % (HD / 4);
-    const float* row = qkv + (base + j) * 3 * H + h * HD + c * 4;
-    *(f32x4*)(ks + j * HD + c * 4) = *(const f32x4*)(row + H);
-    *(f32x4*)(vs + j * HD + c * 4) = *(const f32x4*)(row + 2 * H);
-  }
-  for (int j = threadIdx.x; j < L; j += blockDim.x) ms[j] = mask[base + j];
-  __syncthreads();
-  for (int i = threadIdx.x; i < L; i += blockDim.x) {
+  for (int i0 = 0; i0 < L; i0 += blockDim.x) {       // 64 query rows at a time (block-uniform trip count: the barriers below are safe)
+    const int i = i0 + threadIdx.x;
+    const bool live = i < L;
     float q[HD], acc[HD];
-    const float* qr = qkv + (base + i) * 3 * H + h * HD;
+    const float* qr = qkv + (base + (live ? i : 0)) * 3 * H + h * HD;
 #pragma unroll
     for (int d = 0; d < HD; ++d) {
       q[d] = qr[d];
       acc[d] = 0.f;
     }
     float m = -INFINITY, lsum = 0.f;
-    for (int j = 0; j < L; ++j) {
-      if (!ms[j]) continue;
-      float sc = 0.f;
+    for (int j0 = 0; j0 < L; j0 += chunk) {
+      const int nj = min(chunk, L - j0);
+      if (i0 > 0 || j0 > 0) __syncthreads();          // the previous chunk has been read by everybody
+      if (i0 == 0 || chunk < L) {                     // (one chunk = the whole sequence: staged once, kept for every query group)
+        for (int x = threadIdx.x; x < nj * (HD / 4); x += blockDim.x) {
+          const int j = x / (HD / 4), c = x % (HD / 4);
+          const float* row = qkv + (base + j0 + j) * 3 * H + h * HD + c * 4;
+          *(f32x4*)(ks + j * HD + c * 4) = *(const f32x4*)(row + H);
+          *(f32x4*)(vs + j * HD + c * 4) = *(const f32x4*)(row + 2 * H);
+        }
+        for (int j = threadIdx.x; j < nj; j += blockDim.x) ms[j] = mask[base + j0 + j];
+      }
+      __syncthreads();
+      if (live) {
+        for (int j = 0; j < nj; ++j) {
+          if (!ms[j]) continue;
+          float sc = 0.f;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) sc += q[d] * ks[j * HD + d];
-      sc *= scale;
-      if (rb) sc += rb[j - i];
-      const float mn = fmaxf(m, sc);
-      const float a = expf(m - mn), p = expf(sc - mn);
-      lsum = lsum * a + p;
+          for (int d = 0; d < HD; ++d) sc += q[d] * ks[j * HD + d];
+          sc *= scale;
+          if (rb) sc += rb[j0 + j - i];
+          const float mn = fmaxf(m, sc);
+          const float a = expf(m - mn), p = expf(sc - mn);
+          lsum = lsum * a + p;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) acc[d] = acc[d] * a + p * vs[j * HD + d];
-      m = mn;
+          for (int d = 0; d < HD; ++d) acc[d] = acc[d] * a + p * vs[j * HD + d];
+          m = mn;
+        }
+      }
     }
-    const float inv = 1.0f / lsum;
-    float* o = ctx + (base + i) * H + h * HD;
+    if (live) {
+      const float inv = 1.0f / lsum;
+      float* o = ctx + (base + i) * H + h * HD;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) o[d] = acc[d] * inv;
+      for (int d = 0; d < HD; ++d) o[d] = acc[d] * inv;
+    }
   }
 }
 
@@ -188,47 +203,59 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(const float* __restrict_
 template <int HD>
 __global__ __launch_bounds__(64) void bert_attn_packed_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_start,
                                                               float* __restrict__ ctx, int H, int n_heads, float scale,
-                                                              const float* __restrict__ relb, int rel_span) {
+                                                              const float* __restrict__ relb, int rel_span, int chunk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int s = blockIdx.x / n_heads, h = blockIdx.x % n_heads;
   const long base = seq_start[s];
   const int L = seq_start[s + 1] - (int)base;
   const float* rb = relb ? relb + (long)h * (2 * rel_span - 1) + (rel_span - 1) : nullptr;   // (right-padded rows: packed index = column)
-  float* ks = (float*)smem;           // [L][HD]
-  float* vs = ks + (size_t)L * HD;    // [L][HD]
-  for (int i = threadIdx.x; i < L * (HD / 4); i += blockDim.x) {
-    const int j = i / (HD / 4), c = i % (HD / 4);
-    const float* row = qkv + (base + j) * 3 * H + h * HD + c * 4;
-    *(f32x4*)(ks + j * HD + c * 4) = *(const f32x4*)(row + H);
-    *(f32x4*)(vs + j * HD + c * 4) = *(const f32x4*)(row + 2 * H);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < L; i += blockDim.x) {
+  float* ks = (float*)smem;               // [chunk][HD]
+  float* vs = ks + (size_t)chunk * HD;    // [chunk][HD]
+  for (int i0 = 0; i0 < L; i0 += blockDim.x) {   // (chunked like bert_attn_kernel: same key order, same bits)
+    const int i = i0 + threadIdx.x;
+    const bool live = i < L;
     float q[HD], acc[HD];
-    const float* qr = qkv + (base + i) * 3 * H + h * HD;
+    const float* qr = qkv + (base + (live ? i : 0)) * 3 * H + h * HD;
 #pragma unroll
     for (int d = 0; d < HD; ++d) {
       q[d] = qr[d];
       acc[d] = 0.f;
     }
     float m = -INFINITY, lsum = 0.f;
-    for (int j = 0; j < L; ++j) {   // same key order and online-softmax arithmetic as bert_attn_kernel over the unmasked keys
-      float sc = 0.f;
+    for (int j0 = 0; j0 < L; j0 += chunk) {
+      const int nj = min(chunk, L - j0);
+      if (i0 > 0 || j0 > 0) __syncthreads();
+      if (i0 == 0 || chunk < L) {
+        for (int x = threadIdx.x; x < nj * (HD / 4); x += blockDim.x) {
+          const int j = x / (HD / 4), c = x % (HD / 4);
+          const float* row = qkv + (base + j0 + j) * 3 * H + h * HD + c * 4;
+          *(f32x4*)(ks + j * HD + c * 4) = *(const f32x4*)(row + H);
+          *(f32x4*)(vs + j * HD + c * 4) = *(const f32x4*)(row + 2 * H);
+        }
+      }
+      __syncthreads();
+      if (live) {
+        for (int j = 0; j < nj; ++j) {   // same key order and online-softmax arithmetic as bert_attn_kernel over the unmasked keys
+          float sc = 0.f;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) sc += q[d] * ks[j * HD + d];
-      sc *= scale;
-      if (rb) sc += rb[j - i];
-      const float mn = fmaxf(m, sc);
-      const float a = expf(m - mn), p = expf(sc - mn);
-      lsum = lsum * a + p;
+          for (int d = 0; d < HD; ++d) sc += q[d] * ks[j * HD + d];
+          sc *= scale;
+          if (rb) sc += rb[j0 + j - i];
+          const float mn = fmaxf(m, sc);
+          const float a = expf(m - mn), p = expf(sc - mn);
+          lsum = lsum * a + p;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) acc[d] = acc[d] * a + p * vs[j * HD + d];
-      m = mn;
+          for (int d = 0; d < HD; ++d) acc[d] = acc[d] * a + p * vs[j * HD + d];
+          m = mn;
+        }
+      }
     }
-    const float inv = 1.0f / lsum;
-    float* o = ctx + (base + i) * H + h * HD;
+    if (live) {
+      const float inv = 1.0f / lsum;
+      float* o = ctx + (base + i) * H + h * HD;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) o[d] = acc[d] * inv;
+      for (int d = 0; d < HD; ++d) o[d] = acc[d] * inv;
+    }
   }
 }
 
@@ -406,8 +433,10 @@ int owc_bert_embed(owc_ctx* ctx, const owc_bert_weights* w, const int32_t* ids, 
   float* qkv = (float*)p;
   p += align256((size_t)T * 3 * H * 4);
   float* ff = (float*)p;
-  const size_t attn_lds = (size_t)L * HD * 4 * 2 + (size_t)L * 4;
-  if (attn_lds > 160 * 1024) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_bert_embed: sequence too long for the LDS-resident attention");
+  // keys resident in LDS at a time: the whole sequence when it fits 128 KiB, else chunks of 256 (head_dim 32: 512) keys
+  const int chunk_cap = (128 * 1024) / (HD * 4 * 2 + 4);
+  const int chunk = L <= chunk_cap ? L : (HD > 32 ? 256 : 512);
+  const size_t attn_lds = (size_t)chunk * HD * 4 * 2 + (size_t)chunk * 4;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)bert_attn_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -423,9 +452,9 @@ int owc_bert_embed(owc_ctx* ctx, const owc_bert_weights* w, const int32_t* ids, 
     OWC_TRY(owc_launch_gemm_f32_bert(x, H, Ly.qkv_w, H, Ly.qkv_b, nullptr, 0, qkv, 3 * H, T, 3 * H, H,
                                 OWC_EPI_NONE, ctx->zeros, st));
     if (HD == 32)
-      hipLaunchKernelGGL(bert_attn_kernel<32>, dim3(n * NH), dim3(64), attn_lds, st, qkv, mask, cx, L, H, NH, scale, w->rel_bias, w->rel_span);
+      hipLaunchKernelGGL(bert_attn_kernel<32>, dim3(n * NH), dim3(64), attn_lds, st, qkv, mask, cx, L, H, NH, scale, w->rel_bias, w->rel_span, chunk);
     else
-      hipLaunchKernelGGL(bert_attn_kernel<64>, dim3(n * NH), dim3(64), attn_lds, st, qkv, mask, cx, L, H, NH, scale, w->rel_bias, w->rel_span);
+      hipLaunchKernelGGL(bert_attn_kernel<64>, dim3(n * NH), dim3(64), attn_lds, st, qkv, mask, cx, L, H, NH, scale, w->rel_bias, w->rel_span, chunk);
     // x = LN(dense(ctx) + x)
     OWC_TRY(owc_launch_gemm_f32_bert(cx, H, Ly.o_w, H, Ly.o_b, x, H, x, H, T, H, H, OWC_EPI_RESIDUAL, ctx->zeros, st));
     hipLaunchKernelGGL(ln_f32_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, Ly.ln1_w, Ly.ln1_b, T, H, w->ln_eps);
@@ -465,8 +494,9 @@ int owc_bert_embed_packed(owc_ctx* ctx, const owc_bert_weights* w, const int32_t
   float* qkv = (float*)p;
   p += align256((size_t)T * 3 * H * 4);
   float* ff = (float*)p;
-  const size_t attn_lds = (size_t)max_len * HD * 4 * 2;
-  if (attn_lds > 160 * 1024) OWC_FAIL(ctx, OWC_ERR_SHAPE, "owc_bert_embed_packed: sequence too long for the LDS-resident attention");
+  const int chunk_cap = (128 * 1024) / (HD * 4 * 2);
+  const int chunk = max_len <= chunk_cap ? max_len : (HD > 32 ? 256 : 512);
+  const size_t attn_lds = (size_t)chunk * HD * 4 * 2;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)bert_attn_packed_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -482,9 +512,9 @@ int owc_bert_embed_packed(owc_ctx* ctx, const owc_bert_weights* w, const int32_t
     OWC_TRY(owc_launch_gemm_f32_bert(x, H, Ly.qkv_w, H, Ly.qkv_b, nullptr, 0, qkv, 3 * H, T, 3 * H, H,
                                 OWC_EPI_NONE, ctx->zeros, st));
     if (HD == 32)
-      hipLaunchKernelGGL(bert_attn_packed_kernel<32>, dim3(n * NH), dim3(64), attn_lds, st, qkv, seq_start, cx, H, NH, scale, w->rel_bias, w->rel_span);
+      hipLaunchKernelGGL(bert_attn_packed_kernel<32>, dim3(n * NH), dim3(64), attn_lds, st, qkv, seq_start, cx, H, NH, scale, w->rel_bias, w->rel_span, chunk);
     else
-      hipLaunchKernelGGL(bert_attn_packed_kernel<64>, dim3(n * NH), dim3(64), attn_lds, st, qkv, seq_start, cx, H, NH, scale, w->rel_bias, w->rel_span);
+      hipLaunchKernelGGL(bert_attn_packed_kernel<64>, dim3(n * NH), dim3(64), attn_lds, st, qkv, seq_start, cx, H, NH, scale, w->rel_bias, w->rel_span, chunk);
     OWC_TRY(owc_launch_gemm_f32_bert(cx, H, Ly.o_w, H, Ly.o_b, x, H, x, H, T, H, H, OWC_EPI_RESIDUAL, ctx->zeros, st));
     hipLaunchKernelGGL(ln_f32_kernel, dim3((T + 3) / 4), dim3(256), 0, st, x, Ly.ln1_w, Ly.ln1_b, T, H, w->ln_eps);
     OWC_TRY(owc_launch_gemm_f32_bert(x, H, Ly.fc1_w, H, Ly.fc1_b, nullptr, 0, ff, I, T, I, H, OWC_EPI_GELU_ERF,

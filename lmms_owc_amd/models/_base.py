@@ -582,6 +582,8 @@ def beams_from_gen_kwargs(gen_kwargs: dict) -> int:
     k = int(gen_kwargs.get("num_beams", 1) or 1)
     if k < 1:
         raise ValueError("num_beams must be >= 1")
+    if k > 32:   # owc_beam_candidates returns at most 64 = 2 x num_beams candidates per row: refuse here, not inside the first decode step
+        raise ValueError("num_beams > 32 is not supported by the HIP decoder (owc_beam_candidates: k = 2 * num_beams <= 64)")
     return k
 
 

@@ -163,3 +163,28 @@ def test_mpnet_embed_matches_reference_golden(gpu, kind):
         sc = SentenceScorer(w, max_batch=max_batch)
         np.testing.assert_allclose(to_np(sc.embed(ids, mask)), g[f"{kind}_embeds"], atol=2e-5)
     np.testing.assert_allclose(to_np(sc.embed(ids, mask, packed=False)), g[f"{kind}_embeds"], atol=2e-5)
+
+
+@pytest.mark.parametrize("L", [300, 384, 512])
+def test_long_sequences_through_the_chunked_attention(gpu, L):
+    """Round 6: the sentence encoder's attention kept K and V of a whole sequence in LDS - head_dim 64 (all-mpnet-base-v2,
+    BASELINE.json configs[0]'s encoder) stopped at 317 tokens although the tokenizer truncates at 512 and the reference's
+    `encode_sentence_bert` (src/data/pipelines/text/_text.py:175-202) simply encodes such a prediction.  The kernels now hold 256
+    keys at a time and carry the online softmax across chunks in the same key order (bit-identical to the one-chunk form).  Base width
+    (768 / 12 heads / 3072), 2 layers, sequences of 2..L tokens, packed and padded rows, against the numpy oracle; and MiniLM
+    (head_dim 32) at the same lengths."""
+    from lmms_owc_amd.engine.scorer import BertWeights, SentenceScorer
+
+    c = dict(recipes.mpnet_cfg("base"), num_hidden_layers=2)
+    ids, mask = recipes.mpnet_label_tokens(5, L, c["vocab_size"], seed=L)
+    w = recipes.mpnet_weights(c, 31)
+    want = B.sentence_embed(w, c, ids, mask)
+    sc = SentenceScorer(BertWeights(c, w, gpu), max_batch=64)
+    np.testing.assert_allclose(to_np(sc.embed(ids, mask)), want, atol=2e-5)
+    np.testing.assert_allclose(to_np(sc.embed(ids, mask, packed=False)), want, atol=2e-5)
+    c2 = recipes.bert_cfg("minilm")
+    c2 = dict(c2, num_hidden_layers=2, max_position_embeddings=max(c2.get("max_position_embeddings", 512), 512))
+    w2 = recipes.bert_weights(c2, 78)
+    ids2, mask2 = recipes.label_tokens(4, L, c2["vocab_size"], seed=L + 1)
+    sc2 = SentenceScorer(BertWeights(c2, w2, gpu), max_batch=64)
+    np.testing.assert_allclose(to_np(sc2.embed(ids2, mask2)), B.sentence_embed(w2, c2, ids2, mask2), atol=2e-5)
