@@ -271,6 +271,11 @@ def evaluate(lm, task_dict: dict, limit: int | float | None = None, log_samples:
             results["samples"][task_name] = samples
     if dist is not None:
         dist.barrier()
+    # generation is over: whatever host work follows in this process (writing the files, an in-process scorer) may use every core
+    # again - the plug-in pinned its launch thread and workers to the GPU's NUMA share (models/_base.py `pin_to_gpu_numa_node`)
+    unpin = getattr(lm, "unpin_host_threads", None)
+    if callable(unpin):
+        unpin()
     if rank != 0:
         return None
     if not log_samples:

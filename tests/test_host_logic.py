@@ -767,3 +767,52 @@ def test_gen_kwargs_to_pass_key():
     with pytest.raises(ValueError):
         beams_from_gen_kwargs({"num_beams": -2})
     assert pass_key(16, None) == (16, None) and pass_key(16, None, 3) == (16, None, 3) and pass_key(16, smp) != pass_key(16, None)
+
+
+def test_unpin_host_threads_resets_every_thread_of_the_process():
+    """`os.sched_setaffinity(0, ...)` moves the calling thread only and threads started under a narrow mask keep it.
+    `PassPipeline.unpin_host_threads` walks /proc/self/task: a worker that pinned itself (as the PIL pool's initializer does) and a
+    thread that merely INHERITED a narrow mask both get the original mask back; a second call is a no-op."""
+    import os
+    import threading
+
+    from lmms_owc_amd.models._base import PassPipeline
+
+    if not hasattr(os, "sched_setaffinity") or len(os.sched_getaffinity(0)) < 2:
+        pytest.skip("needs sched_setaffinity and >= 2 CPUs")
+    full = sorted(os.sched_getaffinity(0))
+    narrow = full[:1]
+    seen, go, stop = {}, threading.Event(), threading.Event()
+
+    def worker(name, pin):
+        if pin:
+            os.sched_setaffinity(0, narrow)
+        seen[name + "_tid"] = threading.get_native_id()
+        go.set() if name == "b" else None
+        stop.wait(10)
+        seen[name] = sorted(os.sched_getaffinity(0))
+
+    try:
+        a = threading.Thread(target=worker, args=("a", True))
+        a.start()
+        os.sched_setaffinity(0, narrow)                 # the launch thread pinned ...
+        b = threading.Thread(target=worker, args=("b", False))   # ... and a thread started meanwhile inherits the mask
+        b.start()
+        go.wait(10)
+        assert sorted(os.sched_getaffinity(seen["b_tid"])) == narrow
+
+        class P(PassPipeline):
+            def __init__(self):
+                self._cpu_affinity_before, self._cpu_affinity = full, narrow
+
+        p = P()
+        n = p.unpin_host_threads()
+        assert n >= 3 and sorted(os.sched_getaffinity(0)) == full
+        assert sorted(os.sched_getaffinity(seen["a_tid"])) == full and sorted(os.sched_getaffinity(seen["b_tid"])) == full
+        assert p.unpin_host_threads() == 0
+    finally:
+        stop.set()
+        os.sched_setaffinity(0, full)
+    a.join()
+    b.join()
+    assert seen["a"] == full and seen["b"] == full
