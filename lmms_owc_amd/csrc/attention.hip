@@ -425,9 +425,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
 // ------------------------------------------------------------------------------------------------------------------------
 int g_attn_mfma32 = 0;   // 0 (default): attn_fwd_kernel; 1: attn_fwd32_kernel; 2: attn_fwd32p_kernel (knob "attn_mfma32").  MEASURED, one box, interleaved
                          // (profiles/r06_attn_mfma32_ab.txt): 64 x 1024 patches 781 / 683 / 694 TFLOP/s, 16 x 4096: 937 / 830 / 845 - the
-                         // 32x32x16 kernels are 10-12 % SLOWER and the software pipelining is worth +1.5 %: neither the free issue slots nor the
-                         // interleave is what bounds this loop (round 5's timing build said the same from the other side: with ALL MFMAs
-                         // removed the kernel got 12 % faster).  They stay in the tree as the tested alternative, not on the path.
+                         // 32x32x16 kernels 10-12 % SLOWER at 2 waves per SIMD (170 / 214 VGPRs), the software pipelining worth +1.5 %.
+                         // With attn_fwd32_kernel squeezed to 168 VGPRs = 3 waves per SIMD like attn_fwd_kernel (161): 795 / 765 and
+                         // 961 / 935 - 3-4 % slower.  Resident waves are what this loop runs on (PMC, round 5: a wave issues 30 % of its
+                         // cycles, three of them keep the SIMD's issue port ~90 % busy), not the matrix / vector overlap inside one
+                         // wave.  They stay in the tree as the tested alternative, not on the path.
 
 template <int HD>
 struct Cfg32 {
@@ -452,7 +454,7 @@ struct Cfg32 {
 };
 
 template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(
+__global__ __launch_bounds__(256, 3) void attn_fwd32_kernel(
     const bf16_t* __restrict__ Q, long q_ts, long q_hs, const bf16_t* __restrict__ K, long k_ts,
     long k_hs, const bf16_t* __restrict__ V, long v_ts, long v_hs, bf16_t* __restrict__ O, long o_ts,
     long o_hs, const int* __restrict__ q_start, const int* __restrict__ o_start,
