@@ -504,3 +504,40 @@ def test_repetition_penalty_matches_hf_processor_semantics(setup, gpu):
     s1 = to_np(unshared.generate(text, None, none, T, sampling=smp, repetition_penalty=p))
     s2 = to_np(unshared.generate(text, None, none, T, sampling=smp, repetition_penalty=p))
     assert np.array_equal(s1, s2) and s1.min() >= 0 and s1.max() < 512
+
+
+def test_repetition_penalty_against_hf_generate_golden(setup, gpu):
+    """The engine against HF ITSELF under a repetition penalty (tests/golden/qwen2vl_tiny_rep.npz: HF's generate with 1.3 on the
+    model's generation config and the reference's argument list; prompts on which the seeded model loops without the penalty).
+    Teacher-forced on HF's bf16 tokens, so every step is comparable: the engine's RAW logits stay within the model-level bound of
+    HF's raw logits (2.5 % of max |logit|), and its token - the argmax of its own penalised scores over the same history - equals
+    HF's wherever HF's PROCESSED top-2 margin exceeds twice that bound; on a near-tie it must still be one of the candidates.  The
+    un-penalised engine run differs (it loops like HF's un-penalised run)."""
+    import json
+
+    cfg, w, eng, _ = setup
+    g = np.load(GOLD / "qwen2vl_tiny_rep.npz")
+    meta = json.loads((GOLD / "qwen2vl_tiny_rep.json").read_text())
+    p, T = meta["repetition_penalty"], 12
+    decisive = 0
+    for name, case in meta["cases"].items():
+        grid = [tuple(r) for r in case["grid"]]
+        pix = recipes.pixel_values(grid, 7)
+        ids = g[f"{name}_ids"]
+        emb = eng.encode_images(torch.from_numpy(pix).to(torch.bfloat16).to(gpu), grid)
+        hf_toks, hf_raw, hf_proc = g[f"{name}_bf16_tokens"], g[f"{name}_bf16_logits"], g[f"{name}_bf16_scores"]
+        toks, sl = eng.generate([ids], emb, [grid], T, repetition_penalty=p, forced_tokens=hf_toks[None], return_step_logits=True)
+        toks, sl = to_np(toks)[0].astype(int), to_np(sl)[:, 0]
+        for j in range(T):
+            scale = np.abs(hf_raw[j]).max()
+            assert np.abs(sl[j] - hf_raw[j]).max() <= 0.025 * scale, (name, j, np.abs(sl[j] - hf_raw[j]).max() / scale)
+            top2 = np.sort(hf_proc[j])[-2:]
+            if top2[1] - top2[0] > 0.05 * scale:
+                assert toks[j] == int(hf_toks[j]), (name, j, toks[j], int(hf_toks[j]))
+                decisive += 1
+            else:
+                assert hf_proc[j][toks[j]] >= top2[1] - 0.05 * scale, (name, j)
+        free = to_np(eng.generate([ids], emb, [grid], T))[0].astype(int)
+        if not np.array_equal(g[f"{name}_bf16_tokens"], g[f"{name}_bf16_tokens_without_penalty"]):
+            assert not np.array_equal(free, toks), name      # without the penalty the engine does what HF does without it: something else
+    assert decisive >= 12, decisive

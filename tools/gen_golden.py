@@ -97,6 +97,48 @@ def gen_qwen():
     print("qwen golden:", {k: v.shape for k, v in out.items()})
 
 
+def gen_qwen_rep():
+    """HF's own greedy generation of the tiny Qwen2-VL with `repetition_penalty` set on the model's GENERATION CONFIG (1.3) and the
+    reference's argument list (/root/reference/src/models/_qwen2_vl.py:319-329: do_sample = temperature > 0, temperature, top_p,
+    num_beams, max_new_tokens - no repetition_penalty argument), i.e. the situation of a checkpoint whose generation_config.json
+    carries the field: tokens, RAW logits (`output_logits`) and PROCESSED scores (`output_scores`: after the penalty) of 12 steps."""
+    cfg = recipes.tiny_cfg()
+    w = recipes.qwen2vl_weights(cfg, 1234)
+    out = {}
+    # prompt seeds chosen (scan of 11..39 with HF fp32) so that the penalty DECIDES tokens: without it the seeded model loops
+    # (seed 16: 394 394 394 ...; seed 18: 481 432 481 489 ...), with it it does not
+    cases = {"s13": ([(1, 4, 4)], 13), "s16": ([(1, 4, 4)], 16), "s18": ([(1, 4, 4)], 18), "b12": ([(1, 6, 4), (1, 4, 8)], 12)}
+    for name, (grid, pseed) in cases.items():
+        pix = recipes.pixel_values(grid, seed=7)
+        ids = recipes.prompt_ids(cfg, grid, seed=pseed)
+        for dtype, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+            m = hf_qwen(cfg, w, dtype)
+            m.generation_config.repetition_penalty = 1.3
+            g = torch.tensor(grid)
+            inp = torch.from_numpy(ids)[None]
+            mm = (inp == cfg.image_token_id).int()
+            with torch.no_grad():
+                gen = m.generate(input_ids=inp, attention_mask=torch.ones_like(inp), pixel_values=torch.from_numpy(pix).to(dtype),
+                                 image_grid_thw=g, mm_token_type_ids=mm, do_sample=False, temperature=0, top_p=None, num_beams=1,
+                                 max_new_tokens=12, use_cache=True, eos_token_id=None, pad_token_id=0, output_logits=True,
+                                 output_scores=True, return_dict_in_generate=True)
+                plain = m.generate(input_ids=inp, attention_mask=torch.ones_like(inp), pixel_values=torch.from_numpy(pix).to(dtype),
+                                   image_grid_thw=g, mm_token_type_ids=mm, do_sample=False, temperature=0, top_p=None, num_beams=1,
+                                   max_new_tokens=12, use_cache=True, eos_token_id=None, pad_token_id=0, repetition_penalty=1.0)
+            out[f"{name}_{tag}_tokens"] = gen.sequences[0, inp.shape[1]:].numpy()
+            out[f"{name}_{tag}_logits"] = torch.stack([l[0] for l in gen.logits]).float().numpy()
+            out[f"{name}_{tag}_scores"] = torch.stack([l[0] for l in gen.scores]).float().numpy()
+            out[f"{name}_{tag}_tokens_without_penalty"] = plain[0, inp.shape[1]:].numpy()
+        out[f"{name}_grid"] = np.array(grid)
+        out[f"{name}_ids"] = ids
+    np.savez_compressed(GOLD / "qwen2vl_tiny_rep.npz", **out)
+    (GOLD / "qwen2vl_tiny_rep.json").write_text(json.dumps({"versions": versions(), "weights_seed": 1234, "repetition_penalty": 1.3,
+                                                            "set_on": "model.generation_config (not passed to generate)",
+                                                            "cases": {k: {"grid": v[0], "prompt_seed": v[1]} for k, v in cases.items()}}, indent=1))
+    for name in cases:
+        print("qwen rep golden", name, out[f"{name}_f32_tokens"].tolist(), "without:", out[f"{name}_f32_tokens_without_penalty"].tolist())
+
+
 def hf_qwen25(cfg, weights, dtype):
     from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
 
@@ -710,6 +752,8 @@ if __name__ == "__main__":
         gen_llava_next()
     if "qwen" in which:
         gen_qwen()
+    if "qwen_rep" in which:
+        gen_qwen_rep()
     if "qwen25" in which:
         gen_qwen25()
     if "scorer" in which:
