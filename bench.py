@@ -1259,7 +1259,7 @@ def main() -> None:
         import signal
         import threading
 
-        emit_lock, emitted = threading.Lock(), [False]
+        emit_lock, emitted = threading.RLock(), [False]   # re-entrant: the signal handler runs on the main thread, which may hold it
 
         def emit(why: str | None = None) -> None:
             with emit_lock:
