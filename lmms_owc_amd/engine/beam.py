@@ -85,7 +85,10 @@ class BeamSearcher:
         self.running = np.where(act[:, None, None], c_seqs[rows, nxt], self.running)
         self.run_scores = np.where(act[:, None], r_scores[rows, nxt], self.run_scores).astype(np.float32)
         self.g = g + 1
-        best_possible = self.run_scores[:, 0] / np.float32(self.g ** self.lp)
+        # HF `_check_early_stop_heuristic`: early_stopping == "never" with a positive length penalty prices the running beam at the
+        # LONGEST length it may reach (max_new_tokens), every other setting at its current length
+        hyp_len = self.T if (self.early == "never" and self.lp > 0.0) else self.g
+        best_possible = self.run_scores[:, 0] / np.float32(hyp_len ** self.lp)
         worst_fin = np.where(self.is_fin, self.fin_scores.min(1, keepdims=True), NEG)
         self.unsat = self.unsat & (best_possible[:, None] > worst_fin).any(1)
         open_beam = ~(self.is_fin.all(1) & (self.early is True))

@@ -76,7 +76,9 @@ def beam_search(logits_fn, prompt_len: int, num_beams: int, max_new_tokens: int,
         fin, fin_scores, is_fin = [m_seqs[i] for i in keep], m_scores[keep].astype(np.float32), m_fin[keep]
         running, run_scores = [c_seqs[i] for i in nxt], r_scores[nxt]
         g += 1
-        best_possible = run_scores[0] / np.float32(g ** length_penalty)      # (early_stopping False / True: the current length)
+        # HF `_check_early_stop_heuristic`: early_stopping == "never" with length_penalty > 0 uses max_length - prompt_len, else the current length
+        hyp_len = max_new_tokens if (early_stopping == "never" and length_penalty > 0.0) else g
+        best_possible = run_scores[0] / np.float32(hyp_len ** length_penalty)
         worst_fin = np.where(is_fin, fin_scores.min(), np.float32(NEG))
         unsat = unsat and bool((best_possible > worst_fin).any())
         open_beam = not (bool(is_fin.all()) and early_stopping is True)

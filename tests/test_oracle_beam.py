@@ -135,3 +135,43 @@ def test_length_penalty_and_early_stopping_match_hf(tiny_lm, k, T, lp, es):
             seqs = [seqs[parent[0, j]] + [int(token[0, j])] for j in range(k)]
         toks, scores = bs.result()
         assert np.array_equal(toks[0], want) and abs(scores[0] - score) < 1e-4
+
+
+@pytest.mark.parametrize("k,T,lp,trial,eos_rank", [(2, 10, 1.0, 3, 0), (2, 10, 3.0, 3, 1), (2, 12, 2.0, 2, 0), (3, 10, 1.0, 1, 0), (3, 10, 2.0, 3, 0)])
+def test_early_stopping_never_prices_running_beams_at_the_longest_length(tiny_lm, k, T, lp, trial, eos_rank):
+    """HF's `_check_early_stop_heuristic` divides the best running score by (max_length - prompt_len) ** length_penalty
+    when `early_stopping == "never"` and length_penalty > 0, by the CURRENT length otherwise; the oracle and `BeamSearcher` used the
+    current length for both and round 5's test cases did not separate the two.  These cases do (found by scanning: HF's "never"
+    result differs from its `early_stopping=False` result), and both implementations must give HF's "never" result."""
+    import torch
+
+    from lmms_owc_amd.engine.beam import BeamSearcher
+
+    m, pad = tiny_lm, 0
+    r = np.random.default_rng(1000 * k + 10 * T + int(lp))
+    for t in range(trial + 1):
+        prompt = r.integers(1, 97, 5 + t).tolist()
+
+    def logits_fn(conts):
+        with torch.no_grad():
+            return m(input_ids=torch.tensor([prompt + c for c in conts])).logits[:, -1, :].float().numpy()
+
+    free, _ = BM.beam_search(logits_fn, len(prompt), k, T, -1, pad)
+    vals, counts = np.unique(free, return_counts=True)
+    eos = int(vals[np.argsort(-counts, kind="stable")][min(eos_rank, len(vals) - 1)])
+    want = _hf_beams(m, prompt, k, T, eos, pad, length_penalty=lp, early_stopping="never")
+    other = _hf_beams(m, prompt, k, T, eos, pad, length_penalty=lp, early_stopping=False)
+    assert not np.array_equal(want, other), "this case no longer separates the two heuristics"
+    got, score = BM.beam_search(logits_fn, len(prompt), k, T, eos, pad, length_penalty=lp, early_stopping="never")
+    assert np.array_equal(got, want), (got, want)
+    bs = BeamSearcher(1, k, T, eos, pad, lp, "never")
+    seqs, more = [[] for _ in range(k)], True
+    while more:
+        lg = logits_fn(seqs)[None]
+        order = np.lexsort((np.broadcast_to(np.arange(lg.shape[-1]), lg.shape), -lg.astype(np.float64)), axis=-1)[..., : 2 * k]
+        mx = lg.max(-1)
+        logz = mx + np.log(np.exp(lg - mx[..., None]).sum(-1, dtype=np.float32))
+        parent, token, more = bs.step(logz, np.take_along_axis(lg, order, -1), order.astype(np.int32))
+        seqs = [seqs[parent[0, j]] + [int(token[0, j])] for j in range(k)]
+    toks, scores = bs.result()
+    assert np.array_equal(toks[0], want) and abs(scores[0] - score) < 1e-4
