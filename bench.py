@@ -101,7 +101,8 @@ def pruned_flops_per_image(d, prompts_per_chunk: int, S: int | None = None) -> f
     return float(last_layer + shared_rows * per_row)
 
 
-def cpu_baseline_lmm(dims, device, seed: int, new_tokens: int, pix_dev, hip_tokens, n_images: int, engine=None) -> dict:
+def cpu_baseline_lmm(dims, device, seed: int, new_tokens: int, pix_dev, hip_tokens, n_images: int, engine=None,
+                     budget_s: float = 150.0) -> dict:
     """The reference's CPU path: HF Qwen2VLForConditionalGeneration.generate, batch 1, greedy (src/models/_qwen2_vl.py:308-329),
     on the SAME seeded weights (`random_param`, regenerated per HF parameter name and copied to the host) and the SAME
     pixel_values / prompt ids as the HIP run's first `n_images` images; its tokens are compared with the HIP tokens."""
@@ -151,8 +152,14 @@ def cpu_baseline_lmm(dims, device, seed: int, new_tokens: int, pix_dev, hip_toke
     mm = (inp == d.image_token_id).int()
     grid = torch.tensor([[1, 32, 32]])
     times, same_first, same_all, logit_err, flips, forced_equal = [], 0, 0, [], [], 0
+    t_leg = time.perf_counter()
     with torch.no_grad():
         for i in range(n_images):
+            # a BOUNDED sample: on a slow or busy host (40-50 s per image seen) the leg stops after the image that crosses `budget_s`,
+            # but never before two images are done (the first is the warm-up; `value` needs one after it)
+            if i >= 2 and time.perf_counter() - t_leg > budget_s:
+                n_images = i
+                break
             pix = pix_dev[i * 1024:(i + 1) * 1024].cpu()
             t0 = time.perf_counter()
             gen = model.generate(input_ids=inp, attention_mask=torch.ones_like(inp), pixel_values=pix, image_grid_thw=grid,
@@ -827,6 +834,8 @@ def main() -> None:
     ap.add_argument("--cpu-images", type=int, default=4,
                     help="images of the CPU baseline (HF generate on the host cores, ~25-40 s each for 7B; SURVEY.md section 8d: 4 for 7B); "
                          "the first is the warm-up, `value` = mean of the rest")
+    ap.add_argument("--cpu-budget-s", type=float, default=150.0,
+                    help="the CPU baseline stops after the image that crosses this many seconds of generate time (at least two images run)")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
                     help="owc_tuning_set(KNOB, VALUE) before anything runs (A-B experiments; recorded in config.tuning)")
     ap.add_argument("--dry-run", action="store_true", help="launcher + rendezvous check on CPU (gloo); stops before HIP init")
@@ -1232,7 +1241,7 @@ def main() -> None:
                                                "kernel_ms_total": b16["ms"], "launches": b16["launches"]}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"] = cpu_baseline_lmm(dims, device, 1234, T, pix, out, args.cpu_images, engine)
+                result["cpu_baseline"] = cpu_baseline_lmm(dims, device, 1234, T, pix, out, args.cpu_images, engine, args.cpu_budget_s)
                 result["cpu_baseline_label_cosine"] = cpu_baseline_scorer(4096, L)
             except Exception as e:  # the baseline must never sink the measurement
                 result["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "reference",
