@@ -499,6 +499,9 @@ def test_repetition_penalty_matches_hf_processor_semantics(setup, gpu):
         stop = np.flatnonzero(a[i] == eos)
         n_keep = (stop[0] + 1) if len(stop) else T
         assert np.array_equal(c1[i, :n_keep], a[i, :n_keep]) and (c1[i, n_keep:] == 0).all()
+    # the hipGraph decode path replays the captured step: the mark / penalised-argmax launches are part of it
+    gr = Qwen2VLEngine(eng.w, vit_chunk_tokens=64, prefill_chunk_tokens=4096, share_prefix=False, graph_decode=True)
+    assert np.array_equal(to_np(gr.generate(text, None, none, T, repetition_penalty=p)), b_)
     # sampled requests: penalised values written back as bf16 in front of the draw - runs, is a function of the seed
     smp = {"temperature": 0.8, "top_k": 20, "top_p": 0.9, "seed": 7}
     s1 = to_np(unshared.generate(text, None, none, T, sampling=smp, repetition_penalty=p))
