@@ -325,6 +325,19 @@ def test_real_checkpoint_loading_path(gpu, tmp_path):
     direct = lm.tokenizer.batch_decode([toks[: stop[0]] if len(stop) else toks], skip_special_tokens=True)[0]
     single = lm.generate_until([task.instances[0]])
     assert single[0] == direct
+    # generation_config.json of the checkpoint (what HF merges into the reference's generate call): top_k for sampled requests and
+    # repetition_penalty for EVERY request reach the engine; a checkpoint without the file runs plain greedy (above)
+    assert lm._model.repetition_penalty == 1.0
+    (d / "generation_config.json").write_text(json.dumps({"do_sample": True, "temperature": 0.01, "top_p": 0.001, "top_k": 1,
+                                                          "repetition_penalty": 1.05, "eos_token_id": [s["<|im_end|>"], s["<|endoftext|>"]]}))
+    lm2 = get_model("custom-model", model_type="qwen2-vl", model_name_or_path=str(d), batch_size=2)
+    assert lm2._model.repetition_penalty == 1.05 and lm2._default_top_k == 1
+    lm2.task_dict[task.task_name] = task.dataset
+    toks2 = eng.generate([ids], emb, [[(1, 4, 4)]], 8, eos_token_id=s["<|im_end|>"], pad_token_id=s["<|endoftext|>"],
+                         repetition_penalty=1.05).cpu().numpy()[0]
+    stop2 = np.flatnonzero(toks2 == s["<|im_end|>"])
+    direct2 = lm2.tokenizer.batch_decode([toks2[: stop2[0]] if len(stop2) else toks2], skip_special_tokens=True)[0]
+    assert lm2.generate_until([task.instances[0]])[0] == direct2
 
 
 def test_sentence_encoder_loads_from_directory(gpu, tmp_path, monkeypatch):
