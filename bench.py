@@ -101,6 +101,23 @@ def pruned_flops_per_image(d, prompts_per_chunk: int, S: int | None = None) -> f
     return float(last_layer + shared_rows * per_row)
 
 
+def baseline_threads() -> int:
+    """Intra-op threads of the CPU baselines: the CPUs the cgroup lets this process keep busy (one per physical core at most: 128
+    of the host's 256 logical CPUs).  Rounds 1-5 took `os.cpu_count()` - 128 threads on a box whose cgroup grants 16 CPUs, which
+    throttles the whole group: the baseline's dominant bf16 Linear measured 122 ms on 128 threads and 39 ms on 16
+    (tools/probes/cpu_threads_under_quota.py), so those rounds under-reported the CPU baseline ~3x and spent 90-140 s on it."""
+    from lmms_owc_amd.models._base import usable_cpus
+
+    return max(1, min(usable_cpus()[0], 128))
+
+
+def host_cpu_record() -> dict:
+    from lmms_owc_amd.models._base import usable_cpus
+
+    n, quota = usable_cpus()
+    return {"logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota, "usable_cpus": n}
+
+
 def cpu_baseline_lmm(dims, device, seed: int, new_tokens: int, pix_dev, hip_tokens, n_images: int, engine=None,
                      budget_s: float = 150.0) -> dict:
     """The reference's CPU path: HF Qwen2VLForConditionalGeneration.generate, batch 1, greedy (src/models/_qwen2_vl.py:308-329),
@@ -112,7 +129,7 @@ def cpu_baseline_lmm(dims, device, seed: int, new_tokens: int, pix_dev, hip_toke
 
     d = dims
     affinity = restore_full_affinity()
-    threads = min(os.cpu_count() or 1, 128)
+    threads = baseline_threads()
     torch.set_num_threads(threads)
     cfg = Qwen2VLConfig(
         text_config=dict(hidden_size=d.d_model, num_hidden_layers=d.n_layers, num_attention_heads=d.n_q_heads,
@@ -196,7 +213,7 @@ def cpu_baseline_lmm(dims, device, seed: int, new_tokens: int, pix_dev, hip_toke
     best = float(np.mean(times[1:])) if len(times) > 1 else float(times[0])
     import transformers
 
-    return {"value": 1.0 / best, "unit": "images/s", "cores": threads, "kind": "reference", "thread_affinity": affinity,
+    return {"value": 1.0 / best, "unit": "images/s", "cores": threads, "kind": "reference", "thread_affinity": affinity, "host": host_cpu_record(),
             "sample": f"{n_images} image(s) 448x448 = the HIP run's first images (same pixel_values, prompt ids and seeded weights), batch 1, "
                       f"bf16, transformers {transformers.__version__} Qwen2VLForConditionalGeneration.generate on CPU (greedy, {new_tokens} "
                       f"new tokens); mean of images after the first; per-image s = {[round(t, 2) for t in times]}",
@@ -217,7 +234,7 @@ def cpu_baseline_scorer(n_labels: int, L: int) -> dict:
 
     from lmms_owc_amd.engine.scorer import MINILM_L6
 
-    threads = min(os.cpu_count() or 1, 128)
+    threads = baseline_threads()
     torch.set_num_threads(threads)
     m = BertModel(BertConfig(**MINILM_L6), add_pooling_layer=False).eval()
     g = torch.Generator().manual_seed(0)
@@ -239,7 +256,7 @@ def cpu_baseline_scorer(n_labels: int, L: int) -> dict:
     t0 = time.perf_counter()
     run()
     dt = time.perf_counter() - t0
-    return {"value": n_labels / dt, "unit": "labels/s", "cores": threads, "kind": "reference",
+    return {"value": n_labels / dt, "unit": "labels/s", "cores": threads, "kind": "reference", "host": host_cpu_record(),
             "sample": f"{n_labels} labels x {L} tokens, HF BertModel fp32 CPU batches of 1024 + paired bmm"}
 
 
@@ -1397,7 +1414,7 @@ def pil_leg(engine, dims, host_u8, B: int, T: int, device, sync, lm=None) -> dic
     first = lm.last_timing.get("first_chunk_prep_s", 0.0)
     pinned_to = lm._cpu_affinity
     lm.release_host_resources()     # the CPU baseline below runs in this process: its threads must see every core again
-    return {"seconds": dtp, "images": n, "batch_size": bs, "prep_threads": lm._prep_threads, "host_cores": os.cpu_count(),
+    return {"seconds": dtp, "images": n, "batch_size": bs, "prep_threads": lm._prep_threads, "host_cores": os.cpu_count(), "host": host_cpu_record(),
             "cpu_affinity": None if not pinned_to else f"{len(pinned_to)} CPUs of the GPU's NUMA node ({pinned_to[0]}..{pinned_to[-1]})",
             "chunks": lm.last_timing.get("chunks"),
             "first_chunk_prep_s": first,   # exposed once per generate_until call (a task), whatever its length

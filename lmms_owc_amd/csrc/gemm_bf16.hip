@@ -881,6 +881,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256pp_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// (Round 6, tried and removed: the same kernel with TWO phases per K-tile - MFMA sections of 32 instead of 16, half as many barrier
+// pairs, an A ring of three 32-KiB slots beside the two W stages so that ONE counted wait per K-tile suffices, 64 instead of 80
+// fragment registers, 218 VGPRs, bit-identical.  Interleaved A-B at M = 65 536 (profiles/r06_gemm_two_phase_pingpong_ab.txt):
+// gate/up 1466 -> 1478 TFLOP/s, down 1553 -> 1539, qkv 1474 = 1474, o 1475 -> 1470, vit.fc1 1338 -> 1335, vit.qkv 1325 -> 1307.
+// The barrier count is not what holds this kernel at 0.81 of the clock-limited matrix peak.)
+// ------------------------------------------------------------------------------------------------
 // PERSISTENT form of the ping-pong kernel (round 5; built, bit-identical, measured - and OFF by default, `g_persist`): one block per
 // CU walks its output tiles (tile ids blockIdx.x, + gridDim.x, ...) and the operand ring never drains - the LDS-DMA slots that the last
 // two K-tiles of an output tile leave empty in gemm_bf16_nt_256pp_kernel carry K-tiles 0 and 1 of the NEXT output tile, so its first

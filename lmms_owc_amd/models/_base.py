@@ -221,7 +221,8 @@ class PassPipeline:
         # rate; more workers only take the GIL away from the thread that launches the kernels (measured on the bench's PIL leg:
         # 4-8 workers 0.89 of the engine rate, 32 workers 0.85, 64 workers 0.80)
         ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
-        self._prep_threads = int(os.environ.get("OWC_PREP_THREADS", max(2, min(8, (os.cpu_count() or 8) // ranks_here))))
+        # (CPUs = what the cgroup lets this process use, not what the host has: `usable_cpus`)
+        self._prep_threads = int(os.environ.get("OWC_PREP_THREADS", max(2, min(8, usable_cpus()[0] // ranks_here))))
         self._pool = ThreadPoolExecutor(max_workers=self._prep_threads, thread_name_prefix="owc-pil", initializer=pin_worker)
         # ONE unit in preparation at a time (OWC_PREP_UNITS): two raise one rank's ceiling by ~14 % on an idle host but cost 3 % at the
         # production rate with 8 ranks on a 256-core host (0.975 -> 0.946 of 8 x 205 images/s, profiles/r05_host_soak.txt) - and so did
@@ -232,6 +233,7 @@ class PassPipeline:
         import threading
 
         self._pinned_free, self._pinned_lock = [], threading.Lock()
+        self._host_allocator = keep_image_blocks_mapped()
 
     PINNED_POOL_BYTES = 4 << 30   # retained (idle) pinned staging per rank; buffers in flight are bounded by the look-ahead
 
@@ -469,6 +471,71 @@ class PassPipeline:
         assert carried is None and len(rows) == len(requests)
         return reordered.get_original([rows[i] for i in range(len(requests))])
 
+
+
+def usable_cpus(cgroup_root: str = "/sys/fs/cgroup") -> tuple[int, float | None]:
+    """(CPUs this process can actually keep busy, the cgroup CPU quota in CPUs or None).  `os.cpu_count()` and the affinity mask
+    count the host's logical CPUs; a container's bandwidth limit (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us / cpu.cfs_period_us`) is
+    invisible to both, and more runnable threads than the quota only get the whole group THROTTLED - every thread stopped for the
+    rest of each 100 ms period.  Round 6 found the 1-GPU MI355X boxes at 16 of 256 (tools/probe_cpu_quota.py): a bf16 `nn.Linear`
+    ran 3.1x faster on 16 intra-op threads than on 128, and 8 emulated ranks x 8 PIL workers shared two CPUs per rank - that, not
+    the pipeline, was the "8-rank host ceiling" of rounds 4-5 (profiles/r06_host_soak.txt)."""
+    import math
+    import os
+    from pathlib import Path
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = (Path(cgroup_root) / "cpu.max").read_text().split()[:2]
+        if q != "max":
+            quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            q = int((Path(cgroup_root) / "cpu" / "cpu.cfs_quota_us").read_text())
+            period = int((Path(cgroup_root) / "cpu" / "cpu.cfs_period_us").read_text())
+            if q > 0 and period > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, math.ceil(quota)))
+    return n, quota
+
+
+def keep_image_blocks_mapped() -> dict:
+    """Stop the C allocators from mapping and unmapping memory once per image (round 6, tools/probe_host_prep_scaling.py).
+
+    A prepared image is a handful of 0.2-1 MB blocks (RGB copy, JPEG buffers, two resize outputs, the CHW array); glibc serves
+    blocks above 128 KiB by `mmap` and returns them by `munmap`, so every image costs a few thousand page faults on fresh zeroed
+    pages, and every `munmap` in a process with N running threads takes its address-space lock and interrupts the N cores for the
+    TLB flush.  `mallopt(M_MMAP_THRESHOLD / M_TRIM_THRESHOLD)` keeps such blocks on the (per-thread) heaps, which then stop growing
+    after the first few images; Pillow's own block cache does the same for its image arenas.  One process, 8 PIL threads, Food-101
+    sizes on the 256-core host: 1070 -> 1590 prepared images/s (16 threads: 1180 -> 1900).  `OWC_MALLOC_KEEP=0` / `OWC_PILLOW_BLOCKS=0`
+    switch the two off; what was set is returned (and kept in `_host_allocator`)."""
+    import os
+
+    done = {"mallopt": False, "pillow_blocks": 0}
+    if not os_env_off("OWC_MALLOC_KEEP"):
+        try:
+            import ctypes
+
+            libc = ctypes.CDLL("libc.so.6")
+            m_trim_threshold, m_mmap_threshold = -1, -3              # <malloc.h>
+            limit = 64 << 20                                          # blocks up to 64 MiB stay on the heap (a 4096 x 4096 RGB image is 48 MiB)
+            done["mallopt"] = bool(libc.mallopt(m_mmap_threshold, limit)) and bool(libc.mallopt(m_trim_threshold, 4 * limit))
+        except (OSError, AttributeError):
+            pass
+    blocks = int(os.environ.get("OWC_PILLOW_BLOCKS", "256") or 0)    # x 16 MiB arena blocks kept for reuse instead of freed
+    if blocks > 0:
+        try:
+            from PIL import Image
+
+            Image.core.set_blocks_max(blocks)
+            done["pillow_blocks"] = blocks
+        except Exception:  # noqa: BLE001 - an old Pillow without the arena API
+            pass
+    return done
 
 
 def os_env_off(name: str) -> bool:

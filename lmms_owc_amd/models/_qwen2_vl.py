@@ -419,16 +419,19 @@ class Qwen2VL(PassPipeline, Model):
                 cache[key] = self._prompt_ids(ctx.replace("<image>", ""), list(key[1]))
             prompts.append(cache[key])
         # same-size runs share one patchify launch; each run is staged in pinned memory (parallel copies: memcpy drops the GIL)
-        groups, i = [], 0
+        # (ONE fan-out for the whole unit: real datasets have runs of 1-2 images - Food-101 sizes: 80 runs per 128 images - and a
+        # pool round trip per run cost an eighth of the unit's preparation, tools/probe_host_prep_scaling.py)
+        groups, copies, i = [], [], 0
         while i < len(images):
             j = i
             while j < len(images) and images[j].shape == images[i].shape:
                 j += 1
             buf = self._pinned_take((j - i, *images[i].shape))
             dst = buf.numpy()
-            list(self._pool.map(lambda k, i=i, dst=dst: np.copyto(dst[k - i], images[k]), range(i, j)))
+            copies += [(dst[k - i], images[k]) for k in range(i, j)]
             groups.append(buf)
             i = j
+        list(self._pool.map(lambda c: np.copyto(*c), copies))
         num_beams = beams_from_gen_kwargs(gen_kwargs)
         key = pass_key(max_new, sampling, num_beams)
         return {"prompts": prompts, "grids": grids_per_prompt, "groups": groups, "max_new": max_new, "n": len(chunk),

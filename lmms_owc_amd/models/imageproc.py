@@ -36,11 +36,26 @@ def smart_resize(height: int, width: int, factor: int = IMAGE_FACTOR, min_pixels
 
 
 def jpeg_round_trip(img):
-    """PIL -> JPEG bytes -> PIL, as the reference's base64 data-URI detour does (lossy on purpose: parity)."""
+    """PIL -> JPEG bytes -> PIL, as the reference's base64 data-URI detour does (lossy on purpose: parity).
+
+    The encoder writes to an anonymous in-memory FILE (`memfd_create`), not to a `BytesIO`: with a real file descriptor Pillow
+    runs the whole encode loop outside the GIL (`encode_to_file`, ImageFile._save), with a `BytesIO` it calls the encoder chunk by
+    chunk HOLDING it - one rank's PIL workers then encode one image at a time however many there are (measured on 8 cores, Food-101
+    sizes: 610 encodes/s at 1, 2, 4 and 8 threads into a BytesIO; 540 / 1690 / 2020 at 1 / 4 / 8 threads into a memfd; this round trip
+    was the ~400 images/s per-rank ceiling of tools/soak_host_ranks.py).  Same encoder, same parameters: the JPEG bytes are
+    identical (tests/test_host_logic.py::test_jpeg_round_trip_bytes_do_not_depend_on_where_the_encoder_writes)."""
+    import os
+
     from PIL import Image
 
+    rgb = img.convert("RGB")
+    if hasattr(os, "memfd_create") and os.environ.get("OWC_JPEG_BYTESIO", "0") in ("", "0"):   # (1: the A side of tools/run_host_soak_r6.sh)
+        with os.fdopen(os.memfd_create("owc-jpeg"), "w+b") as f:
+            rgb.save(f, format="JPEG")
+            f.seek(0)
+            return Image.open(f).convert("RGB")     # (convert() loads the pixels: the file can go)
     buf = BytesIO()
-    img.convert("RGB").save(buf, format="JPEG")
+    rgb.save(buf, format="JPEG")
     buf.seek(0)
     return Image.open(buf).convert("RGB")
 

@@ -481,8 +481,7 @@ def test_pingpong_kernel_bit_identical_to_lockstep_race_screen(gpu, m, n, k, epi
         for _ in range(25):
             bad += int(not torch.equal(run(), ref))
     finally:
-        lib.owc_tuning_set(b"gemm_pingpong", 1)
-        _lib.load().owc_tuning_set(b"gemm_pingpong", 1)
+        lib.owc_tuning_set(b"gemm_pingpong", -1)   # (negative: the defaults of both dtypes)
     assert bad == 0, f"{bad} / 25 launches differ from the lock-step kernel"
     if epi == "none":
         assert_bf16_close(to_np(ref[:256]), _oracle(a[:256], w, b), atol=1e-4)

@@ -275,6 +275,91 @@ def test_image_preprocessing_matches_hf_golden():
     np.testing.assert_allclose(p.sum(1), g["row_sums"], rtol=1e-5, atol=1e-3)
 
 
+def test_usable_cpus_reads_the_cgroup_quota(tmp_path):
+    """`usable_cpus` = min(affinity mask, ceil(cgroup CPU quota)): cgroup v2 `cpu.max` ("max" = unlimited), cgroup v1
+    `cpu/cpu.cfs_quota_us` (-1 = unlimited), neither present = the mask.  (The 1-GPU MI355X boxes: "1600000 100000" on 256 CPUs.)"""
+    import os
+
+    from lmms_owc_amd.models._base import usable_cpus
+
+    mask = len(os.sched_getaffinity(0))
+    assert usable_cpus(str(tmp_path)) == (mask, None)
+    (tmp_path / "cpu.max").write_text("1600000 100000\n")
+    assert usable_cpus(str(tmp_path)) == (min(mask, 16), 16.0)
+    (tmp_path / "cpu.max").write_text("150000 100000\n")
+    assert usable_cpus(str(tmp_path)) == (min(mask, 2), 1.5)
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert usable_cpus(str(tmp_path)) == (mask, None)
+    (tmp_path / "cpu.max").unlink()
+    (tmp_path / "cpu").mkdir()
+    (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    (tmp_path / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert usable_cpus(str(tmp_path)) == (mask, None)
+    (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("300000\n")
+    assert usable_cpus(str(tmp_path)) == (min(mask, 3), 3.0)
+
+
+def test_keep_image_blocks_mapped_switches(monkeypatch):
+    """The allocator set-up of the PIL workers (`mallopt` thresholds + Pillow's block cache) reports what it set and obeys its two
+    environment switches; prepared images are the same bytes either way (it only changes where freed blocks go)."""
+    import numpy as np
+    from PIL import Image
+
+    from lmms_owc_amd.models import imageproc
+    from lmms_owc_amd.models._base import keep_image_blocks_mapped
+
+    img = Image.fromarray(np.random.default_rng(3).integers(0, 256, (300, 450, 3), dtype=np.uint8), "RGB")
+    before = imageproc.prepare_image(img, 4 * 28 * 28, 1024 * 28 * 28)
+    monkeypatch.setenv("OWC_MALLOC_KEEP", "0")
+    monkeypatch.setenv("OWC_PILLOW_BLOCKS", "0")
+    assert keep_image_blocks_mapped() == {"mallopt": False, "pillow_blocks": 0}
+    monkeypatch.delenv("OWC_MALLOC_KEEP")
+    monkeypatch.setenv("OWC_PILLOW_BLOCKS", "32")
+    done = keep_image_blocks_mapped()
+    assert done == {"mallopt": True, "pillow_blocks": 32}
+    for _ in range(3):
+        assert np.array_equal(imageproc.prepare_image(img, 4 * 28 * 28, 1024 * 28 * 28), before)
+
+
+def test_jpeg_round_trip_bytes_do_not_depend_on_where_the_encoder_writes():
+    """`imageproc.jpeg_round_trip` encodes into a memfd so that Pillow's encode loop runs outside the GIL (the per-rank ceiling of
+    the PIL workers); the reference's detour encodes into a BytesIO (`/root/reference/src/models/_qwen2_vl.py:237-250`: PIL ->
+    base64 JPEG data URI -> PIL).  Same encoder, same defaults: the decoded pixels must be IDENTICAL - photo-like, noise, palette
+    and RGBA inputs, odd sizes, and 16 round trips from 8 threads at once (each call owns its file)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from io import BytesIO
+
+    from PIL import Image
+
+    from lmms_owc_amd.models import imageproc
+
+    r = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:333, 0:517]
+    smooth = np.stack([(yy * 255 // 333), (xx * 255 // 517), ((yy + xx) % 256)], -1).astype(np.uint8)
+    imgs = [Image.fromarray(smooth, "RGB"), Image.fromarray(r.integers(0, 256, (512, 384, 3), dtype=np.uint8), "RGB"),
+            Image.fromarray(r.integers(0, 256, (37, 53, 4), dtype=np.uint8), "RGBA"),
+            Image.fromarray(r.integers(0, 256, (64, 64), dtype=np.uint8), "L").convert("P"), Image.fromarray(smooth[:1, :1].copy(), "RGB")]
+
+    def by_bytesio(img):
+        buf = BytesIO()
+        img.convert("RGB").save(buf, format="JPEG")
+        buf.seek(0)
+        return np.asarray(Image.open(buf).convert("RGB"))
+
+    want = [by_bytesio(im) for im in imgs]
+    for im, w in zip(imgs, want):
+        got = imageproc.jpeg_round_trip(im)
+        assert got.mode == "RGB" and np.array_equal(np.asarray(got), w)
+    with ThreadPoolExecutor(8) as ex:
+        outs = list(ex.map(lambda i: np.asarray(imageproc.jpeg_round_trip(imgs[i % len(imgs)])), range(16)))
+    assert all(np.array_equal(o, want[i % len(imgs)]) for i, o in enumerate(outs))
+    import os
+    n_fds = len(os.listdir("/proc/self/fd"))
+    for _ in range(8):
+        imageproc.jpeg_round_trip(imgs[0])
+    assert len(os.listdir("/proc/self/fd")) == n_fds      # every anonymous file is closed again
+
+
 def test_checkpoint_readers_cpu(tmp_path):
     """LazyCheckpoint resolves both parameter-name generations over sharded safetensors; dims come from config.json."""
     import numpy as np

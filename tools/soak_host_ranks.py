@@ -179,7 +179,10 @@ def main() -> None:
     rows.sort(key=lambda x: x["rank"])
     wall = max(x["seconds"] for x in rows)
     total = sum(x["images"] for x in rows)
-    print(json.dumps({"ranks": args.ranks, "host_cores": os.cpu_count(), "prep_threads_per_rank": rows[0]["prep_threads"],
+    from lmms_owc_amd.models._base import usable_cpus
+
+    print(json.dumps({"ranks": args.ranks, "host_cores": os.cpu_count(), "usable_cpus": usable_cpus()[0], "cgroup_cpu_quota": usable_cpus()[1],
+                      "prep_threads_per_rank": rows[0]["prep_threads"],
                       "images_per_rank": args.images, "emulated_gpu_rate_per_rank": args.gpu_rate,
                       "aggregate_images_per_s": total / wall, "target_images_per_s": args.ranks * args.gpu_rate,
                       "fraction_of_target": total / wall / (args.ranks * args.gpu_rate),
