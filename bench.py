@@ -848,9 +848,10 @@ def main() -> None:
     ap.add_argument("--nominal-forward", action="store_true",
                     help="run the model's nominal forward: full last prefill layer on every row and no shared-prefix segment "
                          "(same tokens bit for bit; shows what the two dead-work eliminations are worth)")
-    ap.add_argument("--cpu-images", type=int, default=4,
-                    help="images of the CPU baseline (HF generate on the host cores, ~25-40 s each for 7B; SURVEY.md section 8d: 4 for 7B); "
-                         "the first is the warm-up, `value` = mean of the rest")
+    ap.add_argument("--cpu-images", type=int, default=8,
+                    help="images of the CPU baseline (HF generate on the CPUs the cgroup grants: ~3.5 s each for 7B on 16; rounds 1-5 "
+                         "ran 128 throttled threads at 25-40 s each; SURVEY.md section 8d asks for 4 for 7B: 8 = ~30 s of CPU work and 128 "
+                         "teacher-forced steps for the full-size parity gate); the first is the warm-up, `value` = mean of the rest")
     ap.add_argument("--cpu-budget-s", type=float, default=150.0,
                     help="the CPU baseline stops after the image that crosses this many seconds of generate time (at least two images run)")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
