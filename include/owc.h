@@ -74,7 +74,10 @@ const char* owc_last_error(const owc_ctx* ctx);
  * "gemm_pp128" (the 256x128-tile ping-pong kernel for launches with too few 256x256 tiles to fill the chip - the o / down projections
  * of a decode step at 1024-2048 rows: 0 off, n > 0: from n tiles of 256x128, negative: the default), "gemm_walk" (block id -> output
  * tile of the 256x256 ping-pong kernels: 0 the rows-of-4 walk of rounds 1-5, 2 column groups of <= 8 tile columns walked down all
- * tile rows, 1 / negative (default) column groups where they measured faster - K >= 4.5 N with at least as many tile rows as columns).
+ * tile rows, 1 / negative (default) column groups where they measured faster - K >= 4.5 N with at least as many tile rows as columns),
+ * "gemm_tail_split" (1 / negative, the default: when the 256x256 tiles beyond the whole rounds of one tile per CU are at most half a
+ * round, that rest of N runs as one round of 256x128 tiles in a second launch - the gate/up projection of 512- / 1024- / 1792-row
+ * decode steps; 0: one launch).
  * Every knob above selects between kernels that return the SAME results.  The timing-only experiment knobs "gemm_dbg" /
  * "attn_dbg" (parts of a kernel switched off to price them; outputs are garbage) exist only in libowc_hip_timing.so, which
  * `python -m lmms_owc_amd.build --timing` builds with -DOWC_TIMING_KNOBS for tools/; the product library does not know them.

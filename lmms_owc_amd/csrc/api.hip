@@ -61,6 +61,7 @@ int owc_tuning_set(const char* name, int value) {
   }
   else if (!strcmp(name, "gemm_nt_min_mb")) owc_gemm_set_nt_min_mb(value);   // streaming C stores for outputs above this many MiB (negative: default)
   else if (!strcmp(name, "gemm_walk")) owc_gemm_set_walk(value);   // 256x256 ping-pong tile order: 0 rows-of-4 walk, 1 (default, negative) column groups when tiles_m >= tiles_n
+  else if (!strcmp(name, "gemm_tail_split")) owc_gemm_set_tail_split(value);   // short last round of 256x256 tiles as 256x128 tiles: 0 off, 1 (default, negative) on
   else if (!strcmp(name, "gemm_persist")) owc_gemm_set_persist(value);   // persistent 256x256 ping-pong kernel: 0 off, negative: default
   else if (!strcmp(name, "gemm_pp128")) owc_gemm_set_pp128(value);   // 256x128 ping-pong tiles: 0 off, n > 0: from n tiles, negative: default
   else if (!strcmp(name, "decode_fuse")) owc_llm_set_decode_fuse(value);

@@ -81,6 +81,7 @@ int g_nt_min_mb = 64;     // outputs larger than this many MiB leave the 256x256
                           // interleaved pairs: profiles/r05_gemm_persistent_*.txt)
 int g_pp128_min_tiles = 128;  // the 256x128 ping-pong kernel runs from this many of its tiles, up to 256 = one round (knob "gemm_pp128"; 0 off)
 int g_big_min_m = 129;   // M at and above which the 256x256 kernels may run (knob "gemm_big_min_m"; round 1: 1024)
+int g_tail_split = 1;    // a short last round of 256x256 tiles runs as 256x128 tiles in a second launch (knob "gemm_tail_split", 0 = off): see `launch`
 int g_walk = 1;          // tile order of the 256x256 ping-pong kernels (knob "gemm_walk"): 0 = rows-of-4 walk of rounds 1-5 for every shape; 1 = column
                          // groups (`tile_origin`, below) where they measured faster: outputs with at least as many tile rows as tile columns
                          // and K >= 4.5 N (the down projections); 2 = column groups for every shape (A-B)
@@ -1753,6 +1754,34 @@ int launch(const void* A, long lda, const void* W, long ldw, const void* bias, c
         return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
       }
     }
+    // (round 6) A SHORT LAST ROUND: T tiles on 256 CUs take ceil(T / 256) rounds, and the decode steps' gate/up projection sits on
+    // the worst counts (M = 512: 296 tiles = 1.16 rounds for the price of 2; M = 1024: 592 = 2.3 for 3; M = 1792: 1036 = 4.05 for 5).
+    // When the tiles beyond the whole rounds are at most half a round, the tile COLUMNS of the whole rounds go to this kernel and the
+    // rest of N to one round of 256 x 128 tiles (`gemm_bf16_nt_256x128pp_kernel`, <= 256 blocks, each ~0.6 of a 256 x 256 tile's
+    // time): 2 -> ~1.6 rounds at M = 512.  A column split changes no output element's K chain: bit-identical
+    // (tests/test_gemm_gpu.py::test_gemm_short_last_round_split_does_not_change_a_bit).  Plain and SwiGLU epilogues only (no
+    // per-column side inputs to offset); up to 8 rounds (beyond that the last round is < 3 % of the launch).
+    if constexpr (EPI == OWC_EPI_NONE || EPI == OWC_EPI_SWIGLU) {
+      const int cus = cu_count();
+      const long T = (long)tiles_m * tiles_n;
+      if (g_tail_split && bias == nullptr && cus >= 64 && T > cus && T <= 8L * cus && K >= 2 * BK) {
+        const int cols1 = (int)((T / cus) * cus / tiles_m);            // tile columns that fill the whole rounds
+        const long rest = T - (long)cols1 * tiles_m;
+        const int n1 = cols1 * BT, n2 = N - n1;
+        const int tn2 = (n2 + 127) / 128;
+        if (cols1 > 0 && rest > 0 && 2 * rest <= cus && (long)tiles_m * tn2 <= cus) {
+          const long c_off = EPI == OWC_EPI_SWIGLU ? (long)(n1 / 2) * 2 : (long)n1 * 2;   // bytes: both epilogues write bf16
+          hipLaunchKernelGGL(gemm_bf16_nt_256pp_kernel<EPI>, dim3(tiles_m * cols1), dim3(512), 2 * STAGE_BYTES, s,
+                             (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)nullptr,
+                             (const bf16_t*)R, ldr, C, ldc, M, n1, K, tiles_m, cols1, flags, aux);
+          hipLaunchKernelGGL(gemm_bf16_nt_256x128pp_kernel<EPI>, dim3(tiles_m * tn2), dim3(512), P128_LDS, s, (const bf16_t*)A, lda,
+                             (const bf16_t*)((const char*)W + (long)n1 * ldw * 2), ldw, (const bf16_t*)nullptr, (const bf16_t*)R, ldr,
+                             (void*)((char*)C + c_off), ldc, M, n2, K, tiles_m, tn2, g_gemm_dbg, aux);
+          owc_gemm_profile_end(prof, s);
+          return hipGetLastError() == hipSuccess ? OWC_OK : OWC_ERR_HIP;
+        }
+      }
+    }
     hipLaunchKernelGGL(gemm_bf16_nt_256pp_kernel<EPI>, dim3(tiles_m * tiles_n), dim3(512), 2 * STAGE_BYTES, s,
                        (const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
                        (const bf16_t*)R, ldr, C, ldc, M, N, K, tiles_m, tiles_n, flags, aux);
@@ -2103,5 +2132,6 @@ void owc_gemm_set_ring_128(int v) { g_ring_128 = v < 0 ? 1 : v != 0; }
 void owc_gemm_set_pp128(int v) { g_pp128_min_tiles = v < 0 ? 128 : v; }
 void owc_gemm_set_persist(int v) { g_persist = v < 0 ? 0 : v; }
 void owc_gemm_set_walk(int v) { g_walk = v < 0 ? 1 : v; }
+void owc_gemm_set_tail_split(int v) { g_tail_split = v < 0 ? 1 : v; }
 void owc_gemm_set_nt_min_mb(int v) { g_nt_min_mb = v < 0 ? 64 : v; }
 int owc_gemm_nt_min_mb() { return g_nt_min_mb; }   // (the fp8 kernels use the same threshold)

@@ -105,6 +105,7 @@ void owc_gemm_set_ring_128(int v);
 void owc_gemm_set_pp128(int v);
 void owc_gemm_set_persist(int v);
 void owc_gemm_set_walk(int v);
+void owc_gemm_set_tail_split(int v);
 void owc_gemm_set_nt_min_mb(int v);
 int owc_gemm_nt_min_mb();
 void owc_gemm_fp8_set_ring_128(int v);

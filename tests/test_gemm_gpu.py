@@ -455,6 +455,44 @@ def test_gemm_wide_tiles_race_screen(gpu, m, n, k, epi):
         lib.owc_tuning_set(b"gemm_skinny_max_m", SKINNY_MAX_M)
 
 
+@pytest.mark.parametrize("m,n,k,epi", [(512, 37888, 3584, "swiglu"),     # the 7B gate/up of a 512-row decode step: 296 tiles -> 256 + 80 half tiles
+                                       (1024, 37888, 3584, "swiglu"),    # 592 -> 512 + 160
+                                       (1792, 37888, 512, "swiglu"),     # 7 tile rows: 1036 -> 1022 + 28
+                                       (500, 37888, 256, "swiglu"),      # ragged M (clamped rows in both kernels), two K-tiles
+                                       (768, 25000, 384, "none"),        # 3 x 98 = 294 tiles -> 255 + 39 whole tiles' worth; ragged N in the second launch
+                                       (512, 33024, 384, "none"),        # 258 tiles -> 256 + one tile column
+                                       (512, 45056, 384, "none")])       # 352 tiles: the rest (96) is more than half a round -> no split (same path both ways)
+def test_gemm_short_last_round_split_does_not_change_a_bit(gpu, m, n, k, epi):
+    """Round 6: when the 256x256 tiles beyond the whole rounds of 256 are at most half a round, `launch` gives the tile columns of the
+    whole rounds to `gemm_bf16_nt_256pp_kernel` and the rest of N to one round of `gemm_bf16_nt_256x128pp_kernel` (knob
+    "gemm_tail_split", 0 = one launch as in rounds 2-5).  A column split leaves every output element's K chain alone: outputs must
+    be equal bit for bit, with a canary in the output buffer (a column range that neither launch writes would keep it), and 8 launches
+    per shape (the second kernel starts while the first one's last tiles drain)."""
+    from lmms_owc_amd import _lib, ops
+
+    lib = _lib.load()
+    a = bf16_randn((m, k), 170 + (m % 97), device=gpu)
+    w = bf16_randn((n, k), 171, 0.05, device=gpu)
+    E = {"none": _lib.EPI_NONE, "swiglu": _lib.EPI_SWIGLU}[epi]
+    cols = n // 2 if epi == "swiglu" else n
+
+    def run():
+        out = torch.full((m, cols), 777.0, dtype=torch.bfloat16, device=gpu)
+        return ops.gemm_bf16(a, w, None, epilogue=E, out=out)
+
+    try:
+        assert lib.owc_tuning_set(b"gemm_tail_split", 0) == 0
+        want = run()
+        assert lib.owc_tuning_set(b"gemm_tail_split", 1) == 0
+        for i in range(8):
+            got = run()
+            assert torch.equal(got, want), (i, (got != want).sum().item())
+    finally:
+        lib.owc_tuning_set(b"gemm_tail_split", -1)
+    if epi == "none":
+        assert_bf16_close(to_np(want[:128]), _oracle(a[:128], w, None), atol=1e-4)
+
+
 @pytest.mark.parametrize("m,n,k,epi", [(4096, 4096, 4096, "none"), (2048, 37888, 3584, "swiglu"), (32768, 1280, 1280, "residual"),
                                        (1100, 13000, 384, "none"), (65536, 1280, 256, "quick_gelu"), (3000, 5120, 5120, "f32")])
 def test_pingpong_kernel_bit_identical_to_lockstep_race_screen(gpu, m, n, k, epi):
