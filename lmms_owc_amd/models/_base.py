@@ -473,7 +473,7 @@ class PassPipeline:
 
 
 
-def usable_cpus(cgroup_root: str = "/sys/fs/cgroup") -> tuple[int, float | None]:
+def usable_cpus(cgroup_root: str = "/sys/fs/cgroup", proc_cgroup: str = "/proc/self/cgroup") -> tuple[int, float | None]:
     """(CPUs this process can actually keep busy, the cgroup CPU quota in CPUs or None).  `os.cpu_count()` and the affinity mask
     count the host's logical CPUs; a container's bandwidth limit (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us / cpu.cfs_period_us`) is
     invisible to both, and more runnable threads than the quota only get the whole group THROTTLED - every thread stopped for the
@@ -486,11 +486,27 @@ def usable_cpus(cgroup_root: str = "/sys/fs/cgroup") -> tuple[int, float | None]
 
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     quota = None
+    # cgroup v2: the tightest `cpu.max` from this process's group up to the mounted root (a limit on any ancestor binds)
+    rel = ""
     try:
-        q, period = (Path(cgroup_root) / "cpu.max").read_text().split()[:2]
-        if q != "max":
-            quota = int(q) / int(period)
-    except (OSError, ValueError):
+        for line in Path(proc_cgroup).read_text().splitlines():
+            if line.startswith("0::"):
+                rel = line[3:].strip().lstrip("/")
+    except OSError:
+        pass
+    node, seen_v2 = Path(cgroup_root) / rel, False
+    while True:
+        try:
+            q, period = (node / "cpu.max").read_text().split()[:2]
+            seen_v2 = True
+            if q != "max":
+                quota = min(quota, int(q) / int(period)) if quota is not None else int(q) / int(period)
+        except (OSError, ValueError):
+            pass
+        if node == Path(cgroup_root) or Path(cgroup_root) not in node.parents:
+            break
+        node = node.parent
+    if not seen_v2:
         try:
             q = int((Path(cgroup_root) / "cpu" / "cpu.cfs_quota_us").read_text())
             period = int((Path(cgroup_root) / "cpu" / "cpu.cfs_period_us").read_text())

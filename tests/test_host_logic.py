@@ -276,27 +276,50 @@ def test_image_preprocessing_matches_hf_golden():
 
 
 def test_usable_cpus_reads_the_cgroup_quota(tmp_path):
-    """`usable_cpus` = min(affinity mask, ceil(cgroup CPU quota)): cgroup v2 `cpu.max` ("max" = unlimited), cgroup v1
-    `cpu/cpu.cfs_quota_us` (-1 = unlimited), neither present = the mask.  (The 1-GPU MI355X boxes: "1600000 100000" on 256 CPUs.)"""
+    """`usable_cpus` = min(affinity mask, ceil(cgroup CPU quota)): cgroup v2 `cpu.max` ("max" = unlimited) - the tightest one from the
+    process's own group up to the mounted root -, cgroup v1 `cpu/cpu.cfs_quota_us` (-1 = unlimited), neither present = the mask.
+    (The 1-GPU MI355X boxes: "1600000 100000" at the root of the container's mount, on 256 CPUs.)"""
     import os
 
     from lmms_owc_amd.models._base import usable_cpus
 
     mask = len(os.sched_getaffinity(0))
-    assert usable_cpus(str(tmp_path)) == (mask, None)
-    (tmp_path / "cpu.max").write_text("1600000 100000\n")
-    assert usable_cpus(str(tmp_path)) == (min(mask, 16), 16.0)
-    (tmp_path / "cpu.max").write_text("150000 100000\n")
-    assert usable_cpus(str(tmp_path)) == (min(mask, 2), 1.5)
-    (tmp_path / "cpu.max").write_text("max 100000\n")
-    assert usable_cpus(str(tmp_path)) == (mask, None)
-    (tmp_path / "cpu.max").unlink()
-    (tmp_path / "cpu").mkdir()
-    (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
-    (tmp_path / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
-    assert usable_cpus(str(tmp_path)) == (mask, None)
-    (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("300000\n")
-    assert usable_cpus(str(tmp_path)) == (min(mask, 3), 3.0)
+    proc = tmp_path / "proc_cgroup"
+    proc.write_text("0::/\n")
+    root = tmp_path / "cg"
+    root.mkdir()
+
+    def got():
+        return usable_cpus(str(root), str(proc))
+
+    assert got() == (mask, None)
+    (root / "cpu.max").write_text("1600000 100000\n")
+    assert got() == (min(mask, 16), 16.0)
+    (root / "cpu.max").write_text("150000 100000\n")
+    assert got() == (min(mask, 2), 1.5)
+    (root / "cpu.max").write_text("max 100000\n")
+    assert got() == (mask, None)
+    # a nested group: the tightest limit on the way up binds; a group directory that is not visible in the mount is skipped
+    proc.write_text("12:cpuset:/x\n0::/jobs/abc\n")
+    (root / "jobs" / "abc").mkdir(parents=True)
+    (root / "jobs" / "abc" / "cpu.max").write_text("max 100000\n")
+    (root / "jobs" / "cpu.max").write_text("400000 100000\n")
+    (root / "cpu.max").write_text("1600000 100000\n")
+    assert got() == (min(mask, 4), 4.0)
+    (root / "jobs" / "abc" / "cpu.max").write_text("100000 100000\n")
+    assert got() == (1, 1.0)
+    proc.write_text("0::/not/mounted/here\n")
+    assert got() == (min(mask, 16), 16.0)
+    # cgroup v1
+    proc.write_text("3:cpu,cpuacct:/\n")
+    for f in root.rglob("cpu.max"):
+        f.unlink()
+    (root / "cpu").mkdir()
+    (root / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    (root / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert got() == (mask, None)
+    (root / "cpu" / "cpu.cfs_quota_us").write_text("300000\n")
+    assert got() == (min(mask, 3), 3.0)
 
 
 def test_keep_image_blocks_mapped_switches(monkeypatch):
